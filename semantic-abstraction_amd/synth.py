@@ -1,0 +1,58 @@
+"""Seeded synthetic scenes: there is no dataset here (matterport.png is a missing blob, the
+269 GB THOR dataset cannot be fetched), so every test / bench input is generated from a seed.
+
+RGB: uint8 smooth noise (4 octaves of bilinearly-upsampled uniform noise) so the bicubic resampler sees
+non-trivial content; depth: fp32 in [1.5, 2.5] m, no zeros; intrinsics fx = fy = 400 * W/480, principal point at
+the image centre; pose: the `arkit_vn_poster` extrinsics pattern (camera at (-2.056, -0.2, 1.901) looking along
++x, pitched down 0.3 rad) so most points fall inside scene_bounds [[-1,-1,-0.1],[1,1,1.9]].
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SCENE_BOUNDS = ((-1.0, -1.0, -0.1), (1.0, 1.0, 1.9))
+
+
+def _upsample_bilinear(a: np.ndarray, H: int, W: int) -> np.ndarray:
+    h, w = a.shape[:2]
+    ys = (np.arange(H) + 0.5) * h / H - 0.5
+    xs = (np.arange(W) + 0.5) * w / W - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, h - 1); y1 = np.clip(y0 + 1, 0, h - 1)
+    x0 = np.clip(np.floor(xs).astype(int), 0, w - 1); x1 = np.clip(x0 + 1, 0, w - 1)
+    wy = np.clip(ys - y0, 0, 1)[:, None, None]
+    wx = np.clip(xs - x0, 0, 1)[None, :, None]
+    a = a.reshape(h, w, -1)
+    top = a[y0][:, x0] * (1 - wx) + a[y0][:, x1] * wx
+    bot = a[y1][:, x0] * (1 - wx) + a[y1][:, x1] * wx
+    return top * (1 - wy) + bot * wy
+
+
+def smooth_noise(H: int, W: int, C: int, rng: np.random.Generator) -> np.ndarray:
+    """float64 [H, W, C] in [0, 1]."""
+    acc = np.zeros((H, W, C))
+    amp, tot = 1.0, 0.0
+    for cells in (3, 7, 17, 41):
+        acc += amp * _upsample_bilinear(rng.random((cells, cells, C)), H, W)
+        tot += amp
+        amp *= 0.5
+    return acc / tot
+
+
+def synth_rgb(H: int, W: int, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    x = smooth_noise(H, W, 3, rng)
+    x = (x - x.min()) / (x.max() - x.min())
+    return np.clip(np.round(x * 255), 0, 255).astype(np.uint8)
+
+
+def synth_scene(H: int = 480, W: int = 480, seed: int = 0) -> dict:
+    rng = np.random.default_rng(10_000 + seed)
+    rgb = synth_rgb(H, W, seed)
+    d = smooth_noise(H, W, 1, rng)[..., 0]
+    d = (d - d.min()) / (d.max() - d.min())
+    depth = (1.5 + 1.0 * d).astype(np.float32)
+    f = 400.0 * W / 480.0
+    K = np.array([[f, 0.0, W / 2.0], [0.0, f, H / 2.0], [0.0, 0.0, 1.0]])
+    s, c = np.sin(0.3), np.cos(0.3)
+    pose = np.array([[0.0, -s, c, -2.05570605], [-1.0, 0.0, 0.0, -0.2], [0.0, -c, -s, 1.90137071], [0.0, 0.0, 0.0, 1.0]])
+    return dict(rgb=rgb, depth=depth, cam_intr=K, cam_pose=pose)

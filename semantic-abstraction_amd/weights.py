@@ -1,0 +1,156 @@
+"""Seeded synthetic weights for the two networks on the path.
+
+There is no network here and the released checkpoints (OpenAI CLIP ``ViT-B-32.pt`` / ``ViT-B-16.pt``,
+``ovssc.pth``) cannot be fetched, so every run uses random-init weights of the exact released
+architectures, generated from a seed with numpy's PCG64 so that the golden-vector generator (which
+loads them into the *reference* modules), the CPU oracle and the HIP path all see the same numbers
+without a multi-hundred-MB fixture.
+
+Key names follow the checkpoints the reference loads (`CLIP/clip/model_explainability.py:530-602`
+for CLIP, `utils.py:276-290` for SemAbs3D) so a real state_dict can be dropped in unchanged.
+
+`build_model` converts Conv/Linear/MHA/proj tensors to fp16 and (on CPU) back to fp32
+(`model_explainability.py:501-527`, `clip_explainability.py:165-169`), so those tensors are
+fp16-representable; LayerNorm parameters, class/positional/token embeddings stay fp32.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+CLIP_ARCHS = {
+    # name: (patch, vision_width, vision_layers, vision_heads, embed_dim, text_width, text_heads, text_layers)
+    "ViT-B/32": dict(patch=32, width=768, layers=12, heads=12, embed=512, twidth=512, theads=8, tlayers=12),
+    "ViT-B/16": dict(patch=16, width=768, layers=12, heads=12, embed=512, twidth=512, theads=8, tlayers=12),
+}
+CONTEXT_LENGTH = 77
+VOCAB_SIZE = 49408
+IMAGE_RES = 224
+
+
+def _f16(x: np.ndarray) -> np.ndarray:
+    """Round to the nearest fp16 value, returned as fp32 (what `convert_weights` + `.float()` leaves)."""
+    return x.astype(np.float16).astype(np.float32)
+
+
+def _block(rng, prefix, width, sd, attn_std, proj_std, fc_std, sharpen, half=True):
+    r = _f16 if half else (lambda a: a.astype(np.float32))
+    n = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    w_in = n(3 * width, width) * attn_std
+    # sharpen q/k so the softmax is not near-uniform (random CLIP init gives almost flat attention)
+    w_in[: 2 * width] *= sharpen
+    sd[prefix + "attn.in_proj_weight"] = r(w_in)
+    sd[prefix + "attn.in_proj_bias"] = r(n(3 * width) * 0.02)
+    sd[prefix + "attn.out_proj.weight"] = r(n(width, width) * proj_std)
+    sd[prefix + "attn.out_proj.bias"] = r(n(width) * 0.02)
+    sd[prefix + "ln_1.weight"] = 1.0 + 0.1 * n(width)
+    sd[prefix + "ln_1.bias"] = 0.05 * n(width)
+    sd[prefix + "mlp.c_fc.weight"] = r(n(4 * width, width) * fc_std)
+    sd[prefix + "mlp.c_fc.bias"] = r(n(4 * width) * 0.02)
+    sd[prefix + "mlp.c_proj.weight"] = r(n(width, 4 * width) * proj_std)
+    sd[prefix + "mlp.c_proj.bias"] = r(n(width) * 0.02)
+    sd[prefix + "ln_2.weight"] = 1.0 + 0.1 * n(width)
+    sd[prefix + "ln_2.bias"] = 0.05 * n(width)
+
+
+def make_clip_state_dict(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 4.0,
+                         text_tower: bool = True) -> dict:
+    """State dict with the OpenAI CLIP key names for a ViT-B model, values from `seed`.
+
+    Standard deviations follow `CLIP.initialize_parameters` (`model_explainability.py:418-452`);
+    biases / LayerNorm affine parameters are made non-trivial on purpose so parity tests exercise them.
+    """
+    a = CLIP_ARCHS[arch]
+    rng = np.random.default_rng(seed)
+    n = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    W, p = a["width"], a["patch"]
+    g = IMAGE_RES // p
+    sd = {}
+    scale = W ** -0.5
+    sd["visual.conv1.weight"] = _f16(n(W, 3, p, p) * (3 * p * p) ** -0.5)
+    sd["visual.class_embedding"] = scale * n(W)
+    sd["visual.positional_embedding"] = scale * n(g * g + 1, W)
+    sd["visual.ln_pre.weight"] = 1.0 + 0.1 * n(W)
+    sd["visual.ln_pre.bias"] = 0.05 * n(W)
+    proj_std = (W ** -0.5) * ((2 * a["layers"]) ** -0.5)
+    for i in range(a["layers"]):
+        _block(rng, f"visual.transformer.resblocks.{i}.", W, sd, W ** -0.5, proj_std, (2 * W) ** -0.5, sharpen)
+    sd["visual.ln_post.weight"] = 1.0 + 0.1 * n(W)
+    sd["visual.ln_post.bias"] = 0.05 * n(W)
+    sd["visual.proj"] = _f16(scale * n(W, a["embed"]))
+    if text_tower:
+        TW = a["twidth"]
+        sd["token_embedding.weight"] = 0.02 * n(VOCAB_SIZE, TW)
+        sd["positional_embedding"] = 0.01 * n(CONTEXT_LENGTH, TW)
+        tproj_std = (TW ** -0.5) * ((2 * a["tlayers"]) ** -0.5)
+        for i in range(a["tlayers"]):
+            _block(rng, f"transformer.resblocks.{i}.", TW, sd, TW ** -0.5, tproj_std, (2 * TW) ** -0.5, 2.0)
+        sd["ln_final.weight"] = 1.0 + 0.1 * n(TW)
+        sd["ln_final.bias"] = 0.05 * n(TW)
+        sd["text_projection"] = _f16(n(TW, a["embed"]) * TW ** -0.5)
+        sd["logit_scale"] = np.float32(np.log(1 / 0.07)) * np.ones((), dtype=np.float32)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# SemAbs3D (point MLP + ResidualUNet3D + implicit decoder), key names as `net.py:319-381`
+# ----------------------------------------------------------------------------------------------
+
+def unet_layer_plan(in_channels: int, out_channels: int, f_maps: int, num_levels: int):
+    """Channel plan of `ResidualUNet3D` (`unet3d.py:529-580`): list of (key_prefix, kind, cin, cout)."""
+    fm = [f_maps * 2 ** k for k in range(num_levels)]
+    plan = []
+    for i, c in enumerate(fm):
+        cin = in_channels if i == 0 else fm[i - 1]
+        pre = f"encoders.{i}.basic_module."
+        plan += [(pre + "conv1.", "gcr", cin, c), (pre + "conv2.", "gcr", c, c), (pre + "conv3.", "gc", c, c)]
+    rf = fm[::-1]
+    for i in range(len(rf) - 1):
+        plan.append((f"decoders.{i}.upsampling.upsample.", "convT", rf[i], rf[i + 1]))
+        pre = f"decoders.{i}.basic_module."
+        c = rf[i + 1]
+        plan += [(pre + "conv1.", "gcr", c, c), (pre + "conv2.", "gcr", c, c), (pre + "conv3.", "gc", c, c)]
+    plan.append(("final_conv.", "conv1", fm[0], out_channels))
+    return plan
+
+
+def make_semabs3d_state_dict(seed: int = 0, unet_num_channels: int = 16, unet_f_maps: int = 16,
+                             unet_num_groups: int = 8, unet_num_levels: int = 6,
+                             pts_feat_extractor_hidden_dim: int = 128, pts_feature_dim: int = 1,
+                             output_dim: int = 1, decoder_concat_xyz_pts: bool = True) -> dict:
+    """fp32 state dict for `SemAbs3D` (`net.py:319-381`) with torch-default-like init scales."""
+    rng = np.random.default_rng(seed)
+    n = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    u = lambda fan_in, *s: ((rng.random(s, dtype=np.float32) * 2 - 1) / np.sqrt(fan_in)).astype(np.float32)
+    sd = {"steps": np.zeros(1, dtype=np.float32)}
+    H = pts_feat_extractor_hidden_dim
+    dims = [(pts_feature_dim + 3, H), (H, H), (H, unet_num_channels)]
+    for li, (i, o) in zip((0, 2, 4), dims):
+        sd[f"pts_feat_extractor.{li}.weight"] = u(i, o, i)
+        sd[f"pts_feat_extractor.{li}.bias"] = u(i, o)
+    for pre, kind, cin, cout in unet_layer_plan(unet_num_channels, unet_num_channels, unet_f_maps, unet_num_levels):
+        k = "vol_feature_extractor." + pre
+        if kind in ("gcr", "gc"):
+            sd[k + "groupnorm.weight"] = 1.0 + 0.1 * n(cin)
+            sd[k + "groupnorm.bias"] = 0.05 * n(cin)
+            sd[k + "conv.weight"] = u(cin * 27, cout, cin, 3, 3, 3) * np.float32(1.7)
+        elif kind == "convT":
+            sd[k + "weight"] = u(cout * 27 / 8, cin, cout, 3, 3, 3)
+            sd[k + "bias"] = u(cin * 27, cout)
+        else:
+            sd[k + "weight"] = u(cin, cout, cin, 1, 1, 1)
+            sd[k + "bias"] = u(cin, cout)
+    hid = unet_num_channels
+    din = hid + 3 * int(decoder_concat_xyz_pts)
+    sd["visual_sampler.mlp.0.weight"] = u(din, hid, din)
+    sd["visual_sampler.mlp.0.bias"] = u(din, hid)
+    sd["visual_sampler.mlp.2.weight"] = u(hid, output_dim, hid)
+    sd["visual_sampler.mlp.2.bias"] = u(hid, output_dim)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+DEFAULT_LABELS = [
+    "chair", "table", "lamp", "sofa", "bed", "mirror", "carpet", "wall",
+    "floor", "door", "window", "shelf", "plant", "television", "cushion", "cabinet",
+]
+DEFAULT_PROMPT = "a photograph of a {} in a home."

@@ -1,0 +1,404 @@
+"""Generate the golden vectors under tests/golden/*.npz by running the UNMODIFIED reference
+(`/root/reference`, imported through the stand-ins in refimport.py) on seeded inputs.
+
+Run here (the build container), once:   python tests/golden/gen_golden.py [group ...]
+The GPU box never runs this (it has no /root/reference); it only reads the committed .npz files.
+Fixtures hold inputs' seeds/recipes + the reference's outputs (data only, no reference source).
+Weights come from `semabs_amd.weights` (seeded numpy PCG64), loaded into the reference modules.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import refimport  # noqa: E402
+import semabs_amd  # noqa: E402,F401
+from semabs_amd.weights import DEFAULT_PROMPT, make_semabs3d_state_dict  # noqa: E402
+from semabs_amd.synth import synth_rgb, synth_scene  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(os.cpu_count())
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1e3:.1f} kB")
+
+
+def digest(a: np.ndarray) -> np.ndarray:
+    """sha256 of the raw bytes as uint8[32] (for bit-exact integer outputs too big to commit)."""
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def sample_idx(n, k, seed=123):
+    return np.sort(np.random.default_rng(seed).choice(n, size=min(k, n), replace=False))
+
+
+# ----------------------------------------------------------------------------------------------------
+def g1_tiling(rc):
+    """create_tiles geometry: tile table, tile_sizes, counts for 480^2 / 120^2 / 256x192 (ours + chefer)."""
+    W = rc.ClipWrapper
+    out = {}
+    for tag, (H, Wd), cfgname, dim in [("480", (480, 480), "ours", 480), ("120", (120, 120), "ours", 120),
+                                        ("256x192", (256, 192), "ours", 256), ("96c", (96, 96), "chefer_et_al", 96),
+                                        ("100x130", (100, 130), "ours", 100)]:
+        cfg = rc.saliency_configs[cfgname](dim)
+        img = np.zeros((H, Wd, 3), np.uint8)
+        # preprocessing 1 224 tiles is slow and irrelevant here: stub the per-tile preprocess
+        real_pre = W.clip_gradcam.preprocess
+        W.clip_gradcam.preprocess = lambda pil: torch.zeros(1)
+        aug = 1 if cfgname == "ours" else 0
+        tiles, _, counts, sizes = W.create_tiles(img=img, augmentations=aug,
+                                                 cropping_augmentations=cfg["cropping_augmentations"])
+        W.clip_gradcam.preprocess = real_pre
+        # tiles are (slice(None), slice(x, x+ts), slice(y, y+ts)); image index is implied by order
+        per_img = len(tiles) // (aug + 1)
+        table = np.array([(i // per_img, t[1].start, t[2].start, t[1].stop - t[1].start)
+                          for i, t in enumerate(tiles)], dtype=np.int32).reshape(-1, 4)
+        out[f"table_{tag}"] = table
+        out[f"sizes_{tag}"] = np.asarray(sizes, np.int32)
+        out[f"count_keys_{tag}"] = np.asarray(list(counts.keys()), np.int32)
+        for k, c in counts.items():
+            c = c.numpy()
+            out[f"count_{tag}_{k}_sum"] = np.float64(c.astype(np.float64).sum())
+            out[f"count_{tag}_{k}_sub"] = c[::7, ::5].copy()
+    save("g1_tiling", **out)
+
+
+def g2_preprocess(rc):
+    """clip_gradcam.preprocess (Resize bicubic 224 -> ToTensor -> Normalize) on synthetic square crops."""
+    from PIL import Image
+    W = rc.ClipWrapper
+    out = {}
+    for ts in (480, 320, 240, 120, 80, 30, 224):
+        crop = synth_rgb(ts, ts, seed=1000 + ts)
+        t = W.clip_gradcam.preprocess(Image.fromarray(crop)).numpy()
+        out[f"ts{ts}_sum"] = np.float64(t.astype(np.float64).sum())
+        out[f"ts{ts}_sub"] = t[:, ::9, ::7].copy()
+        out[f"ts{ts}_sha"] = digest(t)
+    save("g2_preprocess", **out)
+
+
+def _tiles_from_seed(rc, n, seed):
+    from PIL import Image
+    W = rc.ClipWrapper
+    sizes = [120, 80, 60, 30, 97]
+    return torch.stack([W.clip_gradcam.preprocess(Image.fromarray(synth_rgb(sizes[i % 5], sizes[i % 5], seed=seed + i)))
+                        for i in range(n)])
+
+
+def g3_g4_vit(arch, tag):
+    """ViT forward + ClipGradcam.interpret (autograd) on 3 tiles x 3 labels, positive_attn_only True/False."""
+    rc = refimport.load_reference_clip(arch, seed=0)
+    W = rc.ClipWrapper
+    gc = W.clip_gradcam
+    labels = ["chair", "table", "lamp"]
+    gc.templates = [DEFAULT_PROMPT]
+    gc.set_classes(labels)
+    w_text = torch.cat([gc.class_to_language_feature[c] for c in labels], dim=1)
+    tiles = _tiles_from_seed(rc, 3, seed=7)
+    out = {"w_text": w_text.numpy(), "tiles_sum": np.float64(tiles.double().sum().item())}
+    with torch.no_grad():
+        vis = gc.model.visual
+        x = vis.conv1(tiles)
+        T = x.shape[-1] * x.shape[-2] + 1
+        if T != 50:
+            from CLIP.clip.auxiliary import interpolate_positional_emb
+            out["pos_emb"] = interpolate_positional_emb(vis.positional_embedding, T).numpy()
+        out["feat"] = gc.model.encode_image(tiles).numpy()
+    for pos in (True, False):
+        gc.positive_attn_only = pos
+        rel = gc(x=tiles, o=labels)
+        out[f"rel_pos{int(pos)}"] = rel.detach().numpy()
+    blk = list(gc.model.visual.transformer.resblocks.children())[-1]
+    probs = blk.attn_probs.detach()
+    out["probs_cls"] = probs.view(3, 12, T, T)[:, :, 0, :].numpy()
+    # logits + raw gradient of the CLS row for label 1
+    feats = gc.model.encode_image(tiles)
+    feats = feats / feats.norm(dim=-1, keepdim=True)
+    logits = 100.0 * feats @ w_text
+    out["logits"] = logits.detach().numpy()
+    blk = list(gc.model.visual.transformer.resblocks.children())[-1]
+    g = torch.autograd.grad(logits.sum(dim=0)[1], [blk.attn_probs])[0]
+    out["grad_l1_cls"] = g.view(3, 12, T, T)[:, :, 0, :].numpy()
+    out["grad_l1_noncls_absmax"] = np.float64(g.view(3, 12, T, T)[:, :, 1:, :].abs().max().item())
+    save(f"g3g4_vit_{tag}", **out)
+    return rc
+
+
+def g5_aggregate(rc):
+    """get_clip_saliency_convolve with clip_gradcam replaced by a seeded fake: pins flip-average,
+    bilinear upsampling, fp16 canvases, count normalisation and the mean over scales."""
+    W = rc.ClipWrapper
+    real = W.clip_gradcam
+    out = {}
+    for tag, H, cfgname, g, L, aug in [("ours120", 120, "ours", 7, 3, 1), ("chefer96", 96, "chefer_et_al", 7, 2, 0),
+                                        ("ours56_g14", 56, "ours", 14, 2, 0)]:
+        cfg = rc.saliency_configs[cfgname](H)
+
+        class Fake:
+            positive_attn_only = False
+            preprocess = staticmethod(lambda pil: torch.zeros(3, 4, 4))
+
+            def __init__(self):
+                self.rng = np.random.default_rng(99)
+                self.calls = []
+
+            def __call__(self, x, o):
+                r = torch.from_numpy((self.rng.standard_normal((len(o), len(x), g, g)) * 0.01).astype(np.float32))
+                self.calls.append(r)
+                return r
+
+        fake = Fake()
+        W.clip_gradcam = fake
+        labels = [f"l{i}" for i in range(L)]
+        maps = W.get_clip_saliency_convolve(img=np.zeros((H, H, 3), np.uint8), text_labels=labels,
+                                            horizontal_flipping=cfg["horizontal_flipping"],
+                                            positive_attn_only=True, augmentations=aug,
+                                            cropping_augmentations=cfg["cropping_augmentations"])
+        n_pass = 2 if cfg["horizontal_flipping"] else 1
+        per = len(fake.calls) // n_pass
+        out[f"{tag}_rel"] = torch.cat(fake.calls[:per], dim=1).numpy()
+        if n_pass == 2:
+            out[f"{tag}_rel_flip"] = torch.cat(fake.calls[per:], dim=1).numpy()
+        out[f"{tag}_maps"] = maps.numpy()
+        out[f"{tag}_meta"] = np.asarray([H, g, L, aug, int(cfg["horizontal_flipping"])], np.int32)
+    W.clip_gradcam = real
+    save("g5_aggregate", **out)
+
+
+def g6_end_to_end(rc, arch, tag):
+    """ClipWrapper.get_clip_saliency on a synthetic image (identity ColorJitter stub)."""
+    W = rc.ClipWrapper
+    out = {}
+    labels = ["chair", "table", "lamp"]
+    if arch == "ViT-B/32":
+        runs = [("ours96", 96, dict(rc.saliency_configs["ours"](96), augmentations=0)),
+                ("chefer96", 96, rc.saliency_configs["chefer_et_al"](96))]
+    else:
+        runs = [("two_scale64", 64, dict(rc.saliency_configs["chefer_et_al"](64), horizontal_flipping=True,
+                                         cropping_augmentations=[{"tile_size": 64, "stride": 16},
+                                                                 {"tile_size": 32, "stride": 8}]))]
+    for name, H, cfg in runs:
+        img = synth_rgb(H, H, seed=42)
+        t = time.time()
+        maps, feats = W.get_clip_saliency(img=img, text_labels=labels, prompts=[DEFAULT_PROMPT], **cfg)
+        print(f"    {tag}/{name}: {time.time() - t:.1f}s  max|map| {maps.abs().max():.4g}")
+        out[f"{name}_maps"] = maps.numpy()
+        out[f"{name}_text"] = feats.numpy()
+    save(f"g6_e2e_{tag}", **out)
+
+
+def g7_text(rc):
+    import CLIP.clip.clip_explainability as rexp
+    W = rc.ClipWrapper
+    gc = W.clip_gradcam
+    out = {}
+    labels = ["chair", "table", "pink make up bag", "brown modern upholstered chair in faux leather with wooden legs"]
+    for tag, templates in [("t1", [DEFAULT_PROMPT]), ("t3", ["a photo of a {}.", "a bad photo of the {}.", DEFAULT_PROMPT])]:
+        texts = [t.format(c) for c in labels for t in templates]
+        out[f"{tag}_tokens"] = rexp.tokenize(texts).numpy()
+        gc.templates = templates
+        gc.set_classes(labels)
+        out[f"{tag}_weights"] = torch.cat([gc.class_to_language_feature[c] for c in labels], dim=1).numpy()
+    out["misc_tokens"] = rexp.tokenize(["Hello, World! it's 42 degrees", "a  b\tc", "don't you're we've"]).numpy()
+    save("g7_text", **out)
+
+
+# ----------------------------------------------------------------------------------------------------
+SCENE_BOUNDS = [[-1.0, -1.0, -0.1], [1.0, 1.0, 1.9]]
+
+
+def g8_geometry():
+    fusion, pc = refimport.load_reference_geometry()
+    net, _ = refimport.load_reference_net()
+    out = {}
+    for tag, hw, S in [("48", 48, 32), ("480", 480, 128)]:
+        sc = synth_scene(hw, hw, seed=5)
+        pts = pc.get_pointcloud(sc["depth"], None, sc["cam_intr"], sc["cam_pose"])[0]
+        pts32 = pts.astype(np.float32)
+        mask = pc.filter_pts_bounds(pts32, np.array(SCENE_BOUNDS))
+        vg = net.VirtualGrid(scene_bounds=np.array(SCENE_BOUNDS), grid_shape=(S, S, S), batch_size=1)
+        idx = vg.get_points_grid_idxs(torch.from_numpy(pts32)[None])
+        flat = vg.flatten_idxs(idx)[0].numpy()
+        fr = pc.check_pts_in_frustum(pts32[::3].astype(np.float64) * 1.01, sc["depth"], sc["cam_pose"], sc["cam_intr"])
+        out[f"{tag}_mask_sha"] = digest(mask)
+        out[f"{tag}_mask_count"] = np.int64(mask.sum())
+        out[f"{tag}_flat_sha"] = digest(flat.astype(np.int64))
+        out[f"{tag}_pts32_sha"] = digest(pts32)
+        out[f"{tag}_frustum_sha"] = digest(fr)
+        out[f"{tag}_frustum_count"] = np.int64(fr.sum())
+        if hw == 48:
+            out["48_pts64"] = pts
+            out["48_flat"] = flat
+            out["48_mask"] = mask
+        else:
+            si = sample_idx(len(flat), 2048)
+            out["480_si"] = si
+            out["480_flat_s"] = flat[si]
+            out["480_pts64_s"] = pts[si]
+    save("g8_geometry", **out)
+
+
+def g11_tsdf():
+    fusion, pc = refimport.load_reference_geometry()
+    out = {}
+    for tag, hw, S in [("16", 48, 16), ("32", 64, 32), ("128", 480, 128)]:
+        sc = synth_scene(hw, hw, seed=6)
+        vs = (SCENE_BOUNDS[1][0] - SCENE_BOUNDS[0][0]) / S
+        tv = fusion.TSDFVolume(vol_bnds=np.array(SCENE_BOUNDS).T.copy(), voxel_size=vs)
+        tv._voxel_size = np.float64(tv._voxel_size)        # numba would type the python float as float64
+        pix_rec = {}
+        real_c2p = tv.cam2pix
+
+        def rec(cam_pts, intr):
+            p = real_c2p(cam_pts, intr)
+            pix_rec["pix"] = p
+            pix_rec["z"] = cam_pts[:, 2].copy()
+            return p
+
+        tv.cam2pix = rec
+        t = time.time()
+        n_int = 2 if S <= 32 else 1
+        for k in range(n_int):
+            sck = sc if k == 0 else synth_scene(hw, hw, seed=16)
+            tv.integrate(sck["rgb"], sck["depth"], sck["cam_intr"], sck["cam_pose"], obs_weight=np.float64(1.0))
+        print(f"    tsdf {tag}: {time.time() - t:.1f}s")
+        tsdf, wgt, col = tv._tsdf_vol_cpu, tv._weight_vol_cpu, tv._color_vol_cpu
+        out[f"{tag}_dim"] = np.asarray(tv._vol_dim, np.int32)
+        out[f"{tag}_pix_sha"] = digest(pix_rec["pix"].astype(np.int64))     # of the LAST integrate
+        out[f"{tag}_tsdf_sha"] = digest(tsdf)
+        out[f"{tag}_weight_sha"] = digest(wgt)
+        out[f"{tag}_color_sha"] = digest(col)
+        out[f"{tag}_n_obs"] = np.int64((wgt > 0).sum())
+        if S <= 32:
+            out[f"{tag}_pix"] = pix_rec["pix"].astype(np.int64)
+            out[f"{tag}_tsdf"] = tsdf
+            out[f"{tag}_weight"] = wgt
+            out[f"{tag}_color"] = col
+        else:
+            si = sample_idx(tsdf.size, 4096)
+            out[f"{tag}_si"] = si
+            out[f"{tag}_pix_s"] = pix_rec["pix"].astype(np.int64)[si]
+            out[f"{tag}_tsdf_s"] = tsdf.reshape(-1)[si]
+    save("g11_tsdf", **out)
+
+
+def _semabs_inputs(S, N, M, P, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    xyz = (lo + (hi - lo) * rng.random((1, N, 3))).astype(np.float32)
+    xyz[0, : N // 8] = xyz[0, N // 8: 2 * (N // 8)] + np.float32(1e-3)  # make sure many voxels get >1 point
+    feat = (rng.standard_normal((1, P, N, 1)) * 0.5).astype(np.float32)
+    q = (lo - 0.05 + (hi - lo + 0.1) * rng.random((1, P, M, 3))).astype(np.float32)  # some outside bounds
+    return xyz, feat, q
+
+
+def g9_semabs3d():
+    net, unet3d = refimport.load_reference_net()
+    S, N, M, P = 32, 3000, 2048, 2
+    m = net.SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16,
+                     unet_num_groups=8, unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True,
+                     pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1, device="cpu",
+                     decoder_concat_xyz_pts=True, batch_size=1)
+    sd = make_semabs3d_state_dict(seed=3)
+    missing = m.load_state_dict(sd, strict=True)
+    m.eval()
+    assert m.vg.reduce_method == "mean"
+    xyz, feat, q = _semabs_inputs(S, N, M, P, seed=11)
+    taps = {}
+    hooks = []
+    ue = m.vol_feature_extractor
+    for i, e in enumerate(ue.encoders):
+        hooks.append(e.register_forward_hook(lambda mod, a, o, i=i: taps.__setitem__(f"enc{i}", o.detach().clone())))
+    for i, d in enumerate(ue.decoders):
+        hooks.append(d.register_forward_hook(lambda mod, a, o, i=i: taps.__setitem__(f"dec{i}", o.detach().clone())))
+    hooks.append(ue.register_forward_pre_hook(lambda mod, a: taps.__setitem__("scatter", a[0].detach().clone())))
+    with torch.no_grad():
+        out = m(input_xyz_pts=torch.from_numpy(xyz), input_feature_pts=torch.from_numpy(feat), tsdf_vol=None,
+                output_xyz_pts=torch.from_numpy(q))
+    res = {"out": out.numpy(), "unet_sub": m.visual_volumetric_features.numpy()[:, :, ::3, ::3, ::3].copy(),
+           "scatter_sum": np.float64(taps["scatter"].double().sum().item()),
+           "scatter_nonzero": np.int64((taps["scatter"][:, 0] != 0).sum().item()),
+           "scatter_sub": taps["scatter"].numpy()[:, :, ::3, ::3, ::3].copy(),
+           "meta": np.asarray([S, N, M, P, 11, 3], np.int32)}
+    for k, v in taps.items():
+        if k != "scatter":
+            res[f"tap_{k}_sum"] = np.float64(v.double().sum().item())
+            res[f"tap_{k}_abs"] = np.float64(v.double().abs().sum().item())
+            res[f"tap_{k}_sub"] = v.numpy()[:, ::max(1, v.shape[1] // 8), ::2, ::2, ::2].copy()
+    save("g9_semabs3d", **res)
+
+
+def g10_unet128():
+    _, unet3d = refimport.load_reference_net()
+    u = unet3d.ResidualUNet3D(in_channels=16, out_channels=16, f_maps=16, num_groups=8, num_levels=6)
+    sd = make_semabs3d_state_dict(seed=3)
+    pre = "vol_feature_extractor."
+    u.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    u.eval()
+    rng = np.random.default_rng(21)
+    x = np.zeros((1, 16, 128, 128, 128), np.float32)
+    occ = rng.random((128, 128, 128)) < 0.03                # sparse like a scattered point cloud
+    x[0][:, occ] = rng.standard_normal((16, int(occ.sum()))).astype(np.float32)
+    t = time.time()
+    with torch.no_grad():
+        y = u(torch.from_numpy(x)).numpy()
+    print(f"    unet128: {time.time() - t:.1f}s")
+    si = sample_idx(y.size, 8192)
+    save("g10_unet128", y_s=y.reshape(-1)[si], si=si, y_sum=np.float64(y.astype(np.float64).sum()),
+         y_abs=np.float64(np.abs(y.astype(np.float64)).sum()), meta=np.asarray([21, 3], np.int32))
+
+
+GROUPS = ["g1", "g2", "g3b32", "g3b16", "g5", "g6b32", "g6b16", "g7", "g8", "g9", "g10", "g11"]
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or GROUPS
+    rc = None
+
+    def clip32():
+        global rc
+        if rc is None or rc.ClipWrapper.clip_gradcam.clip_model_name != "ViT-B/32":
+            rc = refimport.load_reference_clip("ViT-B/32", seed=0)
+        return rc
+
+    for gname in want:
+        t0 = time.time()
+        print(f"[{gname}]")
+        if gname == "g1":
+            g1_tiling(clip32())
+        elif gname == "g2":
+            g2_preprocess(clip32())
+        elif gname == "g3b32":
+            rc = g3_g4_vit("ViT-B/32", "b32")
+        elif gname == "g3b16":
+            rc = g3_g4_vit("ViT-B/16", "b16")
+        elif gname == "g5":
+            g5_aggregate(clip32())
+        elif gname == "g6b32":
+            g6_end_to_end(clip32(), "ViT-B/32", "b32")
+        elif gname == "g6b16":
+            rc = refimport.load_reference_clip("ViT-B/16", seed=0)
+            g6_end_to_end(rc, "ViT-B/16", "b16")
+        elif gname == "g7":
+            g7_text(clip32())
+        elif gname == "g8":
+            g8_geometry()
+        elif gname == "g9":
+            g9_semabs3d()
+        elif gname == "g10":
+            g10_unet128()
+        elif gname == "g11":
+            g11_tsdf()
+        print(f"  {time.time() - t0:.1f}s")
