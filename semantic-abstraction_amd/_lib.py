@@ -1,0 +1,111 @@
+"""ctypes binding of libsemabs_hip.so (the C ABI in include/semabs.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.  Nothing
+on the product path routes through `oracle/` or a torch/CPU re-implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsemabs_hip.so")
+
+_lib = None
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+D = C.c_double
+
+# name -> argtypes (all return int).  Kept in the order of include/semabs.h.
+SIGNATURES = {
+    "semabs_abi_version": [],
+    "semabs_device_info": [C.c_char_p, I, C.POINTER(I), C.POINTER(C.c_longlong)],
+    # geometry.hip
+    "semabs_pointcloud": [P, I, I, P, I, P, P, P],
+    "semabs_voxel_index": [P, L, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P],
+    "semabs_tsdf_integrate": [P, P, I, I, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, P],
+    "semabs_frustum_mask": [P, L, P, I, I, P, P],
+    # tiles.hip
+    "semabs_resize_coeffs": [I, I, P, P, I, P],
+    "semabs_tile_patches": [P, I, I, I, P, I, P, P, P, P, P, I, I, I, P],
+    "semabs_patchify": [P, P, I, I, I, P],
+    "semabs_aggregate": [P, P, I, I, I, I, I, P, I, I, I, P, P],
+    "semabs_color_jitter": [P, I, I, C.POINTER(I), C.POINTER(F), P, P],
+    # gemm.hip
+    "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
+    # vit.hip
+    "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
+    "semabs_embed_finish": [P, P, P, I, I, I, P],
+    "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
+    "semabs_attention_cls": [P, P, P, P, I, I, I, I, P],
+    "semabs_rows_gather": [P, P, L, I, L, L, P],
+    "semabs_quickgelu": [P, P, L, P],
+    "semabs_logit_grad": [P, P, I, I, I, P, P, P, P],
+    "semabs_ln_bwd": [P, P, P, P, P, P, L, I, I, L, F, P],
+    "semabs_gelu_bwd": [P, P, P, L, I, I, P],
+    "semabs_rollout": [P, P, P, P, P, I, I, I, I, I, L, L, P],
+    "semabs_gather_text": [P, P, P, P, I, I, I, P],
+    "semabs_text_finish": [P, P, I, I, I, P],
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly when the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension was not built. Run "
+                "`python semantic-abstraction_amd/build.py` (or __graft_entry__.build()). There is no CPU fallback."
+            )
+        h = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            if not hasattr(h, name):
+                continue  # reported by tests/test_abi.py; calling it raises below
+            fn = getattr(h, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        h.semabs_last_error.restype = C.c_char_p
+        _lib = h
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    h = lib()
+    fn = getattr(h, name, None)
+    if fn is None:
+        raise RuntimeError(f"libsemabs_hip.so does not export {name}")
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {h.semabs_last_error().decode()}")
+
+
+def ptr(t) -> int | None:
+    """Device (or host) address of a tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "semabs C ABI takes contiguous buffers"
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("semabs_amd needs a HIP device (MI355X); there is no CPU fallback on the product path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def farr(vals):
+    return (F * len(vals))(*[float(v) for v in vals])
+
+
+def iarr(vals):
+    return (I * len(vals))(*[int(v) for v in vals])

@@ -1,0 +1,277 @@
+"""Host orchestration of the CLIP ViT forward + closed-form attention x gradient rollout on the HIP kernels.
+
+Mirrors what `ClipGradcam.forward` + `interpret` compute (CLIP/clip/clip_gradcam.py:58-132) for the hooked
+VisionTransformer (CLIP/clip/model_explainability.py:291-355), without autograd:
+
+* blocks 0..L-2 run for all tokens (LN -> QKV GEMM -> fused attention -> out-proj(+residual) -> LN -> c_fc+QuickGELU
+  GEMM -> c_proj(+residual));
+* the last block only needs what reaches the image feature `ln_post(x[:, 0]) @ proj`: K and V for all tokens, Q /
+  attention / out-proj / MLP for the CLS token only (the other rows never influence the output), its softmax row is
+  kept in fp32;
+* for ViT-B the rollout keeps only that block (`i <= num_layers(10)` are skipped, clip_gradcam.py:85-87), so
+  rel[l, n, j-1] = mean_h clamp(A[n,h,0,j] * (V[n,h,j,:] . (W_o^T g1[l,n])[h]), 0) with g1 the VJP of logit_l through
+  L2-normalise -> proj -> ln_post -> CLS-token MLP + residual: six batched GEMMs with [L*n] rows.
+
+All arithmetic is in libsemabs_hip.so; this file only owns buffers, weights and launch order.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP = 0, 1, 2, 3, 4
+
+
+def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):
+    _lib.call("semabs_gemm_f16", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
+              int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, _lib.stream())
+
+
+def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5):
+    _lib.call("semabs_layernorm", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out), int(M), int(D), float(eps),
+              int(out_f32), int(ld_in if ld_in is not None else D), _lib.stream())
+
+
+def _interp_pos_emb(pe: torch.Tensor, T: int) -> torch.Tensor:
+    """The reference's hard-coded-50 positional "interpolation" (CLIP/clip/auxiliary.py:24-38), taken whenever
+    T != 50 (model_explainability.py:339-343).  A [T, D] table built once at weight-load time on the host."""
+    out = torch.zeros(T, pe.shape[1], dtype=pe.dtype)
+    for i in range(T):
+        i3 = float(i) / (T / 50)
+        i1, i2 = math.floor(i3), math.ceil(i3)
+        out[i] = torch.lerp(pe[i1], pe[i2], i3 - i1) if i2 < len(pe) else pe[-1]
+    return out
+
+
+class _BlockWeights:
+    def __init__(self, sd, pre, D, heads, dev, last=False):
+        dh = D // heads
+        w_in = sd[pre + "attn.in_proj_weight"].float().clone()
+        b_in = sd[pre + "attn.in_proj_bias"].float().clone()
+        # q = (x W_q^T + b_q) * dh^-0.5 (auxiliary.py:207): dh^-0.5 = 2^-3 for dh = 64, folding it into W_q / b_q is exact
+        scaling = float(dh) ** -0.5
+        w_in[:D] *= scaling
+        b_in[:D] *= scaling
+        h = lambda t: t.to(dev, torch.float16).contiguous()
+        f = lambda t: t.to(dev, torch.float32).contiguous()
+        self.w_in, self.b_in = h(w_in), f(b_in)
+        self.w_o, self.b_o = h(sd[pre + "attn.out_proj.weight"]), f(sd[pre + "attn.out_proj.bias"])
+        self.ln1_w, self.ln1_b = f(sd[pre + "ln_1.weight"]), f(sd[pre + "ln_1.bias"])
+        self.ln2_w, self.ln2_b = f(sd[pre + "ln_2.weight"]), f(sd[pre + "ln_2.bias"])
+        self.w_fc, self.b_fc = h(sd[pre + "mlp.c_fc.weight"]), f(sd[pre + "mlp.c_fc.bias"])
+        self.w_pr, self.b_pr = h(sd[pre + "mlp.c_proj.weight"]), f(sd[pre + "mlp.c_proj.bias"])
+        if last:  # transposed copies: B operands ([N, K]) of the VJP GEMMs
+            self.w_o_t = h(sd[pre + "attn.out_proj.weight"].float().t())
+            self.w_fc_t = h(sd[pre + "mlp.c_fc.weight"].float().t())
+            self.w_pr_t = h(sd[pre + "mlp.c_proj.weight"].float().t())
+
+
+class VisionRollout:
+    """ViT-B image tower + last-block rollout for chunks of tiles."""
+
+    def __init__(self, state_dict, heads: int = 12, chunk_tiles: int = 256, max_labels: int = 16):
+        dev = self.dev = _lib.require_gpu()
+        sd = state_dict
+        w = sd["visual.conv1.weight"]
+        self.D, self.p = int(w.shape[0]), int(w.shape[-1])
+        self.g = 224 // self.p
+        self.T = self.g * self.g + 1
+        self.H = heads
+        self.layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        assert self.layers == 12, "the closed-form rollout covers ViT-B (only the last block contributes)"
+        self.E = int(sd["visual.proj"].shape[1])
+        h = lambda t: t.to(dev, torch.float16).contiguous()
+        f = lambda t: t.to(dev, torch.float32).contiguous()
+        self.w_patch = h(w.float().reshape(self.D, -1))                     # [D, 3 p p], column = c*p*p + iy*p + ix
+        pe = sd["visual.positional_embedding"].float()
+        self.pos = f(_interp_pos_emb(pe, self.T) if self.T != 50 else pe)
+        self.cls = f(sd["visual.class_embedding"])
+        self.ln_pre = (f(sd["visual.ln_pre.weight"]), f(sd["visual.ln_pre.bias"]))
+        self.ln_post = (f(sd["visual.ln_post.weight"]), f(sd["visual.ln_post.bias"]))
+        self.proj = h(sd["visual.proj"])                                    # [D, E] = B operand of dy = dfeat . proj^T
+        self.proj_t = h(sd["visual.proj"].float().t())                      # [E, D] = B operand of feat = y . proj
+        self.blocks = [_BlockWeights(sd, f"visual.transformer.resblocks.{i}.", self.D, heads, dev, last=(i == self.layers - 1))
+                       for i in range(self.layers)]
+        self.chunk = int(chunk_tiles)
+        self.max_labels = int(max_labels)
+        self._ws = None
+
+    # ---- workspace ---------------------------------------------------------------------------------
+    def _workspace(self):
+        if self._ws is None:
+            n, T, D, Lm, E = self.chunk, self.T, self.D, self.max_labels, self.E
+            dev = self.dev
+            e16 = lambda *s: torch.empty(*s, dtype=torch.float16, device=dev)
+            e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            R = Lm * n
+            self._ws = dict(
+                x=e32(n * T, D), h=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
+                kv32=e32(n * T, 2 * D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
+                h2c=e16(n, D), fc=e32(n, 4 * D), actc=e16(n, 4 * D), x2c=e32(n, D), yc=e16(n, D), feat=e32(n, E),
+                logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, D),
+                dact=e32(R, 4 * D), dfc=e16(R, 4 * D), dh2=e32(R, D), g1h=e16(R, D), u=e32(R, D),
+            )
+        return self._ws
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def embed(self, patches: torch.Tensor, n: int):
+        """patches fp16 [n * g*g, 3 p p] -> ws['x'] = ln_pre(cat(cls, conv) + pos)  [n * T, D] fp32."""
+        ws = self._workspace()
+        T, D, G = self.T, self.D, self.g * self.g
+        x = ws["x"]
+        gemm(patches, self.w_patch, x, None, n * G, D, 3 * self.p * self.p, 3 * self.p * self.p, 3 * self.p * self.p, D,
+             EPI_ROWMAP, addend=self.pos, rowmap=(G, T, 1))
+        _lib.call("semabs_embed_finish", _lib.ptr(x), _lib.ptr(self.cls), _lib.ptr(self.pos), n, T, D, _lib.stream())
+        layernorm(x, *self.ln_pre, x, n * T, D, out_f32=True)
+
+    def trunk(self, n: int):
+        """blocks 0 .. layers-2 on ws['x'] in place."""
+        ws = self._workspace()
+        T, D, H = self.T, self.D, self.H
+        M = n * T
+        x, h, qkv, att, hid = ws["x"], ws["h"], ws["qkv"], ws["att"], ws["hid"]
+        for b in self.blocks[:-1]:
+            layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
+            gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16)
+            _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, 0, _lib.stream())
+            gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32)
+            layernorm(x, b.ln2_w, b.ln2_b, h, M, D)
+            gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
+            gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
+
+    def head(self, n: int):
+        """last block for the CLS token + ln_post + proj -> ws['feat'] [n, E]; keeps probs / kv32 / x1c / fc / x2c."""
+        ws = self._workspace()
+        T, D, H, E = self.T, self.D, self.H, self.E
+        b = self.blocks[-1]
+        x, h = ws["x"], ws["h"]
+        st = _lib.stream()
+        layernorm(x, b.ln1_w, b.ln1_b, h, n * T, D)
+        # K | V for every token (fp32 out: they feed the kept softmax row and the rollout directly)
+        gemm(h, b.w_in[D:], ws["kv32"], b.b_in[D:], n * T, 2 * D, D, D, D, 2 * D, EPI_F32)
+        # Q for the CLS rows only (row stride T * D)
+        gemm(h, b.w_in[:D], ws["q32"], b.b_in[:D], n, D, D, T * D, D, D, EPI_F32)
+        _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["kv32"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
+                  n, T, H, 64, st)
+        _lib.call("semabs_rows_gather", _lib.ptr(x), _lib.ptr(ws["x1c"]), n, D, T * D, 0, st)
+        gemm(ws["o_cls"], b.w_o, ws["x1c"], b.b_o, n, D, D, D, D, D, EPI_RESID_F32)
+        layernorm(ws["x1c"], b.ln2_w, b.ln2_b, ws["h2c"], n, D)
+        gemm(ws["h2c"], b.w_fc, ws["fc"], b.b_fc, n, 4 * D, D, D, D, 4 * D, EPI_F32)
+        _lib.call("semabs_quickgelu", _lib.ptr(ws["fc"]), _lib.ptr(ws["actc"]), n * 4 * D, st)
+        _lib.call("semabs_rows_gather", _lib.ptr(ws["x1c"]), _lib.ptr(ws["x2c"]), n, D, D, 0, st)
+        gemm(ws["actc"], b.w_pr, ws["x2c"], b.b_pr, n, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
+        layernorm(ws["x2c"], *self.ln_post, ws["yc"], n, D)
+        gemm(ws["yc"], self.proj_t, ws["feat"], None, n, E, D, D, D, E, EPI_F32)
+
+    def rollout(self, n: int, w_text: torch.Tensor, positive_attn_only: bool, rel_out: torch.Tensor, tile0: int):
+        """w_text fp32 [L, E] on the GPU; writes rel_out[:, tile0:tile0+n] (rel_out fp32 [L, N_total, g, g])."""
+        ws = self._workspace()
+        T, D, H, E = self.T, self.D, self.H, self.E
+        L = int(w_text.shape[0])
+        assert L <= self.max_labels
+        R = L * n
+        b = self.blocks[-1]
+        st = _lib.stream()
+        _lib.call("semabs_logit_grad", _lib.ptr(ws["feat"]), _lib.ptr(w_text), n, L, E, _lib.ptr(ws["logits"]),
+                  _lib.ptr(ws["dfeat"]), _lib.ptr(ws["scale"]), st)
+        gemm(ws["dfeat"], self.proj, ws["dy"], None, R, D, E, E, E, D, EPI_F32)
+        _lib.call("semabs_ln_bwd", _lib.ptr(ws["x2c"]), _lib.ptr(self.ln_post[0]), _lib.ptr(ws["dy"]), None,
+                  _lib.ptr(ws["dx2"]), _lib.ptr(ws["dx2h"]), R, D, n, D, 1e-5, st)
+        gemm(ws["dx2h"], b.w_pr_t, ws["dact"], None, R, 4 * D, D, D, D, 4 * D, EPI_F32)
+        _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(ws["fc"]), _lib.ptr(ws["dfc"]), R, 4 * D, n, st)
+        gemm(ws["dfc"], b.w_fc_t, ws["dh2"], None, R, D, 4 * D, 4 * D, 4 * D, D, EPI_F32)
+        _lib.call("semabs_ln_bwd", _lib.ptr(ws["x1c"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh2"]), _lib.ptr(ws["dx2"]),
+                  None, _lib.ptr(ws["g1h"]), R, D, n, D, 1e-5, st)
+        gemm(ws["g1h"], b.w_o_t, ws["u"], None, R, D, D, D, D, D, EPI_F32)
+        _lib.call("semabs_rollout", _lib.ptr(ws["probs"]), _lib.ptr(ws["kv32"]), _lib.ptr(ws["u"]), _lib.ptr(ws["scale"]),
+                  _lib.ptr(rel_out), n, T, H, L, int(positive_attn_only), int(rel_out.shape[1]), int(tile0), st)
+
+    def gradcam_patches(self, patches: torch.Tensor, n: int, w_text: torch.Tensor, positive_attn_only: bool,
+                        rel_out: torch.Tensor, tile0: int):
+        assert n <= self.chunk
+        self.embed(patches, n)
+        self.trunk(n)
+        self.head(n)
+        self.rollout(n, w_text, positive_attn_only, rel_out, tile0)
+
+    def gradcam_tiles(self, tiles: torch.Tensor, w_text: torch.Tensor, positive_attn_only: bool, flip: bool = False):
+        """tiles fp32 [n, 3, 224, 224] (GPU) -> (rel [L, n, g, g], logits [n, L], feat [n, E]) — `ClipGradcam.forward`."""
+        n = int(tiles.shape[0])
+        L = int(w_text.shape[0])
+        G, Kp = self.g * self.g, 3 * self.p * self.p
+        rel = torch.empty(L, n, self.g, self.g, dtype=torch.float32, device=self.dev)
+        logits = torch.empty(n, L, dtype=torch.float32, device=self.dev)
+        feat = torch.empty(n, self.E, dtype=torch.float32, device=self.dev)
+        patches = torch.empty(min(n, self.chunk) * G, Kp, dtype=torch.float16, device=self.dev)
+        for t0 in range(0, n, self.chunk):
+            m = min(self.chunk, n - t0)
+            _lib.call("semabs_patchify", _lib.ptr(tiles[t0:t0 + m].contiguous()), _lib.ptr(patches), m, self.p, int(flip), _lib.stream())
+            self.gradcam_patches(patches, m, w_text, positive_attn_only, rel, t0)
+            ws = self._workspace()
+            logits[t0:t0 + m] = ws["logits"].view(-1)[: m * L].view(m, L)       # the kernel packs rows with stride L
+            feat[t0:t0 + m] = ws["feat"][:m]
+        return rel, logits, feat
+
+
+class TextEncoder:
+    """CLIP text tower on the same kernels (model_explainability.py:469-482) -> zero-shot weights
+    (clip_gradcam.py:12-27: per-template L2 normalise, mean over templates, not re-normalised)."""
+
+    def __init__(self, state_dict, heads: int = 8):
+        dev = self.dev = _lib.require_gpu()
+        sd = state_dict
+        f = lambda t: t.to(dev, torch.float32).contiguous()
+        self.emb = f(sd["token_embedding.weight"])
+        self.pos = f(sd["positional_embedding"])
+        self.D = int(self.emb.shape[1])
+        self.ctx = int(self.pos.shape[0])
+        self.H = heads
+        self.layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.")})
+        self.blocks = [_BlockWeights(sd, f"transformer.resblocks.{i}.", self.D, heads, dev) for i in range(self.layers)]
+        self.ln_final = (f(sd["ln_final.weight"]), f(sd["ln_final.bias"]))
+        self.proj_t = sd["text_projection"].float().t().to(dev, torch.float16).contiguous()     # [E, D]
+        self.E = int(self.proj_t.shape[0])
+
+    def zeroshot_weights(self, tokens: torch.Tensor, n_classes: int, n_templates: int) -> torch.Tensor:
+        """tokens int64 [n_classes * n_templates, 77] (class-major) -> fp32 [n_classes, E] on the GPU."""
+        assert int(tokens.shape[0]) == n_classes * n_templates
+        e = self.encode(tokens)
+        w = torch.empty(n_classes, self.E, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_text_finish", _lib.ptr(e), _lib.ptr(w), n_classes, n_templates, self.E, _lib.stream())
+        return w
+
+    def encode(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens int64 [B, 77] -> fp32 [B, E] on the GPU (`CLIP.encode_text`)."""
+        dev, D, T, H, E = self.dev, self.D, self.ctx, self.H, self.E
+        B = int(tokens.shape[0])
+        assert tokens.shape[1] == T
+        tok = tokens.to(dev, torch.int64).contiguous()
+        M = B * T
+        x = torch.empty(M, D, dtype=torch.float32, device=dev)
+        h = torch.empty(M, D, dtype=torch.float16, device=dev)
+        qkv = torch.empty(M, 3 * D, dtype=torch.float16, device=dev)
+        att = torch.empty(M, D, dtype=torch.float16, device=dev)
+        hid = torch.empty(M, 4 * D, dtype=torch.float16, device=dev)
+        st = _lib.stream()
+        _lib.call("semabs_gather_text", _lib.ptr(tok), _lib.ptr(self.emb), _lib.ptr(self.pos), _lib.ptr(x), B, T, D, st)
+        for b in self.blocks:
+            layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
+            gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16)
+            _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, B, T, H, 64, 3 * D, 1, st)
+            gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32)
+            layernorm(x, b.ln2_w, b.ln2_b, h, M, D)
+            gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
+            gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
+        # EOT rows (the highest token id in each sequence) -> ln_final -> text_projection
+        eot = tokens.argmax(dim=-1).to(dev)
+        rows = torch.arange(B, device=dev) * T + eot
+        xe = x.index_select(0, rows).contiguous()                       # row gather (data movement only)
+        ye = torch.empty(B, D, dtype=torch.float16, device=dev)
+        layernorm(xe, *self.ln_final, ye, B, D)
+        e = torch.empty(B, E, dtype=torch.float32, device=dev)
+        gemm(ye, self.proj_t, e, None, B, E, D, D, D, E, EPI_F32)
+        return e

@@ -1,0 +1,26 @@
+// Library-level entry points: error string, version, device sanity.
+#include "semabs_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void semabs_set_error(const char* msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+
+extern "C" const char* semabs_last_error(void) { return g_err; }
+
+extern "C" int semabs_abi_version(void) { return 1; }
+
+// Returns 0 and fills name/cu_count for the current device; the library only carries gfx950 code objects.
+extern "C" int semabs_device_info(char* name, int name_len, int* cu_count, long long* hbm_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { semabs_set_error("no HIP device"); return SEMABS_EHIP; }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) { semabs_set_error("hipGetDeviceProperties failed"); return SEMABS_EHIP; }
+    if (name && name_len > 0) { strncpy(name, p.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (long long)p.totalGlobalMem;
+    return SEMABS_OK;
+}

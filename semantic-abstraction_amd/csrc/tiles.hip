@@ -1,0 +1,345 @@
+// Multi-scale sliding-window tiling (front) and aggregation (back) of the relevancy extractor.
+// Compiled with -ffp-contract=off: the uint8 resampler is an integer, bit-exact target.
+//
+// Replaces (reference file:line):
+//   ClipWrapper.create_tiles crop + preprocess        CLIP/clip/__init__.py:254-281
+//   _transform: Resize(224, BICUBIC) / ToTensor / Normalize   CLIP/clip/clip_explainability.py:98-108
+//       (the resize itself is Pillow's ImagingResample: 22-bit fixed-point separable bicubic, uint8 between passes)
+//   horizontal flip of the tile batch                  CLIP/clip/__init__.py:171-173
+//   VisionTransformer.conv1 im2col (the GEMM A operand) CLIP/clip/model_explainability.py:325-328
+//   un-flip average, bilinear upsample, fp16 canvases, count normalise, mean over scales   __init__.py:196-233
+#include "semabs_common.h"
+#include <math.h>
+#include <vector>
+
+#define OUT_RES 224
+#define PRECISION_BITS 22
+#define KMAX 24            // max taps supported (ksize = 2 * ceil(2 * max(scale, 1)) + 1  ->  scale <= 5.5)
+
+// ------------------------------------------------------------------------------------------------
+// Host: Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter (a = -0.5).
+// Writes xmin[out_size], kk[out_size * KMAX] (zero padded) and *ksize.  Pure host arithmetic in double.
+// ------------------------------------------------------------------------------------------------
+static double bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+extern "C" int semabs_resize_coeffs(int in_size, int out_size, int* xmin_out, int* kk_out, int kmax, int* ksize_out) {
+    SEMABS_REQUIRE(in_size > 0 && out_size > 0 && xmin_out && kk_out && ksize_out, "semabs_resize_coeffs: bad args");
+    double scale = (double)((float)in_size - 0.0f) / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    double support = 2.0 * filterscale;
+    int ksize = (int)ceil(support) * 2 + 1;
+    SEMABS_REQUIRE(ksize <= kmax, "semabs_resize_coeffs: down-scale factor too large for KMAX taps");
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        double center = 0.0 + (xx + 0.5) * scale;
+        double ww = 0.0, ss = 1.0 / filterscale;
+        int lo = (int)(center - support + 0.5);
+        if (lo < 0) lo = 0;
+        int hi = (int)(center + support + 0.5);
+        if (hi > in_size) hi = in_size;
+        int n = hi - lo;
+        for (int x = 0; x < n; ++x) {
+            double w = bicubic((x + lo - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < n; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < kmax; ++x) {
+            int v = 0;
+            if (x < n) v = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PRECISION_BITS)) : (int)(0.5 + k[x] * (1 << PRECISION_BITS));
+            kk_out[xx * kmax + x] = v;
+        }
+        xmin_out[xx] = lo;
+    }
+    *ksize_out = ksize;
+    return SEMABS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile -> patch matrix.  grid = (n_tiles, 224 / BAND); one workgroup resamples a band of output rows:
+//   phase A: horizontal pass of the input rows the band needs -> uint8 in LDS
+//   phase B: vertical pass -> uint8 -> (u/255 - mean)/std via a 768-entry fp16 LUT -> im2col store
+// tiles: int32 [n, 5] = (image, row0, col0, tile_size, coef_id)
+// coef_xmin int32 [n_sizes, 224], coef_kk int32 [n_sizes, 224, KMAX], coef_ksize int32 [n_sizes]
+// lut fp16 [3, 256];  patches fp16 [n * g * g, 3 * p * p], column = c * p*p + iy * p + ix
+// ------------------------------------------------------------------------------------------------
+#define BAND 16
+#define MAX_IN_ROWS 64      // input rows a 16-row output band can touch: 16 * scale + 2 * support + 2  (scale <= 2.2)
+
+__global__ __launch_bounds__(256) void k_tile_patches(const unsigned char* __restrict__ images, int H, int W,
+                                                      const int* __restrict__ tiles, const int* __restrict__ coef_xmin,
+                                                      const int* __restrict__ coef_kk, const int* __restrict__ coef_ksize,
+                                                      const f16* __restrict__ lut, f16* __restrict__ patches, int p,
+                                                      int flip) {
+    __shared__ unsigned char sh[MAX_IN_ROWS][OUT_RES][3];
+    __shared__ int s_xmin[OUT_RES];
+    const int t = blockIdx.x, band = blockIdx.y, tid = threadIdx.x;
+    const int img = tiles[t * 5 + 0], row0 = tiles[t * 5 + 1], col0 = tiles[t * 5 + 2], ts = tiles[t * 5 + 3], cid = tiles[t * 5 + 4];
+    const int* xmin = coef_xmin + cid * OUT_RES;
+    const int* kk = coef_kk + (long)cid * OUT_RES * KMAX;
+    const int ksize = coef_ksize[cid];
+    for (int i = tid; i < OUT_RES; i += 256) s_xmin[i] = xmin[i];
+    __syncthreads();
+    const int y_first = band * BAND, y_last = y_first + BAND - 1;
+    const int r_lo = s_xmin[y_first];
+    int r_hi = s_xmin[y_last] + ksize;          // exclusive
+    if (r_hi > ts) r_hi = ts;
+    const int n_rows = r_hi - r_lo;
+    const unsigned char* src = images + ((long)img * H + row0) * W * 3 + (long)col0 * 3;
+    const bool identity = (ts == OUT_RES);
+    // ---- phase A: horizontal pass ----
+    for (int e = tid; e < n_rows * OUT_RES; e += 256) {
+        const int rr = e / OUT_RES, x = e - rr * OUT_RES;
+        const unsigned char* srow = src + (long)(r_lo + rr) * W * 3;
+        if (identity) {
+            sh[rr][x][0] = srow[x * 3]; sh[rr][x][1] = srow[x * 3 + 1]; sh[rr][x][2] = srow[x * 3 + 2];
+            continue;
+        }
+        const int x0 = s_xmin[x];
+        const int* kx = kk + x * KMAX;
+        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+        for (int k = 0; k < ksize; ++k) {
+            int xi = x0 + k; if (xi > ts - 1) xi = ts - 1;        // taps past the edge carry weight 0
+            const int w = kx[k];
+            a0 += (int)srow[xi * 3] * w; a1 += (int)srow[xi * 3 + 1] * w; a2 += (int)srow[xi * 3 + 2] * w;
+        }
+        a0 >>= PRECISION_BITS; a1 >>= PRECISION_BITS; a2 >>= PRECISION_BITS;
+        sh[rr][x][0] = (unsigned char)(a0 < 0 ? 0 : (a0 > 255 ? 255 : a0));
+        sh[rr][x][1] = (unsigned char)(a1 < 0 ? 0 : (a1 > 255 ? 255 : a1));
+        sh[rr][x][2] = (unsigned char)(a2 < 0 ? 0 : (a2 > 255 ? 255 : a2));
+    }
+    __syncthreads();
+    // ---- phase B: vertical pass + normalise + im2col ----
+    const int g = OUT_RES / p, pp = p * p, Kp = 3 * pp;
+    for (int e = tid; e < BAND * OUT_RES; e += 256) {
+        const int yy = e / OUT_RES, x = e - yy * OUT_RES;
+        const int y = y_first + yy;
+        int v0, v1, v2;
+        if (identity) {
+            const int rr = y - r_lo;
+            v0 = sh[rr][x][0]; v1 = sh[rr][x][1]; v2 = sh[rr][x][2];
+        } else {
+            const int yb = s_xmin[y] - r_lo;
+            const int* ky = kk + y * KMAX;
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+            for (int k = 0; k < ksize; ++k) {
+                int rr = yb + k; if (rr > n_rows - 1) rr = n_rows - 1;
+                const int w = ky[k];
+                a0 += (int)sh[rr][x][0] * w; a1 += (int)sh[rr][x][1] * w; a2 += (int)sh[rr][x][2] * w;
+            }
+            a0 >>= PRECISION_BITS; a1 >>= PRECISION_BITS; a2 >>= PRECISION_BITS;
+            v0 = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0); v1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1); v2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
+        }
+        const int xo = flip ? (OUT_RES - 1 - x) : x;
+        const int py = y / p, iy = y - py * p, px = xo / p, ix = xo - px * p;
+        f16* dst = patches + ((long)t * g * g + py * g + px) * Kp + iy * p + ix;
+        dst[0] = lut[v0]; dst[pp] = lut[256 + v1]; dst[2 * pp] = lut[512 + v2];
+    }
+}
+
+extern "C" int semabs_tile_patches(const unsigned char* images, int n_img, int H, int W, const int* tiles_dev, int n_tiles,
+                                   const int* coef_xmin, const int* coef_kk, const int* coef_ksize, const void* lut,
+                                   void* patches, int patch, int flip, int max_ksize, void* stream) {
+    if (n_tiles == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(images && tiles_dev && coef_xmin && coef_kk && coef_ksize && lut && patches, "semabs_tile_patches: null pointer");
+    SEMABS_REQUIRE(n_img > 0 && H > 0 && W > 0 && (patch == 16 || patch == 32 || patch == 14), "semabs_tile_patches: bad shape / patch size");
+    SEMABS_REQUIRE(OUT_RES % patch == 0, "semabs_tile_patches: patch must divide 224");
+    // a 16-row band touches at most 16 * scale + ksize input rows; ksize = 2 ceil(2 scale) + 1
+    SEMABS_REQUIRE(max_ksize <= KMAX && (max_ksize - 1) / 4.0 * BAND + max_ksize + 2 <= MAX_IN_ROWS,
+                   "semabs_tile_patches: tile_size / 224 too large for the LDS band (tile_size must be <= ~490)");
+    hipLaunchKernelGGL(k_tile_patches, dim3(n_tiles, OUT_RES / BAND), dim3(256), 0, (hipStream_t)stream, images, H, W, tiles_dev,
+                       coef_xmin, coef_kk, coef_ksize, (const f16*)lut, (f16*)patches, patch, flip);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// fp32 tile images [n, 3, 224, 224] (already preprocessed, e.g. by a caller of ClipGradcam.forward) -> patch matrix
+__global__ void k_patchify(const float* __restrict__ x, f16* __restrict__ patches, int n, int p, int flip) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)n * 3 * OUT_RES * OUT_RES;
+    if (i >= tot) return;
+    int xq = (int)(i % OUT_RES); long r = i / OUT_RES;
+    int y = (int)(r % OUT_RES); r /= OUT_RES;
+    int c = (int)(r % 3); long t = r / 3;
+    const int g = OUT_RES / p, pp = p * p;
+    const int xo = flip ? OUT_RES - 1 - xq : xq;
+    const int py = y / p, iy = y % p, px = xo / p, ix = xo % p;
+    patches[((long)t * g * g + py * g + px) * 3 * pp + c * pp + iy * p + ix] = (f16)x[i];
+}
+extern "C" int semabs_patchify(const float* x, void* patches, int n, int patch, int flip, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && patches && n > 0 && OUT_RES % patch == 0, "semabs_patchify: bad args");
+    hipLaunchKernelGGL(k_patchify, dim3(semabs_cdiv((long)n * 3 * OUT_RES * OUT_RES, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (f16*)patches, n, patch, flip);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Aggregation, gather form: one thread per (label, pixel) walks the tiles that cover the pixel in the
+// reference's accumulation order (image -> column start -> row start), bilinearly samples each tile's g x g map
+// (align_corners = False), adds into an fp16 accumulator per scale (rounded after every add, as the reference's
+// half canvases are), then sum_s (acc_s / count_s) / n_scales.  No atomics; deterministic.
+//   rel / rel_flip fp32 [L, N, g, g] (tile order = the tile table's); rel_flip may be null (no flip pass)
+//   scales int32 [n_scales, 5] = (tile_size, stride, n_row_starts, n_col_starts, first tile index within an image)
+// ------------------------------------------------------------------------------------------------
+struct AggArgs {
+    int L, N, g, H, W, n_img, tiles_per_img, n_scales;
+};
+
+__device__ __forceinline__ void bil_setup(int d, int ts, int g, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)g / (float)ts;
+    float s = scale * ((float)d + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > g - 1) i0 = g - 1;
+    i1 = i0 + (i0 < g - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void k_aggregate(const float* __restrict__ rel, const float* __restrict__ rel_flip,
+                                                   const int* __restrict__ scales, AggArgs a, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)a.L * a.H * a.W;
+    if (i >= tot) return;
+    const int c = (int)(i % a.W); const long t = i / a.W;
+    const int r = (int)(t % a.H); const int l = (int)(t / a.H);
+    const int g = a.g, gg = g * g;
+    float total = 0.f;
+    for (int s = 0; s < a.n_scales; ++s) {
+        const int ts = scales[s * 5], stride = scales[s * 5 + 1], nx = scales[s * 5 + 2], ny = scales[s * 5 + 3], base = scales[s * 5 + 4];
+        // covering row starts x0 = ix * stride with x0 <= r < x0 + ts
+        int ix_hi = r / stride; if (ix_hi > nx - 1) ix_hi = nx - 1;
+        int ix_lo = r - ts + 1 <= 0 ? 0 : (r - ts + 1 + stride - 1) / stride;
+        int iy_hi = c / stride; if (iy_hi > ny - 1) iy_hi = ny - 1;
+        int iy_lo = c - ts + 1 <= 0 ? 0 : (c - ts + 1 + stride - 1) / stride;
+        __half acc = __float2half(0.f);
+        float cnt = 1e-5f;
+        for (int im = 0; im < a.n_img; ++im) {
+            for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+                int w0, w1; float lw0, lw1;
+                bil_setup(c - iy * stride, ts, g, w0, w1, lw0, lw1);
+                for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+                    int h0, h1; float lh0, lh1;
+                    bil_setup(r - ix * stride, ts, g, h0, h1, lh0, lh1);
+                    const long tile = (long)im * a.tiles_per_img + base + iy * nx + ix;
+                    const float* p = rel + ((long)l * a.N + tile) * gg;
+                    float v00 = p[h0 * g + w0], v01 = p[h0 * g + w1], v10 = p[h1 * g + w0], v11 = p[h1 * g + w1];
+                    if (rel_flip) {
+                        const float* q = rel_flip + ((long)l * a.N + tile) * gg;
+                        v00 = (v00 + q[h0 * g + (g - 1 - w0)]) / 2; v01 = (v01 + q[h0 * g + (g - 1 - w1)]) / 2;
+                        v10 = (v10 + q[h1 * g + (g - 1 - w0)]) / 2; v11 = (v11 + q[h1 * g + (g - 1 - w1)]) / 2;
+                    }
+                    const float val = lh0 * (lw0 * v00 + lw1 * v01) + lh1 * (lw0 * v10 + lw1 * v11);
+                    acc = __float2half(__half2float(acc) + val);
+                    cnt += 1.0f;
+                }
+            }
+        }
+        total = total + __half2float(acc) / cnt;
+    }
+    out[i] = total / (float)a.n_scales;
+}
+
+extern "C" int semabs_aggregate(const float* rel, const float* rel_flip, int L, int N, int g, int H, int W,
+                                const int* scales_dev, int n_scales, int n_img, int tiles_per_img, float* out, void* stream) {
+    if (L == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(rel && scales_dev && out && L > 0 && N > 0 && g > 0 && H > 0 && W > 0 && n_scales > 0 && n_img > 0,
+                   "semabs_aggregate: bad args");
+    SEMABS_REQUIRE((long)n_img * tiles_per_img == N, "semabs_aggregate: tile count does not match n_img * tiles_per_img");
+    AggArgs a{L, N, g, H, W, n_img, tiles_per_img, n_scales};
+    hipLaunchKernelGGL(k_aggregate, dim3(semabs_cdiv((long)L * H * W, 256)), dim3(256), 0, (hipStream_t)stream, rel, rel_flip,
+                       scales_dev, a, out);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Colour jitter for the augmentation copies (ClipWrapper.jittering_transforms = ColorJitter(0.6, 0.6, 0.6, 0.1),
+// CLIP/clip/__init__.py:55-57, 246-247).  The reference's jitter is random (torchvision), so there is no parity
+// target; this is the same family of uint8 -> uint8 point operations (brightness / contrast / saturation blends with
+// truncation, hue rotation in HSV), applied one op per launch in a caller-chosen order with caller-drawn factors.
+//   op: 0 brightness, 1 contrast (needs `mean` = rounded mean of the grey image), 2 saturation, 3 hue
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int grey_u8(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+__device__ __forceinline__ unsigned char blend_u8(float a, float b, float f) {
+    float t = a + f * (b - a);
+    return (unsigned char)(t <= 0.f ? 0.f : (t >= 255.f ? 255.f : t));
+}
+
+__global__ void k_grey_sum(const unsigned char* __restrict__ img, long n, unsigned long long* __restrict__ sum) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (i < n) v = (float)grey_u8(img[i * 3], img[i * 3 + 1], img[i * 3 + 2]);
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, (unsigned long long)(v + 0.5f));
+}
+
+__global__ void k_jitter_op(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long n, int op, float f,
+                            const unsigned long long* __restrict__ grey_sum) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = src[i * 3], g = src[i * 3 + 1], b = src[i * 3 + 2];
+    if (op == 0) {
+        r = blend_u8(0.f, r, f); g = blend_u8(0.f, g, f); b = blend_u8(0.f, b, f);
+    } else if (op == 1) {
+        float m = (float)(int)((double)(*grey_sum) / (double)n + 0.5);
+        r = blend_u8(m, r, f); g = blend_u8(m, g, f); b = blend_u8(m, b, f);
+    } else if (op == 2) {
+        float m = (float)grey_u8(r, g, b);
+        r = blend_u8(m, r, f); g = blend_u8(m, g, f); b = blend_u8(m, b, f);
+    } else {
+        float fr = r / 255.f, fg = g / 255.f, fb = b / 255.f;
+        float mx = fmaxf(fr, fmaxf(fg, fb)), mn = fminf(fr, fminf(fg, fb)), d = mx - mn;
+        float h = 0.f, s = mx > 0.f ? d / mx : 0.f, v = mx;
+        if (d > 0.f) {
+            if (mx == fr) h = fmodf((fg - fb) / d, 6.f);
+            else if (mx == fg) h = (fb - fr) / d + 2.f;
+            else h = (fr - fg) / d + 4.f;
+            h /= 6.f;
+            if (h < 0.f) h += 1.f;
+        }
+        h = h + f; h -= floorf(h);
+        float hh = h * 6.f; int sector = (int)hh; float fr2 = hh - sector;
+        float p = v * (1.f - s), q = v * (1.f - s * fr2), t = v * (1.f - s * (1.f - fr2));
+        float R, G, B;
+        switch (sector % 6) {
+            case 0: R = v; G = t; B = p; break;
+            case 1: R = q; G = v; B = p; break;
+            case 2: R = p; G = v; B = t; break;
+            case 3: R = p; G = q; B = v; break;
+            case 4: R = t; G = p; B = v; break;
+            default: R = v; G = p; B = q; break;
+        }
+        r = (int)(R * 255.f + 0.5f); g = (int)(G * 255.f + 0.5f); b = (int)(B * 255.f + 0.5f);
+    }
+    dst[i * 3] = (unsigned char)r; dst[i * 3 + 1] = (unsigned char)g; dst[i * 3 + 2] = (unsigned char)b;
+}
+
+// img uint8 [H, W, 3] jittered IN PLACE; order4 / factors4 are host arrays; scratch = 8 bytes of device memory
+extern "C" int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, const float* factors4,
+                                   void* scratch8, void* stream) {
+    SEMABS_REQUIRE(img && order4 && factors4 && scratch8 && H > 0 && W > 0, "semabs_color_jitter: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)H * W;
+    for (int k = 0; k < 4; ++k) {
+        const int op = order4[k];
+        SEMABS_REQUIRE(op >= 0 && op < 4, "semabs_color_jitter: op must be 0..3");
+        if (op == 1) {
+            if (hipMemsetAsync(scratch8, 0, 8, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+            hipLaunchKernelGGL(k_grey_sum, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, n, (unsigned long long*)scratch8);
+        }
+        hipLaunchKernelGGL(k_jitter_op, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, img, n, op, factors4[op],
+                           (const unsigned long long*)scratch8);
+    }
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

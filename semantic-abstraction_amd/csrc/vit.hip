@@ -1,0 +1,594 @@
+// Transformer kernels around the GEMMs: LayerNorm, fused multi-head attention (MFMA, softmax in registers),
+// CLS-row attention of the last block (keeps the softmax row), embedding glue, and the element-wise pieces of
+// the closed-form attention x gradient rollout.
+//
+// Replaces (reference file:line):
+//   LayerNorm (fp32)                       CLIP/clip/model_explainability.py:188-194
+//   multi_head_attention_forward           CLIP/clip/auxiliary.py:207, 260-340   (q scaling is folded into W_q)
+//   class/positional embedding             CLIP/clip/model_explainability.py:329-344
+//   ClipGradcam.forward / interpret        CLIP/clip/clip_gradcam.py:58-132  (autograd replaced by the analytic VJP)
+//   token embedding / EOT gather           CLIP/clip/model_explainability.py:469-482
+//   zeroshot_classifier normalise + mean   CLIP/clip/clip_gradcam.py:24-27
+#include "semabs_common.h"
+
+// =================================================================================================
+// LayerNorm: one wave per row, row held in registers (D <= 1024, D % 256 == 0), two-pass mean / variance.
+// =================================================================================================
+template <int VPL, bool OUT_F32>   // VPL = float4 vectors per lane (D = 256 * VPL)
+__global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, void* __restrict__ out, long M, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D = 256 * VPL;
+    const float* xr = x + row * ld_in;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+        float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gm.x + bt.x; o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[i].z - mean) * rstd * gm.z + bt.z; o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        if (OUT_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * D + c0) = o;
+        } else {
+            f16x4 h; h[0] = (f16)o.x; h[1] = (f16)o.y; h[2] = (f16)o.z; h[3] = (f16)o.w;
+            *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + row * D + c0) = h;
+        }
+    }
+}
+
+// x fp32 rows (stride ld_in elements) -> out [M, D] dense, fp16 (out_f32 = 0) or fp32 (1; may alias x when ld_in == D)
+extern "C" int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D,
+                                float eps, int out_f32, long ld_in, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && gamma && beta && out && M > 0, "semabs_layernorm: bad args");
+    SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024 && ld_in % 4 == 0, "semabs_layernorm: D must be 256..1024 step 256");
+    dim3 grid(semabs_cdiv(M, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_CASE(V)                                                                                              \
+    case V:                                                                                                     \
+        if (out_f32) hipLaunchKernelGGL((k_layernorm<V, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps); \
+        else hipLaunchKernelGGL((k_layernorm<V, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps);        \
+        break;
+    switch (D / 256) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) }
+#undef LN_CASE
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// CLS rows of the token matrix: x[n, 0, :] = class_embedding + pos[0, :]   (patch rows come from the GEMM epilogue)
+// =================================================================================================
+__global__ void k_embed_cls(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos0,
+                            int n, int T, int D) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * D) return;
+    int d = (int)(i % D); long t = i / D;
+    x[t * T * D + d] = cls[d] + pos0[d];
+}
+
+extern "C" int semabs_embed_finish(float* x, const float* cls, const float* pos, int n, int T, int D, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && cls && pos && n > 0 && T > 0 && D > 0, "semabs_embed_finish: bad args");
+    hipLaunchKernelGGL(k_embed_cls, dim3(semabs_cdiv((long)n * D, 256)), dim3(256), 0, (hipStream_t)stream, x, cls, pos, n, T, D);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Fused attention, head dim 64.  One workgroup (4 waves) per (sequence, head): K [TP, 64] (swizzled) and
+// V^T [64, TP + 4] in LDS; each wave owns 32-query blocks.  S^T = K Q^T with v_mfma_f32_32x32x16_f16 so that a
+// lane holds one query's scores (row max/sum = in-lane + one lane^32 exchange), softmax in fp32, P stays in
+// registers as the B operand of O^T = V^T P^T (the MFMA k-slot permutation is matched on the V^T side).
+// =================================================================================================
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int NKB, bool CAUSAL>   // number of 32-key blocks: TP = 32 * NKB
+__global__ __launch_bounds__(256, 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int H,
+                                                   int ld, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = 32 * NKB;
+    constexpr int VS = TP + 4;                    // V^T row stride (elements): keeps ds_read_b64 8-byte aligned
+    char* sK = smem;
+    f16* sV = reinterpret_cast<f16*>(smem + TP * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int seq = blockIdx.x / H, h = blockIdx.x % H;
+    const f16* base = qkv + (long)seq * T * ld + h * 64;
+
+    for (int c = tid; c < TP * 8; c += 256) {
+        int row = c >> 3, kc = c & 7;
+        f16x8 kv, vv;
+        if (row < T) {
+            kv = *reinterpret_cast<const f16x8*>(base + (long)row * ld + D + kc * 8);
+            vv = *reinterpret_cast<const f16x8*>(base + (long)row * ld + 2 * D + kc * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kv[e] = (f16)0.f; vv[e] = (f16)0.f; }
+        }
+        *reinterpret_cast<f16x8*>(sK + kswz(row, kc)) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sV[(kc * 8 + e) * VS + row] = vv[e];
+    }
+    __syncthreads();
+
+    const int ql = lane & 31, hi = lane >> 5;
+    int koff[4];                                   // swizzled K-row offsets: row-block independent
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = kswz(ql, ks * 2 + hi);
+#pragma unroll 1
+    for (int qb = wid; qb < NKB; qb += 4) {
+        const int q = qb * 32 + ql;
+        const int qc = q < T ? q : T - 1;
+        f16x8 fq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+        f32x16 s[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x8 fk = *reinterpret_cast<const f16x8*>(sK + kb * 4096 + koff[ks]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fq[ks], s[kb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every block's K reads (VGPR blow-up)
+        }
+        // s[kb][r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*hi, query = q)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            // only a block that reaches past T (or, for the causal text tower, past the query) needs masking
+            if (CAUSAL || kb * 32 + 31 >= T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    bool dead = key >= T || (CAUSAL && key > q);
+                    s[kb][r] = dead ? -INFINITY : s[kb][r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[kb][r] = __expf(s[kb][r] - mx); sum += s[kb][r]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f16x8 p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = (f16)(s[kb][hf * 8 + j] * inv);
+                const int kbase = kb * 32 + hf * 16 + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const f16* vr = sV + (db * 32 + ql) * VS + kbase;
+                    f16x4 v0 = *reinterpret_cast<const f16x4*>(vr);
+                    f16x4 v1 = *reinterpret_cast<const f16x4*>(vr + 8);
+                    f16x8 fv;
+                    fv[0] = v0[0]; fv[1] = v0[1]; fv[2] = v0[2]; fv[3] = v0[3];
+                    fv[4] = v1[0]; fv[5] = v1[1]; fv[6] = v1[2]; fv[7] = v1[3];
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv, p, o[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // o[db][r] = O[query q][d = db*32 + (r&3) + 8*(r>>2) + 4*hi]
+        if (q < T) {
+            f16* orow = out + ((long)seq * T + q) * D + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f16x4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (f16)o[db][rq * 4 + j];
+                    *reinterpret_cast<f16x4*>(orow + db * 32 + rq * 8 + 4 * hi) = hv;
+                }
+        }
+    }
+}
+
+// qkv fp16 [n_seq, T, ld] with q | k | v at column offsets 0, D, 2D (q already scaled); out fp16 [n_seq, T, D]
+extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved, int n_seq, int T, int H, int head_dim,
+                                int ld, int causal, void* stream) {
+    (void)reserved;
+    if (n_seq == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(qkv && out && n_seq > 0 && T > 0 && H > 0, "semabs_attention: bad args");
+    SEMABS_REQUIRE(head_dim == 64, "semabs_attention: head_dim must be 64");
+    SEMABS_REQUIRE(T <= 224 && ld % 8 == 0, "semabs_attention: T must be <= 224");
+    const int D = H * 64;
+    const int nkb = (T + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(n_seq * H), block(256);
+#define ATT_LAUNCH(N, C)                                                                                             \
+    {                                                                                                                \
+        size_t lds = (size_t)(32 * N) * 128 + 64 * (32 * N + 4) * 2;                                                 \
+        static bool set = false;                                                                                     \
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
+        hipLaunchKernelGGL((k_attention<N, C>), grid, block, lds, s, (const f16*)qkv, (f16*)out, T, H, ld, D);       \
+    }
+#define ATT_CASE(N) { if (causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }
+    switch (nkb) {
+        case 1: case 2: ATT_CASE(2) break;
+        case 3: ATT_CASE(3) break;
+        case 4: ATT_CASE(4) break;
+        case 5: ATT_CASE(5) break;
+        case 6: ATT_CASE(6) break;
+        default: ATT_CASE(7) break;
+    }
+#undef ATT_CASE
+#undef ATT_LAUNCH
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Last block, CLS query only (only x[CLS] reaches the image feature): one wave per (tile, head).
+//   q fp32 [n, D] (scaled), kv fp32 [n, T, 2D] (k | v)  ->  probs fp32 [n, H, T] (kept for the rollout),
+//   o fp16 [n, D] (input of out_proj)
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__ q, const float* __restrict__ kv,
+                                                       float* __restrict__ probs, f16* __restrict__ o, int n, int T, int H) {
+    __shared__ float sp[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long wh = (long)blockIdx.x * 4 + w;
+    if (wh >= (long)n * H) return;
+    const int D = H * 64;
+    const int i = (int)(wh / H), h = (int)(wh % H);
+    const float* qr = q + (long)i * D + h * 64;
+    const float* kb = kv + (long)i * T * 2 * D + h * 64;
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int j = t * 64 + lane;
+        float acc = -INFINITY;
+        if (j < T) {
+            const float4* kr = reinterpret_cast<const float4*>(kb + (long)j * 2 * D);
+            const float4* q4 = reinterpret_cast<const float4*>(qr);
+            acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                float4 a = q4[d], b = kr[d];
+                acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+        }
+        sc[t] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { sc[t] = (t * 64 + lane < T) ? __expf(sc[t] - mx) : 0.f; sum += sc[t]; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int j = t * 64 + lane;
+        float p = sc[t] * inv;
+        sp[w][j] = p;
+        if (j < T) probs[wh * T + j] = p;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const float* vb = kb + D + lane;       // lane = d
+    float acc = 0.f;
+    for (int j = 0; j < T; ++j) acc += sp[w][j] * vb[(long)j * 2 * D];
+    o[(long)i * D + h * 64 + lane] = (f16)acc;
+}
+
+extern "C" int semabs_attention_cls(const float* q, const float* kv, float* probs, void* o, int n, int T, int H,
+                                    int head_dim, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(q && kv && probs && o && n > 0, "semabs_attention_cls: bad args");
+    SEMABS_REQUIRE(head_dim == 64 && T <= 256 && T > 0, "semabs_attention_cls: head_dim 64, T <= 256");
+    hipLaunchKernelGGL(k_attention_cls, dim3(semabs_cdiv((long)n * H, 4)), dim3(256), 0, (hipStream_t)stream, q, kv, probs,
+                       (f16*)o, n, T, H);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Small element-wise pieces
+// =================================================================================================
+// strided row gather: dst[r, :] = src[r * src_stride + offset ...][:cols]  (fp32), e.g. the CLS rows of x
+__global__ void k_rows_gather(const float* __restrict__ src, float* __restrict__ dst, long rows, int cols, long stride, long off) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    long r = i / cols; int c = (int)(i % cols);
+    dst[i] = src[r * stride + off + c];
+}
+extern "C" int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream) {
+    if (rows == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(src && dst && rows > 0 && cols > 0, "semabs_rows_gather: bad args");
+    hipLaunchKernelGGL(k_rows_gather, dim3(semabs_cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, src_stride, offset);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// quick-GELU forward on fp32 pre-activations -> fp16 (CLS-row MLP of the last block keeps fc for the VJP)
+__global__ void k_quickgelu(const float* __restrict__ fc, f16* __restrict__ act, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = fc[i];
+    act[i] = (f16)(v / (1.f + __expf(-1.702f * v)));
+}
+extern "C" int semabs_quickgelu(const float* fc, void* act, long n, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(fc && act && n > 0, "semabs_quickgelu: bad args");
+    hipLaunchKernelGGL(k_quickgelu, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, fc, (f16*)act, n);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// logits + d logit / d feat, one wave per tile (clip_gradcam.py:63-67 and the head of the analytic VJP):
+//   fh = f / |f|;  logit[i, l] = 100 fh . w_l;  dfeat[l, i, :] = 100 (w_l - fh (fh . w_l)) / |f|
+// Each gradient row is normalised to max-abs 1 before the fp16 GEMM chain (the VJP is linear, the rollout
+// multiplies the factor back in: scale[l, i]).  w_text fp32 [L, E] (row per label).
+template <int PER>   // E = 64 * PER
+__global__ __launch_bounds__(256) void k_logit_grad(const float* __restrict__ feat, const float* __restrict__ wt, int n, int L,
+                                                    float* __restrict__ logits, f16* __restrict__ dfeat,
+                                                    float* __restrict__ scale) {
+    constexpr int E = 64 * PER;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float f[PER];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { f[k] = feat[(long)i * E + k * 64 + lane]; ss += f[k] * f[k]; }
+    const float nrm = sqrtf(wave_sum(ss));
+#pragma unroll
+    for (int k = 0; k < PER; ++k) f[k] = f[k] / nrm;
+    for (int l = 0; l < L; ++l) {
+        float w[PER], g[PER];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { w[k] = wt[(long)l * E + k * 64 + lane]; dot += f[k] * w[k]; }
+        dot = wave_sum(dot);
+        if (logits && lane == 0) logits[(long)i * L + l] = 100.f * dot;
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { g[k] = 100.f * (w[k] - f[k] * dot) / nrm; mx = fmaxf(mx, fabsf(g[k])); }
+        mx = wave_max(mx);
+        const float sc = mx > 0.f ? mx : 1.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) dfeat[((long)l * n + i) * E + k * 64 + lane] = (f16)(g[k] / sc);
+        if (lane == 0) scale[(long)l * n + i] = sc;
+    }
+}
+extern "C" int semabs_logit_grad(const float* feat, const float* w_text, int n, int L, int E, float* logits, void* dfeat,
+                                 float* scale, void* stream) {
+    if (n == 0 || L == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(feat && w_text && dfeat && scale, "semabs_logit_grad: bad args");
+    SEMABS_REQUIRE(E == 512 || E == 768, "semabs_logit_grad: embed dim must be 512 or 768");
+    dim3 grid(semabs_cdiv(n, 4)), block(256);
+    if (E == 512) hipLaunchKernelGGL(k_logit_grad<8>, grid, block, 0, (hipStream_t)stream, feat, w_text, n, L, logits, (f16*)dfeat, scale);
+    else hipLaunchKernelGGL(k_logit_grad<12>, grid, block, 0, (hipStream_t)stream, feat, w_text, n, L, logits, (f16*)dfeat, scale);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// LayerNorm VJP wrt the input, rows (l, i): x row = i = m % n_x.  out = [resid +] rstd (g - mean(g) - xh mean(g xh)),
+// g = gy * gamma.  Writes fp32 (out32, optional) and fp16 (out16, optional).
+template <int VPL>
+__global__ void k_ln_bwd(const float* __restrict__ x, long ld_x, const float* __restrict__ gamma, const float* __restrict__ gy,
+                         const float* __restrict__ resid, float* __restrict__ out32, f16* __restrict__ out16, long M, int n_x,
+                         float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D = 256 * VPL;
+    const float* xr = x + (row % n_x) * ld_x;
+    float4 v[VPL], g[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+        float4 gg = *reinterpret_cast<const float4*>(gy + row * D + c0);
+        g[i].x = gg.x * gm.x; g[i].y = gg.y * gm.y; g[i].z = gg.z * gm.z; g[i].w = gg.w * gm.w;
+        v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xh
+        sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        sgx += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+    const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        float4 o;
+        o.x = rstd * (g[i].x - mg - v[i].x * mgx); o.y = rstd * (g[i].y - mg - v[i].y * mgx);
+        o.z = rstd * (g[i].z - mg - v[i].z * mgx); o.w = rstd * (g[i].w - mg - v[i].w * mgx);
+        if (resid) {
+            float4 r = *reinterpret_cast<const float4*>(resid + row * D + c0);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (out32) *reinterpret_cast<float4*>(out32 + row * D + c0) = o;
+        if (out16) {
+            f16x4 h; h[0] = (f16)o.x; h[1] = (f16)o.y; h[2] = (f16)o.z; h[3] = (f16)o.w;
+            *reinterpret_cast<f16x4*>(out16 + row * D + c0) = h;
+        }
+    }
+}
+extern "C" int semabs_ln_bwd(const float* x, const float* gamma, const float* gy, const float* resid, float* out32,
+                             void* out16, long M, int D, int n_x, long ld_x, float eps, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && gamma && gy && (out32 || out16) && M > 0 && n_x > 0, "semabs_ln_bwd: bad args");
+    SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024, "semabs_ln_bwd: D must be 256..1024 step 256");
+    dim3 grid(semabs_cdiv(M, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(k_ln_bwd<1>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
+        case 2: hipLaunchKernelGGL(k_ln_bwd<2>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
+        case 3: hipLaunchKernelGGL(k_ln_bwd<3>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
+        case 4: hipLaunchKernelGGL(k_ln_bwd<4>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
+    }
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// quick-GELU VJP: dfc[m, :] = dact[m, :] * (s (1 + 1.702 fc (1 - s))),  s = sigmoid(1.702 fc[m % n_x, :])   -> fp16
+__global__ void k_gelu_bwd(const float* __restrict__ dact, const float* __restrict__ fc, f16* __restrict__ dfc, long M, int W, int n_x) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * (W / 4)) return;
+    long m = i / (W / 4); int c = (int)(i % (W / 4)) * 4;
+    float4 a = *reinterpret_cast<const float4*>(dact + m * W + c);
+    float4 f = *reinterpret_cast<const float4*>(fc + (m % n_x) * W + c);
+    auto d = [](float x) { float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); };
+    f16x4 h;
+    h[0] = (f16)(a.x * d(f.x)); h[1] = (f16)(a.y * d(f.y)); h[2] = (f16)(a.z * d(f.z)); h[3] = (f16)(a.w * d(f.w));
+    *reinterpret_cast<f16x4*>(dfc + m * W + c) = h;
+}
+extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(dact && fc && dfc && M > 0 && W % 4 == 0 && n_x > 0, "semabs_gelu_bwd: bad args");
+    hipLaunchKernelGGL(k_gelu_bwd, dim3(semabs_cdiv(M * (W / 4), 256)), dim3(256), 0, (hipStream_t)stream, dact, fc, (f16*)dfc, M, W, n_x);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Rollout (closed form of clip_gradcam.py:90-131 for the only contributing block):
+//   rel[l, i, j-1] = scale[l, i] / H * sum_h clampmin0?(A[i, h, j] * (V[i, j, h, :] . u[l, i, h, :])),  j = 1..T-1
+// One workgroup per tile i; u rows for all labels staged in LDS; thread = token j.
+//   probs fp32 [n, H, T]; kv fp32 [n, T, 2D] (V at column offset D); u fp32 [L, n, D]; out fp32 [L, n_total, T-1]
+//   written at tile offset `tile0` (so chunks of tiles fill one [L, N, g, g] array).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs, const float* __restrict__ kv,
+                                                 const float* __restrict__ u, const float* __restrict__ scale,
+                                                 float* __restrict__ rel, int n, int T, int H, int L, int positive_only,
+                                                 long n_total, long tile0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* su = reinterpret_cast<float*>(smem);            // [L][D]
+    const int D = H * 64;
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < L * D; c += blockDim.x) su[c] = u[((long)(c / D) * n + i) * D + (c % D)];
+    __syncthreads();
+    for (int j = 1 + threadIdx.x; j < T; j += blockDim.x) {
+        const float* vrow = kv + ((long)i * T + j) * 2 * D + D;
+        for (int l0 = 0; l0 < L; l0 += 4) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < H; ++h) {
+                float dot[4] = {0.f, 0.f, 0.f, 0.f};
+                const float4* v4 = reinterpret_cast<const float4*>(vrow + h * 64);
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    float4 vv = v4[d];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (l0 + k < L) {
+                            const float4 uu = *reinterpret_cast<const float4*>(su + (l0 + k) * D + h * 64 + d * 4);
+                            dot[k] += vv.x * uu.x + vv.y * uu.y + vv.z * uu.z + vv.w * uu.w;
+                        }
+                    }
+                }
+                const float a = probs[((long)i * H + h) * T + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float c = a * dot[k];
+                    acc[k] += positive_only ? fmaxf(c, 0.f) : c;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (l0 + k < L)
+                    rel[((long)(l0 + k) * n_total + tile0 + i) * (T - 1) + (j - 1)] = acc[k] / H * scale[(long)(l0 + k) * n + i];
+        }
+    }
+}
+extern "C" int semabs_rollout(const float* probs, const float* kv, const float* u, const float* scale, float* rel, int n,
+                              int T, int H, int L, int positive_only, long n_total, long tile0, void* stream) {
+    if (n == 0 || L == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(probs && kv && u && scale && rel && n > 0 && T > 1 && H > 0, "semabs_rollout: bad args");
+    size_t lds = (size_t)L * H * 64 * 4;
+    SEMABS_REQUIRE(lds <= 160 * 1024, "semabs_rollout: too many labels per call (L * D * 4 bytes must fit LDS)");
+    static size_t set_for = 0;
+    if (lds > set_for) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_for = lds; }
+    hipLaunchKernelGGL(k_rollout, dim3(n), dim3(256), lds, (hipStream_t)stream, probs, kv, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Text tower glue
+// =================================================================================================
+// x[b, t, :] = token_embedding[tokens[b, t], :] + positional_embedding[t, :]
+__global__ void k_gather_text(const long long* __restrict__ tokens, const float* __restrict__ emb, const float* __restrict__ pos,
+                              float* __restrict__ x, int B, int T, int D) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T * D) return;
+    int d = (int)(i % D); long bt = i / D; int t = (int)(bt % T);
+    x[i] = emb[tokens[bt] * D + d] + pos[(long)t * D + d];
+}
+extern "C" int semabs_gather_text(const long long* tokens, const float* emb, const float* pos, float* x, int B, int T, int D, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(tokens && emb && pos && x && B > 0 && T > 0 && D > 0, "semabs_gather_text: bad args");
+    hipLaunchKernelGGL(k_gather_text, dim3(semabs_cdiv((long)B * T * D, 256)), dim3(256), 0, (hipStream_t)stream, tokens, emb, pos, x, B, T, D);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// e fp32 [C * P, E] (class-major) -> w fp32 [C, E] = mean_p e / |e|   (not re-normalised)
+__global__ void k_text_finish(const float* __restrict__ e, float* __restrict__ w, int C, int P, int E) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    for (int k = lane; k < E; k += 64) w[(long)c * E + k] = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float* r = e + ((long)c * P + p) * E;
+        float ss = 0.f;
+        for (int k = lane; k < E; k += 64) ss += r[k] * r[k];
+        const float nrm = sqrtf(wave_sum(ss));
+        for (int k = lane; k < E; k += 64) w[(long)c * E + k] += r[k] / nrm;
+    }
+    for (int k = lane; k < E; k += 64) w[(long)c * E + k] /= (float)P;
+}
+extern "C" int semabs_text_finish(const float* e, float* w, int C, int P, int E, void* stream) {
+    if (C == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(e && w && C > 0 && P > 0 && E > 0, "semabs_text_finish: bad args");
+    hipLaunchKernelGGL(k_text_finish, dim3(semabs_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, e, w, C, P, E);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

@@ -1,0 +1,73 @@
+"""Drop-in for the on-path functions of the reference's `point_cloud.py` (numpy in / numpy out), computed
+by HIP kernels (csrc/geometry.hip):
+
+  get_pointcloud        point_cloud.py:34-66   (f64 math on device; returned as f64 like the reference)
+  filter_pts_bounds     point_cloud.py:24-31
+  check_pts_in_frustum  point_cloud.py:88-110
+
+`pointcloud_device` is the fused device-resident form the scene pipeline uses (fp32 points + bounds mask in
+one launch, nothing copied to the host).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _params(cam_intr, cam_pose, bounds, dev):
+    p = np.zeros(22, np.float64)
+    K = np.asarray(cam_intr, np.float64)
+    p[0:4] = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    if cam_pose is not None:
+        p[4:16] = np.asarray(cam_pose, np.float64)[:3, :4].reshape(-1)
+    if bounds is not None:
+        b = np.asarray(bounds, np.float64)
+        p[16:19], p[19:22] = b[0], b[1]
+    return torch.from_numpy(p).to(dev)
+
+
+def pointcloud_device(depth: torch.Tensor, cam_intr, cam_pose, bounds=None):
+    """depth fp32 [H, W] on the GPU -> (xyz fp32 [H*W, 3], in-bounds mask uint8 [H*W] or None), on the GPU."""
+    dev = _lib.require_gpu()
+    H, W = depth.shape
+    xyz = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
+    mask = torch.empty(H * W, dtype=torch.uint8, device=dev) if bounds is not None else None
+    prm = _params(cam_intr, cam_pose, bounds, dev)
+    _lib.call("semabs_pointcloud", _lib.ptr(depth.contiguous()), H, W, _lib.ptr(prm), int(cam_pose is not None),
+              _lib.ptr(xyz), _lib.ptr(mask), _lib.stream())
+    return xyz, mask
+
+
+def get_pointcloud(depth_img, color_img, cam_intr, cam_pose=None):
+    dev = _lib.require_gpu()
+    d = torch.from_numpy(np.ascontiguousarray(depth_img, dtype=np.float32)).to(dev)
+    xyz, _ = pointcloud_device(d, cam_intr, cam_pose)
+    # the reference returns f64; its only on-path consumer casts to f32 at once (visualize.py:103-105), which is
+    # what the kernel already did, so the f64 array below holds exactly those f32 values
+    cam_pts = xyz.cpu().numpy().astype(np.float64)
+    color_pts = None if color_img is None else color_img.reshape(-1, 3)
+    return cam_pts, color_pts
+
+
+def filter_pts_bounds(xyz, bounds):
+    xyz = xyz.cpu().numpy() if isinstance(xyz, torch.Tensor) else np.asarray(xyz)
+    b = np.asarray(bounds)
+    m = np.ones(len(xyz), bool)
+    for a in range(3):  # six compares: host glue, identical semantics to point_cloud.py:24-31
+        m &= (xyz[:, a] >= b[0, a]) & (xyz[:, a] <= b[1, a])
+    return m
+
+
+def check_pts_in_frustum(xyz_pts, depth, cam_pose, cam_intr):
+    dev = _lib.require_gpu()
+    pts = torch.from_numpy(np.ascontiguousarray(xyz_pts, dtype=np.float64)).to(dev)
+    T = np.linalg.inv(np.asarray(cam_pose, np.float64))
+    K = np.asarray(cam_intr, np.float64)
+    prm = np.concatenate([T[:3, :4].reshape(-1), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]])
+    prm = torch.from_numpy(prm).to(dev)
+    h, w = depth.shape
+    mask = torch.empty(len(pts), dtype=torch.uint8, device=dev)
+    _lib.call("semabs_frustum_mask", _lib.ptr(pts), len(pts), _lib.ptr(prm), h, w, _lib.ptr(mask), _lib.stream())
+    return mask.cpu().numpy().astype(bool)

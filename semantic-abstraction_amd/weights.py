@@ -53,7 +53,7 @@ def _block(rng, prefix, width, sd, attn_std, proj_std, fc_std, sharpen, half=Tru
     sd[prefix + "ln_2.bias"] = 0.05 * n(width)
 
 
-def make_clip_state_dict(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 4.0,
+def make_clip_state_dict(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 2.0,
                          text_tower: bool = True) -> dict:
     """State dict with the OpenAI CLIP key names for a ViT-B model, values from `seed`.
 

@@ -166,7 +166,7 @@ def install_stubs():
 _CKPT = {}
 
 
-def checkpoint_path(arch: str, seed: int, sharpen: float = 4.0) -> str:
+def checkpoint_path(arch: str, seed: int, sharpen: float = 2.0) -> str:
     """Save our seeded state dict once to a temp .pt the reference `load()` can read."""
     import semabs_amd  # noqa: F401
     from semabs_amd.weights import make_clip_state_dict
@@ -202,7 +202,7 @@ class TileList:
         return len(self.items)
 
 
-def load_reference_clip(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 4.0):
+def load_reference_clip(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 2.0):
     """Return the reference `CLIP.clip` package with ClipWrapper initialised on our seeded weights."""
     install_stubs()
     if REF not in sys.path:

@@ -1,0 +1,68 @@
+"""GPU parity: HIP geometry kernels (through the C ABI) vs the oracle and the committed golden vectors.
+Integer outputs (voxel indices, pixel indices) and the fp32 volumes they drive are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+import semabs_amd  # noqa: F401
+from conftest import sha
+from oracle import geometry as og
+from semabs_amd.synth import synth_scene
+
+pytestmark = pytest.mark.gpu
+SCENE_BOUNDS = [[-1.0, -1.0, -0.1], [1.0, 1.0, 1.9]]
+
+
+@pytest.mark.parametrize("tag,hw,S", [("48", 48, 32), ("480", 480, 128)])
+def test_pointcloud_and_voxel_index(golden, tag, hw, S):
+    from semabs_amd import point_cloud as pc
+    from semabs_amd.net import VirtualGrid
+    g = golden("g8_geometry")
+    sc = synth_scene(hw, hw, seed=5)
+    depth = torch.from_numpy(sc["depth"]).cuda()
+    xyz, mask = pc.pointcloud_device(depth, sc["cam_intr"], sc["cam_pose"], np.array(SCENE_BOUNDS))
+    ref = og.get_pointcloud(sc["depth"], sc["cam_intr"], sc["cam_pose"]).astype(np.float32)
+    got = xyz.cpu().numpy()
+    nbad = int((got != ref).sum())
+    assert nbad == 0, f"{nbad} fp32 coordinates differ from the oracle"
+    assert np.array_equal(sha(got), g[f"{tag}_pts32_sha"])
+    assert np.array_equal(sha(mask.cpu().numpy().astype(bool)), g[f"{tag}_mask_sha"])
+    vg = VirtualGrid(np.array(SCENE_BOUNDS), (S, S, S), batch_size=1)
+    flat = vg.flat_idxs(xyz).cpu().numpy()
+    assert np.array_equal(sha(flat.astype(np.int64)), g[f"{tag}_flat_sha"])
+    idx3 = vg.get_points_grid_idxs(xyz)
+    assert torch.equal(vg.flatten_idxs(idx3).cpu(), torch.from_numpy(flat))
+    # numpy-facing drop-ins
+    pts_np, _ = pc.get_pointcloud(sc["depth"], None, sc["cam_intr"], sc["cam_pose"])
+    assert pts_np.dtype == np.float64 and np.array_equal(pts_np.astype(np.float32), ref)
+    fr = pc.check_pts_in_frustum(ref[::3].astype(np.float64) * 1.01, sc["depth"], sc["cam_pose"], sc["cam_intr"])
+    assert np.array_equal(sha(fr), g[f"{tag}_frustum_sha"])
+
+
+def test_voxel_index_edge_cases():
+    from semabs_amd.net import VirtualGrid
+    vg = VirtualGrid(np.array(SCENE_BOUNDS), (128, 128, 128), batch_size=1)
+    pts = np.array([[-1, -1, -0.1], [1, 1, 1.9], [-5, 7, 0.3], [0.99999994, -1.0000001, 1.8999999],
+                    [-1 + 2 * 2 / 127, -1 + 2 * 64 / 127, -0.1 + 2 * 126 / 127]], np.float32)
+    got = vg.flat_idxs(torch.from_numpy(pts).cuda()).cpu().numpy()
+    ref = og.flatten_idxs(og.points_grid_idxs(pts, SCENE_BOUNDS, (128, 128, 128)), (128, 128, 128))
+    assert np.array_equal(got, ref)
+    assert vg.flat_idxs(torch.zeros(0, 3).cuda()).numel() == 0      # empty input
+
+
+@pytest.mark.parametrize("tag,hw,S", [("16", 48, 16), ("32", 64, 32), ("128", 480, 128)])
+def test_tsdf(golden, tag, hw, S):
+    from semabs_amd.fusion import TSDFVolume
+    g = golden("g11_tsdf")
+    vs = (SCENE_BOUNDS[1][0] - SCENE_BOUNDS[0][0]) / S
+    tv = TSDFVolume(np.array(SCENE_BOUNDS).T.copy(), vs)
+    assert np.array_equal(tv._vol_dim, g[f"{tag}_dim"])
+    for k in range(2 if S <= 32 else 1):
+        sc = synth_scene(hw, hw, seed=6 if k == 0 else 16)
+        tv.integrate(sc["rgb"], sc["depth"], sc["cam_intr"], sc["cam_pose"], keep_pix=True)
+    assert np.array_equal(sha(tv.last_pix.cpu().numpy()), g[f"{tag}_pix_sha"])      # int64 pixel indices
+    assert np.array_equal(sha(tv._weight_vol_cpu), g[f"{tag}_weight_sha"])
+    assert np.array_equal(sha(tv._tsdf_vol_cpu), g[f"{tag}_tsdf_sha"])
+    assert np.array_equal(sha(tv._color_vol_cpu), g[f"{tag}_color_sha"])
+    tsdf, col = tv.get_volume()
+    assert tsdf.shape == (S, S, S) and col.shape == (3, S, S, S) and col.dtype == np.uint8

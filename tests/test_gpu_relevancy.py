@@ -1,0 +1,250 @@
+"""GPU parity for the relevancy half: every HIP kernel (through the C ABI) against a plain fp32 torch/numpy
+reference of the same op, then the assembled path against the oracle and the golden vectors captured from the
+reference.  Tolerances are stated where they are used: the ViT GEMM operands are fp16 (fp32 accumulate, fp32
+residual stream / LayerNorm / softmax) against the reference's all-fp32 CPU path."""
+import numpy as np
+import pytest
+import torch
+
+import semabs_amd  # noqa: F401
+from oracle import preprocess as op
+from oracle import relevancy as orl
+from semabs_amd.synth import synth_rgb
+from semabs_amd.weights import DEFAULT_PROMPT, make_clip_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand16(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float16))
+
+
+# ---- GEMM ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (3, 512, 768), (127, 128, 128), (129, 256, 192), (1000, 768, 3072),
+                                   (591, 2304, 768), (4100, 384, 512)])
+def test_gemm_epilogues(M, N, K):
+    from semabs_amd.clip.vit import gemm
+    rng = np.random.default_rng(M * 7 + N)
+    A, B = _rand16(rng, M, K), _rand16(rng, N, K, scale=0.05)
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+    ref = A.double() @ B.double().T + bias.double()                       # asymmetric operands: catches transposes
+    Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
+    tol = dict(rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    c = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    gemm(Ad, Bd, c, bd, M, N, K, K, K, N, 3)
+    np.testing.assert_allclose(c.cpu().double().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    c16 = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    gemm(Ad, Bd, c16, bd, M, N, K, K, K, N, 0)
+    np.testing.assert_allclose(c16.cpu().double().numpy(), ref.numpy(), **tol)
+    gemm(Ad, Bd, c16, bd, M, N, K, K, K, N, 1)
+    np.testing.assert_allclose(c16.cpu().double().numpy(), (ref * torch.sigmoid(1.702 * ref)).numpy(), **tol)
+    res = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    c = res.cuda()
+    gemm(Ad, Bd, c, bd, M, N, K, K, K, N, 2)
+    np.testing.assert_allclose(c.cpu().double().numpy(), (ref + res.double()).numpy(), rtol=1e-4,
+                               atol=1e-4 * float(ref.abs().max()))
+    c = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    gemm(Ad, Bd, c, None, M, N, K, K, K, N, 3)                             # no bias
+    np.testing.assert_allclose(c.cpu().double().numpy(), (ref - bias.double()).numpy(), rtol=1e-4,
+                               atol=1e-4 * float(ref.abs().max()))
+
+
+def test_gemm_rowmap_and_strides():
+    from semabs_amd.clip.vit import gemm
+    rng = np.random.default_rng(5)
+    n, G, T, N, K = 3, 49, 50, 768, 3072
+    A, B = _rand16(rng, n * G, K), _rand16(rng, N, K, scale=0.02)
+    pos = torch.from_numpy(rng.standard_normal((T, N)).astype(np.float32))
+    out = torch.full((n * T, N), -7.0, dtype=torch.float32, device="cuda")
+    gemm(A.cuda(), B.cuda(), out, None, n * G, N, K, K, K, N, 4, addend=pos.cuda(), rowmap=(G, T, 1))
+    ref = (A.double() @ B.double().T).view(n, G, N) + pos[1:].double()
+    got = out.cpu().view(n, T, N)
+    np.testing.assert_allclose(got[:, 1:].double().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    assert (got[:, 0] == -7.0).all()                                       # CLS rows untouched
+    # strided A rows (CLS rows of a [n, T, K] activation) and a row-sliced B
+    n, T, K, N = 5, 7, 768, 768
+    act = _rand16(rng, n * T, K)
+    W = _rand16(rng, 3 * N, K, scale=0.03)
+    c = torch.empty(n, N, dtype=torch.float32, device="cuda")
+    gemm(act.cuda(), W.cuda()[N:2 * N], c, None, n, N, K, T * K, K, N, 3)
+    ref = act.view(n, T, K)[:, 0].double() @ W[N:2 * N].double().T
+    np.testing.assert_allclose(c.cpu().double().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_rejects_bad_shapes():
+    from semabs_amd.clip.vit import gemm
+    a = torch.zeros(4, 64, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        gemm(a, a, torch.zeros(4, 100, device="cuda"), None, 4, 100, 64, 64, 64, 100, 3)      # N not multiple of 128
+
+
+# ---- LayerNorm / attention -------------------------------------------------------------------------
+@pytest.mark.parametrize("M,D", [(1, 768), (5, 512), (1000, 768), (7, 1024), (3, 256)])
+def test_layernorm(M, D):
+    from semabs_amd.clip.vit import layernorm
+    rng = np.random.default_rng(D + M)
+    x = torch.from_numpy((rng.standard_normal((M, D)) * 3 + 1).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal(D).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(D).astype(np.float32))
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    o32 = torch.empty(M, D, dtype=torch.float32, device="cuda")
+    layernorm(x.cuda(), w.cuda(), b.cuda(), o32, M, D, out_f32=True)
+    np.testing.assert_allclose(o32.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    o16 = torch.empty(M, D, dtype=torch.float16, device="cuda")
+    layernorm(x.cuda(), w.cuda(), b.cuda(), o16, M, D)
+    np.testing.assert_allclose(o16.cpu().float().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("T,H,causal", [(50, 12, 0), (197, 12, 0), (77, 8, 1), (33, 2, 0), (128, 3, 1), (20, 1, 0), (161, 2, 0)])
+def test_attention(T, H, causal):
+    from semabs_amd import _lib
+    rng = np.random.default_rng(T)
+    n, D = 3, H * 64
+    qkv = _rand16(rng, n, T, 3 * D)
+    qkv[..., :D] *= 0.4                                                    # moderately peaked softmax
+    out = torch.zeros(n, T, D, dtype=torch.float16, device="cuda")
+    _lib.call("semabs_attention", _lib.ptr(qkv.cuda()), _lib.ptr(out), None, n, T, H, 64, 3 * D, causal, _lib.stream())
+    q, k, v = (t.double().view(n, T, H, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu_(1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n, T, D)
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
+
+
+# ---- tiling front / back -----------------------------------------------------------------------------
+def _init_clip(arch, chunk=64):
+    from semabs_amd.clip import ClipWrapper
+    sd = make_clip_state_dict(arch, 0)
+    ClipWrapper.engine = None
+    ClipWrapper(arch, state_dict=sd, chunk_tiles=chunk, max_labels=4)
+    return ClipWrapper, sd
+
+
+@pytest.mark.parametrize("p", [32, 16])
+def test_tile_patches_bit_exact(p):
+    """crop -> Pillow-exact bicubic -> normalise -> im2col: equal to the oracle's fp32 tile rounded once to fp16."""
+    from semabs_amd import _lib
+    from semabs_amd.clip import ClipWrapper, plan_tiles
+    CW, _ = _init_clip("ViT-B/32" if p == 32 else "ViT-B/16")
+    H = W = 240
+    imgs = np.stack([synth_rgb(H, W, seed=3), synth_rgb(H, W, seed=4)])
+    cfg = [{"tile_size": 240, "stride": 60}, {"tile_size": 224, "stride": 8}, {"tile_size": 160, "stride": 40},
+           {"tile_size": 60, "stride": 90}, {"tile_size": 17, "stride": 111}]
+    table, _ = plan_tiles(H, W, 2, cfg)
+    sel = np.unique(np.concatenate([np.arange(0, len(table), 5), np.arange(len(table) - 3, len(table))]))
+    table = table[sel]
+    co = CW._coeffs
+    ids = np.asarray([co.id_of(int(t)) for t in table[:, 3]], np.int32)
+    xmin_d, kk_d, ks_d = co.device()
+    tiles_dev = torch.from_numpy(np.concatenate([table, ids[:, None]], 1).astype(np.int32)).cuda()
+    g = 224 // p
+    for flip in (0, 1):
+        patches = torch.zeros(len(table) * g * g, 3 * p * p, dtype=torch.float16, device="cuda")
+        _lib.call("semabs_tile_patches", _lib.ptr(torch.from_numpy(imgs).cuda()), 2, H, W, _lib.ptr(tiles_dev), len(table),
+                  _lib.ptr(xmin_d), _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(CW._lut), _lib.ptr(patches), p, flip,
+                  max(co.ksize), _lib.stream())
+        got = patches.cpu().view(len(table), g, g, 3, p, p).permute(0, 3, 1, 4, 2, 5).reshape(len(table), 3, 224, 224)
+        ref = np.stack([op.preprocess_tile(imgs[im][x:x + ts, y:y + ts]) for im, x, y, ts in table])
+        if flip:
+            ref = ref[..., ::-1]
+        assert np.array_equal(got.numpy(), ref.astype(np.float16)), f"flip={flip}"
+
+
+@pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours")])
+def test_aggregate_vs_golden(golden, tag, cfgname):
+    from semabs_amd.clip import ClipWrapper, plan_tiles, saliency_configs
+    CW, _ = _init_clip("ViT-B/32")
+    g = golden("g5_aggregate")
+    H, gg, L, aug, flip = (int(v) for v in g[f"{tag}_meta"])
+    cfg = saliency_configs[cfgname](H)
+    table, scales = plan_tiles(H, H, aug + 1, cfg["cropping_augmentations"])
+    assert np.array_equal(table, orl.tile_table(H, H, aug + 1, cfg["cropping_augmentations"]))
+    rel = [torch.from_numpy(g[f"{tag}_rel"]).cuda()]
+    if flip:
+        rel.append(torch.from_numpy(g[f"{tag}_rel_flip"]).cuda())
+    out = CW.aggregate_device(rel, scales, aug + 1, H, H).cpu().numpy()
+    ref = g[f"{tag}_maps"]
+    err = np.abs(out - ref)
+    # same adds in the same order; an fp32 last-bit difference in the bilinear sample can flip one fp16 rounding of a
+    # canvas (2^-11 of that element), nothing more
+    # canvas (<= 2^-10 of that canvas value, which after cancellation between scales can exceed 2^-10 of the result)
+    assert err.max() <= 2e-3 * np.abs(ref).max(), err.max()
+    assert (err > 1e-6 * np.abs(ref).max()).mean() < 1e-2, (err > 1e-6 * np.abs(ref).max()).mean()
+
+
+# ---- ViT + rollout ------------------------------------------------------------------------------------
+def _tiles(n, seed):
+    sizes = [120, 80, 60, 30, 97]
+    return torch.from_numpy(np.stack([op.preprocess_tile(synth_rgb(sizes[i % 5], sizes[i % 5], seed=seed + i)) for i in range(n)]))
+
+
+@pytest.mark.parametrize("arch,tag", [("ViT-B/32", "b32"), ("ViT-B/16", "b16")])
+def test_vit_gradcam(golden, arch, tag):
+    """HIP ViT + analytic rollout vs the reference's autograd result (golden) and vs the oracle.
+    Tolerance: 1% of max|rel| (fp16 GEMM operands over 12 blocks vs the fp32 CPU reference)."""
+    CW, sd = _init_clip(arch)
+    g = golden(f"g3g4_vit_{tag}")
+    tiles = _tiles(3, 7)
+    w_text = torch.from_numpy(g["w_text"]).T.contiguous().cuda()            # [L, E]
+    for pos in (True, False):
+        rel, logits, feat = CW.engine.gradcam_tiles(tiles.cuda(), w_text, pos)
+        ref = g[f"rel_pos{int(pos)}"]
+        err = np.abs(rel.cpu().numpy() - ref).max()
+        assert err <= 1e-2 * np.abs(ref).max(), (err, np.abs(ref).max())
+        print(f"{arch} pos={pos}: rel Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e}")
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=0, atol=5e-3 * np.abs(g["feat"]).max())
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-3 * np.abs(g["logits"]).max() + 0.05)
+    probs = CW.engine._workspace()["probs"][:3].cpu().numpy()
+    np.testing.assert_allclose(probs, g["probs_cls"], rtol=2e-2, atol=1e-5)
+    # flipped input = flipped tiles
+    rel_f, _, _ = CW.engine.gradcam_tiles(tiles.cuda(), w_text, True, flip=True)
+    with torch.no_grad():
+        ref_f, _ = orl.gradcam_tiles(make_clip_state_dict(arch, 0, text_tower=False), torch.flip(tiles, dims=[-1]),
+                                     torch.from_numpy(g["w_text"]), True)
+    assert np.abs(rel_f.cpu().numpy() - ref_f.numpy()).max() <= 1e-2 * ref_f.abs().max().item()
+
+
+def test_text_tower(golden):
+    CW, sd = _init_clip("ViT-B/32")
+    g = golden("g7_text")
+    for tag, nt in (("t1", 1), ("t3", 3)):
+        w = CW.text.zeroshot_weights(torch.from_numpy(g[f"{tag}_tokens"]), 4, nt).cpu().numpy()
+        ref = g[f"{tag}_weights"].T
+        assert np.abs(w - ref).max() <= 5e-3 * np.abs(ref).max(), np.abs(w - ref).max()
+
+
+def test_tokenizer_matches_reference_ids(golden):
+    from semabs_amd.clip.tokenizer import BPETokenizer, find_vocab
+    if find_vocab() is None:
+        pytest.skip("CLIP BPE merge table not available on this box (third-party data, not carried by the repo)")
+    g = golden("g7_text")
+    tk = BPETokenizer()
+    labels = ["chair", "table", "pink make up bag", "brown modern upholstered chair in faux leather with wooden legs"]
+    assert np.array_equal(tk.tokenize([DEFAULT_PROMPT.format(c) for c in labels]).numpy(), g["t1_tokens"])
+    assert np.array_equal(tk.tokenize(["Hello, World! it's 42 degrees", "a  b\tc", "don't you're we've"]).numpy(), g["misc_tokens"])
+
+
+@pytest.mark.parametrize("arch,tag,name,H", [("ViT-B/32", "b32", "chefer96", 96), ("ViT-B/32", "b32", "ours96", 96),
+                                             ("ViT-B/16", "b16", "two_scale64", 64)])
+def test_end_to_end_maps(golden, arch, tag, name, H):
+    """uint8 image -> fp32 maps, whole HIP path, vs the reference's get_clip_saliency output (golden).
+    Tolerance: 1% of max|map| (L-inf); also reports the relative error for DESIGN.md."""
+    from semabs_amd.clip import saliency_configs
+    CW, sd = _init_clip(arch)
+    g = golden(f"g6_e2e_{tag}")
+    if name == "ours96":
+        cfg = dict(saliency_configs["ours"](96), augmentations=0)
+    elif name == "chefer96":
+        cfg = saliency_configs["chefer_et_al"](96)
+    else:
+        cfg = dict(saliency_configs["chefer_et_al"](64), horizontal_flipping=True,
+                   cropping_augmentations=[{"tile_size": 64, "stride": 16}, {"tile_size": 32, "stride": 8}])
+    w_text = torch.from_numpy(g[f"{name}_text"]).contiguous().cuda()          # [L, E]
+    img = torch.from_numpy(synth_rgb(H, H, seed=42)).cuda()[None].contiguous()
+    maps = CW.relevancy_device(img, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"], cfg["positive_attn_only"])
+    ref = g[f"{name}_maps"]
+    err = np.abs(maps.cpu().numpy() - ref).max()
+    print(f"{arch}/{name}: map Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e} = {err / np.abs(ref).max():.2e}")
+    assert err <= 1e-2 * np.abs(ref).max()
+    assert err <= 1e-3                                                          # BASELINE: within 1e-3 of the reference
