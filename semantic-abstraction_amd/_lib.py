@@ -51,6 +51,15 @@ SIGNATURES = {
     "semabs_rollout": [P, P, P, P, P, I, I, I, I, I, L, L, P],
     "semabs_gather_text": [P, P, P, P, I, I, I, P],
     "semabs_text_finish": [P, P, I, I, I, P],
+    # unet.hip
+    "semabs_point_mlp": [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    "semabs_scatter_mean": [P, P, P, P, P, I, L, I, L, I, P],
+    "semabs_gn_stats": [P, P, I, L, I, I, I, P],
+    "semabs_gn_finalize": [P, P, P, P, P, I, I, I, L, F, P],
+    "semabs_conv3d": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "semabs_convtranspose3d": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P],
+    "semabs_maxpool3d": [P, P, I, I, I, I, I, I, P],
+    "semabs_decoder": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, I, I, L, L, I, P, P],
 }
 
 

@@ -209,7 +209,8 @@ class VisionRollout:
         patches = torch.empty(min(n, self.chunk) * G, Kp, dtype=torch.float16, device=self.dev)
         for t0 in range(0, n, self.chunk):
             m = min(self.chunk, n - t0)
-            _lib.call("semabs_patchify", _lib.ptr(tiles[t0:t0 + m].contiguous()), _lib.ptr(patches), m, self.p, int(flip), _lib.stream())
+            tchunk = tiles[t0:t0 + m].contiguous()
+            _lib.call("semabs_patchify", _lib.ptr(tchunk), _lib.ptr(patches), m, self.p, int(flip), _lib.stream())
             self.gradcam_patches(patches, m, w_text, positive_attn_only, rel, t0)
             ws = self._workspace()
             logits[t0:t0 + m] = ws["logits"].view(-1)[: m * L].view(m, L)       # the kernel packs rows with stride L

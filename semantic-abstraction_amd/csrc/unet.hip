@@ -1,0 +1,611 @@
+// OVSSC voxel-inference kernels: point-feature MLP, deterministic scatter-mean, GroupNorm statistics,
+// implicit-GEMM Conv3d / ConvTranspose3d / 1x1x1 conv on MFMA with GroupNorm-apply fused into the operand load and
+// ReLU / residual / skip-add / bias fused into the store, MaxPool3d, trilinear decoder + MLP.
+//
+// Replaces (reference file:line):
+//   SemAbs3D.pts_feat_extractor                   net.py:358-367, 395-404
+//   VirtualGrid.scatter_points (reduce = MEAN)    net.py:185-201  (torch_scatter.scatter)
+//   create_conv "gcr" / ExtResNetBlock            unet3d.py:20-95, 190-259   (GroupNorm -> Conv3d 3^3 no bias -> ReLU)
+//   Encoder MaxPool3d / Decoder ConvTranspose3d   unet3d.py:298-317, 428-444, 385-396 (sum joining)
+//   final_conv                                    unet3d.py:579
+//   ImplicitVolumetricDecoder                     net.py:215-256   (divide by S, x -> innermost axis quirks kept)
+//
+// Layout: activations are channels-last [B, D0, D1, D2, C] (fp16 in HBM, or fp32 in "exact" mode) so that the 8
+// input channels one MFMA lane needs are one 16-byte load and the 16 channels of a voxel are one 32-byte line.
+// MFMA: v_mfma_f32_16x16x32_f16 with the WEIGHTS as the A operand (rows = output channels) and 16 voxels as the
+// B operand columns, so each lane ends up with 4 consecutive output channels of one voxel (8-byte coalesced store).
+// K order is (tap, cin); for Cin = 16 one MFMA k-step covers two taps, otherwise one tap x 32 input channels.
+// "exact" mode splits both operands into fp16 hi + lo and issues 3 MFMAs (hi*hi + lo*hi + hi*lo): ~fp32 accuracy.
+#include "semabs_common.h"
+
+// =================================================================================================
+// Point MLP: (xyz | feat) 4 -> H -> H -> C, LeakyReLU(0.01); fp32 FMAs, weights in LDS, one thread per (label, point)
+// =================================================================================================
+template <int HID, int COUT>
+__global__ __launch_bounds__(256, 2) void k_point_mlp(const float* __restrict__ xyz, const float* __restrict__ feat,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2,
+                                                   const float* __restrict__ w3, const float* __restrict__ b3,
+                                                   float* __restrict__ out, int P, long N) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sw2 = reinterpret_cast<float*>(smem);          // [HID][HID]
+    float* sw3 = sw2 + HID * HID;                         // [COUT][HID]
+    float* sw1 = sw3 + COUT * HID;                        // [HID][4]
+    float* sb = sw1 + HID * 4;                            // b1[HID] b2[HID] b3[COUT]
+    for (int i = threadIdx.x; i < HID * HID; i += 256) sw2[i] = w2[i];
+    for (int i = threadIdx.x; i < COUT * HID; i += 256) sw3[i] = w3[i];
+    for (int i = threadIdx.x; i < HID * 4; i += 256) sw1[i] = w1[i];
+    for (int i = threadIdx.x; i < HID; i += 256) { sb[i] = b1[i]; sb[HID + i] = b2[i]; }
+    for (int i = threadIdx.x; i < COUT; i += 256) sb[2 * HID + i] = b3[i];
+    __syncthreads();
+    const long total = (long)P * N;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < total; r += (long)gridDim.x * 256) {
+        const long n = r % N;
+        const float x = xyz[n * 3], y = xyz[n * 3 + 1], z = xyz[n * 3 + 2], f = feat[r];
+        float h1[HID];
+#pragma unroll
+        for (int jb = 0; jb < HID; jb += 8) {
+#pragma unroll
+            for (int j = jb; j < jb + 8; ++j) {
+                const float4 w = *reinterpret_cast<const float4*>(sw1 + j * 4);
+                float v = sb[j] + w.x * x + w.y * y + w.z * z + w.w * f;
+                h1[j] = v > 0.f ? v : 0.01f * v;
+            }
+            __builtin_amdgcn_sched_barrier(0);     // stop the scheduler hoisting all 128 LDS reads (register blow-up)
+        }
+        float o[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) o[c] = sb[2 * HID + c];
+#pragma unroll 1
+        for (int j = 0; j < HID; ++j) {
+            float v = sb[HID + j];
+            const float4* wr = reinterpret_cast<const float4*>(sw2 + j * HID);
+#pragma unroll
+            for (int kb = 0; kb < HID / 4; kb += 8) {
+#pragma unroll
+                for (int k = kb; k < kb + 8; ++k) {
+                    const float4 w = wr[k];
+                    v += w.x * h1[4 * k] + w.y * h1[4 * k + 1] + w.z * h1[4 * k + 2] + w.w * h1[4 * k + 3];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            v = v > 0.f ? v : 0.01f * v;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) o[c] += sw3[c * HID + j] * v;
+        }
+        float4* dst = reinterpret_cast<float4*>(out + r * COUT);
+#pragma unroll
+        for (int c = 0; c < COUT / 4; ++c) dst[c] = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+    }
+}
+
+// xyz fp32 [N, 3] (shared by the P label volumes), feat fp32 [P, N] -> out fp32 [P, N, 16]
+extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, float* out, int P, long N, int hidden,
+                                int cout, void* stream) {
+    if (P == 0 || N == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(xyz && feat && w1 && b1 && w2 && b2 && w3 && b3 && out, "semabs_point_mlp: null pointer");
+    SEMABS_REQUIRE(hidden == 128 && cout == 16, "semabs_point_mlp: built for hidden 128 -> 16 channels (net.py:358-367 defaults)");
+    size_t lds = (size_t)(128 * 128 + 16 * 128 + 128 * 4 + 2 * 128 + 16) * 4;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp<128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    long total = (long)P * N;
+    int grid = semabs_cdiv(total, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((k_point_mlp<128, 16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Scatter-mean, deterministic: per-voxel linked lists (atomicExch on a head table), then the list head sorts its
+// (short) list by point index and sums in that order = the order torch_scatter's CPU scatter_add uses.
+// The voxel index is shared by all P label volumes of a scene.
+// =================================================================================================
+__global__ void k_scatter_link(const long long* __restrict__ flat, long N, int* __restrict__ head, int* __restrict__ next) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    next[p] = atomicExch(&head[flat[p]], (int)p);
+}
+
+#define SCATTER_MAXLIST 32
+template <typename TOut>
+__global__ void k_scatter_mean(const long long* __restrict__ flat, const float* __restrict__ feat, const int* __restrict__ head,
+                               const int* __restrict__ next, TOut* __restrict__ vol, int P, long N, int C, long nvox) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)P * N) return;
+    const long p = t % N; const int b = (int)(t / N);
+    const long v = flat[p];
+    if (head[v] != (int)p) return;                  // one worker per occupied voxel (and label)
+    int ids[SCATTER_MAXLIST]; int cnt = 0; int total = 0;
+    for (int q = (int)p; q >= 0; q = next[q]) {
+        if (cnt < SCATTER_MAXLIST) ids[cnt++] = q;
+        ++total;
+    }
+    if (total <= SCATTER_MAXLIST) {                 // insertion sort ascending: reference accumulation order
+        for (int i = 1; i < cnt; ++i) {
+            int k = ids[i], j = i - 1;
+            while (j >= 0 && ids[j] > k) { ids[j + 1] = ids[j]; --j; }
+            ids[j + 1] = k;
+        }
+    }
+    const float denom = (float)total;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        if (total <= SCATTER_MAXLIST) {
+            for (int i = 0; i < cnt; ++i) s += feat[((long)b * N + ids[i]) * C + c];
+        } else {                                    // very crowded voxel: list order (last-bit differences only)
+            for (int q = (int)p; q >= 0; q = next[q]) s += feat[((long)b * N + q) * C + c];
+        }
+        vol[((long)b * nvox + v) * C + c] = (TOut)(s / denom);
+    }
+}
+
+// flat int64 [N]; feat fp32 [P, N, C]; vol [P, nvox, C] (fp16 or fp32), must be zero-filled by the caller;
+// head int32 [nvox] filled with -1 by the caller; next int32 [N] scratch.
+extern "C" int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
+                                   long nvox, int vol_f32, void* stream) {
+    if (P == 0 || N == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(flat && feat && head && next && vol && C > 0 && nvox > 0, "semabs_scatter_mean: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scatter_link, dim3(semabs_cdiv(N, 256)), dim3(256), 0, s, flat, N, head, next);
+    if (vol_f32) hipLaunchKernelGGL(k_scatter_mean<float>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (float*)vol, P, N, C, nvox);
+    else hipLaunchKernelGGL(k_scatter_mean<f16>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (f16*)vol, P, N, C, nvox);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// GroupNorm statistics: per (volume, group) sum and sum of squares -> fp64 atomics; then per (volume, channel)
+// scale = rstd * gamma, shift = beta - mean * scale.
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_stats(const T* __restrict__ x, double* __restrict__ sums, long nvox, int C, int G) {
+    // grid = (blocks_per_volume, B); thread handles 8 consecutive channels of a voxel
+    const int b = blockIdx.y;
+    const int cpv = C / 8;                                  // 8-channel chunks per voxel
+    const long chunks = nvox * cpv;
+    const int cg = C / G;                                   // channels per group (>= 2)
+    const T* xb = x + (long)b * nvox * C;
+    // a thread always sees the same channel chunk when the stride is a multiple of cpv
+    long stride = (long)gridDim.x * 256;
+    stride -= stride % cpv;
+    const long start = (long)blockIdx.x * 256 + threadIdx.x;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (start < stride)
+        for (long i = start; i < chunks; i += stride) {
+            float v[8];
+            if (sizeof(T) == 2) {
+                f16x8 h = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(xb) + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            } else {
+                const float4* p4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xb) + i * 8);
+                float4 a = p4[0], c = p4[1];
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+        }
+    // block reduction through LDS float atomics, then one fp64 global atomic per (group, moment) per block
+    __shared__ float sh[2][512];
+    for (int c = threadIdx.x; c < C; c += 256) { sh[0][c] = 0.f; sh[1][c] = 0.f; }
+    __syncthreads();
+    if (start < stride) {
+        const int c0 = (int)(start % cpv) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { atomicAdd(&sh[0][c0 + j], s[j]); atomicAdd(&sh[1][c0 + j], q[j]); }
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float ss = 0.f, qq = 0.f;
+        for (int k = 0; k < cg; ++k) { ss += sh[0][g * cg + k]; qq += sh[1][g * cg + k]; }
+        atomicAdd(&sums[((long)b * G + g) * 2], (double)ss);
+        atomicAdd(&sums[((long)b * G + g) * 2 + 1], (double)qq);
+    }
+}
+
+// x [B, nvox, C] (fp16 or fp32) -> sums fp64 [B, G, 2] (zero-filled by the caller)
+extern "C" int semabs_gn_stats(const void* x, double* sums, int B, long nvox, int C, int G, int x_f32, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && sums && nvox > 0 && C % 8 == 0 && C <= 512 && G > 0 && C % G == 0, "semabs_gn_stats: bad args (C % 8 == 0, C <= 512)");
+    long chunks = nvox * (C / 8);
+    int bx = semabs_cdiv(chunks, 256 * 16); if (bx < 1) bx = 1; if (bx > 256) bx = 256;
+    // the per-thread channel chunk must be loop-invariant: block count * 256 rounded down to a multiple of C/8 inside
+    if (x_f32) hipLaunchKernelGGL(k_gn_stats<float>, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, (const float*)x, sums, nvox, C, G);
+    else hipLaunchKernelGGL(k_gn_stats<f16>, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, sums, nvox, C, G);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+__global__ void k_gn_finalize(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ scale, float* __restrict__ shift, int B, int C, int G, double count, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C, g = c / (C / G);
+    const double mean = sums[((long)b * G + g) * 2] / count;
+    double var = sums[((long)b * G + g) * 2 + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = rstd * gamma[c];
+    scale[i] = sc;
+    shift[i] = beta[c] - (float)mean * sc;
+}
+// sums fp64 [B, G, 2] -> scale/shift fp32 [B, C]; count = voxels * channels_per_group
+extern "C" int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta, float* scale, float* shift, int B, int C,
+                                  int G, long nvox, float eps, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(sums && gamma && beta && scale && shift && C % G == 0 && nvox > 0, "semabs_gn_finalize: bad args");
+    hipLaunchKernelGGL(k_gn_finalize, dim3(semabs_cdiv((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, scale,
+                       shift, B, C, G, (double)nvox * (C / G), eps);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Implicit-GEMM convolution family
+// =================================================================================================
+struct ConvArgs {
+    const void* x; void* y; const f16* w_hi; const f16* w_lo;
+    const float* gn_scale; const float* gn_shift; const float* bias; const void* resid;
+    int B, I0, I1, I2;          // input spatial dims
+    int O0, O1, O2;             // output spatial dims of the full output tensor
+    int M0, M1, M2;             // index space this launch covers (conv: = output dims; convT: = input dims per parity class)
+    int os, op0, op1, op2;      // output coordinate = m * os + op
+    int Cin, Cout, Kp;          // Kp = padded K (multiple of 32) = weight row stride
+    int ntaps; int relu;
+    signed char td0[28], td1[28], td2[28];   // tap offsets: input coordinate = m + td  (conv pad-1: -1..1; convT: 0/+1)
+};
+
+template <bool F32>
+__device__ __forceinline__ void load8(const void* base, long idx, float (&v)[8]) {
+    if (F32) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+        float4 a = p[0], b = p[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        f16x8 h = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(base) + idx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    }
+}
+
+// NW = 16-channel output blocks per wave (1, 2, 4); MW = 2 voxel blocks of 16 per wave; 4 waves per workgroup.
+template <int NW, bool F32, bool CIN16>
+__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+    constexpr int MW = 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int vl = lane & 15, kg = lane >> 4;
+    const long Mtot = (long)a.B * a.M0 * a.M1 * a.M2;
+    const long mbase = ((long)blockIdx.x * 4 + wid) * (MW * 16);
+    if (mbase >= Mtot) return;
+    const int n0 = blockIdx.y * (NW * 16);
+    const bool has_gn = a.gn_scale != nullptr;
+
+    // this lane's voxel in each m-block
+    int vb[MW], v0[MW], v1[MW], v2[MW]; bool vok[MW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        long m = mbase + mi * 16 + vl;
+        vok[mi] = m < Mtot;
+        if (!vok[mi]) m = Mtot - 1;
+        v2[mi] = (int)(m % a.M2); m /= a.M2;
+        v1[mi] = (int)(m % a.M1); m /= a.M1;
+        v0[mi] = (int)(m % a.M0); vb[mi] = (int)(m / a.M0);
+    }
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // GroupNorm affine for Cin == 16: this lane always touches channels 8*(kg&1) .. +8 of its voxel's volume
+    float gsc[MW][8], gsh[MW][8];
+    if (CIN16 && has_gn) {
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gsc[mi][j] = a.gn_scale[vb[mi] * 16 + 8 * (kg & 1) + j];
+                gsh[mi][j] = a.gn_shift[vb[mi] * 16 + 8 * (kg & 1) + j];
+            }
+    }
+    const int cin_steps = CIN16 ? 1 : a.Cin / 32;
+    const int nsteps = CIN16 ? (a.ntaps + 1) / 2 : a.ntaps * cin_steps;
+    for (int ks = 0; ks < nsteps; ++ks) {
+        int tap, c0;
+        if (CIN16) { tap = 2 * ks + (kg >> 1); c0 = 8 * (kg & 1); }
+        else { tap = ks / cin_steps; c0 = (ks - tap * cin_steps) * 32 + 8 * kg; }
+        const bool tap_ok = tap < a.ntaps;
+        const int d0 = tap_ok ? a.td0[tap] : 0, d1 = tap_ok ? a.td1[tap] : 0, d2 = tap_ok ? a.td2[tap] : 0;
+        f16x8 xh[MW], xl[MW];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const int i0 = v0[mi] + d0, i1 = v1[mi] + d1, i2 = v2[mi] + d2;
+            const bool ok = tap_ok && vok[mi] && i0 >= 0 && i0 < a.I0 && i1 >= 0 && i1 < a.I1 && i2 >= 0 && i2 < a.I2;
+            float v[8];
+            if (ok) {
+                const long idx = ((((long)vb[mi] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cin + c0;
+                load8<F32>(a.x, idx, v);
+                if (has_gn) {
+                    if (CIN16) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = v[j] * gsc[mi][j] + gsh[mi][j];
+                    } else {
+                        const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)vb[mi] * a.Cin + c0);
+                        const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)vb[mi] * a.Cin + c0);
+                        float4 s0 = ps[0], s1 = ps[1], t0 = pt[0], t1 = pt[1];
+                        v[0] = v[0] * s0.x + t0.x; v[1] = v[1] * s0.y + t0.y; v[2] = v[2] * s0.z + t0.z; v[3] = v[3] * s0.w + t0.w;
+                        v[4] = v[4] * s1.x + t1.x; v[5] = v[5] * s1.y + t1.y; v[6] = v[6] * s1.z + t1.z; v[7] = v[7] * s1.w + t1.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;      // zero padding is applied AFTER GroupNorm (pad of the normalised tensor)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xh[mi][j] = (f16)v[j];
+                if (F32) xl[mi][j] = (f16)(v[j] - (float)xh[mi][j]);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const long widx = (long)(n0 + ni * 16 + vl) * a.Kp + ks * 32 + kg * 8;
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[mi], acc[mi][ni], 0, 0, 0);
+            if (F32) {
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+#pragma unroll
+                for (int mi = 0; mi < MW; ++mi) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[mi], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: acc[mi][ni][r] = out[voxel = lane & 15 of block mi][cout = n0 + ni*16 + 4*(lane >> 4) + r]
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        if (!vok[mi]) continue;
+        const long ovox = (((long)vb[mi] * a.O0 + (v0[mi] * a.os + a.op0)) * a.O1 + (v1[mi] * a.os + a.op1)) * a.O2 + (v2[mi] * a.os + a.op2);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const int co = n0 + ni * 16 + 4 * kg;
+            float o[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            }
+            const long oidx = ovox * a.Cout + co;
+            if (a.resid) {
+                if (F32) {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx);
+                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                } else {
+                    const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oidx);
+                    o[0] += (float)r[0]; o[1] += (float)r[1]; o[2] += (float)r[2]; o[3] += (float)r[3];
+                }
+            }
+            if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+            if (F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3];
+                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
+            }
+        }
+    }
+}
+
+static int conv_launch(const ConvArgs& a, int f32, hipStream_t s) {
+    const long Mtot = (long)a.B * a.M0 * a.M1 * a.M2;
+    const int nw = a.Cout >= 64 ? 4 : (a.Cout >= 32 ? 2 : 1);
+    dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / (nw * 16)), block(256);
+    const bool c16 = a.Cin == 16;
+#define CONV_GO(NW_, F_, C_) hipLaunchKernelGGL((k_conv<NW_, F_, C_>), grid, block, 0, s, a)
+#define CONV_NW(F_, C_) { if (nw == 4) CONV_GO(4, F_, C_); else if (nw == 2) CONV_GO(2, F_, C_); else CONV_GO(1, F_, C_); }
+    if (f32) { if (c16) CONV_NW(true, true) else CONV_NW(true, false) }
+    else { if (c16) CONV_NW(false, true) else CONV_NW(false, false) }
+#undef CONV_NW
+#undef CONV_GO
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+static int conv_common_checks(const void* x, const void* w_hi, const void* w_lo, void* y, int Cin, int Cout, int f32) {
+    SEMABS_REQUIRE(x && w_hi && y, "semabs conv: null pointer");
+    SEMABS_REQUIRE(!f32 || w_lo, "semabs conv: exact (fp32) mode needs the lo half of the split weights");
+    SEMABS_REQUIRE(Cin == 16 || Cin % 32 == 0, "semabs conv: Cin must be 16 or a multiple of 32");
+    SEMABS_REQUIRE(Cout % 16 == 0 && (Cout < 64 || Cout % 64 == 0), "semabs conv: Cout must be 16, 32 or a multiple of 64");
+    return SEMABS_OK;
+}
+
+// Conv3d k (1 or 3), stride 1, padding k/2.  x [B, D0, D1, D2, Cin] -> y [B, D0, D1, D2, Cout] (fp16, or fp32 when
+// act_f32).  w_hi / w_lo fp16 [Cout, Kp], k index = ((kd*3 + kh)*3 + kw) * Cin + cin, Kp = K rounded up to 32.
+// gn_scale / gn_shift fp32 [B, Cin] (null = no GroupNorm in front); bias fp32 [Cout] or null; resid like y or null.
+extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                             const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
+                             int relu, int act_f32, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
+    if (rc) return rc;
+    SEMABS_REQUIRE(ksize == 1 || ksize == 3, "semabs_conv3d: kernel size must be 1 or 3");
+    SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_conv3d: gn_scale and gn_shift go together");
+    ConvArgs a;
+    a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = gn_scale; a.gn_shift = gn_shift;
+    a.bias = bias; a.resid = resid; a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = D0; a.O1 = D1; a.O2 = D2;
+    a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    a.ntaps = ksize * ksize * ksize;
+    a.Kp = ((a.ntaps * Cin + 31) / 32) * 32;
+    int t = 0;
+    for (int kd = 0; kd < ksize; ++kd)
+        for (int kh = 0; kh < ksize; ++kh)
+            for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
+    return conv_launch(a, act_f32, (hipStream_t)stream);
+}
+
+// ConvTranspose3d k3 s2 p1 output_padding 1 (+bias) fused with the sum-joining skip: y = skip + convT(x) + bias.
+// x [B, D0, D1, D2, Cin] -> y [B, 2 D0, 2 D1, 2 D2, Cout].  One launch per output parity class (8 of them): output
+// o = 2 m + p takes input m (kernel index 1) when p = 0, inputs m + 1 (k = 0) and m (k = 2) when p = 1.
+// w_hi / w_lo: 8 matrices, class c = p0*4 + p1*2 + p2 at offset class_off[c] (elements), each [Cout, ntaps_c * Cin]
+// with tap order (t0, t1, t2) over each dimension's candidate list above.
+extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y,
+                                      const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout,
+                                      int act_f32, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
+    if (rc) return rc;
+    SEMABS_REQUIRE(class_off && Cin % 32 == 0, "semabs_convtranspose3d: Cin must be a multiple of 32");
+    for (int cls = 0; cls < 8; ++cls) {
+        const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
+        ConvArgs a;
+        a.x = x; a.y = y; a.w_hi = (const f16*)w_hi + class_off[cls]; a.w_lo = w_lo ? (const f16*)w_lo + class_off[cls] : nullptr;
+        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip;
+        a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = 2 * D0; a.O1 = 2 * D1; a.O2 = 2 * D2;
+        a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
+        int t = 0;
+        for (int t0 = 0; t0 <= p0; ++t0)
+            for (int t1 = 0; t1 <= p1; ++t1)
+                for (int t2 = 0; t2 <= p2; ++t2, ++t) {
+                    a.td0[t] = p0 ? (t0 == 0 ? 1 : 0) : 0; a.td1[t] = p1 ? (t1 == 0 ? 1 : 0) : 0; a.td2[t] = p2 ? (t2 == 0 ? 1 : 0) : 0;
+                }
+        a.ntaps = t;
+        a.Kp = a.ntaps * Cin;
+        rc = conv_launch(a, act_f32, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// MaxPool3d(2), channels-last
+// =================================================================================================
+template <typename T>
+__global__ void k_maxpool(const T* __restrict__ x, T* __restrict__ y, int B, int O0, int O1, int O2, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C / 8;
+    const long tot = (long)B * O0 * O1 * O2 * c8;
+    if (i >= tot) return;
+    const int cc = (int)(i % c8); long v = i / c8;
+    const int o2 = (int)(v % O2); v /= O2;
+    const int o1 = (int)(v % O1); v /= O1;
+    const int o0 = (int)(v % O0); const int b = (int)(v / O0);
+    const int I1 = 2 * O1, I2 = 2 * O2;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const long idx = ((((long)b * 2 * O0 + 2 * o0 + (d >> 2)) * I1 + 2 * o1 + ((d >> 1) & 1)) * I2 + 2 * o2 + (d & 1)) * C + cc * 8;
+        float vv[8];
+        load8<sizeof(T) == 4>(x, idx, vv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], vv[j]);
+    }
+    const long oidx = ((((long)b * O0 + o0) * O1 + o1) * O2 + o2) * C + cc * 8;
+    if (sizeof(T) == 4) {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + oidx);
+        p[0] = make_float4(m[0], m[1], m[2], m[3]); p[1] = make_float4(m[4], m[5], m[6], m[7]);
+    } else {
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (f16)m[j];
+        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(y) + oidx) = h;
+    }
+}
+extern "C" int semabs_maxpool3d(const void* x, void* y, int B, int D0, int D1, int D2, int C, int act_f32, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && y && D0 % 2 == 0 && D1 % 2 == 0 && D2 % 2 == 0 && C % 8 == 0, "semabs_maxpool3d: dims must be even, C % 8 == 0");
+    const long tot = (long)B * (D0 / 2) * (D1 / 2) * (D2 / 2) * (C / 8);
+    if (act_f32) hipLaunchKernelGGL(k_maxpool<float>, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, B, D0 / 2, D1 / 2, D2 / 2, C);
+    else hipLaunchKernelGGL(k_maxpool<f16>, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, B, D0 / 2, D1 / 2, D2 / 2, C);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Implicit decoder: q = clamp((p + off) * sc, 0, S-1) / S; qn = 2q - 1; trilinear grid_sample(border, align_corners)
+// with qn.x -> innermost axis (D2), qn.y -> D1, qn.z -> D0; cat(qn); Linear(19,16) LeakyReLU Linear(16, 1).
+// =================================================================================================
+struct DecArgs {
+    float off[3], sc[3];
+    int S0, S1, S2; int concat_xyz;
+    float w1[16 * 19], b1[16], w2[16], b2;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, const float* __restrict__ query, DecArgs a, int P, long M,
+                                                 long q_stride_p, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * M) return;
+    const int b = (int)(i / M); const long m = i % M;
+    const float* qp = query + (long)b * q_stride_p + m * 3;
+    float qn[3];
+    const int S[3] = {a.S0, a.S1, a.S2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = (qp[k] + a.off[k]) * a.sc[k];
+        t = fminf(fmaxf(t, 0.f), (float)(S[k] - 1));
+        t = t / (float)S[k];
+        qn[k] = 2.0f * t - 1.0f;
+    }
+    // unnormalise (align_corners=True) and clip (border): x -> D2, y -> D1, z -> D0
+    float ix = ((qn[0] + 1.f) / 2.f) * (float)(a.S2 - 1), iy = ((qn[1] + 1.f) / 2.f) * (float)(a.S1 - 1), iz = ((qn[2] + 1.f) / 2.f) * (float)(a.S0 - 1);
+    ix = fminf(fmaxf(ix, 0.f), (float)(a.S2 - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(a.S1 - 1)); iz = fminf(fmaxf(iz, 0.f), (float)(a.S0 - 1));
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+    float f[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f[c] = 0.f;
+    const T* vb = vol + (long)b * a.S0 * a.S1 * a.S2 * 16;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int zz = z0 + (d >> 2), yy = y0 + ((d >> 1) & 1), xx = x0 + (d & 1);
+        if (zz > a.S0 - 1 || yy > a.S1 - 1 || xx > a.S2 - 1) continue;       // out-of-bounds corner contributes 0 (its weight is 0 too)
+        const float w = ((d & 1) ? wx1 : wx0) * (((d >> 1) & 1) ? wy1 : wy0) * ((d >> 2) ? wz1 : wz0);
+        const long idx = (((long)zz * a.S1 + yy) * a.S2 + xx) * 16;
+        float v[8];
+        load8<sizeof(T) == 4>(vb, idx, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] += v[c] * w;
+        load8<sizeof(T) == 4>(vb, idx + 8, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[8 + c] += v[c] * w;
+    }
+    float o = a.b2;
+    const int din = a.concat_xyz ? 19 : 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float h = a.b1[j];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h += a.w1[j * din + c] * f[c];
+        if (a.concat_xyz) h += a.w1[j * 19 + 16] * qn[0] + a.w1[j * 19 + 17] * qn[1] + a.w1[j * 19 + 18] * qn[2];
+        h = h > 0.f ? h : 0.01f * h;
+        o += a.w2[j] * h;
+    }
+    out[i] = o;
+}
+
+// vol [P, S0, S1, S2, 16] (fp16 / fp32); query fp32: label b reads query + b * q_stride_p (0 = shared by all labels),
+// M points x 3; out fp32 [P, M].  w1 [16, 19 or 16], b1 [16], w2 [1, 16], b2 [1] host pointers (fp32).
+extern "C" int semabs_decoder(const void* vol, const float* query, const float* off3, const float* sc3, const int* shape3,
+                              const float* w1, const float* b1, const float* w2, const float* b2, int concat_xyz, int P, long M,
+                              long q_stride_p, int vol_f32, float* out, void* stream) {
+    if (P == 0 || M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(vol && query && off3 && sc3 && shape3 && w1 && b1 && w2 && b2 && out, "semabs_decoder: null pointer");
+    DecArgs a;
+    for (int k = 0; k < 3; ++k) { a.off[k] = off3[k]; a.sc[k] = sc3[k]; }
+    a.S0 = shape3[0]; a.S1 = shape3[1]; a.S2 = shape3[2]; a.concat_xyz = concat_xyz;
+    const int din = concat_xyz ? 19 : 16;
+    for (int i = 0; i < 16 * din; ++i) a.w1[i] = w1[i];
+    for (int i = 0; i < 16; ++i) { a.b1[i] = b1[i]; a.w2[i] = w2[i]; }
+    a.b2 = b2[0];
+    dim3 grid(semabs_cdiv((long)P * M, 256)), block(256);
+    if (vol_f32) hipLaunchKernelGGL(k_decoder<float>, grid, block, 0, (hipStream_t)stream, (const float*)vol, query, a, P, M, q_stride_p, out);
+    else hipLaunchKernelGGL(k_decoder<f16>, grid, block, 0, (hipStream_t)stream, (const f16*)vol, query, a, P, M, q_stride_p, out);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

@@ -56,3 +56,125 @@ class VirtualGrid:
         assert idxs.shape[-1] == 3
         flat = idxs[..., 0] * (S1 * S2) + idxs[..., 1] * S2 + idxs[..., 2]
         return flat.unsqueeze(-1) if keepdim else flat
+
+
+class SemAbs3D:
+    """Drop-in (inference) for `net.SemAbs3D` (net.py:319-439): point MLP -> scatter-MEAN into the voxel grid ->
+    ResidualUNet3D -> trilinear implicit decoder, all on HIP kernels, channels-last in between.
+
+    Quirks kept on purpose: the grid is built without a reduce method so points are reduced with MEAN although the
+    constructor asserts "max" (net.py:339-344, 369, 185-199); the decoder divides by S (not S - 1) and feeds point-x
+    to grid_sample's innermost axis (net.py:221-239).
+    """
+
+    def __init__(self, voxel_shape, scene_bounds, unet_num_channels, unet_f_maps, unet_num_groups, unet_num_levels,
+                 network_inputs: List[str], use_pts_feat_extractor: bool, pts_feat_extractor_hidden_dim: int,
+                 reduce_method: str, output_dim=1, device: str = "cuda", decoder_concat_xyz_pts: bool = False,
+                 precision: str = "fp16", **kwargs):
+        from .unet3d import ResidualUNet3D
+        self.device = device
+        self.vg = VirtualGrid(scene_bounds=np.array(scene_bounds), batch_size=kwargs.get("batch_size", 1),
+                              grid_shape=tuple(voxel_shape), device=torch.device(device) if isinstance(device, str) else device)
+        self.steps = torch.zeros(1)
+        self.network_inputs = list(network_inputs)
+        self.use_pts_feat_extractor = use_pts_feat_extractor
+        self.reduce_method = reduce_method
+        self.pts_feature_dim = (("saliency" in self.network_inputs) + ("rgb" in self.network_inputs) * 3
+                                + ("patch_masks" in self.network_inputs))
+        if not (use_pts_feat_extractor and self.pts_feature_dim == 1 and "tsdf" not in self.network_inputs and output_dim == 1):
+            raise NotImplementedError("the HIP path covers the released OVSSC configuration: network_inputs=['saliency'], "
+                                      "use_pts_feat_extractor=True, output_dim=1")
+        assert self.reduce_method == "max"          # asserted by the reference too (and then ignored)
+        self.hidden = pts_feat_extractor_hidden_dim
+        self.C = unet_num_channels
+        self.concat_xyz = bool(decoder_concat_xyz_pts)
+        self.precision = precision
+        self.vol_feature_extractor = ResidualUNet3D(in_channels=unet_num_channels, out_channels=unet_num_channels,
+                                                    f_maps=unet_f_maps, num_groups=unet_num_groups,
+                                                    num_levels=unet_num_levels, precision=precision)
+        self._sd = {}
+        self._w = None
+        self.features_cl = None
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict: bool = True):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}     # DDP checkpoints
+        dev = _lib.require_gpu()
+        f = lambda k: sd[k].float().to(dev).contiguous()
+        self._w = {k: f(f"pts_feat_extractor.{i}.{n}") for k, (i, n) in
+                   dict(w1=(0, "weight"), b1=(0, "bias"), w2=(2, "weight"), b2=(2, "bias"), w3=(4, "weight"), b3=(4, "bias")).items()}
+        self._dec = {k: np.ascontiguousarray(sd[f"visual_sampler.mlp.{i}.{n}"].float().cpu().numpy().reshape(-1)) for k, (i, n) in
+                     dict(w1=(0, "weight"), b1=(0, "bias"), w2=(2, "weight"), b2=(2, "bias")).items()}
+        self.vol_feature_extractor.load_state_dict(sd, strict=strict, prefix="vol_feature_extractor.")
+        if "steps" in sd:
+            self.steps = sd["steps"].clone()
+        self._sd = {k: v.detach().clone() for k, v in sd.items()}
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- stages ------------------------------------------------------------------------------------
+    def feature_volume(self, xyz: torch.Tensor, feat: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
+        """xyz fp32 [N, 3], feat fp32 [P, N] (one scene, P label volumes) -> UNet features channels-last [P, S, S, S, C]."""
+        dev = _lib.require_gpu()
+        P, N = int(feat.shape[0]), int(feat.shape[1])
+        S0, S1, S2 = self.vg.grid_shape
+        nvox = S0 * S1 * S2
+        st = _lib.stream()
+        w = self._w
+        pf = torch.empty(P, N, self.C, dtype=torch.float32, device=dev)
+        xyz, feat = xyz.contiguous(), feat.contiguous()      # held in locals: the kernels read these buffers
+        _lib.call("semabs_point_mlp", _lib.ptr(xyz), _lib.ptr(feat), _lib.ptr(w["w1"]), _lib.ptr(w["b1"]),
+                  _lib.ptr(w["w2"]), _lib.ptr(w["b2"]), _lib.ptr(w["w3"]), _lib.ptr(w["b3"]), _lib.ptr(pf), P, N, self.hidden, self.C, st)
+        flat = self.vg.flat_idxs(xyz)
+        unet = self.vol_feature_extractor
+        vol = torch.zeros(P, S0, S1, S2, self.C, dtype=unet.act_dtype, device=dev)
+        head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
+        nxt = torch.empty(N, dtype=torch.int32, device=dev)
+        _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
+                  unet.f32, st)
+        if taps is not None:
+            taps["scatter"] = vol
+            taps["point_feat"] = pf
+        return unet.forward_cl(vol, taps=taps)
+
+    def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False) -> torch.Tensor:
+        """features [P, S, S, S, C]; query fp32 [P, M, 3] (or [M, 3] with shared=True) -> logits fp32 [P, M]."""
+        dev = _lib.require_gpu()
+        P = int(features_cl.shape[0])
+        M = int(query.shape[-2])
+        out = torch.empty(P, M, dtype=torch.float32, device=dev)
+        d = self._dec
+        fp = lambda a: a.ctypes.data
+        query = query.contiguous()
+        _lib.call("semabs_decoder", _lib.ptr(features_cl), _lib.ptr(query), _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales),
+                  _lib.iarr(self.vg.grid_shape), fp(d["w1"]), fp(d["b1"]), fp(d["w2"]), fp(d["b2"]), int(self.concat_xyz), P, M,
+                  0 if shared else M * 3, self.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
+        return out
+
+    # ---- reference surface ---------------------------------------------------------------------------
+    def forward(self, input_xyz_pts, input_feature_pts, tsdf_vol, output_xyz_pts, **kwargs):
+        dev = _lib.require_gpu()
+        B, P, N = input_feature_pts.shape[:3]
+        M = output_xyz_pts.shape[2]
+        outs, feats = [], []
+        for b in range(B):
+            f = self.feature_volume(input_xyz_pts[b].to(dev, torch.float32), input_feature_pts[b].to(dev, torch.float32).reshape(P, N))
+            feats.append(f)
+            outs.append(self.decode(f, output_xyz_pts[b].to(dev, torch.float32)))
+        self.features_cl = torch.cat(feats, dim=0)
+        return torch.stack(outs, dim=0).view(B, P, M)
+
+    __call__ = forward
+
+    @property
+    def visual_volumetric_features(self):
+        """[B*P, C, S, S, S] fp32 like the reference's cached attribute (net.py:425-427)."""
+        return None if self.features_cl is None else self.features_cl.permute(0, 4, 1, 2, 3).float()

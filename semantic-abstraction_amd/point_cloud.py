@@ -35,7 +35,8 @@ def pointcloud_device(depth: torch.Tensor, cam_intr, cam_pose, bounds=None):
     xyz = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
     mask = torch.empty(H * W, dtype=torch.uint8, device=dev) if bounds is not None else None
     prm = _params(cam_intr, cam_pose, bounds, dev)
-    _lib.call("semabs_pointcloud", _lib.ptr(depth.contiguous()), H, W, _lib.ptr(prm), int(cam_pose is not None),
+    depth = depth.contiguous()
+    _lib.call("semabs_pointcloud", _lib.ptr(depth), H, W, _lib.ptr(prm), int(cam_pose is not None),
               _lib.ptr(xyz), _lib.ptr(mask), _lib.stream())
     return xyz, mask
 

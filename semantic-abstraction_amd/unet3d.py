@@ -1,0 +1,199 @@
+"""Drop-in for the reference's `unet3d.ResidualUNet3D` (unet3d.py:658-689 -> Abstract3DUNet :481-621), inference only,
+computed by the HIP implicit-GEMM kernels in csrc/unet.hip.
+
+Same constructor arguments, same `state_dict` key names (`encoders.{i}.basic_module.conv{1,2,3}.{groupnorm,conv}.*`,
+`decoders.{i}.upsampling.upsample.*`, `final_conv.*`), `forward(x[N, C, D, H, W]) -> [N, out, D, H, W]`.
+Internally activations are channels-last [N, D, H, W, C]; `forward_cl` takes / returns that layout directly
+(what `SemAbs3D` uses, so nothing is transposed on the hot path).
+
+precision = "fp16": fp16 activations in HBM, one fp16 MFMA per k-step, fp32 accumulate, fp64 GroupNorm statistics.
+precision = "exact": fp32 activations, operands split into fp16 hi + lo (3 MFMAs) - ~fp32 accuracy, used to show
+that the residual L-inf of the fp16 mode is rounding, not a defect.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def number_of_features_per_level(init_channel_number, num_levels):
+    return [init_channel_number * 2 ** k for k in range(num_levels)]
+
+
+def _split16(w: torch.Tensor, dev):
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.to(dev).contiguous(), lo.to(dev).contiguous()
+
+
+class _Conv:
+    """GroupNorm (optional) + Conv3d k^3 pad k//2, weights re-laid out as [Cout, (kd, kh, kw, cin)] padded to 32."""
+
+    def __init__(self, weight: torch.Tensor, gn_w, gn_b, bias, groups: int, dev):
+        cout, cin, k = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
+        w = weight.float().permute(0, 2, 3, 4, 1).reshape(cout, k * k * k * cin)
+        kp = (w.shape[1] + 31) // 32 * 32
+        if kp != w.shape[1]:
+            w = torch.cat([w, torch.zeros(cout, kp - w.shape[1])], dim=1)
+        self.w_hi, self.w_lo = _split16(w.contiguous(), dev)
+        self.cin, self.cout, self.k = cin, cout, k
+        self.gn_w = None if gn_w is None else gn_w.float().to(dev).contiguous()
+        self.gn_b = None if gn_b is None else gn_b.float().to(dev).contiguous()
+        self.bias = None if bias is None else bias.float().to(dev).contiguous()
+        self.groups = groups if cin >= groups else 1
+
+
+class _ConvT:
+    """ConvTranspose3d k3 s2 p1 (+ output_padding 1 via output_size): 8 parity-class weight matrices."""
+
+    def __init__(self, weight: torch.Tensor, bias, dev):
+        cin, cout = int(weight.shape[0]), int(weight.shape[1])
+        w = weight.float()
+        mats, offs, off = [], [], 0
+        for cls in range(8):
+            p = (cls >> 2, (cls >> 1) & 1, cls & 1)
+            cols = []
+            for t0 in range(p[0] + 1):
+                for t1 in range(p[1] + 1):
+                    for t2 in range(p[2] + 1):
+                        k = [1 if pp == 0 else (0 if t == 0 else 2) for pp, t in zip(p, (t0, t1, t2))]
+                        cols.append(w[:, :, k[0], k[1], k[2]].t())          # [Cout, Cin]
+            m = torch.cat(cols, dim=1).contiguous()                            # [Cout, ntaps * Cin]
+            mats.append(m.reshape(-1))
+            offs.append(off)
+            off += m.numel()
+        flat = torch.cat(mats)
+        self.w_hi, self.w_lo = _split16(flat, dev)
+        self.class_off = (C.c_long * 8)(*offs)
+        self.bias = bias.float().to(dev).contiguous()
+        self.cin, self.cout = cin, cout
+
+
+class ResidualUNet3D:
+    def __init__(self, in_channels, out_channels, f_maps=64, num_groups=8, num_levels=5, final_sigmoid=False,
+                 layer_order="gcr", is_segmentation=False, precision: str = "fp16", **kwargs):
+        assert layer_order == "gcr" and not is_segmentation, "the path uses order 'gcr' without a final activation"
+        assert precision in ("fp16", "exact")
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
+        self.f_maps = list(f_maps)
+        self.in_channels, self.out_channels, self.num_groups = in_channels, out_channels, num_groups
+        self.precision = precision
+        self.f32 = int(precision == "exact")
+        self.act_dtype = torch.float32 if self.f32 else torch.float16
+        self._sd: Dict[str, torch.Tensor] = {}
+        self.dev = None
+        self.enc: List[List[_Conv]] = []
+        self.dec: List = []
+        self.final = None
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def expected_keys(self):
+        from .weights import unet_layer_plan
+        keys = []
+        for pre, kind, cin, cout in unet_layer_plan(self.in_channels, self.out_channels, self.f_maps[0], len(self.f_maps)):
+            if kind in ("gcr", "gc"):
+                keys += [pre + "groupnorm.weight", pre + "groupnorm.bias", pre + "conv.weight"]
+            else:
+                keys += [pre + "weight", pre + "bias"]
+        return keys
+
+    def load_state_dict(self, sd, strict: bool = True, prefix: str = ""):
+        dev = self.dev = _lib.require_gpu()
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        missing = [k for k in self.expected_keys() if k not in sd]
+        if missing and strict:
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
+        self._sd = {k: sd[k].detach().clone() for k in self.expected_keys() if k in sd}
+        G = self.num_groups
+
+        def block(pre):
+            return [_Conv(sd[pre + f"conv{j}.conv.weight"], sd[pre + f"conv{j}.groupnorm.weight"],
+                          sd[pre + f"conv{j}.groupnorm.bias"], None, G, dev) for j in (1, 2, 3)]
+
+        L = len(self.f_maps)
+        self.enc = [block(f"encoders.{i}.basic_module.") for i in range(L)]
+        self.dec = [(_ConvT(sd[f"decoders.{i}.upsampling.upsample.weight"], sd[f"decoders.{i}.upsampling.upsample.bias"], dev),
+                     block(f"decoders.{i}.basic_module.")) for i in range(L - 1)]
+        self.final = _Conv(sd["final_conv.weight"], None, None, sd["final_conv.bias"], G, dev)
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def eval(self):
+        return self
+
+    # ---- kernels -----------------------------------------------------------------------------------
+    def _gn(self, x, conv: _Conv):
+        B, nvox, Cc = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], x.shape[4]
+        G = conv.groups
+        sums = torch.zeros(B, G, 2, dtype=torch.float64, device=self.dev)
+        st = _lib.stream()
+        _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, self.f32, st)
+        scale = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
+        shift = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_gn_finalize", _lib.ptr(sums), _lib.ptr(conv.gn_w), _lib.ptr(conv.gn_b), _lib.ptr(scale), _lib.ptr(shift),
+                  B, Cc, G, nvox, 1e-5, st)
+        return scale, shift
+
+    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None):
+        B, D0, D1, D2, _ = x.shape
+        y = torch.empty(B, D0, D1, D2, conv.cout, dtype=self.act_dtype, device=self.dev)
+        scale, shift = self._gn(x, conv) if gn else (None, None)
+        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
+                  _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32, _lib.stream())
+        return y
+
+    def _block(self, x, convs):
+        out1 = self._conv(x, convs[0], relu=True)
+        out2 = self._conv(out1, convs[1], relu=True)
+        return self._conv(out2, convs[2], relu=True, resid=out1)          # conv3 (no ReLU) + residual, then ReLU
+
+    def _pool(self, x):
+        B, D0, D1, D2, Cc = x.shape
+        y = torch.empty(B, D0 // 2, D1 // 2, D2 // 2, Cc, dtype=self.act_dtype, device=self.dev)
+        _lib.call("semabs_maxpool3d", _lib.ptr(x), _lib.ptr(y), B, D0, D1, D2, Cc, self.f32, _lib.stream())
+        return y
+
+    def _up(self, x, skip, ct: _ConvT):
+        B, D0, D1, D2, _ = x.shape
+        assert tuple(skip.shape) == (B, 2 * D0, 2 * D1, 2 * D2, ct.cout)
+        y = torch.empty_like(skip)
+        _lib.call("semabs_convtranspose3d", _lib.ptr(x), _lib.ptr(ct.w_hi), _lib.ptr(ct.w_lo), ct.class_off, _lib.ptr(y),
+                  _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32, _lib.stream())
+        return y
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward_cl(self, x: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
+        """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]."""
+        assert self.final is not None, "load_state_dict first"
+        assert x.dtype == self.act_dtype and x.is_contiguous()
+        feats = []
+        for i, convs in enumerate(self.enc):
+            if i > 0:
+                x = self._pool(x)
+            x = self._block(x, convs)
+            if taps is not None:
+                taps[f"enc{i}"] = x
+            feats.insert(0, x)
+        for i, (skip, (ct, convs)) in enumerate(zip(feats[1:], self.dec)):
+            x = self._up(x, skip, ct)
+            x = self._block(x, convs)
+            if taps is not None:
+                taps[f"dec{i}"] = x
+        return self._conv(x, self.final, relu=False, gn=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """NCDHW fp32 in / out like the reference (two layout copies around the channels-last core)."""
+        dev = _lib.require_gpu()
+        xc = x.to(dev).permute(0, 2, 3, 4, 1).contiguous().to(self.act_dtype)
+        y = self.forward_cl(xc)
+        return y.permute(0, 4, 1, 2, 3).contiguous().float()
+
+    __call__ = forward

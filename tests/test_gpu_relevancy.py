@@ -103,7 +103,8 @@ def test_attention(T, H, causal):
     qkv = _rand16(rng, n, T, 3 * D)
     qkv[..., :D] *= 0.4                                                    # moderately peaked softmax
     out = torch.zeros(n, T, D, dtype=torch.float16, device="cuda")
-    _lib.call("semabs_attention", _lib.ptr(qkv.cuda()), _lib.ptr(out), None, n, T, H, 64, 3 * D, causal, _lib.stream())
+    qkv_d = qkv.cuda()
+    _lib.call("semabs_attention", _lib.ptr(qkv_d), _lib.ptr(out), None, n, T, H, 64, 3 * D, causal, _lib.stream())
     q, k, v = (t.double().view(n, T, H, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
     s = q @ k.transpose(-1, -2)
     if causal:
@@ -139,9 +140,10 @@ def test_tile_patches_bit_exact(p):
     xmin_d, kk_d, ks_d = co.device()
     tiles_dev = torch.from_numpy(np.concatenate([table, ids[:, None]], 1).astype(np.int32)).cuda()
     g = 224 // p
+    imgs_d = torch.from_numpy(imgs).cuda()
     for flip in (0, 1):
         patches = torch.zeros(len(table) * g * g, 3 * p * p, dtype=torch.float16, device="cuda")
-        _lib.call("semabs_tile_patches", _lib.ptr(torch.from_numpy(imgs).cuda()), 2, H, W, _lib.ptr(tiles_dev), len(table),
+        _lib.call("semabs_tile_patches", _lib.ptr(imgs_d), 2, H, W, _lib.ptr(tiles_dev), len(table),
                   _lib.ptr(xmin_d), _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(CW._lut), _lib.ptr(patches), p, flip,
                   max(co.ksize), _lib.stream())
         got = patches.cpu().view(len(table), g, g, 3, p, p).permute(0, 3, 1, 4, 2, 5).reshape(len(table), 3, 224, 224)

@@ -1,0 +1,193 @@
+"""GPU parity for the OVSSC voxel-inference half: HIP kernels (C ABI) vs plain torch fp32 references of the same
+ops, then SemAbs3D end to end vs the oracle and the golden vectors captured from the reference.
+fp16 mode: fp16 activations / operands, fp32 accumulate (tolerances stated per test); exact mode: fp32 activations with
+hi/lo-split operands, which must match the fp32 reference to ~1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import semabs_amd  # noqa: F401
+from oracle import semabs3d as os3
+from semabs_amd.weights import make_semabs3d_state_dict
+
+pytestmark = pytest.mark.gpu
+SCENE_BOUNDS = [[-1.0, -1.0, -0.1], [1.0, 1.0, 1.9]]
+
+
+def _cl(x):      # NCDHW -> channels-last
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _unet(precision, sd=None, levels=6):
+    from semabs_amd.unet3d import ResidualUNet3D
+    u = ResidualUNet3D(16, 16, f_maps=16, num_groups=8, num_levels=levels, precision=precision)
+    u.load_state_dict(sd if sd is not None else make_semabs3d_state_dict(seed=3, unet_num_levels=levels), prefix="vol_feature_extractor.")
+    return u
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
+@pytest.mark.parametrize("cin,cout,S,B", [(16, 16, 12, 2), (16, 32, 8, 1), (32, 32, 8, 3), (64, 128, 4, 2), (512, 512, 2, 2), (32, 64, 6, 1)])
+def test_conv3d_gn_relu_resid(precision, tol, cin, cout, S, B):
+    """GroupNorm -> Conv3d 3^3 -> (+residual) -> ReLU against torch fp32."""
+    from semabs_amd import _lib
+    from semabs_amd.unet3d import _Conv
+    rng = np.random.default_rng(cin + cout)
+    x = torch.from_numpy(rng.standard_normal((B, cin, S, S + 1, S + 2)).astype(np.float32)) * 2 + 0.5
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+    gw = torch.from_numpy((1 + 0.2 * rng.standard_normal(cin)).astype(np.float32))
+    gb = torch.from_numpy((0.2 * rng.standard_normal(cin)).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((B, cout, S, S + 1, S + 2)).astype(np.float32))
+    G = 8 if cin >= 8 else 1
+    ref = F.relu(F.conv3d(F.group_norm(x, G, gw, gb, 1e-5), w, None, padding=1) + res)
+    u = _unet(precision)
+    conv = _Conv(w, gw, gb, None, 8, u.dev)
+    xd, rd = _cl(x).cuda().to(u.act_dtype), _cl(res).cuda().to(u.act_dtype)
+    if precision == "fp16":       # compare against the reference evaluated on the same rounded inputs
+        ref = F.relu(F.conv3d(F.group_norm(xd.float().cpu().permute(0, 4, 1, 2, 3), G, gw, gb, 1e-5), w, None, padding=1)
+                     + rd.float().cpu().permute(0, 4, 1, 2, 3))
+    y = u._conv(xd, conv, relu=True, resid=rd)
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
+@pytest.mark.parametrize("cin,cout,S,B", [(32, 16, 6, 2), (64, 32, 4, 1), (512, 256, 2, 2), (128, 64, 3, 1)])
+def test_convtranspose3d_skip(precision, tol, cin, cout, S, B):
+    from semabs_amd.unet3d import _ConvT
+    rng = np.random.default_rng(cin)
+    x = torch.from_numpy(rng.standard_normal((B, cin, S, S + 1, S + 2)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cin, cout, 3, 3, 3)) / np.sqrt(27 * cin / 8)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    skip = torch.from_numpy(rng.standard_normal((B, cout, 2 * S, 2 * S + 2, 2 * S + 4)).astype(np.float32))
+    u = _unet(precision)
+    xd, sd_ = _cl(x).cuda().to(u.act_dtype), _cl(skip).cuda().to(u.act_dtype)
+    ref = skip_r = sd_.float().cpu().permute(0, 4, 1, 2, 3) + F.conv_transpose3d(xd.float().cpu().permute(0, 4, 1, 2, 3), w, b, stride=2,
+                                                                                 padding=1, output_padding=1)
+    y = u._up(xd, sd_, _ConvT(w, b, u.dev))
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["exact", "fp16"])
+def test_maxpool_and_1x1(precision):
+    from semabs_amd.unet3d import _Conv
+    rng = np.random.default_rng(1)
+    u = _unet(precision)
+    x = torch.from_numpy(rng.standard_normal((2, 32, 6, 4, 8)).astype(np.float32))
+    xd = _cl(x).cuda().to(u.act_dtype)
+    got = u._pool(xd).float().cpu().permute(0, 4, 1, 2, 3)
+    assert torch.equal(got, F.max_pool3d(xd.float().cpu().permute(0, 4, 1, 2, 3), 2))
+    x = torch.from_numpy(rng.standard_normal((2, 16, 5, 4, 3)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((16, 16, 1, 1, 1)).astype(np.float32) * 0.3)
+    b = torch.from_numpy(rng.standard_normal(16).astype(np.float32))
+    xd = _cl(x).cuda().to(u.act_dtype)
+    y = u._conv(xd, _Conv(w, None, None, b, 8, u.dev), relu=False, gn=False).float().cpu().permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xd.float().cpu().permute(0, 4, 1, 2, 3), w, b)
+    assert (y - ref).abs().max().item() <= (2e-5 if precision == "exact" else 3e-3) * ref.abs().max().item()
+
+
+def semabs_inputs(S, N, M, P, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    xyz = (lo + (hi - lo) * rng.random((1, N, 3))).astype(np.float32)
+    xyz[0, : N // 8] = xyz[0, N // 8: 2 * (N // 8)] + np.float32(1e-3)
+    feat = (rng.standard_normal((1, P, N, 1)) * 0.5).astype(np.float32)
+    q = (lo - 0.05 + (hi - lo + 0.1) * rng.random((1, P, M, 3))).astype(np.float32)
+    return xyz, feat, q
+
+
+def _model(S, precision):
+    from semabs_amd.net import SemAbs3D
+    m = SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+                 unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128,
+                 reduce_method="max", output_dim=1, device="cuda", decoder_concat_xyz_pts=True, batch_size=1, precision=precision)
+    m.load_state_dict(make_semabs3d_state_dict(seed=3))
+    return m
+
+
+@pytest.mark.parametrize("precision,tol_feat,tol_out", [("exact", 2e-4, 2e-4), ("fp16", 2e-2, 1e-2)])
+def test_semabs3d_forward_vs_golden(golden, precision, tol_feat, tol_out):
+    """SemAbs3D.forward at 32^3 (point MLP -> scatter-mean -> 6-level UNet -> decoder) vs the reference's outputs."""
+    g = golden("g9_semabs3d")
+    S, N, M, P, seed, wseed = (int(v) for v in g["meta"])
+    m = _model(S, precision)
+    xyz, feat, q = semabs_inputs(S, N, M, P, seed)
+    taps = {}
+    f = m.feature_volume(torch.from_numpy(xyz[0]).cuda(), torch.from_numpy(feat[0, :, :, 0]).cuda(), taps=taps)
+    sc = taps["scatter"].float().cpu().permute(0, 4, 1, 2, 3)
+    assert (sc[:, 0] != 0).sum().item() == g["scatter_nonzero"]              # same occupied voxels
+    np.testing.assert_allclose(sc.numpy()[:, :, ::3, ::3, ::3], g["scatter_sub"], rtol=2e-3 if precision == "fp16" else 1e-5,
+                               atol=2e-3 if precision == "fp16" else 1e-5)
+    feats = f.float().cpu().permute(0, 4, 1, 2, 3).numpy()
+    ref = g["unet_sub"]
+    err = np.abs(feats[:, :, ::3, ::3, ::3] - ref).max()
+    print(f"{precision}: UNet feature Linf {err:.3e} (max|ref| {np.abs(ref).max():.3f})")
+    assert err <= tol_feat * np.abs(ref).max()
+    out = m.forward(torch.from_numpy(xyz), torch.from_numpy(feat), None, torch.from_numpy(q)).cpu().numpy()
+    err = np.abs(out - g["out"]).max()
+    print(f"{precision}: logit Linf {err:.3e} (max|ref| {np.abs(g['out']).max():.3f})")
+    assert err <= tol_out * max(1.0, np.abs(g["out"]).max())
+    vvf = m.visual_volumetric_features
+    assert tuple(vvf.shape) == (P, 16, S, S, S)
+
+
+def test_scatter_mean_bit_exact_and_decoder():
+    """scatter-mean is deterministic and sums in point order: bit-exact vs the oracle given the same point features;
+    decoder (trilinear + MLP) vs the oracle in fp32."""
+    from semabs_amd import _lib
+    S, N, M, P = 16, 5000, 3000, 3
+    m = _model(S, "exact")
+    rng = np.random.default_rng(2)
+    xyz, _, q = semabs_inputs(S, N, M, P, 9)
+    pf = torch.from_numpy(rng.standard_normal((P, N, 16)).astype(np.float32))
+    ref = os3.scatter_mean(torch.from_numpy(xyz).repeat(P, 1, 1), pf, SCENE_BOUNDS, (S, S, S))
+    xyzd = torch.from_numpy(xyz[0]).cuda()
+    flat = m.vg.flat_idxs(xyzd)
+    vol = torch.zeros(P, S, S, S, 16, dtype=torch.float32, device="cuda")
+    head = torch.full((S ** 3,), -1, dtype=torch.int32, device="cuda")
+    nxt = torch.empty(N, dtype=torch.int32, device="cuda")
+    pf_d = pf.cuda()
+    _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf_d), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, 16, S ** 3, 1,
+              _lib.stream())
+    assert torch.equal(vol.cpu().permute(0, 4, 1, 2, 3), ref)
+    sd = make_semabs3d_state_dict(seed=3)
+    feats = torch.from_numpy(rng.standard_normal((P, 16, S, S, S)).astype(np.float32))
+    refd = os3.decoder(sd, feats, torch.from_numpy(q[0]), SCENE_BOUNDS, (S, S, S), True)[..., 0]
+    got = m.decode(_cl(feats).cuda(), torch.from_numpy(q[0]).cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), refd.numpy(), rtol=1e-4, atol=1e-5)
+    got_s = m.decode(_cl(feats).cuda(), torch.from_numpy(q[0, 0]).cuda(), shared=True)
+    refs = os3.decoder(sd, feats, torch.from_numpy(q[0, :1]).repeat(P, 1, 1), SCENE_BOUNDS, (S, S, S), True)[..., 0]
+    np.testing.assert_allclose(got_s.cpu().numpy(), refs.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_point_mlp():
+    from semabs_amd import _lib
+    m = _model(16, "fp16")
+    rng = np.random.default_rng(4)
+    N, P = 1000, 3
+    xyz = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32))
+    feat = torch.from_numpy(rng.standard_normal((P, N)).astype(np.float32))
+    sd = make_semabs3d_state_dict(seed=3)
+    ref = os3.point_mlp(sd, xyz[None].repeat(P, 1, 1), feat[..., None])
+    pf = torch.empty(P, N, 16, dtype=torch.float32, device="cuda")
+    w = m._w
+    xyz_d, feat_d = xyz.cuda(), feat.cuda()          # keep the device buffers alive across the launch
+    _lib.call("semabs_point_mlp", _lib.ptr(xyz_d), _lib.ptr(feat_d), _lib.ptr(w["w1"]), _lib.ptr(w["b1"]), _lib.ptr(w["w2"]),
+              _lib.ptr(w["b2"]), _lib.ptr(w["w3"]), _lib.ptr(w["b3"]), _lib.ptr(pf), P, N, 128, 16, _lib.stream())
+    np.testing.assert_allclose(pf.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 3e-4), ("fp16", 3e-2)])
+def test_unet128_vs_golden(golden, precision, tol):
+    """One 128^3 ResidualUNet3D forward (config 3 shape) against sampled voxels of the reference's output."""
+    g = golden("g10_unet128")
+    u = _unet(precision, make_semabs3d_state_dict(seed=int(g["meta"][1])))
+    rng = np.random.default_rng(int(g["meta"][0]))
+    x = np.zeros((1, 16, 128, 128, 128), np.float32)
+    occ = rng.random((128, 128, 128)) < 0.03
+    x[0][:, occ] = rng.standard_normal((16, int(occ.sum()))).astype(np.float32)
+    y = u.forward(torch.from_numpy(x)).cpu().numpy()
+    err = np.abs(y.reshape(-1)[g["si"]] - g["y_s"]).max()
+    print(f"{precision}: unet128 Linf {err:.3e} (max|ref| {np.abs(g['y_s']).max():.3f})")
+    assert err <= tol * np.abs(g["y_s"]).max()
