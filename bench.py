@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py — scenes/s of the relevancy -> fusion -> OVSSC hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE synthetic scene end to end on one GPU: 480x480 RGB-D, 16 labels, ViT-B/16, the "ours" saliency config
+(204 tiles x 6 images (5 colour-jitter copies) x 2 flips = 2 448 ViT forwards), analytic attention x gradient rollout,
+multi-scale aggregation, depth -> points -> voxel indices, point MLP, scatter-mean, 6-level ResidualUNet3D on 16 label
+volumes of 128^3, implicit decoder at the 128^3 voxel centres, TSDF integration and the OVSSC post-mask.  Inputs
+(uint8 images, fp32 depth, weights) are resident in HBM before the timed region.  Ranks process disjoint scenes
+(scene sharding, no data-path collective) -> weak scaling; value = all scenes / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the fp16 MFMA GEMM, timed
+live with HIP events on its launch stream) and `cpu_baseline` (the oracle on the host cores, bounded sample, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import semabs_amd  # noqa: E402,F401
+
+ARCH = "ViT-B/16"
+N_LABELS = 16
+IMG = 480
+VOXEL = 128
+FLOPS_PER_TILE = {"ViT-B/16": 35.127e9, "ViT-B/32": 8.818e9}      # SURVEY.md §8d per-tile forward count
+PEAK_F16_TFLOPS = 2500.0                                          # dense MFMA peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(arch, n_labels, tiles_sample=16):
+    """Oracle ("port" of the reference's CPU path) timed on this host: bounded sample, scaled to one scene."""
+    from oracle import relevancy as orl
+    from oracle import semabs3d as os3
+    from semabs_amd.synth import synth_rgb
+    from semabs_amd.weights import make_clip_state_dict, make_semabs3d_state_dict
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    sd = make_clip_state_dict(arch, 0, text_tower=False)
+    nsd = make_semabs3d_state_dict(seed=3)
+    rng = np.random.default_rng(0)
+    w = torch.from_numpy(rng.standard_normal((512, n_labels)).astype(np.float32))
+    img = synth_rgb(IMG, IMG, 1)
+    cfg = orl.saliency_configs["ours"](IMG)
+    table = orl.tile_table(IMG, IMG, 1, cfg["cropping_augmentations"])
+    pick = table[np.linspace(0, len(table) - 1, tiles_sample).astype(int)]
+    t0 = time.time()
+    tiles = orl.make_tile_images([img], pick)
+    t_pre = time.time() - t0
+    with torch.no_grad():
+        orl.gradcam_tiles(sd, tiles[:2], w, True)                                   # warm-up
+        t0 = time.time()
+        orl.gradcam_tiles(sd, tiles, w, True)
+        t_vit = time.time() - t0
+        x = torch.zeros(1, 16, VOXEL, VOXEL, VOXEL)
+        x[0, :, ::5, ::7, ::3] = 1.0
+        t0 = time.time()
+        os3.unet_forward(nsd, x, 6)
+        t_unet = time.time() - t0
+    n_fwd = 2448
+    scene_s = (t_pre / tiles_sample) * 1224 + (t_vit / tiles_sample) * n_fwd + t_unet * n_labels
+    return {"value": 1.0 / scene_s, "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": f"{tiles_sample} of 2448 tile forwards ({arch}, {n_labels} labels, analytic rollout) + 1 of {n_labels} "
+                      f"128^3 UNet volumes, torch-CPU fp32 oracle, scaled to one scene "
+                      f"(pre {t_pre:.2f}s, vit {t_vit:.2f}s, unet {t_unet:.2f}s); aggregation/decoder not included",
+            "scene_seconds_estimate": scene_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arch", default=ARCH)
+    ap.add_argument("--precision", default="exact", choices=["exact", "fp16"], help="UNet arithmetic (see DESIGN.md)")
+    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from semabs_amd.clip import vit as vitmod
+    from semabs_amd.scene import build_default
+    from semabs_amd.synth import synth_scene
+    pipe = build_default(args.arch, precision=args.precision, chunk_tiles=args.chunk, max_labels=N_LABELS, voxel=VOXEL, text_tower=False)
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((N_LABELS, 512)).astype(np.float32)          # synthetic unit-norm zero-shot text weights
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    w_text = torch.from_numpy(w).cuda()
+    n_scenes = args.steps + args.warmup
+    from semabs_amd.clip import ClipWrapper, saliency_configs
+    cfg = saliency_configs["ours"](IMG)
+    scenes = []
+    for i in range(n_scenes):
+        sc = pipe.upload(synth_scene(IMG, IMG, seed=1000 * rank + i))
+        sc["images_dev"] = ClipWrapper.make_images(sc["rgb"], cfg["augmentations"])       # image + 5 jittered copies, in HBM
+        scenes.append(sc)
+
+    def step(i):
+        sc = scenes[i]
+        return pipe.run(sc, w_text, seed=i, images_dev=sc["images_dev"])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    timer = vitmod.GemmTimer()
+    vitmod.GEMM_TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_scenes):
+        res = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    vitmod.GEMM_TIMER = None
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    gs = timer.summary()
+    total_scenes = args.steps * world
+    value = total_scenes / dt
+    if rank == 0:
+        ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12 if gs["total_ms"] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "gemm_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "scenes/sec (relevancy+3D-UNet infer), 480x480x16-label x128^3",
+            "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "fp16" else "f16 (MFMA operands, fp32 accumulate; UNet hi/lo-split = fp32-equivalent)",
+            "data": "synthetic",
+            "config": {"workload": f"end-to-end relevancy->fusion->OVSSC per scene: {IMG}x{IMG} RGB-D, {N_LABELS} labels, {args.arch}, "
+                                   f"'ours' saliency config (2448 tile forwards), {VOXEL}^3 voxels, 80000 input points; scene-sharded",
+                       "arch": args.arch, "unet_precision": args.precision, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
+            "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
+            "roofline": {"kernel": "k_gemm_f16 (all epilogues)", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "launches": gs["launches"],
+                         "avg_launch_us": gs["total_ms"] * 1e3 / max(1, gs["launches"]),
+                         "gemm_share_of_step": gs["total_ms"] * 1e-3 / (dt * 1.0) if world == 1 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.arch, N_LABELS)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@ SIGNATURES = {
     "semabs_voxel_index": [P, L, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P],
     "semabs_tsdf_integrate": [P, P, I, I, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, P],
     "semabs_frustum_mask": [P, L, P, I, I, P, P],
+    "semabs_gather_point_features": [P, P, P, I, L, L, F, I, P, P, P],
+    "semabs_ovssc_labels": [P, P, P, I, L, F, P, P],
     # tiles.hip
     "semabs_resize_coeffs": [I, I, P, P, I, P],
     "semabs_tile_patches": [P, I, I, I, P, I, P, P, P, P, P, I, I, I, P],

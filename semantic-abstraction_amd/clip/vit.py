@@ -26,7 +26,34 @@ from .. import _lib
 EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP = 0, 1, 2, 3, 4
 
 
+class GemmTimer:
+    """Optional live timing of every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records = []          # (start_event, stop_event, flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return dict(launches=len(self.records), total_ms=ms, flops=fl)
+
+
+GEMM_TIMER: "GemmTimer | None" = None
+
+
 def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):
+    t = GEMM_TIMER
+    if t is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend, rowmap)
+    if t is not None:
+        e1.record()
+        t.records.append((e0, e1, 2.0 * M * N * K))
+
+
+def _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):
     _lib.call("semabs_gemm_f16", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
               int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, _lib.stream())
 

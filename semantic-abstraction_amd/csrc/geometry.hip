@@ -185,3 +185,58 @@ extern "C" int semabs_frustum_mask(const double* pts, long M, const double* para
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Point features for SemAbs3D from the relevancy maps (visualize.py:93-122 + dataset.py:1049-1056 recipe):
+//   r = rel * 50;  r -= mean over labels (if subtract_mean);  feat[l, j] = r[l, sel[j]];  xyz_out[j] = xyz[sel[j]]
+// rel fp32 [L, HW], sel int64 [n] (pixel indices of the sub-sampled in-bounds points), xyz fp32 [HW, 3]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gather_point_features(const float* __restrict__ rel, const long long* __restrict__ sel,
+                                        const float* __restrict__ xyz, int L, long HW, long n, float mult, int subtract_mean,
+                                        float* __restrict__ feat, float* __restrict__ xyz_out) {
+    long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long p = sel[j];
+    float mean = 0.f;
+    if (subtract_mean) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += rel[(long)l * HW + p] * mult;
+        mean = s / (float)L;
+    }
+    for (int l = 0; l < L; ++l) feat[(long)l * n + j] = rel[(long)l * HW + p] * mult - mean;
+    if (xyz_out) { xyz_out[j * 3] = xyz[p * 3]; xyz_out[j * 3 + 1] = xyz[p * 3 + 1]; xyz_out[j * 3 + 2] = xyz[p * 3 + 2]; }
+}
+
+extern "C" int semabs_gather_point_features(const float* rel, const long long* sel, const float* xyz, int L, long HW, long n,
+                                            float mult, int subtract_mean, float* feat, float* xyz_out, void* stream) {
+    if (n == 0 || L == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(rel && sel && feat && HW > 0 && (xyz_out == nullptr || xyz != nullptr), "semabs_gather_point_features: bad args");
+    hipLaunchKernelGGL(k_gather_point_features, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rel, sel, xyz, L, HW, n,
+                       mult, subtract_mean, feat, xyz_out);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// OVSSC post-mask (visualize.py:228-247): prediction = argmax_l logit; a voxel keeps its class unless every logit is
+// below `cutoff`, it is outside the frustum, or tsdf > 0.   logits fp32 [L, M] -> label int32 [M] (-1 = empty)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_ovssc_labels(const float* __restrict__ logits, const unsigned char* __restrict__ in_frustum,
+                               const float* __restrict__ tsdf, int L, long M, float cutoff, int* __restrict__ label) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float best = logits[i]; int arg = 0;
+    for (int l = 1; l < L; ++l) { float v = logits[(long)l * M + i]; if (v > best) { best = v; arg = l; } }
+    bool empty = !(best >= cutoff);                           // (logprobs < cutoff).all()
+    if (in_frustum && !in_frustum[i]) empty = true;
+    if (tsdf && tsdf[i] > 0.f) empty = true;
+    label[i] = empty ? -1 : arg;
+}
+extern "C" int semabs_ovssc_labels(const float* logits, const unsigned char* in_frustum, const float* tsdf, int L, long M,
+                                   float cutoff, int* label, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(logits && label && L > 0, "semabs_ovssc_labels: bad args");
+    hipLaunchKernelGGL(k_ovssc_labels, dim3(semabs_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, logits, in_frustum, tsdf, L, M, cutoff, label);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

@@ -1,0 +1,141 @@
+"""End-to-end OVSSC inference for one RGB-D frame: relevancy -> geometry -> voxel inference, all on one GPU, nothing
+copied to the host in between.  This is the recipe of `visualize.prep_data` + `process_batch_ovssc`
+(visualize.py:61-154, 157-248) with one change that leaves the outputs identical for a fixed sub-sample: the
+reference re-runs scatter + UNet for every 2^20-point chunk of query points (visualize.py:180-211); here the feature
+volume is computed once per (scene, label) and only the decoder is evaluated per query point.
+
+Stage map (reference file:line -> kernel file):
+  ClipWrapper.get_clip_saliency * 50                visualize.py:93-101     tiles.hip, gemm.hip, vit.hip
+  get_pointcloud -> float32, filter_pts_bounds      visualize.py:103-108    geometry.hip
+  relevancies -= mean over labels; per-class points visualize.py:109-122    geometry.hip (gather_point_features)
+  np.random.choice(80 000 of N)                     visualize.py:193        host RNG (seeded), indices only
+  SemAbs3D.forward                                  net.py:383-439          unet.hip
+  TSDFVolume.integrate                              visualize.py:217-227    geometry.hip
+  argmax / cutoff / frustum / tsdf mask             visualize.py:228-247    geometry.hip (ovssc_labels)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .clip import ClipWrapper, saliency_configs
+from .fusion import TSDFVolume
+from .net import SemAbs3D
+from .point_cloud import check_pts_in_frustum, pointcloud_device
+from .synth import SCENE_BOUNDS
+
+DEFAULT_NET_KWARGS = dict(voxel_shape=(128, 128, 128), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16,
+                          unet_num_groups=8, unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True,
+                          pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1, decoder_concat_xyz_pts=True,
+                          batch_size=1)
+
+
+@dataclass
+class SceneResult:
+    relevancies: torch.Tensor          # fp32 [L, H, W]   (x 50, mean-subtracted when subtract_mean)
+    logits: torch.Tensor               # fp32 [L, S^3]    decoder outputs at the voxel centres
+    labels: Optional[torch.Tensor]     # int32 [S^3]      argmax with the cutoff / frustum / tsdf mask, -1 = empty
+    tsdf: Optional[torch.Tensor]       # fp32 [S, S, S]
+    n_in_bounds: int
+
+
+class ScenePipeline:
+    def __init__(self, net: SemAbs3D, num_input_pts: int = 80000, config: str = "ours", subtract_mean: bool = True,
+                 with_tsdf: bool = True, cutoff: float = -3.0):
+        self.net = net
+        self.num_input_pts = int(num_input_pts)
+        self.config = config
+        self.subtract_mean = subtract_mean
+        self.with_tsdf = with_tsdf
+        self.cutoff = cutoff
+        self.dev = _lib.require_gpu()
+        S0, S1, S2 = net.vg.grid_shape
+        lc = np.asarray(net.vg.lower_corner, np.float32)
+        uc = np.asarray(net.vg.upper_corner, np.float32)
+        # VirtualGrid.get_grid_points (net.py:63-82): idx * (uc - lc) / (S - 1) + lc, fp32
+        scales = (uc - lc) / (np.asarray([S0, S1, S2], np.float32) - np.float32(1))
+        g = np.stack(np.meshgrid(np.arange(S0), np.arange(S1), np.arange(S2), indexing="ij"), axis=-1).astype(np.float32)
+        self.grid_points_np = (g * scales + lc).reshape(-1, 3).astype(np.float32)
+        self.grid_points = torch.from_numpy(self.grid_points_np).to(self.dev)
+        self._frustum_cache = {}
+
+    def upload(self, scene: dict) -> dict:
+        """Host -> HBM once, outside the timed region."""
+        d = dict(scene)
+        d["rgb_dev"] = torch.from_numpy(np.ascontiguousarray(scene["rgb"])).to(self.dev)
+        d["depth_dev"] = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(self.dev)
+        return d
+
+    def run(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None, images_dev: torch.Tensor | None = None) -> SceneResult:
+        """scene: dict(rgb uint8 [H, W, 3], depth fp32 [H, W], cam_intr, cam_pose [+ rgb_dev / depth_dev]);
+        w_text fp32 [L, E] on the GPU (zero-shot weights of the labels)."""
+        dev, net = self.dev, self.net
+        st = _lib.stream()
+        H, W = scene["depth"].shape
+        L = int(w_text.shape[0])
+        cfg = saliency_configs[self.config](H)
+        # ---- relevancy --------------------------------------------------------------------------------
+        if images_dev is None:
+            images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images)
+        maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
+                                            cfg["positive_attn_only"])                       # [L, H, W]
+        # ---- geometry ---------------------------------------------------------------------------------
+        depth_dev = scene.get("depth_dev")
+        if depth_dev is None:
+            depth_dev = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(dev)
+        bounds = np.array([net.vg.lower_corner, net.vg.upper_corner], np.float64)
+        xyz, mask = pointcloud_device(depth_dev, scene["cam_intr"], scene["cam_pose"], bounds)
+        pix = torch.nonzero(mask, as_tuple=False).view(-1)                                    # in-bounds pixel ids (compaction)
+        n_in = int(pix.numel())
+        if n_in == 0:
+            raise RuntimeError("no point of the depth image falls inside scene_bounds")
+        rng = np.random.default_rng(seed)
+        choice = torch.from_numpy(rng.integers(0, n_in, size=self.num_input_pts)).to(dev)     # np.random.choice with replacement
+        sel = pix.index_select(0, choice).contiguous()
+        feat = torch.empty(L, self.num_input_pts, dtype=torch.float32, device=dev)
+        xyz_sub = torch.empty(self.num_input_pts, 3, dtype=torch.float32, device=dev)
+        maps_c = maps.contiguous()
+        _lib.call("semabs_gather_point_features", _lib.ptr(maps_c), _lib.ptr(sel), _lib.ptr(xyz), L, H * W, self.num_input_pts, 50.0,
+                  int(self.subtract_mean), _lib.ptr(feat), _lib.ptr(xyz_sub), st)
+        # ---- voxel inference ----------------------------------------------------------------------------
+        features = net.feature_volume(xyz_sub, feat)
+        logits = net.decode(features, self.grid_points, shared=True)                          # [L, S^3]
+        net.features_cl = features
+        tsdf = labels = None
+        if self.with_tsdf:
+            S = net.vg.grid_shape[0]
+            lo, hi = np.asarray(net.vg.lower_corner, np.float64), np.asarray(net.vg.upper_corner, np.float64)
+            tv = TSDFVolume(np.stack([lo, hi], axis=1).copy(), (hi[0] - lo[0]) / S)
+            rgb_dev = scene.get("rgb_dev")
+            tv.integrate(rgb_dev if rgb_dev is not None else scene["rgb"], depth_dev, scene["cam_intr"], scene["cam_pose"])
+            tsdf = tv._tsdf_vol
+            fr = self._frustum(scene, H, W)
+            labels = torch.empty(logits.shape[1], dtype=torch.int32, device=dev)
+            tsdf_flat = tsdf.reshape(-1)
+            _lib.call("semabs_ovssc_labels", _lib.ptr(logits), _lib.ptr(fr), _lib.ptr(tsdf_flat), L, int(logits.shape[1]), float(self.cutoff),
+                      _lib.ptr(labels), st)
+        # relevancies as prep_data returns them (x 50, mean-subtracted)
+        return SceneResult(relevancies=maps, logits=logits, labels=labels, tsdf=tsdf, n_in_bounds=n_in)
+
+    def _frustum(self, scene, H, W):
+        key = (H, W, np.asarray(scene["cam_pose"]).tobytes(), np.asarray(scene["cam_intr"]).tobytes())
+        if key not in self._frustum_cache:
+            m = check_pts_in_frustum(self.grid_points_np.astype(np.float64), np.zeros((H, W), np.float32), scene["cam_pose"], scene["cam_intr"])
+            self._frustum_cache = {key: torch.from_numpy(m.astype(np.uint8)).to(self.dev)}
+        return self._frustum_cache[key]
+
+
+def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 256,
+                  max_labels: int = 16, voxel: int = 128, text_tower: bool = True, **pipe_kwargs) -> ScenePipeline:
+    """Seeded random-init weights of the released architectures (no checkpoints / network here)."""
+    from .weights import make_clip_state_dict, make_semabs3d_state_dict
+    ClipWrapper.engine = None
+    ClipWrapper(arch, state_dict=make_clip_state_dict(arch, clip_seed, text_tower=text_tower), chunk_tiles=chunk_tiles, max_labels=max_labels)
+    kw = dict(DEFAULT_NET_KWARGS, voxel_shape=(voxel, voxel, voxel), precision=precision)
+    net = SemAbs3D(**kw)
+    net.load_state_dict(make_semabs3d_state_dict(seed=net_seed))
+    return ScenePipeline(net, **pipe_kwargs)
