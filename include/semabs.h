@@ -1,0 +1,164 @@
+/* semabs.h — C ABI of libsemabs_hip.so: the MI355X (gfx950) hot path of real-stanford/semantic-abstraction
+ * (multi-scale CLIP relevancy extraction -> depth/TSDF geometry -> OVSSC 3D-UNet voxel inference).
+ *
+ * The reference is pure Python and has no FFI for this path; these are the entry points a maintainer would bind with
+ * ctypes from the reference's own call sites.  Every entry point names the reference code it
+ * replaces as file:line relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  Unless a parameter says "host", pointers are DEVICE pointers.
+ *   - every function returns 0 on success, SEMABS_EINVAL (-1) for a rejected argument, SEMABS_EHIP (-2) when a HIP
+ *     call / launch failed; semabs_last_error() returns the message (thread local).  No exceptions cross the ABI.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous and stream ordered; the library
+ *     never allocates device memory and never synchronises.  All buffers are caller owned, dense and row major.
+ *   - empty inputs (zero rows / points / tiles) are accepted and do nothing.
+ *   - fp16 = IEEE binary16 (the CLIP weights are fp16-exact: model_explainability.py:501-527).
+ */
+#ifndef SEMABS_H
+#define SEMABS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEMABS_OK 0
+#define SEMABS_EINVAL (-1)
+#define SEMABS_EHIP (-2)
+
+const char* semabs_last_error(void);
+int semabs_abi_version(void);
+int semabs_device_info(char* name /*host*/, int name_len, int* cu_count /*host*/, long long* hbm_bytes /*host*/);
+
+/* ============================ geometry (csrc/geometry.hip) =============================================== */
+
+/* get_pointcloud + transform_pointcloud + filter_pts_bounds          point_cloud.py:34-66, 8-21, 24-31
+ * depth fp32 [H, W]; params f64 [22] = {fx, fy, cx, cy, pose 3x4 row major (12), bounds lo[3], hi[3]};
+ * xyz fp32 [H*W, 3] = float32(f64 math); mask uint8 [H*W] (NULL = skip) = inclusive AABB test of the fp32 point. */
+int semabs_pointcloud(const float* depth, int H, int W, const double* params, int has_pose, float* xyz,
+                      unsigned char* mask, void* stream);
+
+/* VirtualGrid.get_points_grid_idxs + flatten_idxs                    net.py:84-133
+ * idx = clamp(trunc((p + off) * scale), 0, S-1) with two separately rounded fp32 ops (bit-exact integer output);
+ * off3 / scale3 / shape3 are HOST arrays; flat int64 [N] and / or idx3 int32 [N, 3] (either may be NULL). */
+int semabs_voxel_index(const float* pts, long N, const float* off3, const float* scale3, const int* shape3,
+                       long long* flat, int* idx3, void* stream);
+
+/* TSDFVolume.vox2world + rigid_transform + cam2pix + integrate_tsdf + integrate      fusion.py:85-195
+ * color uint8 [H, W, 3] (NULL = TSDF only), depth fp32 [H, W]; params f64 [15] = {inv(pose) 3x4, voxel_size,
+ * trunc_margin, obs_weight}; origin3 / intr4 {fx, fy, cx, cy} / dims3 are HOST arrays (fp32 as the reference casts
+ * them); tsdf / weight / colvol fp32 [D0, D1, D2] updated in place; pix_out int64 [D0*D1*D2, 2] optional. */
+int semabs_tsdf_integrate(const unsigned char* color, const float* depth, int H, int W, const double* params,
+                          const float* origin3, const float* intr4, const int* dims3, float* tsdf, float* weight,
+                          float* colvol, long long* pix_out, void* stream);
+
+/* check_pts_in_frustum                                               point_cloud.py:88-110
+ * pts f64 [M, 3]; params f64 [16] = {inv(pose) 3x4, fx, fy, cx, cy}; mask uint8 [M]. */
+int semabs_frustum_mask(const double* pts, long M, const double* params, int H, int W, unsigned char* mask, void* stream);
+
+/* relevancy -> per-point features                                    visualize.py:93-122 (x50, -mean over labels, gather)
+ * rel fp32 [L, HW]; sel int64 [n] pixel ids; xyz fp32 [HW, 3]; feat fp32 [L, n]; xyz_out fp32 [n, 3] (optional). */
+int semabs_gather_point_features(const float* rel, const long long* sel, const float* xyz, int L, long HW, long n,
+                                 float mult, int subtract_mean, float* feat, float* xyz_out, void* stream);
+
+/* OVSSC post-mask: argmax, cutoff, frustum, tsdf > 0                 visualize.py:228-247
+ * logits fp32 [L, M]; in_frustum uint8 [M] / tsdf fp32 [M] optional; label int32 [M] (-1 = empty). */
+int semabs_ovssc_labels(const float* logits, const unsigned char* in_frustum, const float* tsdf, int L, long M,
+                        float cutoff, int* label, void* stream);
+
+/* ============================ tiling front / back (csrc/tiles.hip) ====================================== */
+
+/* Pillow ImagingResample coefficient tables for BICUBIC (third-party algorithm behind torchvision Resize,
+ * clip_explainability.py:98-108).  HOST function, HOST pointers: xmin int32 [out], kk int32 [out, kmax]. */
+int semabs_resize_coeffs(int in_size, int out_size, int* xmin, int* kk, int kmax, int* ksize);
+
+/* ClipWrapper.create_tiles crop + _transform + flip + VisionTransformer.conv1 im2col
+ *                                          CLIP/clip/__init__.py:254-281, 171-173; model_explainability.py:325-328
+ * images uint8 [n_img, H, W, 3]; tiles int32 [n_tiles, 5] = (image, row0, col0, tile_size, coef_id);
+ * coef_xmin int32 [n_sizes, 224], coef_kk int32 [n_sizes, 224, 24], coef_ksize int32 [n_sizes]; lut fp16 [3, 256]
+ * = fp16((u/255 - mean_c)/std_c); patches fp16 [n_tiles * g*g, 3*p*p] (g = 224/p), column = c*p*p + iy*p + ix. */
+int semabs_tile_patches(const unsigned char* images, int n_img, int H, int W, const int* tiles, int n_tiles,
+                        const int* coef_xmin, const int* coef_kk, const int* coef_ksize, const void* lut, void* patches,
+                        int patch, int flip, int max_ksize, void* stream);
+
+/* same im2col for already preprocessed fp32 tiles [n, 3, 224, 224] (ClipGradcam.forward(x=...), clip_gradcam.py:58-62) */
+int semabs_patchify(const float* x, void* patches, int n, int patch, int flip, void* stream);
+
+/* un-flip average, bilinear upsample, fp16 canvases, count normalise, mean over scales   CLIP/clip/__init__.py:196-236
+ * rel / rel_flip fp32 [L, N, g, g] (rel_flip NULL = no flip pass); scales int32 [n_scales, 5] =
+ * (tile_size, stride, n_row_starts, n_col_starts, first tile index within an image); out fp32 [L, H, W]. */
+int semabs_aggregate(const float* rel, const float* rel_flip, int L, int N, int g, int H, int W, const int* scales,
+                     int n_scales, int n_img, int tiles_per_img, float* out, void* stream);
+
+/* ColorJitter(0.6, 0.6, 0.6, 0.1) family for the augmentation copies      CLIP/clip/__init__.py:55-57, 246-247
+ * img uint8 [H, W, 3] in place; order4 / factors4 HOST arrays (op: 0 brightness 1 contrast 2 saturation 3 hue);
+ * scratch8: 8 bytes of device memory. */
+int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, const float* factors4, void* scratch8, void* stream);
+
+/* ============================ dense contractions (csrc/gemm.hip) ======================================== */
+
+/* C = epi(A[M,K] . B[N,K]^T + bias[N]) on fp16 MFMA, fp32 accumulate.   every F.linear / conv1 / proj on the path:
+ * auxiliary.py:129,340; model_explainability.py:210-217,253-254,325,353; clip_gradcam.py:90-97 (VJP chain)
+ * epi: 0 fp16 = acc+bias | 1 fp16 = quickgelu(acc+bias) | 2 fp32 += acc+bias | 3 fp32 = acc+bias |
+ *      4 fp32 row-remapped: out row = (m / g_in) * g_out + g_off + m % g_in, plus addend[(g_off + m % g_in), :]
+ * rowmap3 HOST {g_in, g_out, g_off}; N % 128 == 0, K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0. */
+int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
+                    long lda, int ldb, long ldc, int epi, const int* rowmap3, void* stream);
+
+/* ============================ transformer pieces (csrc/vit.hip) ========================================= */
+
+/* LayerNorm (fp32 statistics)                                        model_explainability.py:188-194 */
+int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D, float eps,
+                     int out_f32, long ld_in, void* stream);
+/* class token rows: x[n, 0, :] = class_embedding + pos[0, :]          model_explainability.py:329-343 */
+int semabs_embed_finish(float* x, const float* cls, const float* pos, int n, int T, int D, void* stream);
+/* fused multi-head attention, head_dim 64, T <= 224                  auxiliary.py:260-340 (q pre-scaled) */
+int semabs_attention(const void* qkv, void* out, const void* reserved, int n_seq, int T, int H, int head_dim, int ld,
+                     int causal, void* stream);
+/* last block, CLS query only; keeps the softmax row (the hooked attn_probs, auxiliary.py:330-335) */
+int semabs_attention_cls(const float* q, const float* kv, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
+int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
+int semabs_quickgelu(const float* fc, void* act, long n, void* stream);                 /* model_explainability.py:197-199 */
+/* logits = 100 f/|f| . w_l and d logit / d f, rows normalised to max-abs 1            clip_gradcam.py:62-67 */
+int semabs_logit_grad(const float* feat, const float* w_text, int n, int L, int E, float* logits, void* dfeat, float* scale, void* stream);
+int semabs_ln_bwd(const float* x, const float* gamma, const float* gy, const float* resid, float* out32, void* out16,
+                  long M, int D, int n_x, long ld_x, float eps, void* stream);
+int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, void* stream);
+/* closed form of ClipGradcam.interpret for the only contributing block             clip_gradcam.py:70-132 */
+int semabs_rollout(const float* probs, const float* kv, const float* u, const float* scale, float* rel, int n, int T, int H,
+                   int L, int positive_only, long n_total, long tile0, void* stream);
+/* text tower glue                                                    model_explainability.py:469-482; clip_gradcam.py:24-27 */
+int semabs_gather_text(const long long* tokens, const float* emb, const float* pos, float* x, int B, int T, int D, void* stream);
+int semabs_text_finish(const float* e, float* w, int C, int P, int E, void* stream);
+
+/* ============================ OVSSC voxel inference (csrc/unet.hip) ===================================== */
+
+/* SemAbs3D.pts_feat_extractor: (xyz | feat) 4 -> 128 -> 128 -> 16, LeakyReLU(0.01)   net.py:358-367, 395-404 */
+int semabs_point_mlp(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* w3, const float* b3, float* out, int P, long N, int hidden, int cout, void* stream);
+/* VirtualGrid.scatter_points, reduce = MEAN (the reference ignores reduce_method)     net.py:185-201
+ * deterministic, sums in point order; vol zero-filled and head filled with -1 by the caller. */
+int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
+                        long nvox, int vol_f32, void* stream);
+/* GroupNorm statistics / affine                                       unet3d.py:66-79 (nn.GroupNorm) */
+int semabs_gn_stats(const void* x, double* sums, int B, long nvox, int C, int G, int x_f32, void* stream);
+int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta, float* scale, float* shift, int B, int C,
+                       int G, long nvox, float eps, void* stream);
+/* [GroupNorm ->] Conv3d k in {1, 3} pad k/2 [+ bias] [+ residual] [-> ReLU], channels-last   unet3d.py:16-17, 98-128, 247-259, 579 */
+int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                  const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
+                  int act_f32, void* stream);
+/* ConvTranspose3d k3 s2 p1 (output_size = skip size) + bias + sum joining          unet3d.py:428-440, 385-396 */
+int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off /*host*/, void* y,
+                           const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout, int act_f32,
+                           void* stream);
+int semabs_maxpool3d(const void* x, void* y, int B, int D0, int D1, int D2, int C, int act_f32, void* stream);   /* unet3d.py:298 */
+/* ImplicitVolumetricDecoder: trilinear grid_sample (border, align_corners) + MLP    net.py:215-256
+ * off3 / sc3 / shape3 / w1 / b1 / w2 / b2 are HOST arrays. */
+int semabs_decoder(const void* vol, const float* query, const float* off3, const float* sc3, const int* shape3, const float* w1,
+                   const float* b1, const float* w2, const float* b2, int concat_xyz, int P, long M, long q_stride_p, int vol_f32,
+                   float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMABS_H */
