@@ -104,6 +104,9 @@ int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, con
 int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
                     long lda, int ldb, long ldc, int epi, const int* rowmap3, void* stream);
 
+/* tuning hook: 0 = heuristic tile choice, 1 = force 128x128 / 4 waves, 2 = force 256x256 / 8 waves (when N % 256 == 0) */
+int semabs_gemm_set_config(int cfg);
+
 /* ============================ transformer pieces (csrc/vit.hip) ========================================= */
 
 /* LayerNorm (fp32 statistics)                                        model_explainability.py:188-194 */

@@ -40,6 +40,7 @@ SIGNATURES = {
     "semabs_color_jitter": [P, I, I, C.POINTER(I), C.POINTER(F), P, P],
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
+    "semabs_gemm_set_config": [I],
     # vit.hip
     "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
     "semabs_embed_finish": [P, P, P, I, I, I, P],

@@ -6,37 +6,56 @@
 // Both operands are K-contiguous (torch Linear weight layout [N, K]); weights are fp16-exact because the
 // reference rounds them to fp16 (`convert_weights`, model_explainability.py:501-527).  fp32 accumulate.
 //
-// Structure (gfx950): 256 threads = 4 waves (2 x 2), block tile 128 x 128 x 64, wave tile 64 x 64 as 2 x 2
-// v_mfma_f32_32x32x16_f16 accumulators; global -> VGPR -> LDS double buffer, one barrier per K tile; LDS rows are
-// 128 B with the 16-B chunk index XOR-swizzled by (row >> 1) & 7 so ds_read_b128 fragment reads and
-// ds_write_b128 staging writes are bank-conflict-free; epilogue stages each wave's 64 x 64 fp32 tile through
-// its own 16 KB LDS slice to emit 16-byte row-contiguous stores; block ids are remapped so the blocks that share
-// an A row-panel run on one XCD (private L2).
+// Structure (gfx950): block tile 256 x 256 x 64 with 8 waves (2 x 4, wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_f16
+// accumulators) for the big GEMMs, 128 x 128 x 64 with 4 waves for small M / N; operands go global -> LDS by
+// direct DMA (global_load_lds_dwordx4, double buffered, one barrier per K tile) - no VGPR round trip and no
+// ds_write traffic; LDS rows are 128 B with the 16-B chunk index XOR-swizzled by (row >> 1) & 7 (applied on the DMA
+// source address and on the read) so ds_read_b128 fragment reads are bank-conflict-free; the epilogue stages 64-row
+// slabs of each wave's fp32 tile through a private 16 KB LDS slice to emit 16-byte row-contiguous stores; block ids
+// are remapped so the blocks that share an A row-panel run on one XCD (private L2).
 #include "semabs_common.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
-#define GEMM_THREADS 256
-#define TILE_BYTES (BM * BK * 2)          // 16 KB per operand tile
-#define GEMM_LDS (4 * TILE_BYTES)         // A0 B0 A1 B1
-
+#define BK 64   // K granularity required by the ABI (both K-tile sizes divide it)
 enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4 };
 
 struct GemmArgs {
     const f16* A; const f16* B; void* C; const float* bias; const float* addend;
     long M; int N, K; long lda; int ldb; long ldc;
     int g_in, g_out, g_off;     // EPI_ROWMAP_ADD_F32: out row = (m / g_in) * g_out + g_off + m % g_in
-    int n_tiles_n; int n_blocks;
+    int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
+    int ablate;     // tuning only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
 };
 
-__device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS tile rows hold BKT fp16 of K (128 B for BKT = 64, 64 B for BKT = 32); the 16-byte chunk index is XOR-ed with a
+// function of the row chosen so that every 16-lane group of a ds_read_b128 fragment read hits 16 distinct 16-byte
+// slots of the 256-byte bank row.
+template <int BKT>
+__device__ __forceinline__ int swz_off(int row, int chunk) {
+    if (BKT == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
 
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f16(GemmArgs g) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BM x BN block tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN) as 32x32 MFMA tiles, K tile BKT, STAGES LDS buffers.
+// Staging: direct-to-LDS DMA (global_load_lds_dwordx4), STAGES - 1 K tiles in flight; counted s_waitcnt vmcnt + raw
+// s_barrier so the prefetches stay in flight across barriers.  One wave instruction fills 1 KB of the lane-linear LDS
+// image, so the swizzle is applied to the per-lane SOURCE address (and again on the read).
+template <int EPI, int BM, int BN, int BKT, int WGM, int WGN, int STAGES>
+__global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64 && WGM * WGN >= 8) ? 4 : 2) void k_gemm_f16(GemmArgs g) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWB = BKT * 2;                           // bytes per tile row
+    constexpr int RPP = 1024 / ROWB;                        // tile rows per 1 KB DMA piece
+    constexpr int CPR = ROWB / 16;                          // 16-byte chunks per row
+    constexpr int A_BYTES = BM * ROWB, BUF = (BM + BN) * ROWB;
+    constexpr int PPW = (BM + BN) / RPP / NW;               // DMA pieces per wave per K tile
+    static_assert((BM + BN) / RPP % NW == 0 && WTN == 64 && WTM % 32 == 0 && STAGES >= 2, "tile / wave layout");
+    static_assert(STAGES * BUF >= NW * 8192, "epilogue staging needs 8 KB per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WGN, wn = wid % WGN;
 
     // XCD-aware bijective remap: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles.
     int b = blockIdx.x;
@@ -44,131 +63,208 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f16(GemmArgs g) {
         const int nb = g.n_blocks, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const long m0 = (long)(b / g.n_tiles_n) * BM;
-    const int n0 = (b % g.n_tiles_n) * BN;
-
-    // staging assignment: 1024 16-byte chunks per operand tile, 4 per thread
-    const f16* a_src[4]; const f16* b_src[4]; int lds_dst[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = tid + i * GEMM_THREADS, row = c >> 3, kc = c & 7;
-        long am = m0 + row; if (am > g.M - 1) am = g.M - 1;
-        a_src[i] = g.A + am * g.lda + kc * 8;
-        b_src[i] = g.B + (long)(n0 + row) * g.ldb + kc * 8;
-        lds_dst[i] = swz_off(row, kc);
+    // grouped rasterisation: consecutive ids walk GROUP_M row-panels (fastest) x the column panels, so the ~32 blocks
+    // resident on one XCD form a compact patch of the output and share operand panels through that XCD's L2
+    int tm, tn;
+    {
+        const int per_group = g.group_m * g.n_tiles_n, gid = b / per_group, first_m = gid * g.group_m;
+        const int gsz = (g.n_tiles_m - first_m < g.group_m) ? g.n_tiles_m - first_m : g.group_m;
+        const int r = b - gid * per_group;
+        tm = first_m + r % gsz; tn = r / gsz;
     }
-    f16x8 ra[4], rb[4];
-    auto gload = [&](int kt) {
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+
+    const f16* src[PPW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f16x8*>(a_src[i] + (long)kt * BK);
-            rb[i] = *reinterpret_cast<const f16x8*>(b_src[i] + (long)kt * BK);
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wid * PPW + j;                        // wave-uniform piece id: A pieces first, then B
+        const int lr = lane / CPR, cp = lane % CPR;
+        if (p < BM / RPP) {
+            const int row = p * RPP + lr;
+            long am = m0 + row; if (am > g.M - 1) am = g.M - 1;
+            src[j] = g.A + am * g.lda + ((swz_off<BKT>(row, cp) - row * ROWB) >> 1);
+        } else {
+            const int row = (p - BM / RPP) * RPP + lr;
+            src[j] = g.B + (long)(n0 + row) * g.ldb + ((swz_off<BKT>(row, cp) - row * ROWB) >> 1);
         }
-    };
-    auto lstore = [&](int buf) {
-        char* sa = smem + buf * 2 * TILE_BYTES; char* sb = sa + TILE_BYTES;
+    }
+    auto stage = [&](int kt) {
+        char* dst = smem + (kt % STAGES) * BUF + wid * PPW * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f16x8*>(sa + lds_dst[i]) = ra[i];
-            *reinterpret_cast<f16x8*>(sb + lds_dst[i]) = rb[i];
-        }
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long)kt * BKT),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = g.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    const int nk = g.K / BKT;
+    constexpr int KS = BKT / 16;                            // MFMA k-steps per K tile (even)
+    // prologue: STAGES - 1 tiles in flight, wait for the first
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) stage(t);
+    if (nk >= STAGES - 1) wait_vmcnt<(STAGES - 2) * PPW>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
     const int frow = lane & 31, fk = lane >> 5;
+    // fragment ping-pong: k-step s+1 (or the first k-step of the next K tile) is read from LDS while the MFMAs of
+    // k-step s run, so the matrix pipe is not parked behind ds_read latency.
+    f16x8 fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int which, int kt, int ks) {
+        const char* sa = smem + (kt % STAGES) * BUF; const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[which][i] = *reinterpret_cast<const f16x8*>(sa + swz_off<BKT>(wm * WTM + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[which][j] = *reinterpret_cast<const f16x8*>(sb + swz_off<BKT>(wn * WTN + j * 32 + frow, ks * 2 + fk));
+    };
+    load_frags(0, 0, 0);
+    if (g.ablate & 2) load_frags(1, 0, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const char* sa = smem + buf * 2 * TILE_BYTES; const char* sb = sa + TILE_BYTES;
+        if (kt + STAGES - 1 < nk && !(g.ablate & 1)) stage(kt + STAGES - 1);  // buffer last read in iteration kt - 1 (reads retired before its barrier)
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            f16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const f16x8*>(sa + swz_off(wm * 64 + i * 32 + frow, ks * 2 + fk));
-                fb[i] = *reinterpret_cast<const f16x8*>(sb + swz_off(wn * 64 + i * 32 + frow, ks * 2 + fk));
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KS) {
+                if (!(g.ablate & 2)) load_frags(nxt, kt, ks + 1);
+            } else if (g.ablate & 4) {
+                if (kt + 1 < nk && !(g.ablate & 2)) load_frags(nxt, kt + 1, 0);
+            } else {
+                // tile kt + 1 must have landed for every wave before anyone reads it; later tiles stay in flight
+                if (kt + STAGES - 1 < nk) wait_vmcnt<(STAGES - 2) * PPW>();
+                else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < nk && !(g.ablate & 2)) load_frags(nxt, kt + 1, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
     }
+    __builtin_amdgcn_s_barrier();                          // every wave is done with the operand tiles before they become epilogue scratch
 
-    // ---- epilogue: wave-private 64 x 64 fp32 staging (16 KB), then row-contiguous 16-byte accesses ----
-    float* st = reinterpret_cast<float*>(smem + wid * 16384);
+    // ---- epilogue: per wave, 32-row slabs of its tile through a private 8 KB LDS slice -> 16-byte row accesses ----
+    if ((g.ablate & 8) && acc[0][0][0] != 12345.678f) return;
+    float* st = reinterpret_cast<float*>(smem + wid * 8192);
+    const int cchunk = lane & 15;          // 4 floats
+    const int ncol = n0 + wn * WTN + cchunk * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 st[row * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
             }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own writes visible to own wave
-    __builtin_amdgcn_wave_barrier();
-    const int cchunk = lane & 15;          // 4 floats
-    const int ncol = n0 + wn * 64 + cchunk * 4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        int row = it * 4 + (lane >> 4);
-        long m = m0 + wm * 64 + row;
-        if (m >= g.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(st + row * 64 + cchunk * 4);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own writes visible to own wave
+        __builtin_amdgcn_wave_barrier();
         if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-            if (EPI == EPI_BIAS_GELU_F16) {
-                v.x = v.x / (1.f + __expf(-1.702f * v.x)); v.y = v.y / (1.f + __expf(-1.702f * v.y));
-                v.z = v.z / (1.f + __expf(-1.702f * v.z)); v.w = v.w / (1.f + __expf(-1.702f * v.w));
+            // fp16 output: 8 columns (16 bytes) per lane, 8 rows per store instruction (dwordx4 stores: the store
+            // tail is issue-bound, not bandwidth-bound, so half the instructions = half the tail)
+            const int c8 = lane & 7;
+            const int ncol8 = n0 + wn * WTN + c8 * 8;
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (g.bias) { b0 = *reinterpret_cast<const float4*>(g.bias + ncol8); b1 = *reinterpret_cast<const float4*>(g.bias + ncol8 + 4); }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const long m = m0 + wm * WTM + i * 32 + row;
+                if (m >= g.M) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(st + row * 64 + c8 * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(st + row * 64 + c8 * 8 + 4);
+                float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+                f16x8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+                    h[e] = (f16)v[e];
+                }
+                if ((g.ablate & 16) && v[0] != 12345.678f) continue;
+                *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(g.C) + m * g.ldc + ncol8) = h;
             }
-            f16x4 h; h[0] = (f16)v.x; h[1] = (f16)v.y; h[2] = (f16)v.z; h[3] = (f16)v.w;
-            *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(g.C) + m * g.ldc + ncol) = h;
-        } else if (EPI == EPI_BIAS_RESID_F32) {
-            float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
-            float4 o = *p;
-            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-            *p = o;
-        } else if (EPI == EPI_BIAS_F32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol) = v;
         } else {
-            long grp = m / g.g_in; int within = (int)(m - grp * g.g_in);
-            long orow = grp * g.g_out + g.g_off + within;
-            if (g.addend) {
-                float4 a = *reinterpret_cast<const float4*>(g.addend + (long)(g.g_off + within) * g.N + ncol);
-                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            int row = it * 4 + (lane >> 4);
+            long m = m0 + wm * WTM + i * 32 + row;
+            if (m >= g.M) continue;
+            float4 v = *reinterpret_cast<const float4*>(st + row * 64 + cchunk * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if ((g.ablate & 16) && v.x != 12345.678f) continue;
+            if (EPI == EPI_BIAS_RESID_F32) {
+                float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
+                float4 o = *p;
+                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                *p = o;
+            } else if (EPI == EPI_BIAS_F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol) = v;
+            } else {
+                long grp = m / g.g_in; int within = (int)(m - grp * g.g_in);
+                long orow = grp * g.g_out + g.g_off + within;
+                if (g.addend) {
+                    float4 a = *reinterpret_cast<const float4*>(g.addend + (long)(g.g_off + within) * g.N + ncol);
+                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + ncol) = v;
             }
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + ncol) = v;
         }
+        }
+        __builtin_amdgcn_wave_barrier();      // slab reads done before the next slab overwrites the slice
     }
+}
+
+static int g_group_m = 8;
+static int g_ablate = 0;
+static int g_force_cfg = 0;     // 0 = heuristic, 1 = 128x128 / 4 waves, 2 = 256x256 / 8 waves (tuning / tests)
+extern "C" int semabs_gemm_set_config(int cfg) {
+    if (cfg >= 1000) { g_ablate = cfg - 1000; return SEMABS_OK; }
+    if (cfg >= 100) { g_group_m = cfg - 100; if (g_group_m < 1) g_group_m = 1; }     // 100 + GROUP_M: rasterisation group (tuning)
+    else g_force_cfg = cfg;
+    return SEMABS_OK;
+}
+
+template <int EPI, int BM, int BN, int BKT, int WGM, int WGN, int STAGES>
+static int launch_cfg(GemmArgs g, hipStream_t s) {
+    constexpr int LDS = STAGES * (BM + BN) * BKT * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    g.n_tiles_n = g.N / BN;
+    long mt = (g.M + BM - 1) / BM;
+    g.n_tiles_m = (int)mt;
+    g.group_m = g_group_m;
+    g.ablate = g_ablate;
+    if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
+    g.n_blocks = (int)(mt * g.n_tiles_n);
+    hipLaunchKernelGGL((k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>), dim3(g.n_blocks), dim3(64 * WGM * WGN), LDS, s, g);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
 }
 
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f16<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_gemm_f16<EPI>, dim3(g.n_blocks), dim3(GEMM_THREADS), GEMM_LDS, s, g);
-    SEMABS_CHECK_LAUNCH();
-    return SEMABS_OK;
+    const bool big_ok = g.N % 256 == 0;
+    const bool big = g_force_cfg >= 2 ? big_ok : (g_force_cfg == 1 ? false : (big_ok && g.M >= 2048));
+    if (big && g_force_cfg == 0) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);      // default: 2 independent blocks / CU
+    if (big && g_force_cfg == 3) return launch_cfg<EPI, 256, 256, 32, 4, 4, 4>(g, s);      // 16 waves, 64 x 64 wave tiles
+    if (big && g_force_cfg == 4) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU
+    if (big && g_force_cfg == 5) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);
+    if (big) return launch_cfg<EPI, 256, 256, 32, 2, 4, 4>(g, s);
+    return launch_cfg<EPI, 128, 128, 64, 2, 2, 2>(g, s);
 }
 
 // C ABI.  A fp16 [M, K] (row stride lda elements), B fp16 [N, K] (row stride ldb), C per `epi`:
@@ -180,8 +276,8 @@ extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const floa
                                void* stream) {
     SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16: null operand");
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
-    SEMABS_REQUIRE(N % BN == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
-    SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
+    SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
+    SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (epi > 1 || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -190,10 +286,7 @@ extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const floa
         SEMABS_REQUIRE(rowmap3 && rowmap3[0] > 0, "semabs_gemm_f16: epi 4 needs rowmap");
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
-    g.n_tiles_n = N / BN;
-    long mt = (M + BM - 1) / BM;
-    SEMABS_REQUIRE(mt * g.n_tiles_n < (1L << 30), "semabs_gemm_f16: grid too large");
-    g.n_blocks = (int)(mt * g.n_tiles_n);
+    g.n_tiles_n = 0; g.n_blocks = 0;
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
         case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s);
