@@ -150,6 +150,9 @@ int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta
 int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                   const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                   int act_f32, void* stream);
+/* tuning / test hook: 1 (default) = Cin = Cout = 16 3^3 convolutions on bricks that are multiples of 8 x 8 x 16 use the
+ * LDS-halo kernel, 0 = always the generic gather kernel */
+int semabs_conv_set_config(int use_lds_brick);
 /* ConvTranspose3d k3 s2 p1 (output_size = skip size) + bias + sum joining          unet3d.py:428-440, 385-396 */
 int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off /*host*/, void* y,
                            const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout, int act_f32,

@@ -400,6 +400,154 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Level-0 specialisation: Cin = Cout = 16, 3x3x3, the six full-resolution convolutions that carry most of the
+// UNet's HBM traffic.  One workgroup (8 waves) owns an 8 x 8 x 16 output brick: the 10 x 10 x 18 input halo is
+// read from HBM ONCE, GroupNorm-applied, split into fp16 hi (+ lo in exact mode) and parked in LDS (57.6 / 115 KB);
+// the 27 taps then come from LDS with conflict-free ds_read_b128 (16 consecutive voxels x 16-byte halves), the weights
+// (14 k-steps) live in registers, and every 16-voxel row is stored as one contiguous 512 B / 1 KB line.
+// -------------------------------------------------------------------------------------------------
+#define C16_T0 8
+#define C16_T1 8
+#define C16_T2 16
+#define C16_H0 (C16_T0 + 2)
+#define C16_H1 (C16_T1 + 2)
+#define C16_H2 (C16_T2 + 2)
+#define C16_HALO (C16_H0 * C16_H1 * C16_H2)
+
+template <bool F32>
+__global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* s_hi = reinterpret_cast<f16*>(smem);                       // [HALO][16]
+    f16* s_lo = s_hi + C16_HALO * 16;                               // exact mode only
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vl = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y;
+    const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1;
+    int t = blockIdx.x;
+    const int t2 = t % n2; t /= n2;
+    const int t1 = t % n1; const int t0 = t / n1;
+    const int z0 = t0 * C16_T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
+
+    // ---- phase 1: halo -> GroupNorm affine -> fp16 hi/lo -> LDS (zero padding AFTER the normalisation) ----
+    float gsc[16], gsh[16];
+    const bool has_gn = a.gn_scale != nullptr;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { gsc[c] = has_gn ? a.gn_scale[b * 16 + c] : 1.f; gsh[c] = has_gn ? a.gn_shift[b * 16 + c] : 0.f; }
+    for (int v = tid; v < C16_HALO; v += 512) {
+        const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        float val[16];
+        if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) {
+            const long idx = ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * 16;
+            float lo8[8], hi8[8];
+            load8<F32>(a.x, idx, lo8);
+            load8<F32>(a.x, idx + 8, hi8);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { val[c] = lo8[c] * gsc[c] + gsh[c]; val[8 + c] = hi8[c] * gsc[8 + c] + gsh[8 + c]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) val[c] = 0.f;
+        }
+        f16x8 h0, h1, l0, l1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
+            if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
+        }
+        *reinterpret_cast<f16x8*>(s_hi + v * 16) = h0; *reinterpret_cast<f16x8*>(s_hi + v * 16 + 8) = h1;
+        if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 16) = l0; *reinterpret_cast<f16x8*>(s_lo + v * 16 + 8) = l1; }
+    }
+    // ---- weights: A operand (rows = cout) for all 14 k-steps, in registers ----
+    f16x8 wh[14], wl[14];
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks) {
+        const long widx = (long)vl * a.Kp + ks * 32 + kg * 8;
+        wh[ks] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+        if (F32) wl[ks] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+    }
+    __syncthreads();
+
+    // ---- phase 2: each wave takes 8 rows (16 voxels along x) of the brick, two at a time ----
+    const int half = kg & 1, tsel = kg >> 1;
+#pragma unroll 1
+    for (int pr = 0; pr < 4; ++pr) {
+        int rz[2], ry[2], lbase[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = wid * 8 + pr * 2 + mi;                  // 0..63 = z * 8 + y
+            rz[mi] = row >> 3; ry[mi] = row & 7;
+            lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 16 + half * 8;     // element offset of the centre tap
+        }
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
+            const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
+            const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 16;
+            const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 16;
+            const int off = tsel ? offb : offa;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + lbase[mi] + off);
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xh, acc[mi], 0, 0, 0);
+                if (F32) {
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + lbase[mi] + off);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], xh, acc[mi], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xl, acc[mi], 0, 0, 0);
+                }
+            }
+        }
+        // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const long ovox = (((long)b * a.I0 + (z0 + rz[mi])) * a.I1 + (y0 + ry[mi])) * a.I2 + (x0 + vl);
+            const long oidx = ovox * 16 + 4 * kg;
+            float o[4] = {acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
+            if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + 4 * kg);
+                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            }
+            if (a.resid) {
+                if (F32) {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx);
+                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                } else {
+                    const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oidx);
+                    o[0] += (float)r[0]; o[1] += (float)r[1]; o[2] += (float)r[2]; o[3] += (float)r[3];
+                }
+            }
+            if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+            if (F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3];
+                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
+            }
+        }
+    }
+}
+
+static int g_conv16_lds = 1;     // tuning / test hook: 0 = always use the generic gather kernel
+extern "C" int semabs_conv_set_config(int use_lds_brick) { g_conv16_lds = use_lds_brick; return SEMABS_OK; }
+
+static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
+    const size_t lds = (size_t)C16_HALO * 16 * 2 * (f32 ? 2 : 1);
+    dim3 grid((a.I0 / C16_T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B), block(512);
+    if (f32) {
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        hipLaunchKernelGGL(k_conv16_lds<true>, grid, block, lds, s, a);
+    } else {
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        hipLaunchKernelGGL(k_conv16_lds<false>, grid, block, lds, s, a);
+    }
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 static int conv_launch(const ConvArgs& a, int f32, hipStream_t s) {
     const long Mtot = (long)a.B * a.M0 * a.M1 * a.M2;
     const int nw = a.Cout >= 64 ? 4 : (a.Cout >= 32 ? 2 : 1);
@@ -444,6 +592,8 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
     for (int kd = 0; kd < ksize; ++kd)
         for (int kh = 0; kh < ksize; ++kh)
             for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
+    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % C16_T0 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
+        return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
     return conv_launch(a, act_f32, (hipStream_t)stream);
 }
 

@@ -52,6 +52,35 @@ def test_conv3d_gn_relu_resid(precision, tol, cin, cout, S, B):
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
+@pytest.mark.parametrize("dims,B,resid", [((8, 8, 16), 1, False), ((16, 24, 32), 2, True), ((8, 16, 48), 3, True)])
+def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid):
+    """The level-0 LDS-halo kernel (Cin = Cout = 16, bricks of 8 x 8 x 16) vs torch fp32 and vs the generic gather kernel."""
+    from semabs_amd import _lib
+    from semabs_amd.unet3d import _Conv
+    rng = np.random.default_rng(dims[2] + B)
+    x = torch.from_numpy(rng.standard_normal((B, 16, *dims)).astype(np.float32)) * 1.5 + 0.3
+    x[:, :, ::3] = 0                                                  # sparse like a scattered volume
+    w = torch.from_numpy((rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32))
+    gw = torch.from_numpy((1 + 0.2 * rng.standard_normal(16)).astype(np.float32))
+    gb = torch.from_numpy((0.2 * rng.standard_normal(16)).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((B, 16, *dims)).astype(np.float32))
+    u = _unet(precision)
+    conv = _Conv(w, gw, gb, None, 8, u.dev)
+    xd, rd = _cl(x).cuda().to(u.act_dtype), _cl(res).cuda().to(u.act_dtype)
+    ref = F.conv3d(F.group_norm(xd.float().cpu().permute(0, 4, 1, 2, 3), 8, gw, gb, 1e-5), w, None, padding=1)
+    if resid:
+        ref = ref + rd.float().cpu().permute(0, 4, 1, 2, 3)
+    ref = F.relu(ref)
+    _lib.call("semabs_conv_set_config", 1)
+    y_lds = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
+    _lib.call("semabs_conv_set_config", 0)
+    y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
+    _lib.call("semabs_conv_set_config", 1)
+    assert (y_lds - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (y_lds - ref).abs().max().item()
+    assert (y_lds - y_gen).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 16, 6, 2), (64, 32, 4, 1), (512, 256, 2, 2), (128, 64, 3, 1)])
 def test_convtranspose3d_skip(precision, tol, cin, cout, S, B):
     from semabs_amd.unet3d import _ConvT
