@@ -114,6 +114,9 @@ class ClipWrapper:
     _coeffs: Optional[_ResizeCoeffs] = None
     _lut = None
     _rng = np.random.default_rng(0)
+    n_streams = 2                       # HIP streams the independent tile chunks are pipelined over
+    _streams = None
+    _patches = {}
     state_dict_provider = None          # callable(clip_model_type) -> state dict; set by tests / bench
 
     # ---- initialisation ----------------------------------------------------------------------------
@@ -131,6 +134,7 @@ class ClipWrapper:
         lut = (u - np.asarray(CLIP_MEAN, np.float32)[:, None]) / np.asarray(CLIP_STD, np.float32)[:, None]
         ClipWrapper._lut = torch.from_numpy(lut.astype(np.float32)).to(dev, torch.float16).contiguous()
         ClipWrapper.class_to_language_feature = {}
+        ClipWrapper._patches = {}
 
     @staticmethod
     def _load_checkpoint(clip_model_type):
@@ -254,19 +258,41 @@ class ClipWrapper:
         passes = 2 if horizontal_flipping else 1
         rel = [torch.zeros(L, N, g, g, dtype=torch.float32, device=dev) for _ in range(passes)]
         G, Kp = g * g, 3 * eng.p * eng.p
-        patches = torch.empty(min(N, eng.chunk) * G, Kp, dtype=torch.float16, device=dev)
         t_lo, t_hi = (0, N) if tile_range is None else tile_range
-        st = _lib.stream()
-        for flip in range(passes):
-            for t0 in range(t_lo, t_hi, eng.chunk):
+        # Tile chunks are independent: alternate them over `n_streams` HIP streams (one workspace each) so one chunk's
+        # memory-bound kernels and GEMM store tails overlap the other chunk's MFMA phases.
+        main = torch.cuda.current_stream()
+        work = [(flip, t0) for flip in range(passes) for t0 in range(t_lo, t_hi, eng.chunk)]
+        ns = max(1, min(cls.n_streams, len(work)))
+        if cls._streams is None or len(cls._streams) < ns:
+            cls._streams = [torch.cuda.Stream() for _ in range(ns)]
+            cls._patches = {}
+        for i in range(ns):
+            cls._streams[i].wait_stream(main)
+        w_chunks = [w_text[l0:l0 + eng.max_labels].contiguous() for l0 in range(0, L, eng.max_labels)]
+        for i, (flip, t0) in enumerate(work):
+            slot = i % ns
+            with torch.cuda.stream(cls._streams[slot]):
+                eng.slot = slot
+                key = (slot, min(N, eng.chunk) * G, Kp)
+                if key not in cls._patches:
+                    cls._patches = {k: v for k, v in cls._patches.items() if k[0] != slot}
+                    cls._patches[key] = torch.empty(key[1], Kp, dtype=torch.float16, device=dev)
+                patches = cls._patches[key]
+                st = _lib.stream()
                 m = min(eng.chunk, t_hi - t0)
                 _lib.call("semabs_tile_patches", _lib.ptr(images), n_img, H, W, tiles_dev[t0:].data_ptr(), m, _lib.ptr(xmin_d),
                           _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(cls._lut), _lib.ptr(patches), eng.p, flip, max_ks, st)
-                for l0 in range(0, L, eng.max_labels):
-                    wl = w_text[l0:l0 + eng.max_labels].contiguous()
-                    if l0 == 0:
-                        eng.embed(patches, m); eng.trunk(m); eng.head(m)
+                eng.embed(patches, m); eng.trunk(m); eng.head(m)
+                for li, wl in enumerate(w_chunks):
+                    l0 = li * eng.max_labels
                     eng.rollout(m, wl, positive_attn_only, rel[flip][l0:l0 + eng.max_labels], t0)
+        for i in range(ns):
+            main.wait_stream(cls._streams[i])
+        eng.slot = 0
+        for t in (images, tiles_dev, w_text, *rel, *w_chunks):
+            for i in range(ns):
+                t.record_stream(cls._streams[i])
         if return_tiles:
             return rel, table, scales
         return cls.aggregate_device(rel, scales, n_img, H, W)

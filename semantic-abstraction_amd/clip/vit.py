@@ -125,24 +125,25 @@ class VisionRollout:
                        for i in range(self.layers)]
         self.chunk = int(chunk_tiles)
         self.max_labels = int(max_labels)
-        self._ws = None
+        self._wss = {}
+        self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
     def _workspace(self):
-        if self._ws is None:
+        if self.slot not in self._wss:
             n, T, D, Lm, E = self.chunk, self.T, self.D, self.max_labels, self.E
             dev = self.dev
             e16 = lambda *s: torch.empty(*s, dtype=torch.float16, device=dev)
             e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             R = Lm * n
-            self._ws = dict(
+            self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
                 kv32=e32(n * T, 2 * D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
                 h2c=e16(n, D), fc=e32(n, 4 * D), actc=e16(n, 4 * D), x2c=e32(n, D), yc=e16(n, D), feat=e32(n, E),
                 logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, D),
                 dact=e32(R, 4 * D), dfc=e16(R, 4 * D), dh2=e32(R, D), g1h=e16(R, D), u=e32(R, D),
             )
-        return self._ws
+        return self._wss[self.slot]
 
     # ---- forward ---------------------------------------------------------------------------------
     def embed(self, patches: torch.Tensor, n: int):

@@ -407,16 +407,14 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 // the 27 taps then come from LDS with conflict-free ds_read_b128 (16 consecutive voxels x 16-byte halves), the weights
 // (14 k-steps) live in registers, and every 16-voxel row is stored as one contiguous 512 B / 1 KB line.
 // -------------------------------------------------------------------------------------------------
-#define C16_T0 8
 #define C16_T1 8
 #define C16_T2 16
-#define C16_H0 (C16_T0 + 2)
 #define C16_H1 (C16_T1 + 2)
 #define C16_H2 (C16_T2 + 2)
-#define C16_HALO (C16_H0 * C16_H1 * C16_H2)
 
-template <bool F32>
-__global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
+template <bool F32, int C16_T0>      // brick depth 8 (fp16: 57.6 KB LDS) or 4 (exact: 69 KB) so that two workgroups share a CU
+__global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
+    constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2, NTHR = 64 * C16_T0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16* s_hi = reinterpret_cast<f16*>(smem);                       // [HALO][16]
     f16* s_lo = s_hi + C16_HALO * 16;                               // exact mode only
@@ -435,7 +433,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     const bool has_gn = a.gn_scale != nullptr;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { gsc[c] = has_gn ? a.gn_scale[b * 16 + c] : 1.f; gsh[c] = has_gn ? a.gn_shift[b * 16 + c] : 0.f; }
-    for (int v = tid; v < C16_HALO; v += 512) {
+    for (int v = tid; v < C16_HALO; v += NTHR) {
         const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
         float val[16];
@@ -533,16 +531,20 @@ static int g_conv16_lds = 1;     // tuning / test hook: 0 = always use the gener
 extern "C" int semabs_conv_set_config(int use_lds_brick) { g_conv16_lds = use_lds_brick; return SEMABS_OK; }
 
 static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
-    const size_t lds = (size_t)C16_HALO * 16 * 2 * (f32 ? 2 : 1);
-    dim3 grid((a.I0 / C16_T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B), block(512);
     if (f32) {
+        constexpr int T0 = 4;
+        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2 * 2;
+        dim3 grid((a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B), block(64 * T0);
         static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-        hipLaunchKernelGGL(k_conv16_lds<true>, grid, block, lds, s, a);
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<true, T0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        hipLaunchKernelGGL((k_conv16_lds<true, T0>), grid, block, lds, s, a);
     } else {
+        constexpr int T0 = 8;
+        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2;
+        dim3 grid((a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B), block(64 * T0);
         static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-        hipLaunchKernelGGL(k_conv16_lds<false>, grid, block, lds, s, a);
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<false, T0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        hipLaunchKernelGGL((k_conv16_lds<false, T0>), grid, block, lds, s, a);
     }
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
@@ -592,7 +594,7 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
     for (int kd = 0; kd < ksize; ++kd)
         for (int kh = 0; kh < ksize; ++kh)
             for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
-    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % C16_T0 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
+    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
         return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
     return conv_launch(a, act_f32, (hipStream_t)stream);
 }
