@@ -164,6 +164,21 @@ int semabs_decoder(const void* vol, const float* query, const float* off3, const
                    const float* b1, const float* w2, const float* b2, int concat_xyz, int P, long M, long q_stride_p, int vol_f32,
                    float* out, void* stream);
 
+/* SemAbsVOOL head: sample two 16-ch volumes (no concat), spatial sampler 35 -> 32 -> 64, cosine similarity with the
+ * relation embedding / temperature                                    net.py:559-579, 215-256, 300-309
+ * params fp32 [32*35 | 32 | 64*32 | 64] and rel fp32 [P, 64] on the device; off3 / sc3 / shape3 host. */
+int semabs_vool_head(const void* vol_t, const void* vol_r, const float* query, const float* params, const float* rel,
+                     const float* off3, const float* sc3, const int* shape3, float temperature, int P, long M, int vol_f32,
+                     float* out, void* stream);
+
+/* ============================ optimizer (csrc/optim.hip) ================================================= */
+
+/* Lamb.step over all parameter tensors at once                        arm/optim/lamb.py:59-127
+ * chunks int64 [n_chunks, 3] = (tensor, offset, count); ptrs int64 [4, n_tensors] = device pointers to fp32 w, g, m, v;
+ * norms fp64 [n_tensors, 2] scratch; stats fp32 [n_tensors, 3] = weight_norm, adam_norm, trust_ratio (optional). */
+int semabs_lamb_step(const long long* chunks, int n_chunks, const long long* ptrs, int n_tensors, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int adam, double* norms, float* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -761,3 +761,103 @@ extern "C" int semabs_decoder(const void* vol, const float* query, const float* 
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
+
+// =================================================================================================
+// VOOL head (SemAbsVOOL.forward, net.py:559-579): per (description d, query point m)
+//   f = cat(trilinear(target_vol[d]), trilinear(reference_vol[d]))  (32 ch)   -- the channel concat of net.py:556 is never materialised
+//   h = LeakyReLU(W1 [32, 35] . cat(f, qn) + b1);  o = W2 [64, 32] . h + b2   -- spatial_sampler (ImplicitVolumetricDecoder, net.py:215-256)
+//   out = cosine_similarity(o, relation_embedding[d]) / temperature               -- PointingAttention.cosine_sim, net.py:300-309
+// params (device fp32): w1 [32*35] | b1 [32] | w2 [64*32] | b2 [64];  rel fp32 [P, 64]
+// =================================================================================================
+template <typename T>
+__device__ __forceinline__ void trilerp16(const T* __restrict__ vb, int S0, int S1, int S2, int z0, int y0, int x0, float wz1, float wy1,
+                                          float wx1, float wz0, float wy0, float wx0, float* f) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int zz = z0 + (d >> 2), yy = y0 + ((d >> 1) & 1), xx = x0 + (d & 1);
+        if (zz > S0 - 1 || yy > S1 - 1 || xx > S2 - 1) continue;
+        const float w = ((d & 1) ? wx1 : wx0) * (((d >> 1) & 1) ? wy1 : wy0) * ((d >> 2) ? wz1 : wz0);
+        const long idx = (((long)zz * S1 + yy) * S2 + xx) * 16;
+        float v[8];
+        load8<sizeof(T) == 4>(vb, idx, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] += v[c] * w;
+        load8<sizeof(T) == 4>(vb, idx + 8, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[8 + c] += v[c] * w;
+    }
+}
+
+struct VoolArgs { float off[3], sc[3]; int S0, S1, S2; float inv_temp; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_vool_head(const T* __restrict__ vol_t, const T* __restrict__ vol_r, const float* __restrict__ query,
+                                                   const float* __restrict__ prm, const float* __restrict__ rel, VoolArgs a, int P, long M,
+                                                   float* __restrict__ out) {
+    __shared__ float sw[32 * 35 + 32 + 64 * 32 + 64];
+    for (int i = threadIdx.x; i < 32 * 35 + 32 + 64 * 32 + 64; i += 256) sw[i] = prm[i];
+    __syncthreads();
+    const float* w1 = sw; const float* b1 = sw + 32 * 35; const float* w2 = b1 + 32; const float* b2 = w2 + 64 * 32;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * M) return;
+    const int d = (int)(i / M);
+    const float* qp = query + i * 3;
+    float qn[3];
+    const int S[3] = {a.S0, a.S1, a.S2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = (qp[k] + a.off[k]) * a.sc[k];
+        t = fminf(fmaxf(t, 0.f), (float)(S[k] - 1));
+        t = t / (float)S[k];
+        qn[k] = 2.0f * t - 1.0f;
+    }
+    float ix = ((qn[0] + 1.f) / 2.f) * (float)(a.S2 - 1), iy = ((qn[1] + 1.f) / 2.f) * (float)(a.S1 - 1), iz = ((qn[2] + 1.f) / 2.f) * (float)(a.S0 - 1);
+    ix = fminf(fmaxf(ix, 0.f), (float)(a.S2 - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(a.S1 - 1)); iz = fminf(fmaxf(iz, 0.f), (float)(a.S0 - 1));
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+    float f[35];
+    const long vstride = (long)a.S0 * a.S1 * a.S2 * 16;
+    trilerp16<T>(vol_t + d * vstride, a.S0, a.S1, a.S2, z0, y0, x0, wz1, wy1, wx1, wz0, wy0, wx0, f);
+    trilerp16<T>(vol_r + d * vstride, a.S0, a.S1, a.S2, z0, y0, x0, wz1, wy1, wx1, wz0, wy0, wx0, f + 16);
+    f[32] = qn[0]; f[33] = qn[1]; f[34] = qn[2];
+    float hcur[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        float hv = b1[j];
+#pragma unroll
+        for (int c = 0; c < 35; ++c) hv += w1[j * 35 + c] * f[c];
+        hcur[j] = hv > 0.f ? hv : 0.01f * hv;
+    }
+    const float* r = rel + (long)d * 64;
+    float dot = 0.f, no = 0.f, nr = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+        float o = b2[k];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) o += w2[k * 32 + j] * hcur[j];
+        const float rk = r[k];
+        dot += o * rk; no += o * o; nr += rk * rk;
+    }
+    const float eps = 1e-8f;
+    out[i] = dot / (fmaxf(sqrtf(no), eps) * fmaxf(sqrtf(nr), eps)) * a.inv_temp;
+}
+
+// vol_t / vol_r [P, S0, S1, S2, 16] (fp16 / fp32), query fp32 [P, M, 3], params fp32 [3264] (device), rel fp32 [P, 64] (device),
+// off3 / sc3 / shape3 host arrays; out fp32 [P, M].  Built for hidden 2*16 -> 32 -> pointing_dim 64 with xyz concat (utils.py defaults).
+extern "C" int semabs_vool_head(const void* vol_t, const void* vol_r, const float* query, const float* params, const float* rel,
+                                const float* off3, const float* sc3, const int* shape3, float temperature, int P, long M, int vol_f32,
+                                float* out, void* stream) {
+    if (P == 0 || M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(vol_t && vol_r && query && params && rel && off3 && sc3 && shape3 && out && temperature > 0.f, "semabs_vool_head: bad args");
+    VoolArgs a;
+    for (int k = 0; k < 3; ++k) { a.off[k] = off3[k]; a.sc[k] = sc3[k]; }
+    a.S0 = shape3[0]; a.S1 = shape3[1]; a.S2 = shape3[2]; a.inv_temp = 1.0f / temperature;
+    dim3 grid(semabs_cdiv((long)P * M, 256)), block(256);
+    if (vol_f32) hipLaunchKernelGGL(k_vool_head<float>, grid, block, 0, (hipStream_t)stream, (const float*)vol_t, (const float*)vol_r, query, params, rel, a, P, M, out);
+    else hipLaunchKernelGGL(k_vool_head<f16>, grid, block, 0, (hipStream_t)stream, (const f16*)vol_t, (const f16*)vol_r, query, params, rel, a, P, M, out);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

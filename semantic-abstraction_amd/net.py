@@ -178,3 +178,62 @@ class SemAbs3D:
     def visual_volumetric_features(self):
         """[B*P, C, S, S, S] fp32 like the reference's cached attribute (net.py:425-427)."""
         return None if self.features_cl is None else self.features_cl.permute(0, 4, 1, 2, 3).float()
+
+
+class SemAbsVOOL:
+    """Drop-in (inference) for `net.SemAbsVOOL` (net.py:469-579) with `pointing_method="cosine_sim"` (the default,
+    utils.py:87-91): two SemAbs3D feature volumes (target / reference saliency), the 35 -> 32 -> 64 spatial sampler and the
+    cosine-similarity pointer against the relation embedding, fused in one HIP kernel (`semabs_vool_head`)."""
+
+    RELATIONS = ["in", "behind", "in front of", "on the left of", "on the right of", "on", "[pad]"]
+
+    def __init__(self, pointing_method: str, pointing_dim: int, device: str, decoder_concat_xyz_pts: bool, **kwargs):
+        if pointing_method != "cosine_sim" or pointing_dim != 64 or not decoder_concat_xyz_pts:
+            raise NotImplementedError("the HIP VOOL head covers pointing_method='cosine_sim', pointing_dim=64, decoder_concat_xyz_pts=True")
+        self.device = device
+        self.steps = torch.zeros(1)
+        self.completion_net = SemAbs3D(device=device, **kwargs)       # like the reference: built without the xyz concat
+        self.pointing_temperature = 0.07
+        self._prm = None
+        self._rel = {}
+        self._sd = {}
+
+    def load_state_dict(self, sd, strict: bool = True):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        dev = _lib.require_gpu()
+        self.completion_net.load_state_dict({k[len("completion_net."):]: v for k, v in sd.items() if k.startswith("completion_net.")}, strict)
+        flat = [sd[f"spatial_sampler.mlp.{i}.{n}"].float().reshape(-1) for i, n in ((0, "weight"), (0, "bias"), (2, "weight"), (2, "bias"))]
+        assert [t.numel() for t in flat] == [32 * 35, 32, 64 * 32, 64], "spatial sampler must be 35 -> 32 -> 64"
+        self._prm = torch.cat(flat).to(dev).contiguous()
+        self._rel = {k: sd["relation_embeddings." + k].float().to(dev) for k in self.RELATIONS}
+        self._sd = {k: v.detach().clone() for k, v in sd.items()}
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def eval(self):
+        return self
+
+    def forward(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts,
+                tsdf_vol=None, **kwargs):
+        dev = _lib.require_gpu()
+        net = self.completion_net
+        batch_size, num_descs = np.array(spatial_relation_name).T.shape
+        M = int(output_xyz_pts.shape[-2])
+        outs = []
+        for b in range(batch_size):
+            xyz = input_xyz_pts[b].to(dev, torch.float32)
+            N = xyz.shape[0]
+            ft = net.feature_volume(xyz, input_target_saliency_pts[b].to(dev, torch.float32).reshape(num_descs, N))
+            fr = net.feature_volume(xyz, input_reference_saliency_pts[b].to(dev, torch.float32).reshape(num_descs, N))
+            rel = torch.stack([self._rel[spatial_relation_name[d][b]] for d in range(num_descs)], dim=0).contiguous()
+            q = output_xyz_pts[b].to(dev, torch.float32).reshape(num_descs, M, 3).contiguous()
+            out = torch.empty(num_descs, M, dtype=torch.float32, device=dev)
+            _lib.call("semabs_vool_head", _lib.ptr(ft), _lib.ptr(fr), _lib.ptr(q), _lib.ptr(self._prm), _lib.ptr(rel), _lib.farr(net.vg.offsets),
+                      _lib.farr(net.vg.scales), _lib.iarr(net.vg.grid_shape), float(self.pointing_temperature), num_descs, M,
+                      net.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
+            outs.append(out)
+        return torch.stack(outs, dim=0).view(batch_size, num_descs, M)
+
+    __call__ = forward

@@ -1,0 +1,74 @@
+"""Drop-in for `arm.optim.lamb.Lamb` (arm/optim/lamb.py:26-127): same constructor, `step()`, and per-parameter state keys
+(`step, exp_avg, exp_avg_sq, weight_norm, adam_norm, trust_ratio` - the checkpoint contract of utils.py:289), with the
+whole step done by two multi-tensor HIP kernels over all parameters (`semabs_lamb_step`, csrc/optim.hip)."""
+from __future__ import annotations
+
+import torch
+from torch.optim import Optimizer
+
+from . import _lib
+
+_CHUNK = 16384
+
+
+class Lamb(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0, adam=False):
+        if not 0.0 <= lr:
+            raise ValueError("Invalid learning rate: {}".format(lr))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {}".format(eps))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
+        self.adam = adam
+        self._plan = None
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def _build_plan(self, ps, dev):
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        if self._plan is None or self._plan["key"] != key:
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+            rows = []
+            for t, p in enumerate(ps):
+                for off in range(0, p.numel(), _CHUNK):
+                    rows.append((t, off, min(_CHUNK, p.numel() - off)))
+            ptrs = [[p.data.data_ptr() for p in ps], [p.grad.data.data_ptr() for p in ps],
+                    [self.state[p]["exp_avg"].data_ptr() for p in ps], [self.state[p]["exp_avg_sq"].data_ptr() for p in ps]]
+            self._plan = dict(key=key, chunks=torch.tensor(rows, dtype=torch.int64, device=dev).contiguous(), n_chunks=len(rows),
+                              ptrs=torch.tensor(ptrs, dtype=torch.int64, device=dev).contiguous(),
+                              norms=torch.zeros(len(ps), 2, dtype=torch.float64, device=dev),
+                              stats=torch.zeros(len(ps), 3, dtype=torch.float32, device=dev))
+        return self._plan
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        dev = _lib.require_gpu()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if p.grad.is_sparse:
+                    raise RuntimeError("Lamb does not support sparse gradients, consider SparseAdam instad.")
+                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+            plan = self._build_plan(ps, dev)
+            beta1, beta2 = group["betas"]
+            _lib.call("semabs_lamb_step", _lib.ptr(plan["chunks"]), plan["n_chunks"], _lib.ptr(plan["ptrs"]), len(ps), float(group["lr"]),
+                      float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), int(self.adam), _lib.ptr(plan["norms"]),
+                      _lib.ptr(plan["stats"]), _lib.stream())
+            stats = plan["stats"]
+            for t, p in enumerate(ps):
+                st = self.state[p]
+                st["step"] += 1
+                st["weight_norm"], st["adam_norm"], st["trust_ratio"] = stats[t, 0], stats[t, 1], stats[t, 2]   # device scalars, no sync
+        return loss

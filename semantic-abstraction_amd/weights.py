@@ -154,3 +154,24 @@ DEFAULT_LABELS = [
     "floor", "door", "window", "shelf", "plant", "television", "cushion", "cabinet",
 ]
 DEFAULT_PROMPT = "a photograph of a {} in a home."
+
+VOOL_RELATIONS = ["in", "behind", "in front of", "on the left of", "on the right of", "on", "[pad]"]
+
+
+def make_semabsvool_state_dict(seed: int = 0, pointing_dim: int = 64, unet_num_channels: int = 16, **semabs_kwargs) -> dict:
+    """fp32 state dict for `SemAbsVOOL` (`net.py:469-504`): completion_net.* (a SemAbs3D), spatial_sampler.mlp.{0,2}.*,
+    relation_embeddings.<name>, steps."""
+    rng = np.random.default_rng(seed + 7919)
+    u = lambda fan_in, *s: ((rng.random(s, dtype=np.float32) * 2 - 1) / np.sqrt(fan_in)).astype(np.float32)
+    # SemAbsVOOL swallows decoder_concat_xyz_pts itself (net.py:470-483), so its completion_net is built WITHOUT the xyz concat
+    sd = {"completion_net." + k: v for k, v in make_semabs3d_state_dict(seed=seed, unet_num_channels=unet_num_channels,
+                                                                         decoder_concat_xyz_pts=False, **semabs_kwargs).items()}
+    hid = 2 * unet_num_channels
+    din = hid + 3
+    extra = {"steps": np.zeros(1, dtype=np.float32),
+             "spatial_sampler.mlp.0.weight": u(din, hid, din), "spatial_sampler.mlp.0.bias": u(din, hid),
+             "spatial_sampler.mlp.2.weight": u(hid, pointing_dim, hid), "spatial_sampler.mlp.2.bias": u(hid, pointing_dim)}
+    for name in VOOL_RELATIONS:
+        extra["relation_embeddings." + name] = rng.standard_normal(pointing_dim, dtype=np.float32)
+    sd.update({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in extra.items()})
+    return sd

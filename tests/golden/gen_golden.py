@@ -402,3 +402,46 @@ if __name__ == "__main__":
         elif gname == "g11":
             g11_tsdf()
         print(f"  {time.time() - t0:.1f}s")
+
+
+# ---- appended: VOOL forward + LAMB goldens (G12, forward / optimizer halves) --------------------------------------
+def g12_vool_lamb():
+    from semabs_amd.weights import make_semabsvool_state_dict
+    net, _ = refimport.load_reference_net()
+    S, N, M, D = 32, 3000, 1500, 3
+    m = net.SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cpu", decoder_concat_xyz_pts=True,
+                       voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+                       unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128,
+                       reduce_method="max", batch_size=1)
+    sd = make_semabsvool_state_dict(seed=3)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    xyz, feat, q = _semabs_inputs(S, N, M, 2 * D, seed=13)
+    rel_names = [["behind"], ["on"], ["in front of"]]
+    with torch.no_grad():
+        out = m(output_xyz_pts=torch.from_numpy(q[:, :D]), spatial_relation_name=rel_names, input_xyz_pts=torch.from_numpy(xyz),
+                input_target_saliency_pts=torch.from_numpy(feat[:, :D]), input_reference_saliency_pts=torch.from_numpy(feat[:, D:]),
+                tsdf_vol=None)
+    res = {"vool_out": out.numpy(), "vool_meta": np.asarray([S, N, M, D, 13, 3], np.int32)}
+    # LAMB: 3 steps on a few tensors with seeded gradients (weight decay on, one all-zero tensor, one tiny tensor)
+    sys.path.insert(0, refimport.REF)
+    from arm.optim.lamb import Lamb
+    rng = np.random.default_rng(77)
+    shapes = [(64, 33), (7,), (128, 128), (5, 3, 3, 3, 3), (1,)]
+    params = [torch.nn.Parameter(torch.from_numpy((rng.standard_normal(s) * (0.0 if i == 1 else 0.3)).astype(np.float32))) for i, s in enumerate(shapes)]
+    opt = Lamb(params, lr=1e-3, weight_decay=1e-5)
+    for step in range(3):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy((rng.standard_normal(p.shape) * 0.1).astype(np.float32))
+        opt.step()
+    for i, p in enumerate(params):
+        res[f"lamb_w{i}"] = p.detach().numpy()
+        st = opt.state[p]
+        res[f"lamb_m{i}"] = st["exp_avg"].numpy()
+        res[f"lamb_v{i}"] = st["exp_avg_sq"].numpy()
+        res[f"lamb_stats{i}"] = np.asarray([float(st["weight_norm"]), float(st["adam_norm"]), float(st["trust_ratio"])], np.float32)
+    save("g12_vool_lamb", **res)
+
+
+if __name__ == "__main__" and "g12" in sys.argv[1:]:
+    g12_vool_lamb()
