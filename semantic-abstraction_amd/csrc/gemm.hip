@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
                 f16x8 h;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+                    if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));   // 1-ulp rcp << fp16 rounding of the result
                     h[e] = (f16)v[e];
                 }
                 if ((g.ablate & 16) && v[0] != 12345.678f) continue;
@@ -263,6 +263,7 @@ static int launch(const GemmArgs& g, hipStream_t s) {
     if (big && g_force_cfg == 3) return launch_cfg<EPI, 256, 256, 32, 4, 4, 4>(g, s);      // 16 waves, 64 x 64 wave tiles
     if (big && g_force_cfg == 4) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU
     if (big && g_force_cfg == 5) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);
+    if (g_force_cfg == 6) return launch_cfg<EPI, 128, 128, 32, 2, 2, 3>(g, s);               // 4 waves, 48 KB: 3 blocks / CU
     if (big) return launch_cfg<EPI, 256, 256, 32, 2, 4, 4>(g, s);
     return launch_cfg<EPI, 128, 128, 64, 2, 2, 2>(g, s);
 }

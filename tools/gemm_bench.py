@@ -12,7 +12,7 @@ shapes = [("qkv", M, 2304, 768, 0), ("out", M, 768, 768, 2), ("fc", M, 3072, 768
 torch.manual_seed(0)
 import itertools
 shapes = shapes[:5]
-for cfg, gm in itertools.product((2, 4, 5), (0,)):
+for cfg, gm in [(5, 0), (5, 0)]:
     _lib.call("semabs_gemm_set_config", cfg)
     _lib.call("semabs_gemm_set_config", 1000 + gm)
     print("ablate", gm)
