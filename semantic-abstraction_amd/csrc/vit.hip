@@ -101,18 +101,20 @@ extern "C" int semabs_embed_finish(float* x, const float* cls, const float* pos,
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int NKB, bool CAUSAL>   // number of 32-key blocks: TP = 32 * NKB
-__global__ __launch_bounds__(256, 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int H,
+__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4)) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int H,
                                                    int ld, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = 32 * NKB;
     constexpr int VS = TP + 4;                    // V^T row stride (elements): keeps ds_read_b64 8-byte aligned
     char* sK = smem;
     f16* sV = reinterpret_cast<f16*>(smem + TP * 128);
+    constexpr int NWAVE = (NKB > 4) ? 8 : 4;        // one 32-query block per wave when there are more than 4 of them
+    constexpr int NTHR = 64 * NWAVE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int seq = blockIdx.x / H, h = blockIdx.x % H;
     const f16* base = qkv + (long)seq * T * ld + h * 64;
 
-    for (int c = tid; c < TP * 8; c += 256) {
+    for (int c = tid; c < TP * 8; c += NTHR) {
         int row = c >> 3, kc = c & 7;
         f16x8 kv, vv;
         if (row < T) {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(const f16* __restrict__ qk
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) koff[ks] = kswz(ql, ks * 2 + hi);
 #pragma unroll 1
-    for (int qb = wid; qb < NKB; qb += 4) {
+    for (int qb = wid; qb < NKB; qb += NWAVE) {
         const int q = qb * 32 + ql;
         const int qc = q < T ? q : T - 1;
         f16x8 fq[4];
@@ -227,13 +229,13 @@ extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved
     const int D = H * 64;
     const int nkb = (T + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(n_seq * H), block(256);
+    dim3 grid(n_seq * H);
 #define ATT_LAUNCH(N, C)                                                                                             \
     {                                                                                                                \
         size_t lds = (size_t)(32 * N) * 128 + 64 * (32 * N + 4) * 2;                                                 \
         static bool set = false;                                                                                     \
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
-        hipLaunchKernelGGL((k_attention<N, C>), grid, block, lds, s, (const f16*)qkv, (f16*)out, T, H, ld, D);       \
+        hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, T, H, ld, D); \
     }
 #define ATT_CASE(N) { if (causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }
     switch (nkb) {

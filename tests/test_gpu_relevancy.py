@@ -250,3 +250,44 @@ def test_end_to_end_maps(golden, arch, tag, name, H):
     print(f"{arch}/{name}: map Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e} = {err / np.abs(ref).max():.2e}")
     assert err <= 1e-2 * np.abs(ref).max()
     assert err <= 1e-3                                                          # BASELINE: within 1e-3 of the reference
+
+
+class _FixtureTokenizer:
+    """String -> token ids from tests/golden/tokens_default.npz (the BPE merge table is not on the GPU box)."""
+
+    def __init__(self, golden):
+        g = golden("tokens_default")
+        prompt = str(g["prompt"])
+        self.map = {prompt.format(l): t for l, t in zip(g["labels"], g["tokens"])}
+
+    def tokenize(self, texts, context_length=77, truncate=False):
+        if isinstance(texts, str):
+            texts = [texts]
+        return torch.from_numpy(np.stack([self.map[t] for t in texts]))
+
+
+def test_public_get_clip_saliency_with_text_tower(golden):
+    """The reference's public call, strings in / CPU tensors out: tokenizer (fixture ids) -> HIP text tower -> HIP
+    relevancy, against the reference's (maps, text features) for the same call."""
+    from semabs_amd.clip import saliency_configs
+    CW, sd = _init_clip("ViT-B/32")
+    CW.tokenizer = _FixtureTokenizer(golden)
+    g = golden("g6_e2e_b32")
+    labels = ["chair", "table", "lamp"]
+    img = synth_rgb(96, 96, seed=42)
+    maps, feats = CW.get_clip_saliency(img=img, text_labels=np.array(labels), prompts=[DEFAULT_PROMPT], **saliency_configs["chefer_et_al"](96))
+    assert maps.device.type == "cpu" and feats.device.type == "cpu" and maps.dtype == torch.float32
+    assert tuple(maps.shape) == (3, 96, 96) and tuple(feats.shape) == (3, 512)
+    ref_t = g["chefer96_text"]
+    assert np.abs(feats.numpy() - ref_t).max() <= 5e-3 * np.abs(ref_t).max()
+    ref = g["chefer96_maps"]
+    err = np.abs(maps.numpy() - ref).max()
+    print(f"public API chefer96: map Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e}")
+    assert err <= 2e-2 * np.abs(ref).max() and err <= 1e-3
+    # distractor labels subtract the mean distractor map (CLIP/clip/__init__.py:125-131)
+    m2, _ = CW.get_clip_saliency(img=img, text_labels=labels[:2], prompts=[DEFAULT_PROMPT],
+                                 **dict(saliency_configs["chefer_et_al"](96), distractor_labels={"lamp", "chair"}))
+    np.testing.assert_allclose(m2.numpy(), (maps[:2] - maps[2:3]).numpy(), atol=2e-6)
+    with pytest.raises(AssertionError):
+        CW.get_clip_saliency(img=img.astype(np.float32), text_labels=labels, prompts=[DEFAULT_PROMPT], **saliency_configs["chefer_et_al"](96))
+    CW.tokenizer = None
