@@ -78,9 +78,12 @@ def tile_table(H: int, W: int, n_images: int, cropping_augmentations) -> np.ndar
     return np.asarray(rows, dtype=np.int32).reshape(-1, 4)
 
 
-def tile_counts(H: int, W: int, table: np.ndarray) -> Dict[int, np.ndarray]:
-    """fp32 [H, W] per tile size, 1e-5 + number of covering tiles (over all images), insertion-ordered."""
-    counts: Dict[int, np.ndarray] = {}
+def tile_counts(H: int, W: int, table: np.ndarray, tile_sizes: Sequence[int] = ()) -> Dict[int, np.ndarray]:
+    """fp32 [H, W] per tile size, 1e-5 + number of covering tiles (over all images), insertion-ordered.
+    `tile_sizes`: every crop_aug's tile size in config order — the reference creates a canvas for each of them
+    (CLIP/clip/__init__.py:249-253), including a scale that ends up with no tile (it then contributes 0 / 1e-5 = 0 and
+    still counts in the mean over scales)."""
+    counts: Dict[int, np.ndarray] = {int(ts): np.zeros((H, W), np.float32) + np.float32(1e-5) for ts in tile_sizes}
     for im, x, y, ts in table:
         c = counts.setdefault(int(ts), np.zeros((H, W), np.float32) + np.float32(1e-5))
         c[x:x + ts, y:y + ts] += 1
@@ -251,9 +254,9 @@ def gradcam_tiles(sd, tiles: torch.Tensor, w_text: torch.Tensor, positive_attn_o
 # a9: flip pass, un-flip average, bilinear upsample, fp16 canvases, count-normalise, mean over scales
 # ------------------------------------------------------------------------------------------------
 def aggregate(rel: torch.Tensor, table: np.ndarray, H: int, W: int,
-              tile_interpolate_batch_size: int = 32) -> torch.Tensor:
+              tile_interpolate_batch_size: int = 32, tile_sizes: Sequence[int] = ()) -> torch.Tensor:
     """rel fp32 [L, N, g, g] (already flip-averaged) -> fp32 [L, H, W]  (__init__.py:205-236)."""
-    counts = tile_counts(H, W, table)
+    counts = tile_counts(H, W, table, tile_sizes)
     L = rel.shape[0]
     outputs = {k: torch.zeros(L, H, W).half() for k in counts}
     sizes = table[:, 3]
@@ -287,5 +290,5 @@ def relevancy_maps(sd, images: Sequence[np.ndarray], w_text: torch.Tensor, cropp
     if horizontal_flipping:
         rel_f = run(torch.flip(tiles, dims=[-1]))
         rel = (rel + torch.flip(rel_f, dims=[-1])) / 2
-    out = aggregate(rel, table, H, W)
+    out = aggregate(rel, table, H, W, tile_sizes=[a["tile_size"] for a in cropping_augmentations])
     return (out, rel, table) if return_tiles else out

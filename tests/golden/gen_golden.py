@@ -144,7 +144,8 @@ def g5_aggregate(rc):
     real = W.clip_gradcam
     out = {}
     for tag, H, cfgname, g, L, aug in [("ours120", 120, "ours", 7, 3, 1), ("chefer96", 96, "chefer_et_al", 7, 2, 0),
-                                        ("ours56_g14", 56, "ours", 14, 2, 0)]:
+                                        ("ours56_g14", 56, "ours", 14, 2, 0), ("ours64x48", 64, "ours", 7, 2, 0)]:
+        Wd = 48 if tag == "ours64x48" else H          # non-square: the 64-pixel scale has no tile, yet stays in the mean
         cfg = rc.saliency_configs[cfgname](H)
 
         class Fake:
@@ -163,7 +164,7 @@ def g5_aggregate(rc):
         fake = Fake()
         W.clip_gradcam = fake
         labels = [f"l{i}" for i in range(L)]
-        maps = W.get_clip_saliency_convolve(img=np.zeros((H, H, 3), np.uint8), text_labels=labels,
+        maps = W.get_clip_saliency_convolve(img=np.zeros((H, Wd, 3), np.uint8), text_labels=labels,
                                             horizontal_flipping=cfg["horizontal_flipping"],
                                             positive_attn_only=True, augmentations=aug,
                                             cropping_augmentations=cfg["cropping_augmentations"])
@@ -173,7 +174,7 @@ def g5_aggregate(rc):
         if n_pass == 2:
             out[f"{tag}_rel_flip"] = torch.cat(fake.calls[per:], dim=1).numpy()
         out[f"{tag}_maps"] = maps.numpy()
-        out[f"{tag}_meta"] = np.asarray([H, g, L, aug, int(cfg["horizontal_flipping"])], np.int32)
+        out[f"{tag}_meta"] = np.asarray([H, g, L, aug, int(cfg["horizontal_flipping"]), Wd], np.int32)
     W.clip_gradcam = real
     save("g5_aggregate", **out)
 

@@ -153,19 +153,19 @@ def test_tile_patches_bit_exact(p):
         assert np.array_equal(got.numpy(), ref.astype(np.float16)), f"flip={flip}"
 
 
-@pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours")])
+@pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours"), ("ours64x48", "ours")])
 def test_aggregate_vs_golden(golden, tag, cfgname):
     from semabs_amd.clip import ClipWrapper, plan_tiles, saliency_configs
     CW, _ = _init_clip("ViT-B/32")
     g = golden("g5_aggregate")
-    H, gg, L, aug, flip = (int(v) for v in g[f"{tag}_meta"])
+    H, gg, L, aug, flip, W = (int(v) for v in g[f"{tag}_meta"])
     cfg = saliency_configs[cfgname](H)
-    table, scales = plan_tiles(H, H, aug + 1, cfg["cropping_augmentations"])
-    assert np.array_equal(table, orl.tile_table(H, H, aug + 1, cfg["cropping_augmentations"]))
+    table, scales = plan_tiles(H, W, aug + 1, cfg["cropping_augmentations"])
+    assert np.array_equal(table, orl.tile_table(H, W, aug + 1, cfg["cropping_augmentations"]))
     rel = [torch.from_numpy(g[f"{tag}_rel"]).cuda()]
     if flip:
         rel.append(torch.from_numpy(g[f"{tag}_rel_flip"]).cuda())
-    out = CW.aggregate_device(rel, scales, aug + 1, H, H).cpu().numpy()
+    out = CW.aggregate_device(rel, scales, aug + 1, H, W).cpu().numpy()
     ref = g[f"{tag}_maps"]
     err = np.abs(out - ref)
     # same adds in the same order; an fp32 last-bit difference in the bilinear sample can flip one fp16 rounding of a

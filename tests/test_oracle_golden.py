@@ -99,16 +99,16 @@ def test_text_weights(golden):
 
 
 # ---- a9 ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours")])
+@pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours"), ("ours64x48", "ours")])
 def test_aggregate(golden, tag, cfgname):
     g = golden("g5_aggregate")
-    H, gg, L, aug, flip = g[f"{tag}_meta"]
+    H, gg, L, aug, flip, W = (int(v) for v in g[f"{tag}_meta"])
     cfg = orl.saliency_configs[cfgname](int(H))
-    table = orl.tile_table(H, H, aug + 1, cfg["cropping_augmentations"])
+    table = orl.tile_table(H, W, aug + 1, cfg["cropping_augmentations"])
     rel = torch.from_numpy(g[f"{tag}_rel"])
     if flip:
         rel = (rel + torch.flip(torch.from_numpy(g[f"{tag}_rel_flip"]), dims=[-1])) / 2
-    out = orl.aggregate(rel, table, int(H), int(H))
+    out = orl.aggregate(rel, table, H, W, tile_sizes=[a["tile_size"] for a in cfg["cropping_augmentations"]])
     assert np.array_equal(out.numpy(), g[f"{tag}_maps"])       # same ops in the same order: bit-exact
 
 
