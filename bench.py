@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--arch", default=ARCH)
     ap.add_argument("--precision", default="exact", choices=["exact", "fp16"], help="UNet arithmetic (see DESIGN.md)")
     ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over (2 = +4%% scenes/s, but "
+                    "overlapping kernels blur the per-launch HIP-event timing the roofline leg relies on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,6 +110,7 @@ def main():
     w_text = torch.from_numpy(w).cuda()
     n_scenes = args.steps + args.warmup
     from semabs_amd.clip import ClipWrapper, saliency_configs
+    ClipWrapper.n_streams = max(1, args.streams)
     cfg = saliency_configs["ours"](IMG)
     scenes = []
     for i in range(n_scenes):
@@ -159,7 +162,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"end-to-end relevancy->fusion->OVSSC per scene: {IMG}x{IMG} RGB-D, {N_LABELS} labels, {args.arch}, "
                                    f"'ours' saliency config (2448 tile forwards), {VOXEL}^3 voxels, 80000 input points; scene-sharded",
-                       "arch": args.arch, "unet_precision": args.precision, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
+                       "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
             "roofline": {"kernel": "k_gemm_f16 (all epilogues)", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "launches": gs["launches"],
