@@ -179,6 +179,69 @@ int semabs_vool_head(const void* vol_t, const void* vol_r, const float* query, c
 int semabs_lamb_step(const long long* chunks, int n_chunks, const long long* ptrs, int n_tensors, double lr, double beta1,
                      double beta2, double eps, double weight_decay, int adam, double* norms, float* stats, void* stream);
 
+/* ============================ training step (csrc/train.hip, csrc/unet.hip) ============================== */
+/* What torch.autograd + train_vool.py / utils.loop do for one optimisation step of SemAbsVOOL (config 5):
+ *   forward graph            net.py:506-579 (SemAbsVOOL), 383-439 (SemAbs3D), unet3d.py:190-259, 596-621
+ *   loss                     train_vool.py:171-178 (binary_cross_entropy_with_logits, weight = utils.get_bce_weight utils.py:727-749)
+ *   backward + clip + step   utils.py:404-417 (loss.backward, clip_grad_norm_, Lamb.step)
+ * All buffers fp32 on the device unless noted; channels-last volumes [B, D0, D1, D2, C]. */
+
+/* General gather convolution y[b, m] = sum_taps W_tap . x[b, m * in_stride + td_tap] (zero padding): the data gradient of Conv3d
+ * (flipped taps, stride 1) and of ConvTranspose3d (stride 2).  w_hi / w_lo fp16 [Cout, Kp], k = tap * Cin + cin; taps int8 [ntaps, 3] host;
+ * in_scale / in_shift fp32 [B, Cin]: optional per-(b, c) input affine (the dynamic gradient scale of semabs_grad_scale). */
+int semabs_conv3d_gather(const void* x, const void* w_hi, const void* w_lo, void* y, const float* in_scale, const float* in_shift, int B,
+                         int I0, int I1, int I2, int M0, int M1, int M2, int in_stride, int Cin, int Cout, int ntaps, const signed char* taps,
+                         int act_f32, void* stream);
+
+/* Weight gradient dW[ca][tap * Cx + cx] += sum_rows A[row][ca] * GN(X)[neighbour(row, tap)][cx]; rows run over [B, M0, M1, M2], the
+ * neighbour is m * in_stride + td with zero padding.  Conv3d: A = dY, X = layer input.  ConvTranspose3d: A = input, X = dY, stride 2.
+ * Linear: M0 = M1 = 1, M2 = rows, one tap.  dW is accumulated (zero it first).  Ca % 16 == 0, Cx % 4 == 0. */
+int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0, int M1, int M2,
+                 int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps, void* stream);
+
+/* out fp64 [B, C, 2] += (sum_v dY, sum_v dY * xhat) per (batch, channel); X = NULL gives plain column sums (bias gradients) */
+int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const float* rstd, double* out, int B, long nvox, int C, int G,
+                       void* stream);
+/* GroupNorm mean / rstd fp32 [B, G] from the fp64 sums of semabs_gn_stats (what the backward needs)      unet3d.py:59-77 */
+int semabs_gn_meanrstd(const double* sums, float* mean, float* rstd, int B, int G, long count, float eps, void* stream);
+/* GroupNorm backward: per-(b, c) coefficients + dgamma / dbeta (accumulated), then dX = k1 dXn - k2 - xhat k3 (+ add1 + add2) */
+int semabs_gn_bwd_coef(const double* red, const float* gamma, const float* rstd, const float* inv_scale, float* coef, float* dgamma,
+                       float* dbeta, int B, int C, int G, long nvox, void* stream);
+int semabs_gn_bwd_apply(const float* dXn, const float* X, const float* mean, const float* rstd, const float* coef, const float* add1,
+                        const float* add2, float* dX, int B, long nvox, int C, int G, void* stream);
+
+/* element-wise over n (% 4 == 0) floats: mode 0 out = a * (b > 0) (ReLU backward from the output), 1 LeakyReLU backward, 2 out = a + b,
+ * 3 out = a * b[0] (b = device scalar) */
+int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, void* stream);
+/* Dynamic power-of-two scale s for a gradient tensor (max |x| * s in [256, 512)) so the split-fp16 data-gradient convolutions keep fp32-like
+ * accuracy for tiny gradients: scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits = uint32 scratch */
+int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, void* stream);
+/* MaxPool3d(2) backward: first maximal element of each window takes dY                                   unet3d.py:298-317 */
+int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, int B, int D0, int D1, int D2, int C, void* stream);
+
+/* Y[R, Co] = act(X[R, Ci] . W[Co, Ci]^T + bias), act 0 none / 1 LeakyReLU(slope): the point MLP and sampler MLP layers and, with W
+ * transposed by the caller, their data gradients                                                         net.py:358-367, 300-309 */
+int semabs_linear_f32(const float* X, const float* W, const float* bias, float* Y, long R, int Ci, int Co, int act, float slope, void* stream);
+
+/* scatter-mean backward: dpf[b, p] = dvol[b, flat[p]] / count[flat[p]]; count int32 [nvox] zero-filled by the caller   net.py:185-201 */
+int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol, float* dpf, int P, long N, int C, long nvox, void* stream);
+
+/* VOOL head pieces for training: f [P*M, 36] = (trilinear(vol_t), trilinear(vol_r), qn, 0) and the scatter of df back into the two
+ * gradient volumes (accumulated, zero first)                                                            net.py:215-256, 556-565 */
+int semabs_vool_sample(const float* vol_t, const float* vol_r, const float* query, const float* off3, const float* sc3, const int* shape3,
+                       int P, long M, float* f, void* stream);
+int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
+                           float* dvol_t, float* dvol_r, void* stream);
+
+/* logits = cos(o, rel) / T; loss += sum w BCEwithlogits(logit, label) / n_total; dO and drel (accumulated) = d loss / d o, d rel
+ *                                                                                                        net.py:566-579, train_vool.py:171-178 */
+int semabs_cos_bce(const float* o, const float* rel, const float* label, const float* weight, int P, long M, float temperature, long n_total,
+                   float* logits, float* dO, float* drel, double* loss, void* stream);
+
+/* clip_grad_norm_ over the LAMB chunk table: g *= extra_scale, then g *= min(1, max_norm / (norm + 1e-6)); sq fp64 [1] = sum g^2   utils.py:415 */
+int semabs_clip_grad_norm(const long long* chunks, int n_chunks, const long long* ptrs, int n_tensors, float max_norm, float extra_scale,
+                          double* sq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

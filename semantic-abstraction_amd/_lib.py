@@ -66,6 +66,22 @@ SIGNATURES = {
     "semabs_vool_head": [P, P, P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), F, I, L, I, P, P],
     "semabs_lamb_step": [P, I, P, I, D, D, D, D, D, I, P, P, P],
     "semabs_decoder": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, I, I, L, L, I, P, P],
+    # training step (train.hip, unet.hip)
+    "semabs_conv3d_gather": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],
+    "semabs_wgrad": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, P],
+    "semabs_chan_reduce": [P, P, P, P, P, I, L, I, I, P],
+    "semabs_gn_meanrstd": [P, P, P, I, I, L, F, P],
+    "semabs_gn_bwd_coef": [P, P, P, P, P, P, P, I, I, I, L, P],
+    "semabs_gn_bwd_apply": [P, P, P, P, P, P, P, P, I, L, I, I, P],
+    "semabs_ew": [P, P, P, L, I, F, P],
+    "semabs_grad_scale": [P, L, P, P, I, P, P, P],
+    "semabs_maxpool3d_bwd": [P, P, P, I, I, I, I, I, P],
+    "semabs_linear_f32": [P, P, P, P, L, I, I, I, F, P],
+    "semabs_scatter_mean_bwd": [P, P, P, P, I, L, I, L, P],
+    "semabs_vool_sample": [P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P],
+    "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P],
+    "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P],
+    "semabs_clip_grad_norm": [P, I, P, I, F, F, P, P],
 }
 
 

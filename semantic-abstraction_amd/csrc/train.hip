@@ -1,0 +1,580 @@
+// Backward / training kernels for the VOOL training step (config 5: train_vool.py -> utils.loop, utils.py:404-417):
+// 3D-UNet backward (weight gradients, GroupNorm / ReLU / MaxPool / ConvTranspose backward), point-MLP and sampler-MLP
+// linear layers, scatter-mean and trilinear-sampling backward, cosine-similarity pointer backward, BCE-with-logits.
+// Data gradients of Conv3d / ConvTranspose3d reuse the forward implicit-GEMM kernels of unet.hip with re-laid-out weights.
+// Everything here is fp32 (training uses the "exact" activation mode).
+//
+// Replaces what torch.autograd does for (reference file:line):
+//   SemAbsVOOL.forward graph                         net.py:506-579
+//   SemAbs3D.forward graph                           net.py:383-439, 185-201 (scatter), 215-256 (decoder)
+//   ResidualUNet3D                                   unet3d.py:190-259, 298-317, 385-444, 596-621
+//   binary_cross_entropy_with_logits                 train_vool.py:171-178
+//   clip_grad_norm_                                  utils.py:415
+#include "semabs_common.h"
+
+// =================================================================================================
+// Weight gradient as a split-K "A^T B" reduction over rows (voxels / points):
+//   dW[ca][tap * Cx + cx] += sum_rows A[row][ca] * Xn(neighbour(row, tap))[cx]
+// A fp32 [R, Ca] (rows over the index space [B, M0, M1, M2]); X fp32 [B, I0, I1, I2, Cx] gathered at m * is + td with
+// zero padding, optionally through a GroupNorm affine (scale / shift per (b, cx)).  A workgroup owns a 16 x 64 tile of dW and
+// a chunk of rows; 32-row batches of A and the gathered X go through LDS; fp32 atomics combine the row chunks.
+// =================================================================================================
+struct WgradArgs {
+    const float* A; const float* X; const float* gn_scale; const float* gn_shift; float* dW;
+    int B, M0, M1, M2, I0, I1, I2, is;
+    int Ca, Cx, ntaps; long rows_per_block;
+    signed char td0[28], td1[28], td2[28];
+};
+
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+    __shared__ float sA[32][16];
+    __shared__ __attribute__((aligned(16))) float sB[32][64];
+    const int t = threadIdx.x;
+    const int ca0 = blockIdx.y * 16, n0 = blockIdx.z * 64;
+    const int N = a.ntaps * a.Cx;
+    const long R = (long)a.B * a.M0 * a.M1 * a.M2;
+    const long r_begin = (long)blockIdx.x * a.rows_per_block;
+    long r_end = r_begin + a.rows_per_block; if (r_end > R) r_end = R;
+    const int ca = t & 15, ng = t >> 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long rb = r_begin; rb < r_end; rb += 32) {
+        // stage A: 32 rows x 16 channels (2 per thread)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = t + k * 256, rr = e >> 4, c = e & 15;
+            const long row = rb + rr;
+            sA[rr][c] = (row < r_end) ? a.A[row * a.Ca + ca0 + c] : 0.f;
+        }
+        // stage gathered X: 32 rows x 64 columns as 16 float4 per row (2 float4 per thread)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = t + k * 256, rr = e >> 4, q = e & 15;
+            const long row = rb + rr;
+            const int n = n0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r_end && n < N) {
+                const int tap = n / a.Cx, cx = n - tap * a.Cx;
+                long m = row;
+                const int m2 = (int)(m % a.M2); m /= a.M2;
+                const int m1 = (int)(m % a.M1); m /= a.M1;
+                const int m0 = (int)(m % a.M0); const int b = (int)(m / a.M0);
+                const int i0 = m0 * a.is + a.td0[tap], i1 = m1 * a.is + a.td1[tap], i2 = m2 * a.is + a.td2[tap];
+                if (i0 >= 0 && i0 < a.I0 && i1 >= 0 && i1 < a.I1 && i2 >= 0 && i2 < a.I2) {
+                    v = *reinterpret_cast<const float4*>(a.X + ((((long)b * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cx + cx);
+                    if (a.gn_scale) {
+                        const float4 s = *reinterpret_cast<const float4*>(a.gn_scale + (long)b * a.Cx + cx);
+                        const float4 h = *reinterpret_cast<const float4*>(a.gn_shift + (long)b * a.Cx + cx);
+                        v.x = v.x * s.x + h.x; v.y = v.y * s.y + h.y; v.z = v.z * s.z + h.z; v.w = v.w * s.w + h.w;
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(&sB[rr][q * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) {
+            const float av = sA[rr][ca];
+            const float4 bv = *reinterpret_cast<const float4*>(&sB[rr][ng * 4]);
+            acc[0] += av * bv.x; acc[1] += av * bv.y; acc[2] += av * bv.z; acc[3] += av * bv.w;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = n0 + ng * 4 + k;
+        if (n < N) atomicAdd(&a.dW[(long)(ca0 + ca) * N + n], acc[k]);
+    }
+}
+
+// dW fp32 [Ca, ntaps * Cx] is ACCUMULATED into (zero it first).  taps int8 [ntaps, 3] host array.  Ca % 16 == 0, Cx % 4 == 0.
+extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0,
+                            int M1, int M2, int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps,
+                            void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(A && X && dW && taps, "semabs_wgrad: null pointer");
+    SEMABS_REQUIRE(Ca % 16 == 0 && Cx % 4 == 0 && ntaps >= 1 && ntaps <= 28, "semabs_wgrad: Ca % 16, Cx % 4, 1 <= ntaps <= 28");
+    WgradArgs a;
+    a.A = A; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.dW = dW;
+    a.B = B; a.M0 = M0; a.M1 = M1; a.M2 = M2; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.is = in_stride; a.Ca = Ca; a.Cx = Cx; a.ntaps = ntaps;
+    for (int i = 0; i < ntaps; ++i) { a.td0[i] = taps[i * 3]; a.td1[i] = taps[i * 3 + 1]; a.td2[i] = taps[i * 3 + 2]; }
+    const long R = (long)B * M0 * M1 * M2;
+    const int ytiles = Ca / 16, ztiles = semabs_cdiv((long)ntaps * Cx, 64);
+    // enough row chunks to fill the chip a few times over, but at least 1024 rows each (keeps the atomic traffic small)
+    long target_blocks = 4096 / ((long)ytiles * ztiles); if (target_blocks < 1) target_blocks = 1;
+    long rpb = (R + target_blocks - 1) / target_blocks; if (rpb < 1024) rpb = 1024;
+    rpb = (rpb + 31) / 32 * 32;
+    a.rows_per_block = rpb;
+    dim3 grid(semabs_cdiv(R, rpb), ytiles, ztiles);
+    hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Per-(batch, channel) reductions over voxels: Sa = sum dY, Sb = sum dY * xhat (xhat = (X - mean_g) * rstd_g), fp64 atomics.
+// Used for bias gradients (X = null) and GroupNorm backward.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_chan_reduce(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, double* __restrict__ out, long nvox, int C, int G) {
+    const int b = blockIdx.y;
+    const int cpv = C / 4;
+    const long chunks = nvox * cpv;
+    long stride = (long)gridDim.x * 256; stride -= stride % cpv;
+    const long start = (long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sh[2][512];
+    for (int c = threadIdx.x; c < C; c += 256) { sh[0][c] = 0.f; sh[1][c] = 0.f; }
+    __syncthreads();
+    if (start < stride) {
+        const int c0 = (int)(start % cpv) * 4;
+        float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
+        if (X) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int g = (c0 + j) / (C / G); mu[j] = mean[b * G + g]; rs[j] = rstd[b * G + g]; }
+        }
+        float sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+        const float* dyb = dY + (long)b * nvox * C; const float* xb = X ? X + (long)b * nvox * C : nullptr;
+        for (long i = start; i < chunks; i += stride) {
+            const float4 d = *reinterpret_cast<const float4*>(dyb + i * 4);
+            sa[0] += d.x; sa[1] += d.y; sa[2] += d.z; sa[3] += d.w;
+            if (xb) {
+                const float4 x = *reinterpret_cast<const float4*>(xb + i * 4);
+                sb[0] += d.x * ((x.x - mu[0]) * rs[0]); sb[1] += d.y * ((x.y - mu[1]) * rs[1]);
+                sb[2] += d.z * ((x.z - mu[2]) * rs[2]); sb[3] += d.w * ((x.w - mu[3]) * rs[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { atomicAdd(&sh[0][c0 + j], sa[j]); atomicAdd(&sh[1][c0 + j], sb[j]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(&out[((long)b * C + c) * 2], (double)sh[0][c]);
+        atomicAdd(&out[((long)b * C + c) * 2 + 1], (double)sh[1][c]);
+    }
+}
+// dY (and X) fp32 [B, nvox, C]; mean / rstd fp32 [B, G] (with X); out fp64 [B, C, 2] accumulated (zero it first)
+extern "C" int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const float* rstd, double* out, int B, long nvox, int C,
+                                  int G, void* stream) {
+    if (B == 0 || nvox == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(dY && out && C % 4 == 0 && C <= 512 && (!X || (mean && rstd && G > 0 && C % G == 0)), "semabs_chan_reduce: bad args");
+    long chunks = nvox * (C / 4);
+    int bx = semabs_cdiv(chunks, 256 * 16); if (bx < 1) bx = 1; if (bx > 128) bx = 128;
+    hipLaunchKernelGGL(k_chan_reduce, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, dY, X, mean, rstd, out, nvox, C, G > 0 ? G : 1);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// GroupNorm forward statistics in the form the backward needs: mean / rstd per (b, g) from the fp64 sums of semabs_gn_stats
+__global__ void k_gn_meanrstd(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd, int n, double count, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double m = sums[i * 2] / count;
+    double var = sums[i * 2 + 1] / count - m * m; if (var < 0) var = 0;
+    mean[i] = (float)m; rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+extern "C" int semabs_gn_meanrstd(const double* sums, float* mean, float* rstd, int B, int G, long count, float eps, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(sums && mean && rstd && count > 0, "semabs_gn_meanrstd: bad args");
+    hipLaunchKernelGGL(k_gn_meanrstd, dim3(semabs_cdiv((long)B * G, 256)), dim3(256), 0, (hipStream_t)stream, sums, mean, rstd, B * G, (double)count, eps);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// GroupNorm backward, coefficient stage: red fp64 [B, C, 2] (Sa, Sb) ->
+//   coef fp32 [B, C, 3] = (rstd * gamma_c, rstd * s1 / n, rstd * s2 / n) with s1 = sum_{c in g} gamma_c Sa, s2 = sum gamma_c Sb
+//   dgamma[c] += sum_b Sb[b, c];  dbeta[c] += sum_b Sa[b, c]
+__global__ void k_gn_bwd_coef(const double* __restrict__ red, const float* __restrict__ gamma, const float* __restrict__ rstd,
+                              const float* __restrict__ inv_scale, float* __restrict__ coef, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, int B, int C, int G, double n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C, cg = C / G, g = c / cg;
+    const double inv = inv_scale ? (double)inv_scale[0] : 1.0;        // dXn (and so red) carry the dynamic gradient scale
+    double s1 = 0, s2 = 0;
+    for (int k = g * cg; k < (g + 1) * cg; ++k) { s1 += (double)gamma[k] * red[((long)b * C + k) * 2]; s2 += (double)gamma[k] * red[((long)b * C + k) * 2 + 1]; }
+    s1 *= inv; s2 *= inv;
+    const float rs = rstd[b * G + g];
+    coef[i * 3] = (float)(rs * gamma[c] * inv); coef[i * 3 + 1] = (float)(rs * s1 / n); coef[i * 3 + 2] = (float)(rs * s2 / n);
+    atomicAdd(&dgamma[c], (float)(red[((long)b * C + c) * 2 + 1] * inv));
+    atomicAdd(&dbeta[c], (float)(red[((long)b * C + c) * 2] * inv));
+}
+extern "C" int semabs_gn_bwd_coef(const double* red, const float* gamma, const float* rstd, const float* inv_scale, float* coef, float* dgamma,
+                                  float* dbeta, int B, int C, int G, long nvox, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(red && gamma && rstd && coef && dgamma && dbeta && C % G == 0, "semabs_gn_bwd_coef: bad args");
+    hipLaunchKernelGGL(k_gn_bwd_coef, dim3(semabs_cdiv((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, red, gamma, rstd, inv_scale, coef,
+                       dgamma, dbeta, B, C, G, (double)nvox * (C / G));
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// dX = k1 * dXn - k2 - xhat * k3  [+ add1] [+ add2]
+__global__ void k_gn_bwd_apply(const float* __restrict__ dXn, const float* __restrict__ X, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ coef, const float* __restrict__ add1,
+                               const float* __restrict__ add2, float* __restrict__ dX, int B, long nvox, int C, int G) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)B * nvox * (C / 4);
+    if (i >= tot) return;
+    const int c0 = (int)(i % (C / 4)) * 4; const int b = (int)(i / (nvox * (C / 4)));
+    const float4 d = *reinterpret_cast<const float4*>(dXn + i * 4);
+    const float4 x = *reinterpret_cast<const float4*>(X + i * 4);
+    float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w}, o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j, g = c / (C / G);
+        const float xh = (xv[j] - mean[b * G + g]) * rstd[b * G + g];
+        const float* k = coef + ((long)b * C + c) * 3;
+        o[j] = k[0] * dv[j] - k[1] - xh * k[2];
+    }
+    if (add1) { const float4 a = *reinterpret_cast<const float4*>(add1 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+    if (add2) { const float4 a = *reinterpret_cast<const float4*>(add2 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+    *reinterpret_cast<float4*>(dX + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+extern "C" int semabs_gn_bwd_apply(const float* dXn, const float* X, const float* mean, const float* rstd, const float* coef, const float* add1,
+                                   const float* add2, float* dX, int B, long nvox, int C, int G, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(dXn && X && mean && rstd && coef && dX && C % 4 == 0 && C % G == 0, "semabs_gn_bwd_apply: bad args");
+    hipLaunchKernelGGL(k_gn_bwd_apply, dim3(semabs_cdiv((long)B * nvox * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, dXn, X, mean, rstd, coef,
+                       add1, add2, dX, B, nvox, C, G);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Element-wise: masked gradients and sums
+//   mode 0: out = dY * (Y > 0)                 (ReLU)
+//   mode 1: out = dY * (Y > 0 ? 1 : slope)     (LeakyReLU, sign of the output = sign of the pre-activation)
+//   mode 2: out = a + b                        (gradient fan-in;  Y = second addend)
+//   mode 3: out = a * b[0]                     (undo the dynamic gradient scale, b = device scalar)
+// =================================================================================================
+__global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ out, long n4, int mode, float slope) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 d = *reinterpret_cast<const float4*>(dY + i * 4);
+    if (mode == 3) { const float k = Y[0]; *reinterpret_cast<float4*>(out + i * 4) = make_float4(d.x * k, d.y * k, d.z * k, d.w * k); return; }
+    const float4 y = *reinterpret_cast<const float4*>(Y + i * 4);
+    float4 o;
+    if (mode == 2) { o.x = d.x + y.x; o.y = d.y + y.y; o.z = d.z + y.z; o.w = d.w + y.w; }
+    else {
+        const float s = mode == 0 ? 0.f : slope;
+        o.x = d.x * (y.x > 0.f ? 1.f : s); o.y = d.y * (y.y > 0.f ? 1.f : s); o.z = d.z * (y.z > 0.f ? 1.f : s); o.w = d.w * (y.w > 0.f ? 1.f : s);
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = o;
+}
+extern "C" int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(a && b && out && n % 4 == 0 && mode >= 0 && mode <= 3, "semabs_ew: bad args (n % 4 == 0)");
+    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// MaxPool3d(2) backward, channels-last fp32: the FIRST maximal element of each 2x2x2 window (scan order d, h, w) gets dY
+__global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX, int B, int O0, int O1, int O2, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)B * O0 * O1 * O2 * C;
+    if (i >= tot) return;
+    const int c = (int)(i % C); long v = i / C;
+    const int o2 = (int)(v % O2); v /= O2;
+    const int o1 = (int)(v % O1); v /= O1;
+    const int o0 = (int)(v % O0); const int b = (int)(v / O0);
+    const int I1 = 2 * O1, I2 = 2 * O2;
+    float best = -INFINITY; int arg = 0; long idx[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        idx[d] = ((((long)b * 2 * O0 + 2 * o0 + (d >> 2)) * I1 + 2 * o1 + ((d >> 1) & 1)) * I2 + 2 * o2 + (d & 1)) * C + c;
+        const float x = X[idx[d]];
+        if (x > best) { best = x; arg = d; }
+    }
+    const float g = dY[i];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dX[idx[d]] = (d == arg) ? g : 0.f;
+}
+extern "C" int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, int B, int D0, int D1, int D2, int C, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(X && dY && dX && D0 % 2 == 0 && D1 % 2 == 0 && D2 % 2 == 0, "semabs_maxpool3d_bwd: bad args");
+    const long tot = (long)B * (D0 / 2) * (D1 / 2) * (D2 / 2) * C;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Dense fp32 linear layer for the point / sampler MLPs: Y[R, Co] = act(X[R, Ci] . W[Co, Ci]^T + b)
+// act: 0 none, 1 LeakyReLU(slope).  One thread = one row x 16 outputs; the 16 x Ci weight slice sits in LDS.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                float* __restrict__ Y, long R, int Ci, int Co, int act, float slope) {
+    extern __shared__ float sw[];                     // [16][Ci]
+    const int co0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 16 * Ci; i += 256) { const int o = i / Ci, k = i - o * Ci; sw[i] = (co0 + o < Co) ? W[(long)(co0 + o) * Ci + k] : 0.f; }
+    __syncthreads();
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = (bias && co0 + o < Co) ? bias[co0 + o] : 0.f;
+    const float* xr = X + r * Ci;
+    for (int k = 0; k < Ci; ++k) {
+        const float xv = xr[k];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] += sw[o * Ci + k] * xv;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+        if (co0 + o < Co) { float v = acc[o]; if (act == 1) v = v > 0.f ? v : slope * v; Y[r * Co + co0 + o] = v; }
+}
+extern "C" int semabs_linear_f32(const float* X, const float* W, const float* bias, float* Y, long R, int Ci, int Co, int act, float slope, void* stream) {
+    if (R == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(X && W && Y && Ci > 0 && Co > 0 && Ci <= 1024, "semabs_linear_f32: bad args");
+    hipLaunchKernelGGL(k_linear, dim3(semabs_cdiv(R, 256), semabs_cdiv(Co, 16)), dim3(256), (size_t)16 * Ci * 4, (hipStream_t)stream, X, W, bias, Y, R, Ci, Co, act, slope);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Scatter-mean backward: dpf[b, p, :] = dvol[b, flat[p], :] / count[flat[p]]   (count via an integer histogram)
+// =================================================================================================
+__global__ void k_voxel_count(const long long* __restrict__ flat, long N, int* __restrict__ count) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < N) atomicAdd(&count[flat[p]], 1);
+}
+__global__ void k_scatter_mean_bwd(const long long* __restrict__ flat, const int* __restrict__ count, const float* __restrict__ dvol,
+                                   float* __restrict__ dpf, int P, long N, int C, long nvox) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * N * (C / 4)) return;
+    const int c4 = (int)(i % (C / 4)); const long bp = i / (C / 4);
+    const long p = bp % N; const int b = (int)(bp / N);
+    const long v = flat[p];
+    const float inv = 1.f / (float)count[v];
+    float4 d = *reinterpret_cast<const float4*>(dvol + ((long)b * nvox + v) * C + c4 * 4);
+    d.x *= inv; d.y *= inv; d.z *= inv; d.w *= inv;
+    *reinterpret_cast<float4*>(dpf + bp * C + c4 * 4) = d;
+}
+// count int32 [nvox] must be zero-filled by the caller
+extern "C" int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol, float* dpf, int P, long N, int C, long nvox, void* stream) {
+    if (P == 0 || N == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(flat && count && dvol && dpf && C % 4 == 0, "semabs_scatter_mean_bwd: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_voxel_count, dim3(semabs_cdiv(N, 256)), dim3(256), 0, s, flat, N, count);
+    hipLaunchKernelGGL(k_scatter_mean_bwd, dim3(semabs_cdiv((long)P * N * (C / 4), 256)), dim3(256), 0, s, flat, count, dvol, dpf, P, N, C, nvox);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// VOOL head, decomposed for training: trilinear sampling of the two volumes (+ qn) -> f [R, 36] (35 used, 1 pad), its
+// backward (scatter of df into the two gradient volumes with the same corner weights), cosine pointer forward/backward.
+// =================================================================================================
+struct SampArgs { float off[3], sc[3]; int S0, S1, S2; };
+__device__ __forceinline__ void samp_setup(const float* qp, const SampArgs& a, float* qn, int& x0, int& y0, int& z0, float* w) {
+    const int S[3] = {a.S0, a.S1, a.S2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = (qp[k] + a.off[k]) * a.sc[k];
+        t = fminf(fmaxf(t, 0.f), (float)(S[k] - 1));
+        t = t / (float)S[k];
+        qn[k] = 2.0f * t - 1.0f;
+    }
+    float ix = ((qn[0] + 1.f) / 2.f) * (float)(a.S2 - 1), iy = ((qn[1] + 1.f) / 2.f) * (float)(a.S1 - 1), iz = ((qn[2] + 1.f) / 2.f) * (float)(a.S0 - 1);
+    ix = fminf(fmaxf(ix, 0.f), (float)(a.S2 - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(a.S1 - 1)); iz = fminf(fmaxf(iz, 0.f), (float)(a.S0 - 1));
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    x0 = (int)fx; y0 = (int)fy; z0 = (int)fz;
+    w[0] = (fx + 1.f) - ix; w[1] = ix - fx; w[2] = (fy + 1.f) - iy; w[3] = iy - fy; w[4] = (fz + 1.f) - iz; w[5] = iz - fz;
+}
+// thread = (point, volume selector v in {0: target, 1: reference}): 16 channels
+__global__ void k_vool_sample(const float* __restrict__ vol_t, const float* __restrict__ vol_r, const float* __restrict__ query, SampArgs a, int P,
+                              long M, float* __restrict__ f) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * M * 2) return;
+    const int sel = (int)(i & 1); const long pt = i >> 1; const int d = (int)(pt / M);
+    float qn[3], w[6]; int x0, y0, z0;
+    samp_setup(query + pt * 3, a, qn, x0, y0, z0, w);
+    const float* vb = (sel ? vol_r : vol_t) + (long)d * a.S0 * a.S1 * a.S2 * 16;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int zz = z0 + (k >> 2), yy = y0 + ((k >> 1) & 1), xx = x0 + (k & 1);
+        if (zz > a.S0 - 1 || yy > a.S1 - 1 || xx > a.S2 - 1) continue;
+        const float wt = w[k & 1] * w[2 + ((k >> 1) & 1)] * w[4 + (k >> 2)];
+        const float4* p = reinterpret_cast<const float4*>(vb + (((long)zz * a.S1 + yy) * a.S2 + xx) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 v = p[q]; acc[4 * q] += v.x * wt; acc[4 * q + 1] += v.y * wt; acc[4 * q + 2] += v.z * wt; acc[4 * q + 3] += v.w * wt; }
+    }
+    float* fo = f + pt * 36 + sel * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) fo[c] = acc[c];
+    if (sel == 0) { f[pt * 36 + 32] = qn[0]; f[pt * 36 + 33] = qn[1]; f[pt * 36 + 34] = qn[2]; f[pt * 36 + 35] = 0.f; }
+}
+__global__ void k_vool_sample_bwd(const float* __restrict__ df, const float* __restrict__ query, SampArgs a, int P, long M,
+                                  float* __restrict__ dvol_t, float* __restrict__ dvol_r) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * M * 2) return;
+    const int sel = (int)(i & 1); const long pt = i >> 1; const int d = (int)(pt / M);
+    float qn[3], w[6]; int x0, y0, z0;
+    samp_setup(query + pt * 3, a, qn, x0, y0, z0, w);
+    float* vb = (sel ? dvol_r : dvol_t) + (long)d * a.S0 * a.S1 * a.S2 * 16;
+    const float* g = df + pt * 36 + sel * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int zz = z0 + (k >> 2), yy = y0 + ((k >> 1) & 1), xx = x0 + (k & 1);
+        if (zz > a.S0 - 1 || yy > a.S1 - 1 || xx > a.S2 - 1) continue;
+        const float wt = w[k & 1] * w[2 + ((k >> 1) & 1)] * w[4 + (k >> 2)];
+        if (wt == 0.f) continue;
+        float* p = vb + (((long)zz * a.S1 + yy) * a.S2 + xx) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) atomicAdd(p + c, g[c] * wt);
+    }
+}
+static void fill_samp(SampArgs& a, const float* off3, const float* sc3, const int* shape3) {
+    for (int k = 0; k < 3; ++k) { a.off[k] = off3[k]; a.sc[k] = sc3[k]; }
+    a.S0 = shape3[0]; a.S1 = shape3[1]; a.S2 = shape3[2];
+}
+// vol_t / vol_r fp32 [P, S, S, S, 16]; query fp32 [P, M, 3]; f fp32 [P*M, 36]
+extern "C" int semabs_vool_sample(const float* vol_t, const float* vol_r, const float* query, const float* off3, const float* sc3, const int* shape3,
+                                  int P, long M, float* f, void* stream) {
+    if (P == 0 || M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(vol_t && vol_r && query && off3 && sc3 && shape3 && f, "semabs_vool_sample: null pointer");
+    SampArgs a; fill_samp(a, off3, sc3, shape3);
+    hipLaunchKernelGGL(k_vool_sample, dim3(semabs_cdiv((long)P * M * 2, 256)), dim3(256), 0, (hipStream_t)stream, vol_t, vol_r, query, a, P, M, f);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+// df fp32 [P*M, 36] -> dvol_t / dvol_r fp32 [P, S, S, S, 16] ACCUMULATED with fp32 atomics (zero them first)
+extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
+                                      float* dvol_t, float* dvol_r, void* stream) {
+    if (P == 0 || M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(df && query && off3 && sc3 && shape3 && dvol_t && dvol_r, "semabs_vool_sample_bwd: null pointer");
+    SampArgs a; fill_samp(a, off3, sc3, shape3);
+    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * M * 2, 256)), dim3(256), 0, (hipStream_t)stream, df, query, a, P, M, dvol_t, dvol_r);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// cosine pointer + BCE: logit = cos(o, rel_d) / T;  loss += w * BCEwithlogits(logit, y) / n_total
+// one wave per point (E = 64 = one element per lane); writes logits, dO [R, 64], accumulates drel [P, 64] and the loss
+__global__ __launch_bounds__(256) void k_cos_bce(const float* __restrict__ o, const float* __restrict__ rel, const float* __restrict__ label,
+                                                 const float* __restrict__ weight, int P, long M, float inv_temp, float inv_n,
+                                                 float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel, double* __restrict__ loss) {
+    __shared__ float s_drel[64];
+    __shared__ float s_loss;
+    if (threadIdx.x < 64) s_drel[threadIdx.x] = 0.f;
+    if (threadIdx.x == 0) s_loss = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // blocks are aligned to descriptions: blockIdx.y = description, blockIdx.x strides over its M points (4 per iteration)
+    const int d = blockIdx.y;
+    const float rv = rel[d * 64 + lane];
+    const float nr = fmaxf(sqrtf(wave_sum(rv * rv)), 1e-8f);
+    const float rh = rv / nr;
+    float acc_drel = 0.f, acc_loss = 0.f;
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
+        const long pt = (long)d * M + m;
+        const float ov = o[pt * 64 + lane];
+        const float no = fmaxf(sqrtf(wave_sum(ov * ov)), 1e-8f);
+        const float oh = ov / no;
+        const float cs = wave_sum(oh * rh);
+        const float z = cs * inv_temp;
+        const float y = label[pt], wgt = weight ? weight[pt] : 1.f;
+        // numerically stable BCE with logits: max(z, 0) - z y + log(1 + exp(-|z|))
+        const float l = fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+        const float dz = (1.f / (1.f + __expf(-z)) - y) * wgt * inv_n;
+        const float dc = dz * inv_temp;
+        if (logits && lane == 0) logits[pt] = z;
+        dO[pt * 64 + lane] = (rh - oh * cs) / no * dc;
+        acc_drel += (oh - rh * cs) / nr * dc;
+        if (lane == 0) acc_loss += l * wgt * inv_n;
+    }
+    atomicAdd(&s_drel[lane], acc_drel);
+    if (lane == 0) atomicAdd(&s_loss, acc_loss);
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&drel[d * 64 + threadIdx.x], s_drel[threadIdx.x]);
+    if (threadIdx.x == 0) atomicAdd(loss, (double)s_loss);
+}
+// o fp32 [P*M, 64]; rel fp32 [P, 64]; label / weight fp32 [P*M] (weight optional); outputs: logits [P*M] (optional), dO [P*M, 64],
+// drel fp32 [P, 64] and loss fp64 [1] ACCUMULATED (zero them first).  n_total = element count of the mean reduction.
+extern "C" int semabs_cos_bce(const float* o, const float* rel, const float* label, const float* weight, int P, long M, float temperature,
+                              long n_total, float* logits, float* dO, float* drel, double* loss, void* stream) {
+    if (P == 0 || M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(o && rel && label && dO && drel && loss && temperature > 0.f && n_total > 0, "semabs_cos_bce: bad args");
+    int bx = semabs_cdiv(M, 4 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_cos_bce, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, label, weight, P, M, 1.0f / temperature, 1.0f / (float)n_total,
+                       logits, dO, drel, loss);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Dynamic per-tensor gradient scale for the split-fp16 data-gradient convolutions: the MFMA operands are fp16 hi + lo pairs, which
+// keep ~22 bits only for magnitudes inside fp16's normal range, while gradients are routinely 1e-6 and smaller.  s = 2^k puts the
+// tensor's max |x| into [256, 512); the convolution applies it through its (GroupNorm-style) per-(b, c) input affine, and the
+// consumer multiplies by 1 / s.  Powers of two: the scaling itself is exact.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long n4, unsigned int* __restrict__ bits) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(bits, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+__global__ void k_scale_fill(const unsigned int* __restrict__ bits, float* __restrict__ scale_arr, float* __restrict__ shift_arr, int n_arr,
+                             float* __restrict__ s2) {
+    const float m = __uint_as_float(*bits);
+    float s = 1.f;
+    if (m > 0.f && m < INFINITY) { int e = 8 - ilogbf(m); e = e < -100 ? -100 : (e > 100 ? 100 : e); s = ldexpf(1.f, e); }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_arr) { scale_arr[i] = s; shift_arr[i] = 0.f; }
+    if (i == 0) { s2[0] = s; s2[1] = 1.f / s; }
+}
+// x fp32 [n] (n % 4 == 0) -> scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits: uint32 scratch
+extern "C" int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, void* stream) {
+    SEMABS_REQUIRE(x && scale_arr && shift_arr && s2 && bits && n > 0 && n % 4 == 0 && n_arr > 0, "semabs_grad_scale: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bits, 0, sizeof(unsigned int), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    int bx = semabs_cdiv(n / 4, 256 * 8); if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, x, n / 4, bits);
+    hipLaunchKernelGGL(k_scale_fill, dim3(semabs_cdiv(n_arr, 256)), dim3(256), 0, s, bits, scale_arr, shift_arr, n_arr, s2);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Global gradient norm over a chunk table (same format as semabs_lamb_step) and in-place scaling of all gradients:
+// clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6))
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_grad_sqsum(const long long* __restrict__ chunks, const long long* __restrict__ ptrs, int n_tensors, double* __restrict__ sq) {
+    const long long tid_ = chunks[blockIdx.x * 3], off = chunks[blockIdx.x * 3 + 1], cnt = chunks[blockIdx.x * 3 + 2];
+    const float* g = reinterpret_cast<const float*>(ptrs[n_tensors + tid_]) + off;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < cnt; i += 256) s += g[i] * g[i];
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sq, (double)((red[0] + red[1]) + (red[2] + red[3])));
+}
+__global__ __launch_bounds__(256) void k_grad_scale(const long long* __restrict__ chunks, const long long* __restrict__ ptrs, int n_tensors,
+                                                    const double* __restrict__ sq, float max_norm, float extra_scale) {
+    const long long tid_ = chunks[blockIdx.x * 3], off = chunks[blockIdx.x * 3 + 1], cnt = chunks[blockIdx.x * 3 + 2];
+    float* g = reinterpret_cast<float*>(ptrs[n_tensors + tid_]) + off;
+    const float norm = (float)sqrt(*sq) * extra_scale;
+    float coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f;
+    coef *= extra_scale;
+    if (coef == 1.f) return;
+    for (long long i = threadIdx.x; i < cnt; i += 256) g[i] *= coef;
+}
+// sq fp64 [1] scratch (zeroed here) holds sum g^2 afterwards; gradients are first multiplied by extra_scale (e.g. 1 / world size)
+extern "C" int semabs_clip_grad_norm(const long long* chunks, int n_chunks, const long long* ptrs, int n_tensors, float max_norm, float extra_scale,
+                                     double* sq, void* stream) {
+    if (n_chunks == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(chunks && ptrs && sq && max_norm > 0.f, "semabs_clip_grad_norm: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sq, 0, sizeof(double), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    hipLaunchKernelGGL(k_grad_sqsum, dim3(n_chunks), dim3(256), 0, s, chunks, ptrs, n_tensors, sq);
+    hipLaunchKernelGGL(k_grad_scale, dim3(n_chunks), dim3(256), 0, s, chunks, ptrs, n_tensors, sq, max_norm, extra_scale);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

@@ -255,6 +255,7 @@ struct ConvArgs {
     int os, op0, op1, op2;      // output coordinate = m * os + op
     int Cin, Cout, Kp;          // Kp = padded K (multiple of 32) = weight row stride
     int ntaps; int relu;
+    int is;                     // input coordinate = m * is + td (1 except for the ConvTranspose data gradient)
     signed char td0[28], td1[28], td2[28];   // tap offsets: input coordinate = m + td  (conv pad-1: -1..1; convT: 0/+1)
 };
 
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         f16x8 xh[MW], xl[MW];
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
-            const int i0 = v0[mi] + d0, i1 = v1[mi] + d1, i2 = v2[mi] + d2;
+            const int i0 = v0[mi] * a.is + d0, i1 = v1[mi] * a.is + d1, i2 = v2[mi] * a.is + d2;
             const bool ok = tap_ok && vok[mi] && i0 >= 0 && i0 < a.I0 && i1 >= 0 && i1 < a.I1 && i2 >= 0 && i2 < a.I2;
             float v[8];
             if (ok) {
@@ -587,7 +588,7 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
     ConvArgs a;
     a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = gn_scale; a.gn_shift = gn_shift;
     a.bias = bias; a.resid = resid; a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = D0; a.O1 = D1; a.O2 = D2;
-    a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.ntaps = ksize * ksize * ksize;
     a.Kp = ((a.ntaps * Cin + 31) / 32) * 32;
     int t = 0;
@@ -596,6 +597,26 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
             for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
     if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
         return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
+    return conv_launch(a, act_f32, (hipStream_t)stream);
+}
+
+// General gather convolution (used for the data gradients of training): y[b, m, :] = sum_taps W_tap . x[b, m * in_stride + td_tap, :]
+// with zero padding outside x.  x [B, I0, I1, I2, Cin] -> y [B, M0, M1, M2, Cout]; w_hi / w_lo fp16 [Cout, Kp], k = tap * Cin + cin,
+// Kp = ntaps * Cin rounded up to 32; taps int8 [ntaps, 3] (host); in_scale / in_shift fp32 [B, Cin] = optional input affine (null = none).
+extern "C" int semabs_conv3d_gather(const void* x, const void* w_hi, const void* w_lo, void* y, const float* in_scale, const float* in_shift,
+                                    int B, int I0, int I1, int I2, int M0, int M1, int M2, int in_stride, int Cin, int Cout, int ntaps,
+                                    const signed char* taps, int act_f32, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
+    if (rc) return rc;
+    SEMABS_REQUIRE(taps && ntaps >= 1 && ntaps <= 28 && in_stride >= 1, "semabs_conv3d_gather: bad taps / stride");
+    ConvArgs a;
+    SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gather: in_scale and in_shift go together");
+    a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
+    a.bias = nullptr; a.resid = nullptr; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
+    a.M0 = M0; a.M1 = M1; a.M2 = M2; a.os = 1; a.is = in_stride; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
+    a.ntaps = ntaps; a.Kp = ((ntaps * Cin + 31) / 32) * 32;
+    for (int t = 0; t < ntaps; ++t) { a.td0[t] = taps[t * 3]; a.td1[t] = taps[t * 3 + 1]; a.td2[t] = taps[t * 3 + 2]; }
     return conv_launch(a, act_f32, (hipStream_t)stream);
 }
 
@@ -617,7 +638,7 @@ extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const voi
         a.x = x; a.y = y; a.w_hi = (const f16*)w_hi + class_off[cls]; a.w_lo = w_lo ? (const f16*)w_lo + class_off[cls] : nullptr;
         a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip;
         a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = 2 * D0; a.O1 = 2 * D1; a.O2 = 2 * D2;
-        a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
+        a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.is = 1; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
         int t = 0;
         for (int t0 = 0; t0 <= p0; ++t0)
             for (int t1 = 0; t1 <= p1; ++t1)

@@ -1,0 +1,471 @@
+"""One optimisation step of SemAbsVOOL on the GPU (config 5 of BASELINE.json: `train_vool.py` -> `utils.loop`, utils.py:404-417):
+forward (net.py:506-579), BCE-with-logits (train_vool.py:171-178), backward, clip_grad_norm_ (utils.py:415), Lamb.step
+(arm/optim/lamb.py:59-127), all on the HIP kernels of csrc/train.hip + csrc/unet.hip + csrc/optim.hip.  There is no autograd graph:
+the backward pass is written out layer by layer against a tape of saved activations, fp32 ("exact" mode) throughout.
+
+`VOOLTrainer` keeps fp32 master parameters under the reference's `state_dict` key names, one flat gradient buffer (a single
+RCCL all-reduce per step when torch.distributed is initialised - what DistributedDataParallel's buckets do, utils.py:283-288), and
+the `Lamb` optimiser of optim.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .net import VirtualGrid
+from .optim import Lamb
+from .unet3d import number_of_features_per_level
+from .weights import unet_layer_plan
+
+RELATIONS = ["in", "behind", "in front of", "on the left of", "on the right of", "on", "[pad]"]
+SLOPE = 0.01
+
+
+def _taps(vals) -> bytes:
+    return np.asarray(vals, np.int8).tobytes()
+
+
+TAPS_CONV3 = _taps([(a - 1, b - 1, c - 1) for a in range(3) for b in range(3) for c in range(3)])
+TAPS_ONE = _taps([(0, 0, 0)])
+
+
+def _split16(w: torch.Tensor):
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def _pad32(w: torch.Tensor) -> torch.Tensor:
+    kp = (w.shape[1] + 31) // 32 * 32
+    if kp == w.shape[1]:
+        return w.contiguous()
+    out = torch.zeros(w.shape[0], kp, dtype=w.dtype, device=w.device)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+class _Rec:
+    """Tape entry of one GroupNorm + Conv3d: what the backward pass needs."""
+    __slots__ = ("name", "x", "y", "mean", "rstd", "scale", "shift")
+
+
+class UNetTrainer:
+    """Forward-with-tape and backward of ResidualUNet3D (unet3d.py:190-259, 596-621), channels-last fp32."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], prefix: str, in_channels: int, out_channels: int,
+                 f_maps, num_groups: int, num_levels: int):
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels)
+        self.f_maps = list(f_maps)
+        self.p, self.g, self.prefix, self.G = params, grads, prefix, num_groups
+        self.plan = unet_layer_plan(in_channels, out_channels, self.f_maps[0], len(self.f_maps))
+        self.mats: Dict[str, dict] = {}
+        self.dev = _lib.require_gpu()
+        self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
+
+    # ---- per-step weight layouts (fp16 hi/lo splits for the MFMA kernels) --------------------------------------------------------
+    def refresh(self):
+        for pre, kind, cin, cout in self.plan:
+            key = self.prefix + pre
+            if kind in ("gcr", "gc"):
+                w = self.p[key + "conv.weight"]
+                k = w.shape[2]
+                fwd = _pad32(w.permute(0, 2, 3, 4, 1).reshape(cout, -1))
+                bwd = _pad32(w.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(cin, -1))
+                self.mats[pre] = dict(kind="conv", cin=cin, cout=cout, k=k, groups=self.G if cin >= self.G else 1,
+                                      fwd=_split16(fwd), bwd=_split16(bwd))
+            elif kind == "convT":
+                w = self.p[key + "weight"]                                             # [cin, cout, 3, 3, 3]
+                mats, offs, off = [], [], 0
+                for cls in range(8):
+                    pp = (cls >> 2, (cls >> 1) & 1, cls & 1)
+                    cols = []
+                    for t0 in range(pp[0] + 1):
+                        for t1 in range(pp[1] + 1):
+                            for t2 in range(pp[2] + 1):
+                                kk = [1 if q == 0 else (0 if t == 0 else 2) for q, t in zip(pp, (t0, t1, t2))]
+                                cols.append(w[:, :, kk[0], kk[1], kk[2]].t())
+                    m = torch.cat(cols, dim=1).contiguous()
+                    mats.append(m.reshape(-1)); offs.append(off); off += m.numel()
+                bwd = _pad32(w.permute(0, 2, 3, 4, 1).reshape(cin, -1))               # [cin, (k, cout)]
+                self.mats[pre] = dict(kind="convT", cin=cin, cout=cout, fwd=_split16(torch.cat(mats)), class_off=(C.c_long * 8)(*offs),
+                                      bwd=_split16(bwd))
+            else:                                                                      # final 1x1x1 conv with bias
+                w = self.p[key + "weight"]
+                self.mats[pre] = dict(kind="final", cin=cin, cout=cout, k=1, fwd=_split16(_pad32(w.reshape(cout, cin))),
+                                      bwd=_split16(_pad32(w.reshape(cout, cin).t().contiguous())))
+
+    # ---- forward -----------------------------------------------------------------------------------------------------------------
+    def _conv_fwd(self, x, pre, relu, resid=None) -> _Rec:
+        m = self.mats[pre]
+        key = self.prefix + pre
+        B, D0, D1, D2, Cc = x.shape
+        nvox, G, st = D0 * D1 * D2, m["groups"], _lib.stream()
+        r = _Rec()
+        r.name, r.x = pre, x
+        sums = torch.zeros(B, G, 2, dtype=torch.float64, device=self.dev)
+        _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, 1, st)
+        r.scale = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
+        r.shift = torch.empty_like(r.scale)
+        r.mean = torch.empty(B, G, dtype=torch.float32, device=self.dev)
+        r.rstd = torch.empty_like(r.mean)
+        _lib.call("semabs_gn_finalize", _lib.ptr(sums), _lib.ptr(self.p[key + "groupnorm.weight"]), _lib.ptr(self.p[key + "groupnorm.bias"]),
+                  _lib.ptr(r.scale), _lib.ptr(r.shift), B, Cc, G, nvox, 1e-5, st)
+        _lib.call("semabs_gn_meanrstd", _lib.ptr(sums), _lib.ptr(r.mean), _lib.ptr(r.rstd), B, G, nvox * (Cc // G), 1e-5, st)
+        r.y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(r.y), _lib.ptr(r.scale), _lib.ptr(r.shift),
+                  None, _lib.ptr(resid), B, D0, D1, D2, m["cin"], m["cout"], 3, int(relu), 1, st)
+        return r
+
+    def _block_fwd(self, x, pre, tape):
+        r1 = self._conv_fwd(x, pre + "conv1.", True)
+        r2 = self._conv_fwd(r1.y, pre + "conv2.", True)
+        r3 = self._conv_fwd(r2.y, pre + "conv3.", True, resid=r1.y)
+        tape.append(("block", r1, r2, r3))
+        return r3.y
+
+    def forward(self, x: torch.Tensor):
+        """x fp32 [B, S, S, S, Cin] -> (y [B, S, S, S, Cout], tape)."""
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        st = _lib.stream()
+        tape: List = []
+        L = len(self.f_maps)
+        feats = []
+        for i in range(L):
+            if i > 0:
+                B, D0, D1, D2, Cc = x.shape
+                y = torch.empty(B, D0 // 2, D1 // 2, D2 // 2, Cc, dtype=torch.float32, device=self.dev)
+                _lib.call("semabs_maxpool3d", _lib.ptr(x), _lib.ptr(y), B, D0, D1, D2, Cc, 1, st)
+                tape.append(("pool", x, i - 1))
+                x = y
+            x = self._block_fwd(x, f"encoders.{i}.basic_module.", tape)
+            feats.insert(0, x)
+        for i, skip in enumerate(feats[1:]):
+            pre = f"decoders.{i}.upsampling.upsample."
+            m = self.mats[pre]
+            B, D0, D1, D2, _ = x.shape
+            y = torch.empty_like(skip)
+            _lib.call("semabs_convtranspose3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), m["class_off"], _lib.ptr(y),
+                      _lib.ptr(self.p[self.prefix + pre + "bias"]), _lib.ptr(skip), B, D0, D1, D2, m["cin"], m["cout"], 1, st)
+            tape.append(("up", pre, x, L - 2 - i))
+            x = self._block_fwd(y, f"decoders.{i}.basic_module.", tape)
+        m = self.mats["final_conv."]
+        B, D0, D1, D2, _ = x.shape
+        y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(y), None, None,
+                  _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1, st)
+        tape.append(("final", x))
+        return y, tape
+
+    # ---- backward ----------------------------------------------------------------------------------------------------------------
+    def _colsum(self, a2d: torch.Tensor, grad: torch.Tensor):
+        R, Cc = a2d.shape
+        red = torch.zeros(1, Cc, 2, dtype=torch.float64, device=self.dev)
+        _lib.call("semabs_chan_reduce", _lib.ptr(a2d), None, None, None, _lib.ptr(red), 1, R, Cc, 1, _lib.stream())
+        grad.add_(red[0, :, 0].float())
+
+    def _scale(self, dz: torch.Tensor, B: int, Cc: int):
+        """Dynamic power-of-two scale of a gradient tensor (csrc/train.hip, semabs_grad_scale): -> (scale_arr, shift_arr, s2)."""
+        sc = torch.empty(B * Cc, dtype=torch.float32, device=self.dev)
+        sh = torch.empty_like(sc)
+        s2 = torch.empty(2, dtype=torch.float32, device=self.dev)
+        bits = torch.empty(1, dtype=torch.int32, device=self.dev)
+        _lib.call("semabs_grad_scale", _lib.ptr(dz), dz.numel(), _lib.ptr(sc), _lib.ptr(sh), B * Cc, _lib.ptr(s2), _lib.ptr(bits), _lib.stream())
+        return sc, sh, s2
+
+    def _unscale(self, a, s2):
+        out = torch.empty_like(a)
+        inv = s2[1:]
+        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(inv), _lib.ptr(out), a.numel(), 3, 0.0, _lib.stream())
+        return out
+
+    def _ew(self, a, b, mode):
+        out = torch.empty_like(a)
+        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.stream())
+        return out
+
+    def _conv_bwd(self, r: _Rec, dZ: torch.Tensor, add1: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dZ = gradient w.r.t. the convolution output (before ReLU / residual); returns the gradient w.r.t. the GroupNorm input
+        (+ add1).  Accumulates the conv weight and GroupNorm affine gradients."""
+        m = self.mats[r.name]
+        key = self.prefix + r.name
+        B, D0, D1, D2, cin = r.x.shape
+        cout, nvox, G, st = m["cout"], D0 * D1 * D2, m["groups"], _lib.stream()
+        dW = torch.zeros(cout, 27 * cin, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
+                  cout, cin, 27, TAPS_CONV3, st)
+        self.g[key + "conv.weight"].add_(dW.view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3))
+        dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
+        sc, sh, s2 = self._scale(dZ, B, cout)
+        inv = s2[1:]
+        _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
+                  B, D0, D1, D2, cout, cin, 3, 0, 1, st)
+        red = torch.zeros(B, cin, 2, dtype=torch.float64, device=self.dev)
+        _lib.call("semabs_chan_reduce", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(red), B, nvox, cin, G, st)
+        coef = torch.empty(B, cin, 3, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_gn_bwd_coef", _lib.ptr(red), _lib.ptr(self.p[key + "groupnorm.weight"]), _lib.ptr(r.rstd), _lib.ptr(inv), _lib.ptr(coef),
+                  _lib.ptr(self.g[key + "groupnorm.weight"]), _lib.ptr(self.g[key + "groupnorm.bias"]), B, cin, G, nvox, st)
+        dX = torch.empty_like(dXn)
+        _lib.call("semabs_gn_bwd_apply", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(coef), _lib.ptr(add1), None,
+                  _lib.ptr(dX), B, nvox, cin, G, st)
+        return dX
+
+    def _block_bwd(self, recs, dOut):
+        r1, r2, r3 = recs
+        dS = self._ew(dOut, r3.y, 0)                        # through the final ReLU of relu(conv3 + out1)
+        d2 = self._conv_bwd(r3, dS)                         # -> d out2 (post-ReLU output of conv2)
+        d1 = self._conv_bwd(r2, self._ew(d2, r2.y, 0), add1=dS)   # -> d out1 = via conv2 + residual branch
+        return self._conv_bwd(r1, self._ew(d1, r1.y, 0))
+
+    def _up_bwd(self, pre: str, xin: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        """ConvTranspose3d k3 s2 p1 op1 backward: g = gradient w.r.t. its output [B, 2D, 2D, 2D, cout] -> gradient w.r.t. xin."""
+        m = self.mats[pre]
+        key = self.prefix + pre
+        st = _lib.stream()
+        B, D0, D1, D2, cin = xin.shape
+        cout = m["cout"]
+        self._colsum(g.view(-1, cout), self.g[key + "bias"])
+        dW = torch.zeros(cin, 27 * cout, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_wgrad", _lib.ptr(xin), _lib.ptr(g), None, None, _lib.ptr(dW), B, D0, D1, D2, 2 * D0, 2 * D1, 2 * D2, 2,
+                  cin, cout, 27, TAPS_CONV3, st)
+        self.g[key + "weight"].add_(dW.view(cin, 3, 3, 3, cout).permute(0, 4, 1, 2, 3))
+        dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
+        sc, sh, s2 = self._scale(g, B, cout)
+        _lib.call("semabs_conv3d_gather", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh),
+                  B, 2 * D0, 2 * D1, 2 * D2, D0, D1, D2, 2, cout, cin, 27, TAPS_CONV3, 1, st)
+        return self._unscale(dx, s2)
+
+    def backward(self, tape, dy: torch.Tensor) -> torch.Tensor:
+        """dy fp32 [B, S, S, S, Cout] -> gradient w.r.t. the UNet input; parameter gradients are accumulated into `grads`."""
+        st = _lib.stream()
+        L = len(self.f_maps)
+        d_skip: Dict[int, torch.Tensor] = {}
+        g = dy.contiguous()
+        for item in reversed(tape):
+            kind = item[0]
+            if self.debug is not None:
+                self.debug.append((kind, g))
+            if kind == "final":
+                x = item[1]
+                m = self.mats["final_conv."]
+                B, D0, D1, D2, cin = x.shape
+                cout = m["cout"]
+                dW = torch.zeros(cout, cin, dtype=torch.float32, device=self.dev)
+                R = B * D0 * D1 * D2
+                _lib.call("semabs_wgrad", _lib.ptr(g), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, cout, cin, 1, TAPS_ONE, st)
+                self.g[self.prefix + "final_conv.weight"].add_(dW.view(cout, cin, 1, 1, 1))
+                self._colsum(g.view(R, cout), self.g[self.prefix + "final_conv.bias"])
+                dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
+                sc, sh, s2 = self._scale(g, B, cout)
+                _lib.call("semabs_conv3d", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh), None, None,
+                          B, D0, D1, D2, cout, cin, 1, 0, 1, st)
+                g = self._unscale(dx, s2)
+            elif kind == "block":
+                g = self._block_bwd(item[1:], g)
+            elif kind == "up":
+                _, pre, xin, level = item
+                d_skip[level] = g                                   # y = skip + convT(x) + bias: the skip gets the same gradient
+                g = self._up_bwd(pre, xin, g)
+            elif kind == "pool":
+                _, x, level = item                                  # x = output of encoder `level`, also used as a skip
+                B, D0, D1, D2, Cc = x.shape
+                dx = torch.empty_like(x)
+                _lib.call("semabs_maxpool3d_bwd", _lib.ptr(x), _lib.ptr(g), _lib.ptr(dx), B, D0, D1, D2, Cc, st)
+                g = self._ew(dx, d_skip.pop(level), 2)
+        assert not d_skip
+        return g
+
+
+class VOOLTrainer:
+    """`SemAbsVOOL` (net.py:469-579, pointing_method "cosine_sim") + loss + optimiser as one training-step object.
+
+        tr = VOOLTrainer(state_dict, voxel_shape=(128,)*3, scene_bounds=..., unet_f_maps=16, unet_num_levels=6, ...)
+        stats = tr.step(batch)            # forward, BCE, backward, (all-reduce), clip, LAMB; returns {"loss", "gradnorm"}
+        tr.state_dict()                   # fp32 tensors under the reference's key names
+
+    `batch` carries the reference's VOOL batch keys (dataset.py / train_vool.py:118-178): input_xyz_pts [B, N, 3],
+    input_target_saliency_pts / input_reference_saliency_pts [B, D, N(, 1)], output_xyz_pts [B, D, M, 3], output_label_pts [B, D, M],
+    spatial_relation_name (D lists of B names).
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], voxel_shape, scene_bounds, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+                 unet_num_levels=6, pts_feat_extractor_hidden_dim=128, pointing_dim=64, lr=1e-3, weight_decay=1e-5, grad_max_norm=2.0,
+                 balance_positive_negative=False, pointing_temperature=0.07):
+        dev = self.dev = _lib.require_gpu()
+        assert pointing_dim == 64 and unet_num_channels == 16, "the VOOL head kernels cover pointing_dim=64 over 16-channel volumes"
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        self.vg = VirtualGrid(scene_bounds=np.array(scene_bounds), batch_size=1, grid_shape=tuple(voxel_shape))
+        self.C, self.H, self.E = unet_num_channels, pts_feat_extractor_hidden_dim, pointing_dim
+        self.grad_max_norm, self.balance, self.temperature = float(grad_max_norm), bool(balance_positive_negative), float(pointing_temperature)
+        self.extra = {k: v.clone() for k, v in sd.items() if not torch.is_floating_point(v) or k.endswith("steps")}
+        names = [k for k in sd if k not in self.extra]
+        self.params: Dict[str, torch.nn.Parameter] = {k: torch.nn.Parameter(sd[k].detach().float().to(dev).contiguous(), requires_grad=False)
+                                                      for k in names}
+        # parameters the VOOL graph never touches get no gradient, like p.grad = None in the reference (completion_net.visual_sampler.*)
+        self.trainable = [k for k in names if ".visual_sampler." not in k]
+        total = sum(self.params[k].numel() for k in self.trainable)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads: Dict[str, torch.Tensor] = {}
+        off = 0
+        for k in self.trainable:
+            n = self.params[k].numel()
+            self.grads[k] = self.flat_grad[off: off + n].view_as(self.params[k])
+            self.params[k].grad = self.grads[k]
+            off += n
+        self.unet = UNetTrainer(self.params, self.grads, "completion_net.vol_feature_extractor.", unet_num_channels, unet_num_channels,
+                                unet_f_maps, unet_num_groups, unet_num_levels)
+        self.opt = Lamb([self.params[k] for k in self.trainable], lr=lr, weight_decay=weight_decay)
+        self.steps = 0
+        self._sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.last = {}
+
+    # ---- helpers -----------------------------------------------------------------------------------------------------------------
+    def _linear(self, x, w, b, act):
+        R, Ci = x.shape
+        Co = w.shape[0]
+        y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
+        return y
+
+    def _wgrad_linear(self, dOut, x, grad_w, cols=None):
+        R, Co = dOut.shape
+        Ci = x.shape[1]
+        dW = torch.zeros(Co, Ci, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_wgrad", _lib.ptr(dOut), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, TAPS_ONE, _lib.stream())
+        grad_w.add_(dW if cols is None else dW[:, :cols])
+
+    def bce_weight(self, label: torch.Tensor) -> Optional[torch.Tensor]:
+        """utils.get_bce_weight (utils.py:727-749); label [B, D, M] fp32 on the device.  None = all ones."""
+        if not self.balance:
+            return None
+        w = torch.ones_like(label)
+        pos = label.bool()
+        pp = pos.float().mean(dim=2, keepdim=True)
+        w = torch.where(pos, 1.0 / (pp + 1e-10), 1.0 / ((1 - pp) + 1e-10))
+        return (w * (label.numel() / w.sum())).contiguous()
+
+    # ---- forward + backward of one scene --------------------------------------------------------------------------------------------
+    def _scene(self, xyz, sal_t, sal_r, query, label, weight, rel_names, n_total, loss_acc, logits_out):
+        dev, st, u = self.dev, _lib.stream(), self.unet
+        p, g = self.params, self.grads
+        D, N = sal_t.shape
+        M = query.shape[1]
+        P = 2 * D
+        S0, S1, S2 = self.vg.grid_shape
+        nvox = S0 * S1 * S2
+        cn = "completion_net.pts_feat_extractor."
+        # point MLP (net.py:395-404) for the 2 D saliency channels at once: target volumes first, reference volumes second
+        feat = torch.cat([sal_t, sal_r], dim=0)                                           # [P, N]
+        x4 = torch.cat([xyz.unsqueeze(0).expand(P, N, 3), feat.unsqueeze(-1)], dim=-1).reshape(P * N, 4).contiguous()
+        h1 = self._linear(x4, p[cn + "0.weight"], p[cn + "0.bias"], 1)
+        h2 = self._linear(h1, p[cn + "2.weight"], p[cn + "2.bias"], 1)
+        pf = self._linear(h2, p[cn + "4.weight"], p[cn + "4.bias"], 0)                   # [P*N, C]
+        flat = self.vg.flat_idxs(xyz)
+        vol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
+        head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
+        nxt = torch.empty(N, dtype=torch.int32, device=dev)
+        _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox, 1, st)
+        fv, tape = u.forward(vol)
+        # VOOL head (net.py:556-579)
+        off3, sc3, shp = _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales), _lib.iarr(self.vg.grid_shape)
+        f = torch.empty(D * M, 36, dtype=torch.float32, device=dev)
+        _lib.call("semabs_vool_sample", _lib.ptr(fv[:D]), _lib.ptr(fv[D:]), _lib.ptr(query), off3, sc3, shp, D, M, _lib.ptr(f), st)
+        ss = "spatial_sampler.mlp."
+        w1p = torch.zeros(32, 36, dtype=torch.float32, device=dev)
+        w1p[:, :35] = p[ss + "0.weight"]
+        h = self._linear(f, w1p, p[ss + "0.bias"], 1)
+        o = self._linear(h, p[ss + "2.weight"], p[ss + "2.bias"], 0)
+        rel = torch.stack([p["relation_embeddings." + n] for n in rel_names], dim=0).contiguous()
+        dO = torch.empty_like(o)
+        drel = torch.zeros(D, self.E, dtype=torch.float32, device=dev)
+        _lib.call("semabs_cos_bce", _lib.ptr(o), _lib.ptr(rel), _lib.ptr(label), _lib.ptr(weight), D, M, self.temperature, n_total,
+                  _lib.ptr(logits_out), _lib.ptr(dO), _lib.ptr(drel), _lib.ptr(loss_acc), st)
+        # ---- backward ----
+        for d, n in enumerate(rel_names):
+            g["relation_embeddings." + n].add_(drel[d])
+        self._wgrad_linear(dO, h, g[ss + "2.weight"])
+        u._colsum(dO, g[ss + "2.bias"])
+        dh = u._ew(self._linear(dO, p[ss + "2.weight"].t().contiguous(), None, 0), h, 1)
+        self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
+        u._colsum(dh, g[ss + "0.bias"])
+        df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
+        dvol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
+        _lib.call("semabs_vool_sample_bwd", _lib.ptr(df), _lib.ptr(query), off3, sc3, shp, D, M, _lib.ptr(dvol[:D]), _lib.ptr(dvol[D:]), st)
+        dscat = u.backward(tape, dvol)
+        count = torch.zeros(nvox, dtype=torch.int32, device=dev)
+        dpf = torch.empty(P * N, self.C, dtype=torch.float32, device=dev)
+        _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
+        self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
+        u._colsum(dpf, g[cn + "4.bias"])
+        dh2 = u._ew(self._linear(dpf, p[cn + "4.weight"].t().contiguous(), None, 0), h2, 1)
+        self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
+        u._colsum(dh2, g[cn + "2.bias"])
+        dh1 = u._ew(self._linear(dh2, p[cn + "2.weight"].t().contiguous(), None, 0), h1, 1)
+        self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
+        u._colsum(dh1, g[cn + "0.bias"])
+
+    # ---- public ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_backward(self, batch: dict) -> dict:
+        """Zero the gradients, run forward + loss + backward over the batch; returns {"loss": device scalar, "logits": [B, D, M]}."""
+        dev = self.dev
+        self.flat_grad.zero_()
+        self.unet.refresh()
+        xyz = batch["input_xyz_pts"].to(dev, torch.float32)
+        B, N = xyz.shape[:2]
+        st_ = batch["input_target_saliency_pts"].to(dev, torch.float32).reshape(B, -1, N)
+        sr_ = batch["input_reference_saliency_pts"].to(dev, torch.float32).reshape(B, -1, N)
+        q = batch["output_xyz_pts"].to(dev, torch.float32)
+        label = batch["output_label_pts"].to(dev, torch.float32).contiguous()
+        D, M = label.shape[1:]
+        names = np.array(batch["spatial_relation_name"]).T.reshape(B, D)                 # [B, D] like net.py:527
+        weight = self.bce_weight(label)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        logits = torch.empty(B, D, M, dtype=torch.float32, device=dev)
+        # like autograd, relation embeddings no description of the batch uses end the step with grad = None: Lamb skips them entirely
+        # (no weight decay either).  Under DDP every rank keeps them all so that the flat all-reduce stays aligned.
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        used = set(names.reshape(-1).tolist())
+        for n in RELATIONS:
+            k = "relation_embeddings." + n
+            if k in self.grads:
+                self.params[k].grad = self.grads[k] if (multi or n in used) else None
+        for b in range(B):
+            self._scene(xyz[b].contiguous(), st_[b].contiguous(), sr_[b].contiguous(), q[b].reshape(D, M, 3).contiguous(), label[b],
+                        None if weight is None else weight[b], list(names[b]), B * D * M, loss, logits[b])
+        return {"loss": loss[0], "logits": logits}
+
+    @torch.no_grad()
+    def optimizer_step(self) -> torch.Tensor:
+        """(all-reduce ->) clip_grad_norm_ -> Lamb.step; returns the pre-clip global gradient norm (device scalar)."""
+        import torch.distributed as dist
+        scale = 1.0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad)                                               # one collective for all 100+ tensors
+            scale = 1.0 / dist.get_world_size()
+        opt = self.opt
+        ps = [p for p in opt.param_groups[0]["params"] if p.grad is not None]
+        plan = opt._build_plan(ps, self.dev)
+        _lib.call("semabs_clip_grad_norm", _lib.ptr(plan["chunks"]), plan["n_chunks"], _lib.ptr(plan["ptrs"]), len(ps), self.grad_max_norm,
+                  scale, _lib.ptr(self._sq), _lib.stream())
+        opt.step()
+        self.steps += 1
+        return torch.sqrt(self._sq[0]) * scale
+
+    def step(self, batch: dict) -> dict:
+        out = self.forward_backward(batch)
+        out["gradnorm"] = self.optimizer_step()
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd = {k: v.detach().clone() for k, v in self.params.items()}
+        sd.update({k: v.clone() for k, v in self.extra.items()})
+        for k in sd:
+            if k.endswith("steps"):
+                sd[k] = sd[k] + self.steps
+        return sd

@@ -446,3 +446,82 @@ def g12_vool_lamb():
 
 if __name__ == "__main__" and "g12" in sys.argv[1:]:
     g12_vool_lamb()
+
+
+# ---- appended: one VOOL training step on the reference (G13: loss, gradients, clipped LAMB update) ------------------
+def g13_vool_train():
+    from semabs_amd.weights import make_semabsvool_state_dict
+    net, _ = refimport.load_reference_net()
+    sys.path.insert(0, refimport.REF)
+    from arm.optim.lamb import Lamb
+    S, N, M, D = 32, 3000, 1500, 3
+    m = net.SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cpu", decoder_concat_xyz_pts=True,
+                       voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+                       unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128,
+                       reduce_method="max", batch_size=1)
+    m.load_state_dict(make_semabsvool_state_dict(seed=3), strict=True)
+    m.train()
+    xyz, feat, q = _semabs_inputs(S, N, M, 2 * D, seed=13)
+    rel_names = [["behind"], ["on"], ["behind"]]                 # a repeated relation: its embedding gets two contributions
+    rng = np.random.default_rng(131)
+    label = (rng.random((1, D, M)) < 0.3).astype(np.float32)
+    params = [(k, p) for k, p in m.named_parameters()]
+    opt = Lamb([p for _, p in params], lr=1e-3, weight_decay=1e-5)
+    before = {k: p.detach().clone() for k, p in params}
+    out = m(output_xyz_pts=torch.from_numpy(q[:, :D]), spatial_relation_name=rel_names, input_xyz_pts=torch.from_numpy(xyz),
+            input_target_saliency_pts=torch.from_numpy(feat[:, :D]), input_reference_saliency_pts=torch.from_numpy(feat[:, D:]),
+            tsdf_vol=None)
+    lab = torch.from_numpy(label)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, lab, weight=torch.ones_like(lab))
+    opt.zero_grad()
+    loss.backward()
+    res = {"meta": np.asarray([S, N, M, D, 13, 3, 131], np.int32), "label": label.astype(np.uint8), "loss": np.float64(loss.item()),
+           "logits": out.detach().numpy()}
+    names, gnorm, has_grad = [], [], []
+    for k, p in params:
+        names.append(k)
+        has_grad.append(p.grad is not None)
+        gnorm.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+        if p.grad is not None:
+            g = p.grad.detach().numpy().copy()           # a copy: clip_grad_norm_ below scales p.grad in place
+            if g.size <= 4096:
+                res["grad/" + k] = g
+            else:
+                si = sample_idx(g.size, 2048)
+                res["gradidx/" + k] = si
+                res["grads/" + k] = g.reshape(-1)[si]
+    res["names"] = np.asarray(names)
+    res["grad_norm"] = np.asarray(gnorm, np.float64)
+    res["has_grad"] = np.asarray(has_grad)
+    total = torch.nn.utils.clip_grad_norm_([p for _, p in params], 2.0)
+    res["total_norm"] = np.float64(float(total))
+    opt.step()
+    dnorm = []
+    for k, p in params:
+        d = (p.detach() - before[k])
+        dnorm.append(float(d.double().norm()))
+        if p.numel() <= 4096:
+            res["new/" + k] = p.detach().numpy()
+        else:
+            si = sample_idx(p.numel(), 2048)
+            res["news/" + k] = p.detach().numpy().reshape(-1)[si]
+    res["delta_norm"] = np.asarray(dnorm, np.float64)
+    # a second configuration of the loss: the balanced BCE weights of utils.get_bce_weight (utils.py:727-749)
+    # utils.py drags in tensorboardX / transformers / the dataset module; run just the one function, unmodified, from its source
+    import ast
+    tree = ast.parse(open(os.path.join(refimport.REF, "utils.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_bce_weight"][0]
+    fn.decorator_list, fn.returns = [], None
+    for a in fn.args.args:
+        a.annotation = None
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "utils.py:get_bce_weight", "exec"), ns)
+    w = ns["get_bce_weight"](output_label_pts=lab, balance_positive_negative=True)
+    res["bce_weight_balanced_sum"] = np.float64(w.double().sum().item())
+    res["bce_weight_balanced_sub"] = w.numpy()[:, :, ::50].copy()
+    res["loss_balanced"] = np.float64(torch.nn.functional.binary_cross_entropy_with_logits(out.detach(), lab, weight=w).item())
+    save("g13_vool_train", **res)
+
+
+if __name__ == "__main__" and "g13" in sys.argv[1:]:
+    g13_vool_train()
