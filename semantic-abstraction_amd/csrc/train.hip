@@ -578,3 +578,175 @@ extern "C" int semabs_clip_grad_norm(const long long* chunks, int n_chunks, cons
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
+
+// =================================================================================================
+// Conv3d 3x3x3 weight gradient on MFMA, for volumes that tile into 4 x 8 x 16 bricks (levels 0-3 of the 128^3 UNet).
+//   dW[ca][tap][cx] += inv_s * sum_vox (s * dZ[vox][ca]) * GN(X)[vox + tap][cx]
+// The contraction runs over VOXELS, so both MFMA operands must be voxel-major while HBM holds them channel-major: a persistent
+// workgroup (9 waves) transposes one brick at a time into LDS - the 6 x 10 x 18 halo of X (GroupNorm affine applied, zero padded) and
+// the 4 x 8 x 16 brick of dZ (times the dynamic gradient scale s), each as split fp16 hi + lo, laid out [z][y][channel][x] so that 8
+// consecutive x of one channel are one aligned 16-byte ds_read.  Wave w owns the tap pairs (dz, dy) = (w / 3 - 1, w % 3 - 1); its
+// three dx taps share one aligned row read, the +-1 shifts are done in registers with v_alignbit on one extra dword.  Every staged
+// element feeds 27 x 16 MACs; the 27 x 16 x 16 partial result stays in registers across all bricks and is added to dW once.
+// Channel counts above 16 are sliced: blockIdx.y = ca slice, blockIdx.z = cx slice.
+// =================================================================================================
+#define WG_T0 4
+#define WG_T1 8
+#define WG_T2 16
+#define WG_H0 (WG_T0 + 2)
+#define WG_H1 (WG_T1 + 2)
+#define WG_XROW 32                           // elements per (z, y, channel) row of the X halo: x = -1 .. 16 sit at 7 .. 24
+#define WG_NTHR 576
+struct Wgrad16Args {
+    const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* s2; float* dW;
+    int B, D0, D1, D2, Ca, Cx;
+};
+
+__device__ __forceinline__ unsigned int pack_hi_lo(float v0, float v1, unsigned int& lo) {
+    const f16 h0 = (f16)v0, h1 = (f16)v1;
+    const f16 l0 = (f16)(v0 - (float)h0), l1 = (f16)(v1 - (float)h1);
+    lo = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+    return (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XH_EL = WG_H0 * WG_H1 * 16 * WG_XROW;            // elements in one X plane (hi or lo)
+    constexpr int A_EL = WG_T0 * WG_T1 * 16 * WG_T2;
+    unsigned short* sXh = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* sXl = sXh + XH_EL;
+    unsigned short* sAh = sXl + XH_EL;
+    unsigned short* sAl = sAh + A_EL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ca0 = blockIdx.y * 16, cx0 = blockIdx.z * 16;
+    const int n0 = a.D0 / WG_T0, n1 = a.D1 / WG_T1, n2 = a.D2 / WG_T2;
+    const int nbricks = a.B * n0 * n1 * n2;
+    const float s_in = a.s2 ? a.s2[0] : 1.f;
+    const int dz = wid / 3 - 1, dy = wid % 3 - 1;
+    const int i16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+    for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+        int t = brick;
+        const int t2 = t % n2; t /= n2;
+        const int t1 = t % n1; t /= n1;
+        const int t0 = t % n0; const int b = t / n0;
+        const int z0 = t0 * WG_T0, y0 = t1 * WG_T1, x0 = t2 * WG_T2;
+        __syncthreads();                                            // previous brick's fragments are no longer being read
+        // ---- stage the X halo: task = (hz, hy, pair of x); elements 6 + 2 px, 7 + 2 px  <->  x = 2 px - 2, 2 px - 1 ----
+        for (int task = tid; task < WG_H0 * WG_H1 * 10; task += WG_NTHR) {
+            const int px = task % 10, hy = (task / 10) % WG_H1, hz = task / (10 * WG_H1);
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1;
+            float v[2][16];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int xl = 2 * px - 2 + e;                      // local x, -2 .. 17 (only -1 .. 16 are ever read)
+                const int gx = x0 + xl;
+                const bool ok = xl >= -1 && xl <= WG_T2 && gz >= 0 && gz < a.D0 && gy >= 0 && gy < a.D1 && gx >= 0 && gx < a.D2;
+                if (ok) {
+                    const float4* p = reinterpret_cast<const float4*>(a.X + ((((long)b * a.D0 + gz) * a.D1 + gy) * a.D2 + gx) * a.Cx + cx0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float4 w = p[q]; v[e][4 * q] = w.x; v[e][4 * q + 1] = w.y; v[e][4 * q + 2] = w.z; v[e][4 * q + 3] = w.w; }
+                    if (a.gn_scale) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) v[e][c] = v[e][c] * a.gn_scale[(long)b * a.Cx + cx0 + c] + a.gn_shift[(long)b * a.Cx + cx0 + c];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) v[e][c] = 0.f;
+                }
+            }
+            const int rowbase = ((hz * WG_H1 + hy) * 16) * WG_XROW + 6 + 2 * px;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                unsigned int lo;
+                const unsigned int hi = pack_hi_lo(v[0][c], v[1][c], lo);
+                *reinterpret_cast<unsigned int*>(sXh + rowbase + c * WG_XROW) = hi;
+                *reinterpret_cast<unsigned int*>(sXl + rowbase + c * WG_XROW) = lo;
+            }
+        }
+        // ---- stage the dZ brick: task = (z, y, pair of x) ----
+        for (int task = tid; task < WG_T0 * WG_T1 * 8; task += WG_NTHR) {
+            const int px = task % 8, yy = (task / 8) % WG_T1, zz = task / (8 * WG_T1);
+            float v[2][16];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float4* p = reinterpret_cast<const float4*>(a.A + ((((long)b * a.D0 + z0 + zz) * a.D1 + y0 + yy) * a.D2 + x0 + 2 * px + e) * a.Ca + ca0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float4 w = p[q]; v[e][4 * q] = w.x * s_in; v[e][4 * q + 1] = w.y * s_in; v[e][4 * q + 2] = w.z * s_in; v[e][4 * q + 3] = w.w * s_in; }
+            }
+            const int rowbase = ((zz * WG_T1 + yy) * 16) * WG_T2 + 2 * px;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                unsigned int lo;
+                const unsigned int hi = pack_hi_lo(v[0][c], v[1][c], lo);
+                *reinterpret_cast<unsigned int*>(sAh + rowbase + c * WG_T2) = hi;
+                *reinterpret_cast<unsigned int*>(sAl + rowbase + c * WG_T2) = lo;
+            }
+        }
+        __syncthreads();
+        // ---- 16 k-steps of 32 voxels (2 rows x 16 x): A = dZ[ca][vox], B = X[vox + tap][cx] ----
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int zz = ks >> 2, yy = (ks & 3) * 2 + (kg >> 1), xg = kg & 1;
+            const int aoff = ((zz * WG_T1 + yy) * 16 + i16) * WG_T2 + xg * 8;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(sAh + aoff);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(sAl + aoff);
+            const int boff = (((zz + 1 + dz) * WG_H1 + (yy + 1 + dy)) * 16 + i16) * WG_XROW + 8 + xg * 8;
+            const u32x4 gh = *reinterpret_cast<const u32x4*>(sXh + boff);
+            const u32x4 gl = *reinterpret_cast<const u32x4*>(sXl + boff);
+            const unsigned int ph = *reinterpret_cast<const unsigned int*>(sXh + boff - 2), pl = *reinterpret_cast<const unsigned int*>(sXl + boff - 2);
+            const unsigned int nh = *reinterpret_cast<const unsigned int*>(sXh + boff + 8), nl = *reinterpret_cast<const unsigned int*>(sXl + boff + 8);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                u32x4 bh, bl;
+                if (d == 1) { bh = gh; bl = gl; }
+                else if (d == 2) {
+                    bh = u32x4{__builtin_amdgcn_alignbit(gh[1], gh[0], 16), __builtin_amdgcn_alignbit(gh[2], gh[1], 16), __builtin_amdgcn_alignbit(gh[3], gh[2], 16), __builtin_amdgcn_alignbit(nh, gh[3], 16)};
+                    bl = u32x4{__builtin_amdgcn_alignbit(gl[1], gl[0], 16), __builtin_amdgcn_alignbit(gl[2], gl[1], 16), __builtin_amdgcn_alignbit(gl[3], gl[2], 16), __builtin_amdgcn_alignbit(nl, gl[3], 16)};
+                } else {
+                    bh = u32x4{__builtin_amdgcn_alignbit(gh[0], ph, 16), __builtin_amdgcn_alignbit(gh[1], gh[0], 16), __builtin_amdgcn_alignbit(gh[2], gh[1], 16), __builtin_amdgcn_alignbit(gh[3], gh[2], 16)};
+                    bl = u32x4{__builtin_amdgcn_alignbit(gl[0], pl, 16), __builtin_amdgcn_alignbit(gl[1], gl[0], 16), __builtin_amdgcn_alignbit(gl[2], gl[1], 16), __builtin_amdgcn_alignbit(gl[3], gl[2], 16)};
+                }
+                const f16x8 xh = __builtin_bit_cast(f16x8, bh), xl = __builtin_bit_cast(f16x8, bl);
+                acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh, acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl, acc[d], 0, 0, 0);
+            }
+        }
+    }
+    // acc[d][r] = dW[ca = 4 * kg + r][tap (dz, dy, d - 1)][cx = i16]
+    const float inv = a.s2 ? a.s2[1] : 1.f;
+    const long N = 27L * a.Cx;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int tap = ((dz + 1) * 3 + (dy + 1)) * 3 + d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&a.dW[(long)(ca0 + 4 * kg + r) * N + (long)tap * a.Cx + cx0 + i16], acc[d][r] * inv);
+    }
+}
+
+// dZ fp32 [B, D0, D1, D2, Ca], X fp32 [B, D0, D1, D2, Cx] (+ GroupNorm affine [B, Cx]); dW fp32 [Ca, 27 * Cx] accumulated.
+// s2 = (s, 1 / s) device scalars of semabs_grad_scale for dZ, or null.  Needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0, Ca % 16 == Cx % 16 == 0.
+extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B,
+                                  int D0, int D1, int D2, int Ca, int Cx, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(dZ && X && dW, "semabs_wgrad_conv3: null pointer");
+    SEMABS_REQUIRE(D0 % WG_T0 == 0 && D1 % WG_T1 == 0 && D2 % WG_T2 == 0 && Ca % 16 == 0 && Cx % 16 == 0,
+                   "semabs_wgrad_conv3: needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0 and channel counts that are multiples of 16");
+    SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_conv3: gn_scale and gn_shift go together");
+    Wgrad16Args a;
+    a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
+    const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + WG_T0 * WG_T1 * 16 * WG_T2) * 2 * 2;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nbricks = B * (D0 / WG_T0) * (D1 / WG_T1) * (D2 / WG_T2);
+    const int combos = (Ca / 16) * (Cx / 16);
+    int bx = 768 / combos; if (bx < 8) bx = 8; if (bx > nbricks) bx = nbricks;
+    hipLaunchKernelGGL(k_wgrad16_lds, dim3(bx, Ca / 16, Cx / 16), dim3(WG_NTHR), lds, (hipStream_t)stream, a);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

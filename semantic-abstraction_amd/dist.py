@@ -46,3 +46,18 @@ def gather_results(local: torch.Tensor) -> torch.Tensor:
     out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(out, local.contiguous())
     return torch.stack(out, dim=0)
+
+
+def allreduce_flat_gradients(flat: torch.Tensor, n_flags: int = 0) -> Tuple[float, torch.Tensor | None]:
+    """Data-parallel gradient exchange of the VOOL training step (what DistributedDataParallel's bucketed all-reduce does in the
+    reference, utils.py:255-258 with find_unused_parameters=True): ONE sum all-reduce of the flat gradient buffer - a single large
+    collective suits xGMI's per-link-bound rings better than 100+ per-tensor ones.  The last `n_flags` entries of `flat` are per-
+    parameter "used on this rank" flags travelling in the same message; -> (scale = 1 / world to apply to the gradients, host bool
+    tensor "used on any rank" or None when n_flags == 0).  World size 1 / no process group: nothing is sent."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if world > 1:
+        dist.all_reduce(flat)
+    flags = None
+    if n_flags:
+        flags = flat[flat.numel() - n_flags:].detach().cpu() > 0
+    return 1.0 / world, flags

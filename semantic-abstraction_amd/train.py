@@ -65,6 +65,7 @@ class UNetTrainer:
         self.plan = unet_layer_plan(in_channels, out_channels, self.f_maps[0], len(self.f_maps))
         self.mats: Dict[str, dict] = {}
         self.dev = _lib.require_gpu()
+        self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
 
     # ---- per-step weight layouts (fp16 hi/lo splits for the MFMA kernels) --------------------------------------------------------
@@ -195,13 +196,17 @@ class UNetTrainer:
         key = self.prefix + r.name
         B, D0, D1, D2, cin = r.x.shape
         cout, nvox, G, st = m["cout"], D0 * D1 * D2, m["groups"], _lib.stream()
+        sc, sh, s2 = self._scale(dZ, B, cout)                # dynamic power-of-two scale of dZ, shared by the weight and data gradients
+        inv = s2[1:]
         dW = torch.zeros(cout, 27 * cin, dtype=torch.float32, device=self.dev)
-        _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
-                  cout, cin, 27, TAPS_CONV3, st)
+        if D0 % 4 == 0 and D1 % 8 == 0 and D2 % 16 == 0 and self.mfma_wgrad:
+            _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
+                      B, D0, D1, D2, cout, cin, st)
+        else:
+            _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
+                      cout, cin, 27, TAPS_CONV3, st)
         self.g[key + "conv.weight"].add_(dW.view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3))
         dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
-        sc, sh, s2 = self._scale(dZ, B, cout)
-        inv = s2[1:]
         _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
                   B, D0, D1, D2, cout, cin, 3, 0, 1, st)
         red = torch.zeros(B, cin, 2, dtype=torch.float64, device=self.dev)
@@ -308,7 +313,9 @@ class VOOLTrainer:
         # parameters the VOOL graph never touches get no gradient, like p.grad = None in the reference (completion_net.visual_sampler.*)
         self.trainable = [k for k in names if ".visual_sampler." not in k]
         total = sum(self.params[k].numel() for k in self.trainable)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # one flat buffer: every gradient + one "used in this step" flag per relation embedding (they ride in the same all-reduce)
+        self.flat_grad = torch.zeros(total + len(RELATIONS), dtype=torch.float32, device=dev)
+        self.rel_flags = self.flat_grad[total:]
         self.grads: Dict[str, torch.Tensor] = {}
         off = 0
         for k in self.trainable:
@@ -426,15 +433,13 @@ class VOOLTrainer:
         weight = self.bce_weight(label)
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
         logits = torch.empty(B, D, M, dtype=torch.float32, device=dev)
-        # like autograd, relation embeddings no description of the batch uses end the step with grad = None: Lamb skips them entirely
-        # (no weight decay either).  Under DDP every rank keeps them all so that the flat all-reduce stays aligned.
-        import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # like autograd, a relation embedding no description of the batch uses ends the step with grad = None, so Lamb skips it
+        # entirely (no weight decay either); under DDP "used" means used on any rank (find_unused_parameters=True, utils.py:257)
         used = set(names.reshape(-1).tolist())
-        for n in RELATIONS:
-            k = "relation_embeddings." + n
-            if k in self.grads:
-                self.params[k].grad = self.grads[k] if (multi or n in used) else None
+        self.rel_flags.copy_(torch.tensor([1.0 if n in used else 0.0 for n in RELATIONS]))
+        for n in RELATIONS:                                                  # local view; optimizer_step() widens it to "any rank"
+            if "relation_embeddings." + n in self.grads:
+                self.params["relation_embeddings." + n].grad = self.grads["relation_embeddings." + n] if n in used else None
         for b in range(B):
             self._scene(xyz[b].contiguous(), st_[b].contiguous(), sr_[b].contiguous(), q[b].reshape(D, M, 3).contiguous(), label[b],
                         None if weight is None else weight[b], list(names[b]), B * D * M, loss, logits[b])
@@ -443,11 +448,12 @@ class VOOLTrainer:
     @torch.no_grad()
     def optimizer_step(self) -> torch.Tensor:
         """(all-reduce ->) clip_grad_norm_ -> Lamb.step; returns the pre-clip global gradient norm (device scalar)."""
-        import torch.distributed as dist
-        scale = 1.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad)                                               # one collective for all 100+ tensors
-            scale = 1.0 / dist.get_world_size()
+        from .dist import allreduce_flat_gradients
+        scale, used = allreduce_flat_gradients(self.flat_grad, len(RELATIONS))
+        for n, u_ in zip(RELATIONS, used.tolist()):
+            k = "relation_embeddings." + n
+            if k in self.grads:
+                self.params[k].grad = self.grads[k] if u_ else None
         opt = self.opt
         ps = [p for p in opt.param_groups[0]["params"] if p.grad is not None]
         plan = opt._build_plan(ps, self.dev)

@@ -53,8 +53,10 @@ def test_gn_conv_layer_backward_strict(gscale):
     import torch.nn.functional as F
     sd, params, grads, u, pre = _unet_setup(3, 5)
     rng = np.random.default_rng(2)
+    # 16^3 volumes take the MFMA brick kernel for the weight gradient (semabs_wgrad_conv3, incl. channel slicing), the others the fp32 one
     for name, cin, cout, s in [("encoders.0.basic_module.conv1.", 16, 16, 16), ("encoders.1.basic_module.conv1.", 16, 32, 8),
-                               ("encoders.2.basic_module.conv2.", 64, 64, 4)]:
+                               ("encoders.2.basic_module.conv2.", 64, 64, 4), ("encoders.1.basic_module.conv1.", 16, 32, 16),
+                               ("encoders.1.basic_module.conv2.", 32, 32, 16)]:
         x = rng.standard_normal((2, cin, s, s, s)).astype(np.float32) + 0.3
         dz = (rng.standard_normal((2, cout, s, s, s)) * gscale).astype(np.float32)
         key = pre + name

@@ -92,7 +92,7 @@ def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import semabs_amd  # noqa: F401
-    from semabs_amd.dist import allreduce_tile_relevance, gather_results, shard_range
+    from semabs_amd.dist import allreduce_flat_gradients, allreduce_tile_relevance, gather_results, shard_range
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L, N, g = 3, 10, 2
     full = torch.arange(L * N * g * g, dtype=torch.float32).view(L, N, g, g)
@@ -103,7 +103,11 @@ def _gloo_worker(rank, world, port, q):
     ok1 = torch.equal(rel[0], full)
     gathered = gather_results(torch.full((2, 4), float(rank)))               # e.g. 2 label volumes per rank
     ok2 = gathered.shape == (world, 2, 4) and all(float(gathered[r, 0, 0]) == r for r in range(world))
-    q.put((rank, bool(ok1), bool(ok2)))
+    # training: one flat all-reduce of gradients + usage flags (rank 0 used relation 0, rank 1 relation 2; relation 1 unused everywhere)
+    flat = torch.cat([torch.arange(6, dtype=torch.float32) * (rank + 1), torch.tensor([1.0, 0.0, 0.0] if rank == 0 else [0.0, 0.0, 1.0])])
+    scale, used = allreduce_flat_gradients(flat, 3)
+    ok3 = scale == 0.5 and torch.equal(flat[:6] * scale, torch.arange(6, dtype=torch.float32) * 1.5) and used.tolist() == [True, False, True]
+    q.put((rank, bool(ok1), bool(ok2 and ok3)))
     dist.destroy_process_group()
 
 
