@@ -209,18 +209,21 @@ int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const
                        void* stream);
 /* GroupNorm mean / rstd fp32 [B, G] from the fp64 sums of semabs_gn_stats (what the backward needs)      unet3d.py:59-77 */
 int semabs_gn_meanrstd(const double* sums, float* mean, float* rstd, int B, int G, long count, float eps, void* stream);
-/* GroupNorm backward: per-(b, c) coefficients + dgamma / dbeta (accumulated), then dX = k1 dXn - k2 - xhat k3 (+ add1 + add2) */
+/* GroupNorm backward: per-(b, c) coefficients + dgamma / dbeta (accumulated), then
+ * dX = (k1 dXn - k2 - xhat k3 (+ add1 + add2)) (* (mask_y > 0): the ReLU in front of the GroupNorm), max |dX| -> absmax_bits (optional) */
 int semabs_gn_bwd_coef(const double* red, const float* gamma, const float* rstd, const float* inv_scale, float* coef, float* dgamma,
                        float* dbeta, int B, int C, int G, long nvox, void* stream);
 int semabs_gn_bwd_apply(const float* dXn, const float* X, const float* mean, const float* rstd, const float* coef, const float* add1,
-                        const float* add2, float* dX, int B, long nvox, int C, int G, void* stream);
+                        const float* add2, const float* mask_y, unsigned int* absmax_bits, float* dX, int B, long nvox, int C, int G, void* stream);
 
 /* element-wise over n (% 4 == 0) floats: mode 0 out = a * (b > 0) (ReLU backward from the output), 1 LeakyReLU backward, 2 out = a + b,
- * 3 out = a * b[0] (b = device scalar) */
-int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, void* stream);
+ * 3 out = a * b[0] (b = device scalar); absmax_bits (optional, zeroed uint32) receives the bit pattern of max |out| */
+int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, unsigned int* absmax_bits, void* stream);
 /* Dynamic power-of-two scale s for a gradient tensor (max |x| * s in [256, 512)) so the split-fp16 data-gradient convolutions keep fp32-like
- * accuracy for tiny gradients: scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits = uint32 scratch */
-int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, void* stream);
+ * accuracy for tiny gradients: scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits = uint32 scratch, or with
+ * have_bits = 1 the max |x| pattern semabs_ew already produced (x is then not read) */
+int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, int have_bits,
+                      void* stream);
 /* MaxPool3d(2) backward: first maximal element of each window takes dY                                   unet3d.py:298-317 */
 int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, int B, int D0, int D1, int D2, int C, void* stream);
 
@@ -232,11 +235,11 @@ int semabs_linear_f32(const float* X, const float* W, const float* bias, float* 
 int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol, float* dpf, int P, long N, int C, long nvox, void* stream);
 
 /* VOOL head pieces for training: f [P*M, 36] = (trilinear(vol_t), trilinear(vol_r), qn, 0) and the scatter of df back into the two
- * gradient volumes (accumulated, zero first)                                                            net.py:215-256, 556-565 */
+ * gradient volumes (gather over per-cell point lists; head int32 [P * S^3], next int32 [P * M] scratch)                                                            net.py:215-256, 556-565 */
 int semabs_vool_sample(const float* vol_t, const float* vol_r, const float* query, const float* off3, const float* sc3, const int* shape3,
                        int P, long M, float* f, void* stream);
 int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
-                           float* dvol_t, float* dvol_r, void* stream);
+                           int* head, int* next, float* dvol_t, float* dvol_r, void* stream);
 
 /* logits = cos(o, rel) / T; loss += sum w BCEwithlogits(logit, label) / n_total; dO and drel (accumulated) = d loss / d o, d rel
  *                                                                                                        net.py:566-579, train_vool.py:171-178 */

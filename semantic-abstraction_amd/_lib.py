@@ -73,14 +73,14 @@ SIGNATURES = {
     "semabs_chan_reduce": [P, P, P, P, P, I, L, I, I, P],
     "semabs_gn_meanrstd": [P, P, P, I, I, L, F, P],
     "semabs_gn_bwd_coef": [P, P, P, P, P, P, P, I, I, I, L, P],
-    "semabs_gn_bwd_apply": [P, P, P, P, P, P, P, P, I, L, I, I, P],
-    "semabs_ew": [P, P, P, L, I, F, P],
-    "semabs_grad_scale": [P, L, P, P, I, P, P, P],
+    "semabs_gn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    "semabs_ew": [P, P, P, L, I, F, P, P],
+    "semabs_grad_scale": [P, L, P, P, I, P, P, I, P],
     "semabs_maxpool3d_bwd": [P, P, P, I, I, I, I, I, P],
     "semabs_linear_f32": [P, P, P, P, L, I, I, I, F, P],
     "semabs_scatter_mean_bwd": [P, P, P, P, I, L, I, L, P],
     "semabs_vool_sample": [P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P],
-    "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P],
+    "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P, P, P],
     "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P],
     "semabs_clip_grad_norm": [P, I, P, I, F, F, P, P],
 }

@@ -12,6 +12,16 @@
 //   clip_grad_norm_                                  utils.py:415
 #include "semabs_common.h"
 
+// max |.| reduction into one global word: a wave-level max, then an atomic only when it would raise the current value (the plain read
+// is a filter, not a synchronisation: millions of waves hitting one address with atomicMax serialise otherwise)
+__device__ __forceinline__ void absmax_commit(unsigned int* bits, float m) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        const unsigned int u = __float_as_uint(m);
+        if (u > __hip_atomic_load(bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(bits, u);
+    }
+}
+
 // =================================================================================================
 // Weight gradient as a split-K "A^T B" reduction over rows (voxels / points):
 //   dW[ca][tap * Cx + cx] += sum_rows A[row][ca] * Xn(neighbour(row, tap))[cx]
@@ -207,34 +217,45 @@ extern "C" int semabs_gn_bwd_coef(const double* red, const float* gamma, const f
     return SEMABS_OK;
 }
 
-// dX = k1 * dXn - k2 - xhat * k3  [+ add1] [+ add2]
+// dX = (k1 * dXn - k2 - xhat * k3 [+ add1] [+ add2]) [* (mask_y > 0)]; optionally max |dX| -> bits (for the next dynamic gradient scale)
 __global__ void k_gn_bwd_apply(const float* __restrict__ dXn, const float* __restrict__ X, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ coef, const float* __restrict__ add1,
-                               const float* __restrict__ add2, float* __restrict__ dX, int B, long nvox, int C, int G) {
+                               const float* __restrict__ add2, const float* __restrict__ mask_y, unsigned int* __restrict__ bits,
+                               float* __restrict__ dX, int B, long nvox, int C, int G) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long tot = (long)B * nvox * (C / 4);
-    if (i >= tot) return;
-    const int c0 = (int)(i % (C / 4)) * 4; const int b = (int)(i / (nvox * (C / 4)));
-    const float4 d = *reinterpret_cast<const float4*>(dXn + i * 4);
-    const float4 x = *reinterpret_cast<const float4*>(X + i * 4);
-    float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w}, o[4];
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < tot) {
+        const int c0 = (int)(i % (C / 4)) * 4; const int b = (int)(i / (nvox * (C / 4)));
+        const float4 d = *reinterpret_cast<const float4*>(dXn + i * 4);
+        const float4 x = *reinterpret_cast<const float4*>(X + i * 4);
+        const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = c0 + j, g = c / (C / G);
-        const float xh = (xv[j] - mean[b * G + g]) * rstd[b * G + g];
-        const float* k = coef + ((long)b * C + c) * 3;
-        o[j] = k[0] * dv[j] - k[1] - xh * k[2];
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j, g = c / (C / G);
+            const float xh = (xv[j] - mean[b * G + g]) * rstd[b * G + g];
+            const float* k = coef + ((long)b * C + c) * 3;
+            o[j] = k[0] * dv[j] - k[1] - xh * k[2];
+        }
+        if (add1) { const float4 a = *reinterpret_cast<const float4*>(add1 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+        if (add2) { const float4 a = *reinterpret_cast<const float4*>(add2 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+        if (mask_y) {                                          // X is the post-ReLU output of the previous layer only when the caller says so
+            const float4 y = *reinterpret_cast<const float4*>(mask_y + i * 4);
+            o[0] = y.x > 0.f ? o[0] : 0.f; o[1] = y.y > 0.f ? o[1] : 0.f; o[2] = y.z > 0.f ? o[2] : 0.f; o[3] = y.w > 0.f ? o[3] : 0.f;
+        }
+        *reinterpret_cast<float4*>(dX + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (add1) { const float4 a = *reinterpret_cast<const float4*>(add1 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
-    if (add2) { const float4 a = *reinterpret_cast<const float4*>(add2 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
-    *reinterpret_cast<float4*>(dX + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (bits) {
+        absmax_commit(bits, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+    }
 }
 extern "C" int semabs_gn_bwd_apply(const float* dXn, const float* X, const float* mean, const float* rstd, const float* coef, const float* add1,
-                                   const float* add2, float* dX, int B, long nvox, int C, int G, void* stream) {
+                                   const float* add2, const float* mask_y, unsigned int* absmax_bits, float* dX, int B, long nvox, int C, int G,
+                                   void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dXn && X && mean && rstd && coef && dX && C % 4 == 0 && C % G == 0, "semabs_gn_bwd_apply: bad args");
     hipLaunchKernelGGL(k_gn_bwd_apply, dim3(semabs_cdiv((long)B * nvox * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, dXn, X, mean, rstd, coef,
-                       add1, add2, dX, B, nvox, C, G);
+                       add1, add2, mask_y, absmax_bits, dX, B, nvox, C, G);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -246,24 +267,32 @@ extern "C" int semabs_gn_bwd_apply(const float* dXn, const float* X, const float
 //   mode 2: out = a + b                        (gradient fan-in;  Y = second addend)
 //   mode 3: out = a * b[0]                     (undo the dynamic gradient scale, b = device scalar)
 // =================================================================================================
-__global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ out, long n4, int mode, float slope) {
+__global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ out, long n4, int mode, float slope,
+                     unsigned int* __restrict__ bits) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const float4 d = *reinterpret_cast<const float4*>(dY + i * 4);
-    if (mode == 3) { const float k = Y[0]; *reinterpret_cast<float4*>(out + i * 4) = make_float4(d.x * k, d.y * k, d.z * k, d.w * k); return; }
-    const float4 y = *reinterpret_cast<const float4*>(Y + i * 4);
-    float4 o;
-    if (mode == 2) { o.x = d.x + y.x; o.y = d.y + y.y; o.z = d.z + y.z; o.w = d.w + y.w; }
-    else {
-        const float s = mode == 0 ? 0.f : slope;
-        o.x = d.x * (y.x > 0.f ? 1.f : s); o.y = d.y * (y.y > 0.f ? 1.f : s); o.z = d.z * (y.z > 0.f ? 1.f : s); o.w = d.w * (y.w > 0.f ? 1.f : s);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4 d = *reinterpret_cast<const float4*>(dY + i * 4);
+        if (mode == 3) { const float k = Y[0]; o = make_float4(d.x * k, d.y * k, d.z * k, d.w * k); }
+        else {
+            const float4 y = *reinterpret_cast<const float4*>(Y + i * 4);
+            if (mode == 2) { o.x = d.x + y.x; o.y = d.y + y.y; o.z = d.z + y.z; o.w = d.w + y.w; }
+            else {
+                const float s = mode == 0 ? 0.f : slope;
+                o.x = d.x * (y.x > 0.f ? 1.f : s); o.y = d.y * (y.y > 0.f ? 1.f : s); o.z = d.z * (y.z > 0.f ? 1.f : s); o.w = d.w * (y.w > 0.f ? 1.f : s);
+            }
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = o;
     }
-    *reinterpret_cast<float4*>(out + i * 4) = o;
+    if (bits) {                                             // max |out| for the dynamic gradient scale of the next convolution
+        absmax_commit(bits, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+    }
 }
-extern "C" int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, void* stream) {
+// absmax_bits: optional uint32 (zero it first) receiving the bit pattern of max |out| - feeds semabs_grad_scale(have_bits = 1)
+extern "C" int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, unsigned int* absmax_bits, void* stream) {
     if (n == 0) return SEMABS_OK;
     SEMABS_REQUIRE(a && b && out && n % 4 == 0 && mode >= 0 && mode <= 3, "semabs_ew: bad args (n % 4 == 0)");
-    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope);
+    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -407,25 +436,50 @@ __global__ void k_vool_sample(const float* __restrict__ vol_t, const float* __re
     for (int c = 0; c < 16; ++c) fo[c] = acc[c];
     if (sel == 0) { f[pt * 36 + 32] = qn[0]; f[pt * 36 + 33] = qn[1]; f[pt * 36 + 34] = qn[2]; f[pt * 36 + 35] = 0.f; }
 }
-__global__ void k_vool_sample_bwd(const float* __restrict__ df, const float* __restrict__ query, SampArgs a, int P, long M,
-                                  float* __restrict__ dvol_t, float* __restrict__ dvol_r) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * M * 2) return;
-    const int sel = (int)(i & 1); const long pt = i >> 1; const int d = (int)(pt / M);
+// Backward of the sampling as a GATHER: points are first threaded into per-cell lists (cell = floor corner of the point), then every
+// voxel of the gradient volumes sums w * df over the points of the 8 cells that touch it - no floating-point atomics (the scatter form
+// issued 8 x 16 of them per point and volume and was atomic-throughput bound), and the volumes need no zero-fill.
+__global__ void k_vool_cells(const float* __restrict__ query, SampArgs a, int P, long M, int* __restrict__ head, int* __restrict__ next) {
+    const long pt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= (long)P * M) return;
+    const int d = (int)(pt / M);
     float qn[3], w[6]; int x0, y0, z0;
     samp_setup(query + pt * 3, a, qn, x0, y0, z0, w);
-    float* vb = (sel ? dvol_r : dvol_t) + (long)d * a.S0 * a.S1 * a.S2 * 16;
-    const float* g = df + pt * 36 + sel * 16;
+    const long cell = (((long)d * a.S0 + z0) * a.S1 + y0) * a.S2 + x0;
+    next[pt] = atomicExch(&head[cell], (int)(pt - (long)d * M));            // list entries are point indices within the description
+}
+// thread = (description, voxel, volume selector): 16 channels in registers
+__global__ __launch_bounds__(256) void k_vool_sample_bwd(const float* __restrict__ df, const float* __restrict__ query, SampArgs a, int P, long M,
+                                                         const int* __restrict__ head, const int* __restrict__ next,
+                                                         float* __restrict__ dvol_t, float* __restrict__ dvol_r) {
+    const long nvox = (long)a.S0 * a.S1 * a.S2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)P * nvox * 2) return;
+    const int sel = (int)(i & 1); const long dv = i >> 1;
+    const int d = (int)(dv / nvox); long v = dv - (long)d * nvox;
+    const int vx = (int)(v % a.S2); v /= a.S2;
+    const int vy = (int)(v % a.S1); const int vz = (int)(v / a.S1);
+    float acc[16];
 #pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
     for (int k = 0; k < 8; ++k) {
-        const int zz = z0 + (k >> 2), yy = y0 + ((k >> 1) & 1), xx = x0 + (k & 1);
-        if (zz > a.S0 - 1 || yy > a.S1 - 1 || xx > a.S2 - 1) continue;
-        const float wt = w[k & 1] * w[2 + ((k >> 1) & 1)] * w[4 + (k >> 2)];
-        if (wt == 0.f) continue;
-        float* p = vb + (((long)zz * a.S1 + yy) * a.S2 + xx) * 16;
+        const int cz = vz - (k >> 2), cy = vy - ((k >> 1) & 1), cx = vx - (k & 1);          // this voxel is corner k of cell (cz, cy, cx)
+        if (cz < 0 || cy < 0 || cx < 0) continue;
+        int p = head[(((long)d * a.S0 + cz) * a.S1 + cy) * a.S2 + cx];
+        while (p >= 0) {
+            const long pt = (long)d * M + p;
+            float qn[3], w[6]; int x0, y0, z0;
+            samp_setup(query + pt * 3, a, qn, x0, y0, z0, w);
+            const float wt = w[k & 1] * w[2 + ((k >> 1) & 1)] * w[4 + (k >> 2)];
+            const float4* g = reinterpret_cast<const float4*>(df + pt * 36 + sel * 16);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) atomicAdd(p + c, g[c] * wt);
+            for (int q = 0; q < 4; ++q) { const float4 gv = g[q]; acc[4 * q] += gv.x * wt; acc[4 * q + 1] += gv.y * wt; acc[4 * q + 2] += gv.z * wt; acc[4 * q + 3] += gv.w * wt; }
+            p = next[pt];
+        }
     }
+    float4* o = reinterpret_cast<float4*>((sel ? dvol_r : dvol_t) + dv * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
 }
 static void fill_samp(SampArgs& a, const float* off3, const float* sc3, const int* shape3) {
     for (int k = 0; k < 3; ++k) { a.off[k] = off3[k]; a.sc[k] = sc3[k]; }
@@ -441,13 +495,18 @@ extern "C" int semabs_vool_sample(const float* vol_t, const float* vol_r, const 
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
-// df fp32 [P*M, 36] -> dvol_t / dvol_r fp32 [P, S, S, S, 16] ACCUMULATED with fp32 atomics (zero them first)
+// df fp32 [P*M, 36] -> dvol_t / dvol_r fp32 [P, S, S, S, 16] (fully written).  head int32 [P * S^3] and next int32 [P * M] are scratch.
 extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
-                                      float* dvol_t, float* dvol_r, void* stream) {
-    if (P == 0 || M == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(df && query && off3 && sc3 && shape3 && dvol_t && dvol_r, "semabs_vool_sample_bwd: null pointer");
+                                      int* head, int* next, float* dvol_t, float* dvol_r, void* stream) {
+    if (P == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(df && query && off3 && sc3 && shape3 && head && next && dvol_t && dvol_r, "semabs_vool_sample_bwd: null pointer");
+    SEMABS_REQUIRE(M < (1L << 31), "semabs_vool_sample_bwd: at most 2^31 - 1 query points per description");
     SampArgs a; fill_samp(a, off3, sc3, shape3);
-    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * M * 2, 256)), dim3(256), 0, (hipStream_t)stream, df, query, a, P, M, dvol_t, dvol_r);
+    hipStream_t s = (hipStream_t)stream;
+    const long nvox = (long)a.S0 * a.S1 * a.S2;
+    if (hipMemsetAsync(head, 0xff, sizeof(int) * P * nvox, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    if (M > 0) hipLaunchKernelGGL(k_vool_cells, dim3(semabs_cdiv((long)P * M, 256)), dim3(256), 0, s, query, a, P, M, head, next);
+    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * nvox * 2, 256)), dim3(256), 0, s, df, query, a, P, M, head, next, dvol_t, dvol_r);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -517,8 +576,7 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, lon
         const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(bits, __float_as_uint(m));      // non-negative floats order like their bit patterns
+    absmax_commit(bits, m);                                 // non-negative floats order like their bit patterns
 }
 __global__ void k_scale_fill(const unsigned int* __restrict__ bits, float* __restrict__ scale_arr, float* __restrict__ shift_arr, int n_arr,
                              float* __restrict__ s2) {
@@ -529,13 +587,17 @@ __global__ void k_scale_fill(const unsigned int* __restrict__ bits, float* __res
     if (i < n_arr) { scale_arr[i] = s; shift_arr[i] = 0.f; }
     if (i == 0) { s2[0] = s; s2[1] = 1.f / s; }
 }
-// x fp32 [n] (n % 4 == 0) -> scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits: uint32 scratch
-extern "C" int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, void* stream) {
-    SEMABS_REQUIRE(x && scale_arr && shift_arr && s2 && bits && n > 0 && n % 4 == 0 && n_arr > 0, "semabs_grad_scale: bad args");
+// x fp32 [n] (n % 4 == 0) -> scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits: uint32 scratch, or
+// (have_bits = 1) the max |x| bit pattern already produced by semabs_ew, in which case x is not read again
+extern "C" int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, int have_bits,
+                                 void* stream) {
+    SEMABS_REQUIRE(scale_arr && shift_arr && s2 && bits && n_arr > 0 && (have_bits || (x && n > 0 && n % 4 == 0)), "semabs_grad_scale: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(bits, 0, sizeof(unsigned int), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
-    int bx = semabs_cdiv(n / 4, 256 * 8); if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, x, n / 4, bits);
+    if (!have_bits) {
+        if (hipMemsetAsync(bits, 0, sizeof(unsigned int), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+        int bx = semabs_cdiv(n / 4, 256 * 8); if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, x, n / 4, bits);
+    }
     hipLaunchKernelGGL(k_scale_fill, dim3(semabs_cdiv(n_arr, 256)), dim3(256), 0, s, bits, scale_arr, shift_arr, n_arr, s2);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;

@@ -390,7 +390,11 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
                     o[0] += (float)r[0]; o[1] += (float)r[1]; o[2] += (float)r[2]; o[3] += (float)r[3];
                 }
             }
-            if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+            if (a.relu == 1) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+            else if (a.relu == 2) {                                  // LeakyReLU(0.01): the point / sampler MLP layers run as 1x1x1 convolutions
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.01f * o[j];
+            }
             if (F32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
@@ -577,6 +581,7 @@ static int conv_common_checks(const void* x, const void* w_hi, const void* w_lo,
 // Conv3d k (1 or 3), stride 1, padding k/2.  x [B, D0, D1, D2, Cin] -> y [B, D0, D1, D2, Cout] (fp16, or fp32 when
 // act_f32).  w_hi / w_lo fp16 [Cout, Kp], k index = ((kd*3 + kh)*3 + kw) * Cin + cin, Kp = K rounded up to 32.
 // gn_scale / gn_shift fp32 [B, Cin] (null = no GroupNorm in front); bias fp32 [Cout] or null; resid like y or null.
+// relu: 0 none, 1 ReLU, 2 LeakyReLU(0.01) (generic kernel only: ksize 1, i.e. the MLP layers of the training step).
 extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                              const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
                              int relu, int act_f32, void* stream) {
@@ -595,6 +600,7 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
     for (int kd = 0; kd < ksize; ++kd)
         for (int kh = 0; kh < ksize; ++kh)
             for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
+    SEMABS_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && ksize == 1), "semabs_conv3d: relu must be 0, 1, or 2 (LeakyReLU, ksize 1 only)");
     if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
         return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
     return conv_launch(a, act_f32, (hipStream_t)stream);

@@ -170,28 +170,37 @@ class UNetTrainer:
         grad.add_(red[0, :, 0].float())
 
     def _scale(self, dz: torch.Tensor, B: int, Cc: int):
-        """Dynamic power-of-two scale of a gradient tensor (csrc/train.hip, semabs_grad_scale): -> (scale_arr, shift_arr, s2)."""
+        """Dynamic power-of-two scale of a gradient tensor (csrc/train.hip, semabs_grad_scale): -> (scale_arr, shift_arr, s2).
+        When dz came out of `_ew(..., want_max=True)` its max |.| is already known and the tensor is not read again."""
         sc = torch.empty(B * Cc, dtype=torch.float32, device=self.dev)
         sh = torch.empty_like(sc)
         s2 = torch.empty(2, dtype=torch.float32, device=self.dev)
-        bits = torch.empty(1, dtype=torch.int32, device=self.dev)
-        _lib.call("semabs_grad_scale", _lib.ptr(dz), dz.numel(), _lib.ptr(sc), _lib.ptr(sh), B * Cc, _lib.ptr(s2), _lib.ptr(bits), _lib.stream())
+        bits = getattr(dz, "_semabs_absmax", None)
+        have = bits is not None
+        if not have:
+            bits = torch.empty(1, dtype=torch.int32, device=self.dev)
+        _lib.call("semabs_grad_scale", _lib.ptr(dz), dz.numel(), _lib.ptr(sc), _lib.ptr(sh), B * Cc, _lib.ptr(s2), _lib.ptr(bits), int(have), _lib.stream())
         return sc, sh, s2
 
     def _unscale(self, a, s2):
         out = torch.empty_like(a)
         inv = s2[1:]
-        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(inv), _lib.ptr(out), a.numel(), 3, 0.0, _lib.stream())
+        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(inv), _lib.ptr(out), a.numel(), 3, 0.0, None, _lib.stream())
         return out
 
-    def _ew(self, a, b, mode):
+    def _ew(self, a, b, mode, want_max=False):
         out = torch.empty_like(a)
-        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.stream())
+        bits = torch.zeros(1, dtype=torch.int32, device=self.dev) if want_max else None
+        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.ptr(bits), _lib.stream())
+        if want_max:
+            out._semabs_absmax = bits
         return out
 
-    def _conv_bwd(self, r: _Rec, dZ: torch.Tensor, add1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _conv_bwd(self, r: _Rec, dZ: torch.Tensor, add1: Optional[torch.Tensor] = None, relu_in: bool = False) -> torch.Tensor:
         """dZ = gradient w.r.t. the convolution output (before ReLU / residual); returns the gradient w.r.t. the GroupNorm input
-        (+ add1).  Accumulates the conv weight and GroupNorm affine gradients."""
+        (+ add1).  relu_in: the layer's input r.x is a post-ReLU activation and the caller wants the gradient in front of that
+        ReLU (masked by r.x > 0, with its max |.| recorded for the next dynamic scale).  Accumulates the conv weight and GroupNorm
+        affine gradients."""
         m = self.mats[r.name]
         key = self.prefix + r.name
         B, D0, D1, D2, cin = r.x.shape
@@ -215,16 +224,19 @@ class UNetTrainer:
         _lib.call("semabs_gn_bwd_coef", _lib.ptr(red), _lib.ptr(self.p[key + "groupnorm.weight"]), _lib.ptr(r.rstd), _lib.ptr(inv), _lib.ptr(coef),
                   _lib.ptr(self.g[key + "groupnorm.weight"]), _lib.ptr(self.g[key + "groupnorm.bias"]), B, cin, G, nvox, st)
         dX = torch.empty_like(dXn)
+        bits = torch.zeros(1, dtype=torch.int32, device=self.dev) if relu_in else None
         _lib.call("semabs_gn_bwd_apply", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(coef), _lib.ptr(add1), None,
-                  _lib.ptr(dX), B, nvox, cin, G, st)
+                  _lib.ptr(r.x if relu_in else None), _lib.ptr(bits), _lib.ptr(dX), B, nvox, cin, G, st)
+        if relu_in:
+            dX._semabs_absmax = bits
         return dX
 
     def _block_bwd(self, recs, dOut):
         r1, r2, r3 = recs
-        dS = self._ew(dOut, r3.y, 0)                        # through the final ReLU of relu(conv3 + out1)
-        d2 = self._conv_bwd(r3, dS)                         # -> d out2 (post-ReLU output of conv2)
-        d1 = self._conv_bwd(r2, self._ew(d2, r2.y, 0), add1=dS)   # -> d out1 = via conv2 + residual branch
-        return self._conv_bwd(r1, self._ew(d1, r1.y, 0))
+        dS = self._ew(dOut, r3.y, 0, want_max=True)         # through the final ReLU of relu(conv3 + out1)
+        dz2 = self._conv_bwd(r3, dS, relu_in=True)          # d out2, already through conv2's ReLU (r3.x = out2)
+        dz1 = self._conv_bwd(r2, dz2, add1=dS, relu_in=True)   # d out1 = via conv2 + the residual branch, through conv1's ReLU
+        return self._conv_bwd(r1, dz1)
 
     def _up_bwd(self, pre: str, xin: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
         """ConvTranspose3d k3 s2 p1 op1 backward: g = gradient w.r.t. its output [B, 2D, 2D, 2D, cout] -> gradient w.r.t. xin."""
@@ -338,6 +350,21 @@ class VOOLTrainer:
         _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
         return y
 
+    def _linear_mfma(self, x, w, b, act, grad_in=False):
+        """The 128 -> 128 MLP layers as 1x1x1 convolutions on the split-fp16 MFMA kernel (fp32-like accuracy).  grad_in: x is a
+        gradient (arbitrarily small): scaled by a power of two on the way in and back on the way out."""
+        R, Ci = x.shape
+        Co = w.shape[0]
+        hi, lo = _split16(_pad32(w.contiguous()))
+        y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
+        u = self.unet
+        sc = sh = s2 = None
+        if grad_in:
+            sc, sh, s2 = u._scale(x, 1, Ci)
+        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(b), None,
+                  1, 1, 1, R, Ci, Co, 1, 2 if act else 0, 1, _lib.stream())
+        return u._unscale(y, s2) if grad_in else y
+
     def _wgrad_linear(self, dOut, x, grad_w, cols=None):
         R, Co = dOut.shape
         Ci = x.shape[1]
@@ -369,7 +396,7 @@ class VOOLTrainer:
         feat = torch.cat([sal_t, sal_r], dim=0)                                           # [P, N]
         x4 = torch.cat([xyz.unsqueeze(0).expand(P, N, 3), feat.unsqueeze(-1)], dim=-1).reshape(P * N, 4).contiguous()
         h1 = self._linear(x4, p[cn + "0.weight"], p[cn + "0.bias"], 1)
-        h2 = self._linear(h1, p[cn + "2.weight"], p[cn + "2.bias"], 1)
+        h2 = self._linear_mfma(h1, p[cn + "2.weight"], p[cn + "2.bias"], 1)
         pf = self._linear(h2, p[cn + "4.weight"], p[cn + "4.bias"], 0)                   # [P*N, C]
         flat = self.vg.flat_idxs(xyz)
         vol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
@@ -400,8 +427,11 @@ class VOOLTrainer:
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
-        dvol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
-        _lib.call("semabs_vool_sample_bwd", _lib.ptr(df), _lib.ptr(query), off3, sc3, shp, D, M, _lib.ptr(dvol[:D]), _lib.ptr(dvol[D:]), st)
+        dvol = torch.empty(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
+        cell_head = torch.empty(D * nvox, dtype=torch.int32, device=dev)
+        cell_next = torch.empty(D * M, dtype=torch.int32, device=dev)
+        _lib.call("semabs_vool_sample_bwd", _lib.ptr(df), _lib.ptr(query), off3, sc3, shp, D, M, _lib.ptr(cell_head), _lib.ptr(cell_next),
+                  _lib.ptr(dvol[:D]), _lib.ptr(dvol[D:]), st)
         dscat = u.backward(tape, dvol)
         count = torch.zeros(nvox, dtype=torch.int32, device=dev)
         dpf = torch.empty(P * N, self.C, dtype=torch.float32, device=dev)
@@ -411,7 +441,7 @@ class VOOLTrainer:
         dh2 = u._ew(self._linear(dpf, p[cn + "4.weight"].t().contiguous(), None, 0), h2, 1)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
-        dh1 = u._ew(self._linear(dh2, p[cn + "2.weight"].t().contiguous(), None, 0), h1, 1)
+        dh1 = u._ew(self._linear_mfma(dh2, p[cn + "2.weight"].t().contiguous(), None, 0, grad_in=True), h1, 1)
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
 
