@@ -195,14 +195,15 @@ int semabs_conv3d_gather(const void* x, const void* w_hi, const void* w_lo, void
 
 /* Weight gradient dW[ca][tap * Cx + cx] += sum_rows A[row][ca] * GN(X)[neighbour(row, tap)][cx]; rows run over [B, M0, M1, M2], the
  * neighbour is m * in_stride + td with zero padding.  Conv3d: A = dY, X = layer input.  ConvTranspose3d: A = input, X = dY, stride 2.
- * Linear: M0 = M1 = 1, M2 = rows, one tap.  dW is accumulated (zero it first).  Ca % 16 == 0, Cx % 4 == 0. */
+ * Linear: M0 = M1 = 1, M2 = rows, one tap.  dW is accumulated into; tap_minor = 1 writes torch's parameter layout [Ca, Cx, ntaps] instead of
+ * [Ca, ntaps, Cx].  Ca % 16 == 0, Cx % 4 == 0. */
 int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0, int M1, int M2,
-                 int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps, void* stream);
+                 int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps, int tap_minor, void* stream);
 
 /* The same for Conv3d 3x3x3 on MFMA (split fp16, LDS-transposed 4 x 8 x 16 bricks): dW[ca][tap * Cx + cx] += sum_vox dZ[vox][ca] * GN(X)[vox + tap][cx].
  * s2 = (s, 1 / s) of semabs_grad_scale(dZ) or NULL.  Needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0, Ca % 16 == 0, Cx % 16 == 0. */
 int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B, int D0,
-                       int D1, int D2, int Ca, int Cx, void* stream);
+                       int D1, int D2, int Ca, int Cx, int tap_minor, void* stream);
 
 /* out fp64 [B, C, 2] += (sum_v dY, sum_v dY * xhat) per (batch, channel); X = NULL gives plain column sums (bias gradients) */
 int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const float* rstd, double* out, int B, long nvox, int C, int G,

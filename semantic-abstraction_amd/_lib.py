@@ -68,8 +68,8 @@ SIGNATURES = {
     "semabs_decoder": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, I, I, L, L, I, P, P],
     # training step (train.hip, unet.hip)
     "semabs_conv3d_gather": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],
-    "semabs_wgrad": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, P],
-    "semabs_wgrad_conv3": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "semabs_wgrad": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],
+    "semabs_wgrad_conv3": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "semabs_chan_reduce": [P, P, P, P, P, I, L, I, I, P],
     "semabs_gn_meanrstd": [P, P, P, I, I, L, F, P],
     "semabs_gn_bwd_coef": [P, P, P, P, P, P, P, I, I, I, L, P],

@@ -32,7 +32,7 @@ __device__ __forceinline__ void absmax_commit(unsigned int* bits, float m) {
 struct WgradArgs {
     const float* A; const float* X; const float* gn_scale; const float* gn_shift; float* dW;
     int B, M0, M1, M2, I0, I1, I2, is;
-    int Ca, Cx, ntaps; long rows_per_block;
+    int Ca, Cx, ntaps, tap_minor; long rows_per_block;
     signed char td0[28], td1[28], td2[28];
 };
 
@@ -92,20 +92,27 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int n = n0 + ng * 4 + k;
-        if (n < N) atomicAdd(&a.dW[(long)(ca0 + ca) * N + n], acc[k]);
+        if (n < N) {
+            const int tap = n / a.Cx, cx = n - tap * a.Cx;
+            const long idx = a.tap_minor ? ((long)(ca0 + ca) * a.Cx + cx) * a.ntaps + tap : (long)(ca0 + ca) * N + n;
+            atomicAdd(&a.dW[idx], acc[k]);
+        }
     }
 }
 
-// dW fp32 [Ca, ntaps * Cx] is ACCUMULATED into (zero it first).  taps int8 [ntaps, 3] host array.  Ca % 16 == 0, Cx % 4 == 0.
+// dW fp32 is ACCUMULATED into: [Ca, ntaps, Cx] (tap_minor = 0, the forward kernels' K order) or [Ca, Cx, ntaps] (tap_minor = 1, the
+// layout of torch's Conv3d / ConvTranspose3d / Linear weights, so gradients land in the parameter-shaped buffer directly).
+// taps int8 [ntaps, 3] host array.  Ca % 16 == 0, Cx % 4 == 0.
 extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0,
                             int M1, int M2, int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps,
-                            void* stream) {
+                            int tap_minor, void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(A && X && dW && taps, "semabs_wgrad: null pointer");
     SEMABS_REQUIRE(Ca % 16 == 0 && Cx % 4 == 0 && ntaps >= 1 && ntaps <= 28, "semabs_wgrad: Ca % 16, Cx % 4, 1 <= ntaps <= 28");
     WgradArgs a;
     a.A = A; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.dW = dW;
     a.B = B; a.M0 = M0; a.M1 = M1; a.M2 = M2; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.is = in_stride; a.Ca = Ca; a.Cx = Cx; a.ntaps = ntaps;
+    a.tap_minor = tap_minor;
     for (int i = 0; i < ntaps; ++i) { a.td0[i] = taps[i * 3]; a.td1[i] = taps[i * 3 + 1]; a.td2[i] = taps[i * 3 + 2]; }
     const long R = (long)B * M0 * M1 * M2;
     const int ytiles = Ca / 16, ztiles = semabs_cdiv((long)ntaps * Cx, 64);
@@ -661,7 +668,7 @@ extern "C" int semabs_clip_grad_norm(const long long* chunks, int n_chunks, cons
 #define WG_NTHR 576
 struct Wgrad16Args {
     const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* s2; float* dW;
-    int B, D0, D1, D2, Ca, Cx;
+    int B, D0, D1, D2, Ca, Cx, tap_minor;
 };
 
 __device__ __forceinline__ unsigned int pack_hi_lo(float v0, float v1, unsigned int& lo) {
@@ -780,28 +787,42 @@ __global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
             }
         }
     }
-    // acc[d][r] = dW[ca = 4 * kg + r][tap (dz, dy, d - 1)][cx = i16]
+    // acc[d][r] = dW[ca = 4 * kg + r][tap (dz, dy, d - 1)][cx = i16].  Park the 16 x 16 x 27 block in LDS in the order of the output
+    // layout, then flush it with lane-consecutive atomics (for a fixed ca the block is one contiguous run of the output row).
     const float inv = a.s2 ? a.s2[1] : 1.f;
-    const long N = 27L * a.Cx;
+    float* sOut = reinterpret_cast<float*>(smem);
+    __syncthreads();
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int tap = ((dz + 1) * 3 + (dy + 1)) * 3 + d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&a.dW[(long)(ca0 + 4 * kg + r) * N + (long)tap * a.Cx + cx0 + i16], acc[d][r] * inv);
+        for (int r = 0; r < 4; ++r) {
+            const int ca = 4 * kg + r;
+            sOut[a.tap_minor ? (ca * 16 + i16) * 27 + tap : (ca * 27 + tap) * 16 + i16] = acc[d][r] * inv;
+        }
+    }
+    __syncthreads();
+    const long N = 27L * a.Cx;
+    for (int e = tid; e < 16 * 432; e += WG_NTHR) {
+        const int ca = e / 432, rem = e - ca * 432;
+        long idx;
+        if (a.tap_minor) idx = ((long)(ca0 + ca) * a.Cx + cx0) * 27 + rem;                       // rem = cx * 27 + tap
+        else idx = (long)(ca0 + ca) * N + (long)(rem >> 4) * a.Cx + cx0 + (rem & 15);            // rem = tap * 16 + cx
+        atomicAdd(&a.dW[idx], sOut[e]);
     }
 }
 
-// dZ fp32 [B, D0, D1, D2, Ca], X fp32 [B, D0, D1, D2, Cx] (+ GroupNorm affine [B, Cx]); dW fp32 [Ca, 27 * Cx] accumulated.
+// dZ fp32 [B, D0, D1, D2, Ca], X fp32 [B, D0, D1, D2, Cx] (+ GroupNorm affine [B, Cx]); dW fp32 [Ca, 27, Cx] or (tap_minor) [Ca, Cx, 27], accumulated.
 // s2 = (s, 1 / s) device scalars of semabs_grad_scale for dZ, or null.  Needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0, Ca % 16 == Cx % 16 == 0.
 extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B,
-                                  int D0, int D1, int D2, int Ca, int Cx, void* stream) {
+                                  int D0, int D1, int D2, int Ca, int Cx, int tap_minor, void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dZ && X && dW, "semabs_wgrad_conv3: null pointer");
     SEMABS_REQUIRE(D0 % WG_T0 == 0 && D1 % WG_T1 == 0 && D2 % WG_T2 == 0 && Ca % 16 == 0 && Cx % 16 == 0,
                    "semabs_wgrad_conv3: needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0 and channel counts that are multiples of 16");
     SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_conv3: gn_scale and gn_shift go together");
     Wgrad16Args a;
-    a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
+    a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx; a.tap_minor = tap_minor;
     const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + WG_T0 * WG_T1 * 16 * WG_T2) * 2 * 2;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }

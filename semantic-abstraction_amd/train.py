@@ -207,14 +207,13 @@ class UNetTrainer:
         cout, nvox, G, st = m["cout"], D0 * D1 * D2, m["groups"], _lib.stream()
         sc, sh, s2 = self._scale(dZ, B, cout)                # dynamic power-of-two scale of dZ, shared by the weight and data gradients
         inv = s2[1:]
-        dW = torch.zeros(cout, 27 * cin, dtype=torch.float32, device=self.dev)
+        dW = self.g[key + "conv.weight"]                     # [cout, cin, 3, 3, 3]: the kernels accumulate in this layout directly
         if D0 % 4 == 0 and D1 % 8 == 0 and D2 % 16 == 0 and self.mfma_wgrad:
             _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
-                      B, D0, D1, D2, cout, cin, st)
+                      B, D0, D1, D2, cout, cin, 1, st)
         else:
             _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
-                      cout, cin, 27, TAPS_CONV3, st)
-        self.g[key + "conv.weight"].add_(dW.view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3))
+                      cout, cin, 27, TAPS_CONV3, 1, st)
         dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
         _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
                   B, D0, D1, D2, cout, cin, 3, 0, 1, st)
@@ -246,10 +245,8 @@ class UNetTrainer:
         B, D0, D1, D2, cin = xin.shape
         cout = m["cout"]
         self._colsum(g.view(-1, cout), self.g[key + "bias"])
-        dW = torch.zeros(cin, 27 * cout, dtype=torch.float32, device=self.dev)
-        _lib.call("semabs_wgrad", _lib.ptr(xin), _lib.ptr(g), None, None, _lib.ptr(dW), B, D0, D1, D2, 2 * D0, 2 * D1, 2 * D2, 2,
-                  cin, cout, 27, TAPS_CONV3, st)
-        self.g[key + "weight"].add_(dW.view(cin, 3, 3, 3, cout).permute(0, 4, 1, 2, 3))
+        _lib.call("semabs_wgrad", _lib.ptr(xin), _lib.ptr(g), None, None, _lib.ptr(self.g[key + "weight"]), B, D0, D1, D2, 2 * D0, 2 * D1, 2 * D2, 2,
+                  cin, cout, 27, TAPS_CONV3, 1, st)                      # [cin, cout, 3, 3, 3] directly
         dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
         sc, sh, s2 = self._scale(g, B, cout)
         _lib.call("semabs_conv3d_gather", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh),
@@ -271,10 +268,9 @@ class UNetTrainer:
                 m = self.mats["final_conv."]
                 B, D0, D1, D2, cin = x.shape
                 cout = m["cout"]
-                dW = torch.zeros(cout, cin, dtype=torch.float32, device=self.dev)
                 R = B * D0 * D1 * D2
-                _lib.call("semabs_wgrad", _lib.ptr(g), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, cout, cin, 1, TAPS_ONE, st)
-                self.g[self.prefix + "final_conv.weight"].add_(dW.view(cout, cin, 1, 1, 1))
+                _lib.call("semabs_wgrad", _lib.ptr(g), _lib.ptr(x), None, None, _lib.ptr(self.g[self.prefix + "final_conv.weight"]), 1, 1, 1, R, 1, 1, R, 1,
+                          cout, cin, 1, TAPS_ONE, 1, st)
                 self._colsum(g.view(R, cout), self.g[self.prefix + "final_conv.bias"])
                 dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
                 sc, sh, s2 = self._scale(g, B, cout)
@@ -368,9 +364,13 @@ class VOOLTrainer:
     def _wgrad_linear(self, dOut, x, grad_w, cols=None):
         R, Co = dOut.shape
         Ci = x.shape[1]
-        dW = torch.zeros(Co, Ci, dtype=torch.float32, device=self.dev)
-        _lib.call("semabs_wgrad", _lib.ptr(dOut), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, TAPS_ONE, _lib.stream())
-        grad_w.add_(dW if cols is None else dW[:, :cols])
+        if cols is None:
+            dW = grad_w                                           # [Co, Ci]: accumulate in place
+        else:
+            dW = torch.zeros(Co, Ci, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_wgrad", _lib.ptr(dOut), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, TAPS_ONE, 1, _lib.stream())
+        if cols is not None:
+            grad_w.add_(dW[:, :cols])
 
     def bce_weight(self, label: torch.Tensor) -> Optional[torch.Tensor]:
         """utils.get_bce_weight (utils.py:727-749); label [B, D, M] fp32 on the device.  None = all ones."""

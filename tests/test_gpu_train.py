@@ -138,7 +138,7 @@ def test_linear_wgrad_colsum_vs_torch():
         dOut = torch.from_numpy(rng.standard_normal((R, Co)).astype(np.float32))
         dd = dOut.to(dev)
         dW = torch.zeros(Co, Ci, device=dev)
-        _lib.call("semabs_wgrad", _lib.ptr(dd), _lib.ptr(xd), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, bytes(3), _lib.stream())
+        _lib.call("semabs_wgrad", _lib.ptr(dd), _lib.ptr(xd), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, bytes(3), 0, _lib.stream())
         assert _rel(dW.cpu().numpy(), (dOut.double().t() @ x.double()).numpy()) < 1e-5
         red = torch.zeros(1, Co, 2, dtype=torch.float64, device=dev)
         _lib.call("semabs_chan_reduce", _lib.ptr(dd), None, None, None, _lib.ptr(red), 1, R, Co, 1, _lib.stream())
