@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default=ARCH)
     ap.add_argument("--precision", default="exact", choices=["exact", "fp16"], help="UNet arithmetic (see DESIGN.md)")
-    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=220, help="tiles per ViT batch: 220 x 197 rows = 170 row panels of 256 -> 510 / 1530 / 2040 "
+                    "output tiles for N = 768 / 2304 / 3072, i.e. 1.99 / 5.98 / 7.97 waves of the 256 CUs (no ragged last wave)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over (2 = +4%% scenes/s, but "
                     "overlapping kernels blur the per-launch HIP-event timing the roofline leg relies on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -14,6 +14,7 @@
 // slabs of each wave's fp32 tile through a private 16 KB LDS slice to emit 16-byte row-contiguous stores; block ids
 // are remapped so the blocks that share an A row-panel run on one XCD (private L2).
 #include "semabs_common.h"
+#include <type_traits>
 
 #define BK 64   // K granularity required by the ABI (both K-tile sizes divide it)
 enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4 };
@@ -255,11 +256,279 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
     return SEMABS_OK;
 }
 
+// =================================================================================================
+// 256 x 256 x 64 "phased" kernel for the large GEMMs (M >= 2048, N % 256 == 0, K >= 128).
+//
+// 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile as four quadrants: rows = 64 from each A half-tile, columns = 32 from
+// each B half-tile, so that every 16 KB half-tile (A0, B0, B1, A1) is read by the whole workgroup in exactly ONE of the four
+// phases of a K tile.  Phase = { ds_read this quadrant's new fragments | issue ONE half-tile of a later K tile as direct-to-LDS
+// DMA | s_waitcnt vmcnt(8) | barrier | 16 x v_mfma_f32_16x16x32_f16 | barrier }.  The two wave rows run one barrier apart, so on
+// every SIMD one wave is in its MFMA block while the other reads LDS / issues DMA (s_setprio favours the MFMA wave).
+// Hazard schedule (phase numbers are global, 4 per K tile t; two LDS buffers by K-tile parity):
+//   reads :  A0(t), B0(t) at 4t      B1(t) at 4t+1      A1(t) at 4t+2      (4t+3 reuses registers only)
+//   stages:  B1(t+1) at 4t           A1(t+1) at 4t+1    A0(t+2) at 4t+2    B0(t+2) at 4t+3
+//   -> every half-tile is re-staged >= 2 phases after its last read (needed because the wave rows are skewed by one barrier) and
+//      is staged >= 4 phases before the phase that precedes its first read, so "vmcnt(8)" (four half-tiles = 8 DMA instructions
+//      per lane still in flight) in every phase retires it in time: 64 KB of operands stay in flight per CU across barriers.
+// Operands are swapped in the MFMA (D = B_frag x A_frag) and the B fragment rows are interleaved (n = (i >> 2) * 8 + jt * 4 + (i & 3))
+// so that a lane ends up with 8 CONSECUTIVE columns of one output row: the epilogue stores straight from registers, 16 B (fp16) or
+// 2 x 16 B (fp32) per lane and a full 64 / 128-byte line per row - no LDS round trip.
+// =================================================================================================
+__device__ __forceinline__ int swzA8(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int swzB8(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
+    constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
+    constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int l15 = lane & 15, kg = lane >> 4;
+
+    int b = blockIdx.x;
+    {
+        const int nb = g.n_blocks, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int tm, tn;
+    {
+        const int per_group = g.group_m * g.n_tiles_n, gid = b / per_group, first_m = gid * g.group_m;
+        const int gsz = (g.n_tiles_m - first_m < g.group_m) ? g.n_tiles_m - first_m : g.group_m;
+        const int r = b - gid * per_group;
+        tm = first_m + r % gsz; tn = r / gsz;
+    }
+    const long m0 = (long)tm * 256;
+    const int n0 = tn * 256;
+
+    // ---- DMA sources: thread -> (row = j * 64 + tid / 8, 16-byte chunk position tid % 8) of every half-tile, j = 0, 1 ----
+    const int srow = tid >> 3, scp = tid & 7;
+    long aoff[2][2];                                        // [half][j] element offsets into A (rows clamped for the M tail)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = j * 64 + srow;
+            long am = m0 + h * 128 + row; if (am > g.M - 1) am = g.M - 1;
+            aoff[h][j] = am * g.lda + ((swzA8(row, scp) - row * 128) >> 1);
+        }
+    int boff[2];                                            // [j]; the half adds 128 * ldb
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = j * 64 + srow;
+        boff[j] = row * g.ldb + ((swzB8(row, scp) - row * 128) >> 1);
+    }
+    const f16* Bblk = g.B + (long)n0 * g.ldb;
+    auto stage_a = [&](int h, int kt) {
+        char* dst = smem + (kt & 1) * BUFSZ + (h ? OFF_A1 : OFF_A0) + wid * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + aoff[h][j] + (long)kt * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    };
+    auto stage_b = [&](int h, int kt) {
+        char* dst = smem + (kt & 1) * BUFSZ + (h ? OFF_B1 : OFF_B0) + wid * 1024;
+        const f16* src = Bblk + (long)h * 128 * g.ldb + (long)kt * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + boff[j]),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets (bytes within a half-tile) ----
+    int offA[2], offB[2][2];
+    {
+        const int rowa = wr * 64 + l15;                     // + it * 16: swizzle term does not depend on it
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) offA[kk] = swzA8(rowa, kk * 4 + kg);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int rowb = wc * 32 + (l15 >> 2) * 8 + jt * 4 + (l15 & 3);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) offB[jt][kk] = swzB8(rowb, kk * 4 + kg);
+        }
+    }
+    f32x4 acc[2][4][2][2];                                  // [A half][row tile][B half][col tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 fa[4][2], fb[2][2][2];                            // fa[row tile][kk] (A0 then A1 reuse it); fb[B half][col tile][kk]
+
+    auto read_a = [&](int h, int par) {
+        const char* base = smem + par * BUFSZ + (h ? OFF_A1 : OFF_A0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const f16x8*>(base + i * 2048 + offA[kk]);
+    };
+    auto read_b = [&](int h, int par) {
+        const char* base = smem + par * BUFSZ + (h ? OFF_B1 : OFF_B0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[h][j][kk] = *reinterpret_cast<const f16x8*>(base + offB[j][kk]);
+    };
+    auto mma = [&](int ha, int hb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[hb][j][kk], fa[i][kk], acc[ha][i][hb][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // between the read / DMA-issue block and the MFMA block of a phase
+#define GEMM8_SYNC(staged)                                                       \
+    do {                                                                         \
+        if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>();                       \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_barrier();                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#define GEMM8_END()                                                              \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+
+    const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1);
+    wait_vmcnt<8>();                                        // A0(0), B0(0) have landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // skew the second wave row by one barrier
+    for (int t = 0; t < nk; ++t) {
+        const int par = t & 1;
+        const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+        // phase 0: quadrant (A0, B0)
+        read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par);
+        if (s1) stage_b(1, t + 1);
+        GEMM8_SYNC(s1);
+        mma(0, 0);
+        GEMM8_END();
+        // phase 1: quadrant (A0, B1)
+        read_b(1, par);
+        if (s1) stage_a(1, t + 1);
+        GEMM8_SYNC(s1);
+        mma(0, 1);
+        GEMM8_END();
+        // phase 2: quadrant (A1, B1)
+        read_a(1, par);
+        if (s2) stage_a(0, t + 2);
+        GEMM8_SYNC(s2);
+        mma(1, 1);
+        GEMM8_END();
+        // phase 3: quadrant (A1, B0) - fragments already in registers
+        if (s2) stage_b(0, t + 2);
+        GEMM8_SYNC(s2);
+        mma(1, 0);
+        GEMM8_END();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();              // balance the skew barrier
+#undef GEMM8_SYNC
+#undef GEMM8_END
+
+    // ---- epilogue straight from registers: lane = row m (l15), 8 consecutive columns n = nb + kg * 8 + (jt * 4 + r) ----
+    // Interior tiles (all 256 rows valid - every tile but the last row panel) take a branch-free path: per-row guards would put
+    // every store in its own basic block, each opening with a conservative s_waitcnt vmcnt(0) that also waits for the previous
+    // STORE (gfx9 counts stores in vmcnt) and serialises the whole tail.
+    if (g.ablate & 8) { if (acc[0][0][0][0][0] != 12345.678f) return; }
+    auto epilogue = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int ncol = n0 + hb * 128 + wc * 32 + kg * 8;
+            float bia[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (g.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
+                bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w; bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
+            }
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha) {
+                // fp32 residual read-modify-write: issue the four rows' loads together (32 VGPRs), then add and store
+                float4 res[4][2];
+                if (EPI == EPI_BIAS_RESID_F32) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long m = m0 + ha * 128 + wr * 64 + i * 16 + l15;
+                        if (CHECK && m >= g.M) { res[i][0] = res[i][1] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + m * g.ldc + ncol);
+                        res[i][0] = p[0]; res[i][1] = p[1];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long m = m0 + ha * 128 + wr * 64 + i * 16 + l15;
+                    if (CHECK && m >= g.M) continue;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[4 + e]; }
+                    if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+                        f16x8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+                            h[e] = (f16)v[e];
+                        }
+                        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(g.C) + m * g.ldc + ncol) = h;
+                    } else if (EPI == EPI_BIAS_RESID_F32) {
+                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
+                        const float4 o0 = res[i][0], o1 = res[i][1];
+                        p[0] = make_float4(o0.x + v[0], o0.y + v[1], o0.z + v[2], o0.w + v[3]);
+                        p[1] = make_float4(o1.x + v[4], o1.y + v[5], o1.z + v[6], o1.w + v[7]);
+                    } else if (EPI == EPI_BIAS_F32) {
+                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
+                        p[0] = make_float4(v[0], v[1], v[2], v[3]); p[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        const long grp = m / g.g_in; const int within = (int)(m - grp * g.g_in);
+                        const long orow = grp * g.g_out + g.g_off + within;
+                        if (g.addend) {
+                            const float4* ap = reinterpret_cast<const float4*>(g.addend + (long)(g.g_off + within) * g.N + ncol);
+                            const float4 a0 = ap[0], a1 = ap[1];
+                            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                        }
+                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + ncol);
+                        p[0] = make_float4(v[0], v[1], v[2], v[3]); p[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+            }
+        }
+    };
+    if (m0 + 256 <= g.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
+}
+
+template <int EPI>
+static int launch_gemm8(GemmArgs g, hipStream_t s) {
+    constexpr int LDS = 2 * 4 * 16384;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    g.n_tiles_n = g.N / 256;
+    const long mt = (g.M + 255) / 256;
+    g.n_tiles_m = (int)mt;
+    g.group_m = g_group_m;
+    g.ablate = g_ablate;
+    if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
+    g.n_blocks = (int)(mt * g.n_tiles_n);
+    hipLaunchKernelGGL((k_gemm8<EPI>), dim3(g.n_blocks), dim3(512), LDS, s, g);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
     const bool big_ok = g.N % 256 == 0;
     const bool big = g_force_cfg >= 2 ? big_ok : (g_force_cfg == 1 ? false : (big_ok && g.M >= 2048));
-    if (big && g_force_cfg == 0) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);      // default: 2 independent blocks / CU
+    if (big && (g_force_cfg == 0 || g_force_cfg == 8) && g.K >= 128) return launch_gemm8<EPI>(g, s);   // default: 256 x 256 x 64 phased kernel
+    if (big && g_force_cfg == 0) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);      // K = 64: one K tile, nothing to pipeline
     if (big && g_force_cfg == 3) return launch_cfg<EPI, 256, 256, 32, 4, 4, 4>(g, s);      // 16 waves, 64 x 64 wave tiles
     if (big && g_force_cfg == 4) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU
     if (big && g_force_cfg == 5) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);
