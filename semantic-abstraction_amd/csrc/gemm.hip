@@ -408,21 +408,21 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     if (wr == 1) __builtin_amdgcn_s_barrier();              // skew the second wave row by one barrier
     for (int t = 0; t < nk; ++t) {
         const int par = t & 1;
-        const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+        const bool s1 = t + 1 < nk && !(g.ablate & 1), s2 = t + 2 < nk && !(g.ablate & 1);
         // phase 0: quadrant (A0, B0)
-        read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par);
+        if (!(g.ablate & 2) || t == 0) { read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par); }
         if (s1) stage_b(1, t + 1);
         GEMM8_SYNC(s1);
         mma(0, 0);
         GEMM8_END();
         // phase 1: quadrant (A0, B1)
-        read_b(1, par);
+        if (!(g.ablate & 2) || t == 0) read_b(1, par);
         if (s1) stage_a(1, t + 1);
         GEMM8_SYNC(s1);
         mma(0, 1);
         GEMM8_END();
         // phase 2: quadrant (A1, B1)
-        read_a(1, par);
+        if (!(g.ablate & 2) || t == 0) read_a(1, par);
         if (s2) stage_a(0, t + 2);
         GEMM8_SYNC(s2);
         mma(1, 1);
