@@ -699,7 +699,11 @@ static int conv32_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
 
 static int conv_launch(const ConvArgs& a, int f32, hipStream_t s) {
     const long Mtot = (long)a.B * a.M0 * a.M1 * a.M2;
-    const int nw = a.Cout >= 64 ? 4 : (a.Cout >= 32 ? 2 : 1);
+    // output channels per wave: 64 / 32 / 16.  Wide slices reuse each gathered input fragment more, but the deep UNet levels have only
+    // a few thousand voxels: there the k-loop (up to 432 steps of dependent L2 weight loads) is latency-bound and the chip is filled
+    // by slicing Cout finer instead (4^3 x 512 channels: 32 -> 128 workgroups).
+    int nw = a.Cout >= 64 ? 4 : (a.Cout >= 32 ? 2 : 1);
+    while (nw > 1 && (long)semabs_cdiv(Mtot, 4 * 32) * (a.Cout / (nw * 16)) < 1024) nw >>= 1;
     dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / (nw * 16)), block(256);
     const bool c16 = a.Cin == 16;
 #define CONV_GO(NW_, F_, C_) hipLaunchKernelGGL((k_conv<NW_, F_, C_>), grid, block, 0, s, a)
