@@ -459,9 +459,8 @@ __global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
             h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
             if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
         }
-        const int sw = ((v >> 3) & 1) * 8;                  // swap the two 16-byte halves of every other group of 8 voxels: the 16 voxels of a
-        *reinterpret_cast<f16x8*>(s_hi + v * 16 + sw) = h0; *reinterpret_cast<f16x8*>(s_hi + v * 16 + (8 ^ sw)) = h1;      // fragment read then cover all 64 banks
-        if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 16 + sw) = l0; *reinterpret_cast<f16x8*>(s_lo + v * 16 + (8 ^ sw)) = l1; }
+        *reinterpret_cast<f16x8*>(s_hi + v * 16) = h0; *reinterpret_cast<f16x8*>(s_hi + v * 16 + 8) = h1;
+        if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 16) = l0; *reinterpret_cast<f16x8*>(s_lo + v * 16 + 8) = l1; }
     }
     // ---- weights: A operand (rows = cout) for all 14 k-steps, in registers ----
     f16x8 wh[14], wl[14];
@@ -482,24 +481,22 @@ __global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
         for (int mi = 0; mi < 2; ++mi) {
             const int row = wid * 8 + pr * 2 + mi;                  // 0..63 = z * 8 + y
             rz[mi] = row >> 3; ry[mi] = row & 7;
-            lbase[mi] = ((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1);                       // halo voxel index of the centre tap
+            lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 16 + half * 8;     // element offset of the centre tap
         }
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
             // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
             const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
-            const int offa = ((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1);
-            const int offb = ((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1);
-            const int voff = tsel ? offb : offa;
+            const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 16;
+            const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 16;
+            const int off = tsel ? offb : offa;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                const int vv = lbase[mi] + voff;
-                const int eoff = vv * 16 + ((half ^ ((vv >> 3) & 1)) << 3);
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + eoff);
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + lbase[mi] + off);
                 acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xh, acc[mi], 0, 0, 0);
                 if (F32) {
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + eoff);
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + lbase[mi] + off);
                     acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], xh, acc[mi], 0, 0, 0);
                     acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xl, acc[mi], 0, 0, 0);
                 }
@@ -559,116 +556,125 @@ static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Level-1 specialisation: Cout = 32, Cin = 16 or 32, 3x3x3 (the 64^3 level of the 128^3 UNet, where the generic gather kernel
-// re-reads every voxel 27 times through L1 / the texture path and runs at < 10 % of either roof).  Same idea as k_conv16_lds: a
-// workgroup (8 waves) owns a 4 x 8 x 16 output brick, stages the 6 x 10 x 18 input halo ONCE (GroupNorm applied, split fp16 hi/lo,
-// [voxel][Cin] with the 16-byte chunk index XOR-ed by (voxel >> 2) & 3 resp. (voxel >> 3) & 1 so the 16 consecutive-x voxels of a
-// fragment read spread over all 64 banks), then runs the 27 taps out of LDS.  A wave keeps 4 rows x 32 output channels in
-// registers (8 accumulators); the weights (55 / 110 KB, too many for registers) stream from L2 once per k-step and wave.
+// LDS-halo brick kernel for the levels below full resolution (3x3x3, Cin = 16 or a multiple of 32, Cout a multiple of 32) - the
+// generic gather kernel re-reads every voxel 27 times through L1 / the texture path and runs at < 10 % of either roof there.  Same
+// idea as k_conv16_lds: a workgroup (8 waves) owns a 4 x 8 x 16 output brick and NB x 16 output channels (blockIdx.z slices Cout),
+// stages the 6 x 10 x 18 input halo of 32 input channels at a time (GroupNorm applied, split fp16 hi/lo, [voxel][channel] with the
+// 16-byte chunk index XOR-ed by (voxel >> 2) & 3, resp. (voxel >> 3) & 1 for Cin = 16, so that the 16 consecutive-x voxels of a
+// fragment read cover all 64 banks) and runs the 27 taps of that channel chunk out of LDS.  A wave keeps 4 rows x NB x 16 output
+// channels in registers; the weights (too many for registers) stream from L2 once per k-step and wave.
 // -------------------------------------------------------------------------------------------------
-template <bool F32, int CIN>
-__global__ __launch_bounds__(512) void k_conv32_lds(ConvArgs a) {
+template <bool F32, int CW, int NB>                        // CW = channels staged at a time (16: Cin == 16, else 32)
+__global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     constexpr int T0 = 4, H0 = T0 + 2, HALO = H0 * C16_H1 * C16_H2, NTHR = 512;
-    constexpr int CPV = CIN / 8;                            // 16-byte chunks per voxel
-    constexpr int NSTEPS = CIN == 32 ? 27 : 14;
+    constexpr int CPV = CW / 8;                             // 16-byte chunks per staged voxel
+    constexpr int NSTEPS = CW == 32 ? 27 : 14;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* s_hi = reinterpret_cast<f16*>(smem);               // [HALO][CIN], chunk-swizzled
-    f16* s_lo = s_hi + HALO * CIN;                          // exact mode only
+    f16* s_hi = reinterpret_cast<f16*>(smem);               // [HALO][CW], chunk-swizzled
+    f16* s_lo = s_hi + HALO * CW;                           // exact mode only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vl = lane & 15, kg = lane >> 4;
     const int b = blockIdx.y;
+    const int cout0 = blockIdx.z * (NB * 16);
     const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1;
     int t = blockIdx.x;
     const int t2 = t % n2; t /= n2;
     const int t1 = t % n1; const int t0 = t / n1;
     const int z0 = t0 * T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
-    auto swz = [](int v, int chunk) { return CIN == 32 ? (chunk ^ ((v >> 2) & 3)) : (chunk ^ ((v >> 3) & 1)); };
-
-    // ---- phase 1: halo -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
+    auto swz = [](int v, int chunk) { return CW == 32 ? (chunk ^ ((v >> 2) & 3)) : (chunk ^ ((v >> 3) & 1)); };
     const bool has_gn = a.gn_scale != nullptr;
-    for (int task = tid; task < HALO * CPV; task += NTHR) {
-        const int v = task / CPV, c = task - v * CPV;
-        const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float val[8];
-        if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) {
-            load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * CIN + c * 8, val);
-            if (has_gn) {
-                const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + b * CIN + c * 8);
-                const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + b * CIN + c * 8);
-                const float4 s0 = ps[0], s1 = ps[1], h0 = pt[0], h1 = pt[1];
-                val[0] = val[0] * s0.x + h0.x; val[1] = val[1] * s0.y + h0.y; val[2] = val[2] * s0.z + h0.z; val[3] = val[3] * s0.w + h0.w;
-                val[4] = val[4] * s1.x + h1.x; val[5] = val[5] * s1.y + h1.y; val[6] = val[6] * s1.z + h1.z; val[7] = val[7] * s1.w + h1.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = 0.f;     // zero padding AFTER the normalisation
-        }
-        f16x8 h, l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { h[j] = (f16)val[j]; if (F32) l[j] = (f16)(val[j] - (float)h[j]); }
-        const int off = v * CIN + swz(v, c) * 8;
-        *reinterpret_cast<f16x8*>(s_hi + off) = h;
-        if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
-    }
-    __syncthreads();
 
-    // ---- phase 2: wave = 4 rows (16 voxels along x each) x 32 output channels ----
-    f32x4 acc[4][2];
+    f32x4 acc[4][NB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[r][1] = acc[r][0]; }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     int rbase[4];                                           // halo voxel index of the centre tap of this lane's voxel in each row
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = wid * 4 + r;                        // 0..31 = z * 8 + y
         rbase[r] = (((row >> 3) + 1) * C16_H1 + ((row & 7) + 1)) * C16_H2 + (vl + 1);
     }
+    const int nchunks = a.Cin / CW;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc) __syncthreads();                            // every wave is done reading the previous channel chunk
+        // ---- halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
+        for (int task = tid; task < HALO * CPV; task += NTHR) {
+            const int v = task / CPV, c = task - v * CPV;
+            const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const int ch = cc * CW + c * 8;
+            float val[8];
+            if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) {
+                load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * a.Cin + ch, val);
+                if (has_gn) {
+                    const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)b * a.Cin + ch);
+                    const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)b * a.Cin + ch);
+                    const float4 s0 = ps[0], s1 = ps[1], h0 = pt[0], h1 = pt[1];
+                    val[0] = val[0] * s0.x + h0.x; val[1] = val[1] * s0.y + h0.y; val[2] = val[2] * s0.z + h0.z; val[3] = val[3] * s0.w + h0.w;
+                    val[4] = val[4] * s1.x + h1.x; val[5] = val[5] * s1.y + h1.y; val[6] = val[6] * s1.z + h1.z; val[7] = val[7] * s1.w + h1.w;
+                }
+            } else {
 #pragma unroll
-    for (int ks = 0; ks < NSTEPS; ++ks) {
-        int voff, chunk;
-        bool tap_ok = true;
-        if (CIN == 32) { chunk = kg; voff = ((ks / 9) - 1) * C16_H1 * C16_H2 + (((ks / 3) % 3) - 1) * C16_H2 + ((ks % 3) - 1); }
-        else {
-            const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;      // tap 27 has zero weights: reuse tap 26's address
-            const int offa = ((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1);
-            const int offb = ((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1);
-            voff = (kg >> 1) ? offb : offa; chunk = kg & 1;
+                for (int j = 0; j < 8; ++j) val[j] = 0.f; // zero padding AFTER the normalisation
+            }
+            f16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { h[j] = (f16)val[j]; if (F32) l[j] = (f16)(val[j] - (float)h[j]); }
+            const int off = v * CW + swz(v, c) * 8;
+            *reinterpret_cast<f16x8*>(s_hi + off) = h;
+            if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
         }
-        (void)tap_ok;
-        f16x8 wh[2], wl[2];
+        __syncthreads();
+        // ---- 27 taps of this channel chunk; wave = 4 rows (16 voxels along x each) x NB x 16 output channels ----
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const long widx = (long)(nb * 16 + vl) * a.Kp + ks * 32 + kg * 8;
-            wh[nb] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
-            if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
-        }
+        for (int ks = 0; ks < NSTEPS; ++ks) {
+            int voff, chunk; long kofs;                     // kofs: k index of this lane's 8 weights = tap * Cin + channel
+            if (CW == 32) {
+                chunk = kg; voff = ((ks / 9) - 1) * C16_H1 * C16_H2 + (((ks / 3) % 3) - 1) * C16_H2 + ((ks % 3) - 1);
+                kofs = (long)ks * a.Cin + cc * 32 + kg * 8;
+            } else {
+                const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;  // tap 27 has zero weights: reuse tap 26's address
+                const int offa = ((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1);
+                const int offb = ((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1);
+                voff = (kg >> 1) ? offb : offa; chunk = kg & 1;
+                kofs = ks * 32 + kg * 8;
+            }
+            f16x8 wh[NB], wl[NB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int v = rbase[r] + voff;
-            const int off = v * CIN + swz(v, chunk) * 8;
-            const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + off);
+            for (int nb = 0; nb < NB; ++nb) {
+                const long widx = (long)(cout0 + nb * 16 + vl) * a.Kp + kofs;
+                wh[nb] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+                if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+            }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh, acc[r][nb], 0, 0, 0);
-            if (F32) {
-                const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + off);
+            for (int r = 0; r < 4; ++r) {
+                const int v = rbase[r] + voff;
+                const int off = v * CW + swz(v, chunk) * 8;
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + off);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh, acc[r][nb], 0, 0, 0);
-                    acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl, acc[r][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh, acc[r][nb], 0, 0, 0);
+                if (F32) {
+                    const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + off);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh, acc[r][nb], 0, 0, 0);
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl, acc[r][nb], 0, 0, 0);
+                    }
                 }
             }
         }
     }
-    // acc[r][nb][e] = out[voxel x0 + vl of row r][cout = nb * 16 + 4 * kg + e]
+    // acc[r][nb][e] = out[voxel x0 + vl of row r][cout = cout0 + nb * 16 + 4 * kg + e]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = wid * 4 + r;
         const long ovox = (((long)b * a.I0 + (z0 + (row >> 3))) * a.I1 + (y0 + (row & 7))) * a.I2 + (x0 + vl);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int co = nb * 16 + 4 * kg;
-            const long oidx = ovox * 32 + co;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int co = cout0 + nb * 16 + 4 * kg;
+            const long oidx = ovox * a.Cout + co;
             float o[4] = {acc[r][nb][0], acc[r][nb][1], acc[r][nb][2], acc[r][nb][3]};
             if (a.bias) { const float4 bv = *reinterpret_cast<const float4*>(a.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
             if (a.resid) {
@@ -682,19 +688,25 @@ __global__ __launch_bounds__(512) void k_conv32_lds(ConvArgs a) {
     }
 }
 
-template <bool F32, int CIN>
-static int conv32_lds_launch_t(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)6 * C16_H1 * C16_H2 * CIN * 2 * (F32 ? 2 : 1);
+template <bool F32, int CW, int NB>
+static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)6 * C16_H1 * C16_H2 * CW * 2 * (F32 ? 2 : 1);
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv32_lds<F32, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    dim3 grid((a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B);
-    hipLaunchKernelGGL((k_conv32_lds<F32, CIN>), grid, dim3(512), lds, s, a);
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    dim3 grid((a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B, a.Cout / (NB * 16));
+    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB>), grid, dim3(512), lds, s, a);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
-static int conv32_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
-    if (a.Cin == 32) return f32 ? conv32_lds_launch_t<true, 32>(a, s) : conv32_lds_launch_t<false, 32>(a, s);
-    return f32 ? conv32_lds_launch_t<true, 16>(a, s) : conv32_lds_launch_t<false, 16>(a, s);
+static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
+    const long bricks = (long)a.B * (a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
+    const bool nb4 = a.Cout % 64 == 0 && bricks * (a.Cout / 64) >= 512;      // wider Cout slices only while the grid still fills the chip
+    if (a.Cin == 16) {
+        if (nb4) return f32 ? conv_brick_launch_t<true, 16, 4>(a, s) : conv_brick_launch_t<false, 16, 4>(a, s);
+        return f32 ? conv_brick_launch_t<true, 16, 2>(a, s) : conv_brick_launch_t<false, 16, 2>(a, s);
+    }
+    if (nb4) return f32 ? conv_brick_launch_t<true, 32, 4>(a, s) : conv_brick_launch_t<false, 32, 4>(a, s);
+    return f32 ? conv_brick_launch_t<true, 32, 2>(a, s) : conv_brick_launch_t<false, 32, 2>(a, s);
 }
 
 static int conv_launch(const ConvArgs& a, int f32, hipStream_t s) {
@@ -749,8 +761,8 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
     SEMABS_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && ksize == 1), "semabs_conv3d: relu must be 0, 1, or 2 (LeakyReLU, ksize 1 only)");
     if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
         return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
-    if (g_conv16_lds && ksize == 3 && Cout == 32 && (Cin == 16 || Cin == 32) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
-        return conv32_lds_launch(a, act_f32, (hipStream_t)stream);
+    if (g_conv16_lds && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
+        return conv_brick_launch(a, act_f32, (hipStream_t)stream);
     return conv_launch(a, act_f32, (hipStream_t)stream);
 }
 
