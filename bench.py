@@ -165,7 +165,7 @@ def main():
                                    f"'ours' saliency config (2448 tile forwards), {VOXEL}^3 voxels, 80000 input points; scene-sharded",
                        "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
-            "roofline": {"kernel": "k_gemm_f16 (all epilogues)", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"kernel": "fp16 GEMM: k_gemm8 (large shapes) + k_gemm_f16 (small), all epilogues", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "launches": gs["launches"],
                          "avg_launch_us": gs["total_ms"] * 1e3 / max(1, gs["launches"]),
                          "gemm_share_of_step": gs["total_ms"] * 1e-3 / (dt * 1.0) if world == 1 else None},

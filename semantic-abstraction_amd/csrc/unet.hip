@@ -564,7 +564,7 @@ static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
 // fragment read cover all 64 banks) and runs the 27 taps of that channel chunk out of LDS.  A wave keeps 4 rows x NB x 16 output
 // channels in registers; the weights (too many for registers) stream from L2 once per k-step and wave.
 // -------------------------------------------------------------------------------------------------
-template <bool F32, int CW, int NB>                        // CW = channels staged at a time (16: Cin == 16, else 32)
+template <bool F32, int CW, int NB, bool ONE>             // CW = channels staged at a time (16: Cin == 16, else 32); ONE: Cin == CW
 __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     constexpr int T0 = 4, H0 = T0 + 2, HALO = H0 * C16_H1 * C16_H2, NTHR = 512;
     constexpr int CPV = CW / 8;                             // 16-byte chunks per staged voxel
@@ -596,7 +596,8 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
         const int row = wid * 4 + r;                        // 0..31 = z * 8 + y
         rbase[r] = (((row >> 3) + 1) * C16_H1 + ((row & 7) + 1)) * C16_H2 + (vl + 1);
     }
-    const int nchunks = a.Cin / CW;
+    const int Cin = ONE ? CW : a.Cin;                       // compile-time when there is a single chunk: immediate weight offsets
+    const int nchunks = ONE ? 1 : Cin / CW;
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                            // every wave is done reading the previous channel chunk
         // ---- halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
@@ -607,10 +608,10 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
             const int ch = cc * CW + c * 8;
             float val[8];
             if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) {
-                load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * a.Cin + ch, val);
+                load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * Cin + ch, val);
                 if (has_gn) {
-                    const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)b * a.Cin + ch);
-                    const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)b * a.Cin + ch);
+                    const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)b * Cin + ch);
+                    const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)b * Cin + ch);
                     const float4 s0 = ps[0], s1 = ps[1], h0 = pt[0], h1 = pt[1];
                     val[0] = val[0] * s0.x + h0.x; val[1] = val[1] * s0.y + h0.y; val[2] = val[2] * s0.z + h0.z; val[3] = val[3] * s0.w + h0.w;
                     val[4] = val[4] * s1.x + h1.x; val[5] = val[5] * s1.y + h1.y; val[6] = val[6] * s1.z + h1.z; val[7] = val[7] * s1.w + h1.w;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
             int voff, chunk; long kofs;                     // kofs: k index of this lane's 8 weights = tap * Cin + channel
             if (CW == 32) {
                 chunk = kg; voff = ((ks / 9) - 1) * C16_H1 * C16_H2 + (((ks / 3) % 3) - 1) * C16_H2 + ((ks % 3) - 1);
-                kofs = (long)ks * a.Cin + cc * 32 + kg * 8;
+                kofs = (long)ks * Cin + cc * 32 + kg * 8;
             } else {
                 const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;  // tap 27 has zero weights: reuse tap 26's address
                 const int offa = ((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1);
@@ -688,13 +689,13 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     }
 }
 
-template <bool F32, int CW, int NB>
+template <bool F32, int CW, int NB, bool ONE>
 static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)6 * C16_H1 * C16_H2 * CW * 2 * (F32 ? 2 : 1);
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     dim3 grid((a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B, a.Cout / (NB * 16));
-    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE>), grid, dim3(512), lds, s, a);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -702,11 +703,15 @@ static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
     const long bricks = (long)a.B * (a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
     const bool nb4 = a.Cout % 64 == 0 && bricks * (a.Cout / 64) >= 512;      // wider Cout slices only while the grid still fills the chip
     if (a.Cin == 16) {
-        if (nb4) return f32 ? conv_brick_launch_t<true, 16, 4>(a, s) : conv_brick_launch_t<false, 16, 4>(a, s);
-        return f32 ? conv_brick_launch_t<true, 16, 2>(a, s) : conv_brick_launch_t<false, 16, 2>(a, s);
+        if (nb4) return f32 ? conv_brick_launch_t<true, 16, 4, true>(a, s) : conv_brick_launch_t<false, 16, 4, true>(a, s);
+        return f32 ? conv_brick_launch_t<true, 16, 2, true>(a, s) : conv_brick_launch_t<false, 16, 2, true>(a, s);
     }
-    if (nb4) return f32 ? conv_brick_launch_t<true, 32, 4>(a, s) : conv_brick_launch_t<false, 32, 4>(a, s);
-    return f32 ? conv_brick_launch_t<true, 32, 2>(a, s) : conv_brick_launch_t<false, 32, 2>(a, s);
+    if (a.Cin == 32) {
+        if (nb4) return f32 ? conv_brick_launch_t<true, 32, 4, true>(a, s) : conv_brick_launch_t<false, 32, 4, true>(a, s);
+        return f32 ? conv_brick_launch_t<true, 32, 2, true>(a, s) : conv_brick_launch_t<false, 32, 2, true>(a, s);
+    }
+    if (nb4) return f32 ? conv_brick_launch_t<true, 32, 4, false>(a, s) : conv_brick_launch_t<false, 32, 4, false>(a, s);
+    return f32 ? conv_brick_launch_t<true, 32, 2, false>(a, s) : conv_brick_launch_t<false, 32, 2, false>(a, s);
 }
 
 static int conv_launch(const ConvArgs& a, int f32, hipStream_t s) {
