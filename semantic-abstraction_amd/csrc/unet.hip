@@ -314,36 +314,59 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     }
     const int cin_steps = CIN16 ? 1 : a.Cin / 32;
     const int nsteps = CIN16 ? (a.ntaps + 1) / 2 : a.ntaps * cin_steps;
-    for (int ks = 0; ks < nsteps; ++ks) {
+    // The k-loop is software-pipelined by hand: the gathered activations and the weight rows of k-step ks + 1 are requested before
+    // the MFMAs of k-step ks.  On the deep levels a wave walks 200-400 k-steps of L2 / HBM weight rows with nothing else to hide their
+    // latency (few workgroups exist there), and the compiler does not pipeline a loop with a run-time trip count by itself.
+    struct Raw { float v[MW][8]; bool ok[MW]; f16x8 wh[NW], wl[NW]; };
+    auto fetch = [&](int ks, Raw& R) {
         int tap, c0;
         if (CIN16) { tap = 2 * ks + (kg >> 1); c0 = 8 * (kg & 1); }
         else { tap = ks / cin_steps; c0 = (ks - tap * cin_steps) * 32 + 8 * kg; }
         const bool tap_ok = tap < a.ntaps;
         const int d0 = tap_ok ? a.td0[tap] : 0, d1 = tap_ok ? a.td1[tap] : 0, d2 = tap_ok ? a.td2[tap] : 0;
-        f16x8 xh[MW], xl[MW];
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             const int i0 = v0[mi] * a.is + d0, i1 = v1[mi] * a.is + d1, i2 = v2[mi] * a.is + d2;
             const bool ok = tap_ok && vok[mi] && i0 >= 0 && i0 < a.I0 && i1 >= 0 && i1 < a.I1 && i2 >= 0 && i2 < a.I2;
+            R.ok[mi] = ok;                                  // outside the volume: zero padding, applied AFTER GroupNorm
+            if (ok) load8<F32>(a.x, ((((long)vb[mi] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cin + c0, R.v[mi]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) R.v[mi][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const long widx = (long)(n0 + ni * 16 + vl) * a.Kp + ks * 32 + kg * 8;
+            R.wh[ni] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+            if (F32) R.wl[ni] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+        }
+    };
+    auto consume = [&](int ks, Raw& R) {
+        int c0 = 0;
+        if (!CIN16) { const int tap = ks / cin_steps; c0 = (ks - tap * cin_steps) * 32 + 8 * kg; }
+        f16x8 xh[MW], xl[MW];
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
             float v[8];
-            if (ok) {
-                const long idx = ((((long)vb[mi] * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cin + c0;
-                load8<F32>(a.x, idx, v);
-                if (has_gn) {
-                    if (CIN16) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = v[j] * gsc[mi][j] + gsh[mi][j];
-                    } else {
-                        const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)vb[mi] * a.Cin + c0);
-                        const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)vb[mi] * a.Cin + c0);
-                        float4 s0 = ps[0], s1 = ps[1], t0 = pt[0], t1 = pt[1];
-                        v[0] = v[0] * s0.x + t0.x; v[1] = v[1] * s0.y + t0.y; v[2] = v[2] * s0.z + t0.z; v[3] = v[3] * s0.w + t0.w;
-                        v[4] = v[4] * s1.x + t1.x; v[5] = v[5] * s1.y + t1.y; v[6] = v[6] * s1.z + t1.z; v[7] = v[7] * s1.w + t1.w;
-                    }
+            for (int j = 0; j < 8; ++j) v[j] = R.v[mi][j];
+            const bool ok = R.ok[mi];
+            if (ok && has_gn) {
+                if (CIN16) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] * gsc[mi][j] + gsh[mi][j];
+                } else {
+                    const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)vb[mi] * a.Cin + c0);
+                    const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)vb[mi] * a.Cin + c0);
+                    float4 s0 = ps[0], s1 = ps[1], t0 = pt[0], t1 = pt[1];
+                    v[0] = v[0] * s0.x + t0.x; v[1] = v[1] * s0.y + t0.y; v[2] = v[2] * s0.z + t0.z; v[3] = v[3] * s0.w + t0.w;
+                    v[4] = v[4] * s1.x + t1.x; v[5] = v[5] * s1.y + t1.y; v[6] = v[6] * s1.z + t1.z; v[7] = v[7] * s1.w + t1.w;
                 }
-            } else {
+            }
+            if (!ok) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;      // zero padding is applied AFTER GroupNorm (pad of the normalised tensor)
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -353,18 +376,25 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         }
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
-            const long widx = (long)(n0 + ni * 16 + vl) * a.Kp + ks * 32 + kg * 8;
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
 #pragma unroll
-            for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.wh[ni], xh[mi], acc[mi][ni], 0, 0, 0);
             if (F32) {
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
 #pragma unroll
                 for (int mi = 0; mi < MW; ++mi) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[mi], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.wl[ni], xh[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.wh[ni], xl[mi], acc[mi][ni], 0, 0, 0);
                 }
             }
+        }
+    };
+    Raw R0, R1;
+    fetch(0, R0);
+    for (int ks = 0; ks < nsteps; ks += 2) {
+        if (ks + 1 < nsteps) fetch(ks + 1, R1);
+        consume(ks, R0);
+        if (ks + 1 < nsteps) {
+            if (ks + 2 < nsteps) fetch(ks + 2, R0);
+            consume(ks + 1, R1);
         }
     }
     // epilogue: acc[mi][ni][r] = out[voxel = lane & 15 of block mi][cout = n0 + ni*16 + 4*(lane >> 4) + r]
@@ -438,29 +468,42 @@ __global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
     const bool has_gn = a.gn_scale != nullptr;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { gsc[c] = has_gn ? a.gn_scale[b * 16 + c] : 1.f; gsh[c] = has_gn ? a.gn_shift[b * 16 + c] : 0.f; }
-    for (int v = tid; v < C16_HALO; v += NTHR) {
+    // All of this thread's halo loads are issued before the first one is consumed: written as "load, convert, store" per voxel the
+    // loop serialises into one HBM round trip per iteration (5 of them per brick) and the whole kernel becomes latency-bound.
+    constexpr int NIT = (C16_HALO + NTHR - 1) / NTHR;
+    float raw[NIT][16];
+    bool inb[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int v = tid + it * NTHR;
         const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
         const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float val[16];
-        if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) {
+        inb[it] = v < C16_HALO && gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
+        if (inb[it]) {
             const long idx = ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * 16;
             float lo8[8], hi8[8];
             load8<F32>(a.x, idx, lo8);
             load8<F32>(a.x, idx + 8, hi8);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { val[c] = lo8[c] * gsc[c] + gsh[c]; val[8 + c] = hi8[c] * gsc[8 + c] + gsh[8 + c]; }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) val[c] = 0.f;
+            for (int c = 0; c < 8; ++c) { raw[it][c] = lo8[c]; raw[it][8 + c] = hi8[c]; }
         }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int v = tid + it * NTHR;
+        float val[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) val[c] = inb[it] ? raw[it][c] * gsc[c] + gsh[c] : 0.f;
         f16x8 h0, h1, l0, l1;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
             if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
         }
-        *reinterpret_cast<f16x8*>(s_hi + v * 16) = h0; *reinterpret_cast<f16x8*>(s_hi + v * 16 + 8) = h1;
-        if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 16) = l0; *reinterpret_cast<f16x8*>(s_lo + v * 16 + 8) = l1; }
+        if (v < C16_HALO) {
+            *reinterpret_cast<f16x8*>(s_hi + v * 16) = h0; *reinterpret_cast<f16x8*>(s_hi + v * 16 + 8) = h1;
+            if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 16) = l0; *reinterpret_cast<f16x8*>(s_lo + v * 16 + 8) = l1; }
+        }
     }
     // ---- weights: A operand (rows = cout) for all 14 k-steps, in registers ----
     f16x8 wh[14], wl[14];
@@ -601,35 +644,53 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                            // every wave is done reading the previous channel chunk
         // ---- halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
-        for (int task = tid; task < HALO * CPV; task += NTHR) {
-            const int v = task / CPV, c = task - v * CPV;
+        // NTHR % CPV == 0, so a thread keeps the same 8-channel chunk c for all of its tasks: one GroupNorm scale / shift fetch, and all
+        // of its halo loads in flight together (see k_conv16_lds: one round trip per iteration otherwise)
+        constexpr int NIT = (HALO * CPV + NTHR - 1) / NTHR;
+        const int c = tid % CPV;
+        const int ch = cc * CW + c * 8;
+        float gs[8], gh[8];
+        if (has_gn) {
+            const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)b * Cin + ch);
+            const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)b * Cin + ch);
+            const float4 s0 = ps[0], s1 = ps[1], h0 = pt[0], h1 = pt[1];
+            gs[0] = s0.x; gs[1] = s0.y; gs[2] = s0.z; gs[3] = s0.w; gs[4] = s1.x; gs[5] = s1.y; gs[6] = s1.z; gs[7] = s1.w;
+            gh[0] = h0.x; gh[1] = h0.y; gh[2] = h0.z; gh[3] = h0.w; gh[4] = h1.x; gh[5] = h1.y; gh[6] = h1.z; gh[7] = h1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gs[j] = 1.f; gh[j] = 0.f; }
+        }
+        float raw[NIT][8];
+        bool inb[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int v = (tid + it * NTHR) / CPV;
             const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const int ch = cc * CW + c * 8;
-            float val[8];
-            if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) {
-                load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * Cin + ch, val);
-                if (has_gn) {
-                    const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)b * Cin + ch);
-                    const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)b * Cin + ch);
-                    const float4 s0 = ps[0], s1 = ps[1], h0 = pt[0], h1 = pt[1];
-                    val[0] = val[0] * s0.x + h0.x; val[1] = val[1] * s0.y + h0.y; val[2] = val[2] * s0.z + h0.z; val[3] = val[3] * s0.w + h0.w;
-                    val[4] = val[4] * s1.x + h1.x; val[5] = val[5] * s1.y + h1.y; val[6] = val[6] * s1.z + h1.z; val[7] = val[7] * s1.w + h1.w;
-                }
-            } else {
+            inb[it] = v < HALO && gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
+            if (inb[it]) load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * Cin + ch, raw[it]);
+        }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) val[j] = 0.f; // zero padding AFTER the normalisation
-            }
+        for (int it = 0; it < NIT; ++it) {
+            const int v = (tid + it * NTHR) / CPV;
             f16x8 h, l;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { h[j] = (f16)val[j]; if (F32) l[j] = (f16)(val[j] - (float)h[j]); }
-            const int off = v * CW + swz(v, c) * 8;
-            *reinterpret_cast<f16x8*>(s_hi + off) = h;
-            if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
+            for (int j = 0; j < 8; ++j) {
+                const float val = inb[it] ? raw[it][j] * gs[j] + gh[j] : 0.f;     // zero padding AFTER the normalisation
+                h[j] = (f16)val; if (F32) l[j] = (f16)(val - (float)h[j]);
+            }
+            if (v < HALO) {
+                const int off = v * CW + swz(v, c) * 8;
+                *reinterpret_cast<f16x8*>(s_hi + off) = h;
+                if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
+            }
         }
         __syncthreads();
         // ---- 27 taps of this channel chunk; wave = 4 rows (16 voxels along x each) x NB x 16 output channels ----
-#pragma unroll
+        // (fully unrolled with immediate offsets when Cin is a compile-time constant; a rolled loop for the multi-chunk variant, whose
+        //  unrolled form makes the scheduler hoist dozens of run-time-addressed weight loads and spill)
+    constexpr int KUNROLL = ONE ? NSTEPS : 1;
+#pragma unroll KUNROLL
         for (int ks = 0; ks < NSTEPS; ++ks) {
             int voff, chunk; long kofs;                     // kofs: k index of this lane's 8 weights = tap * Cin + channel
             if (CW == 32) {
