@@ -223,3 +223,36 @@ def test_vool_training_reduces_loss_and_balanced_weights(golden):
     losses = [float(first["loss"])] + [float(tr.step(batch)["loss"]) for _ in range(7)]
     assert losses[-1] < 0.9 * losses[0], losses
     assert all(np.isfinite(losses))
+
+
+def test_vool_train_step_batch2_pad_relation_vs_oracle():
+    """Two scenes per batch, a "[pad]" description, a 4-level UNet at 16^3 (level 3 = 2^3 voxels): loss / logits tight, gradient norms
+    with the flip-tolerant bound, parameters without gradient untouched - against the autograd oracle."""
+    from oracle import train as ot
+    from semabs_amd.train import VOOLTrainer
+    S, N, M, D, L = 16, 1500, 700, 3, 4
+    rng = np.random.default_rng(21)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    batch = dict(input_xyz_pts=torch.from_numpy((lo + (hi - lo) * rng.random((2, N, 3))).astype(np.float32)),
+                 input_target_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                 input_reference_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                 output_xyz_pts=torch.from_numpy((lo - 0.05 + (hi - lo + 0.1) * rng.random((2, D, M, 3))).astype(np.float32)),
+                 output_label_pts=torch.from_numpy((rng.random((2, D, M)) < 0.25).astype(np.float32)),
+                 spatial_relation_name=[["on", "behind"], ["in", "[pad]"], ["on the left of", "on"]])      # D lists of B names
+    sd = make_semabsvool_state_dict(seed=9, unet_num_levels=L)
+    ref = ot.vool_train_step(sd, batch, SCENE_BOUNDS, (S, S, S), num_levels=L)
+    tr = VOOLTrainer(sd, voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_levels=L)
+    out = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - ref["loss"]) <= 1e-4 * ref["loss"]
+    assert np.abs(out["logits"].cpu().numpy() - ref["logits"].numpy()).max() <= 2e-3
+    for k, g in ref["grads"].items():
+        n = float(g.double().norm())
+        assert abs(float(tr.grads[k].double().norm()) - n) <= 0.1 * n + 1e-12, k
+    assert tr.params["relation_embeddings.in front of"].grad is None            # not in this batch
+    assert tr.params["relation_embeddings.[pad]"].grad is not None              # padding descriptions still contribute (train_vool.py:171)
+    total = float(tr.optimizer_step())
+    assert abs(total - ref["total_norm"]) <= 3e-2 * ref["total_norm"]
+    new = tr.state_dict()
+    for k in ("relation_embeddings.in front of", "completion_net.visual_sampler.mlp.0.weight"):
+        assert torch.equal(new[k].cpu(), sd[k]), k
