@@ -2,6 +2,9 @@
 points, 400 000 query points, UNet f_maps 16 x 6 levels, LAMB lr 1e-3) on one MI355X with synthetic data.
 
     python tools/train_bench.py [--steps 3] [--warmup 1] [--S 128] [--N 80000] [--M 400000] [--D 4]
+Data parallel (config 4 asks for 8 GPUs): python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    --master-port P tools/train_bench.py ...   - one rank per GPU, a different synthetic batch per rank, ONE RCCL all-reduce of the flat
+gradient buffer per step (semabs_amd.dist.allreduce_flat_gradients); rank 0 prints the line (max-over-ranks step time, all-reduce time).
 """
 import argparse
 import json
@@ -43,12 +46,21 @@ if __name__ == "__main__":
     ap.add_argument("--M", type=int, default=400000)
     ap.add_argument("--D", type=int, default=4)
     a = ap.parse_args()
+    import os
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     tr = VOOLTrainer(make_semabsvool_state_dict(seed=3), voxel_shape=(a.S,) * 3, scene_bounds=SCENE_BOUNDS)
-    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(a.S, a.N, a.M, a.D).items()}
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(a.S, a.N, a.M, a.D, seed=rank).items()}
     losses = []
     for _ in range(a.warmup):
         losses.append(float(tr.step(batch)["loss"]))
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     fb = 0.0
     for _ in range(a.steps):
@@ -56,10 +68,17 @@ if __name__ == "__main__":
         out = tr.forward_backward(batch)
         torch.cuda.synchronize()
         fb += time.perf_counter() - t1
-        out["gradnorm"] = tr.optimizer_step()
+        out["gradnorm"] = tr.optimizer_step()                   # all-reduce (world > 1) + clip + LAMB
         losses.append(float(out["loss"]))
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"metric": "vool_train_step_ms", "value": dt * 1e3, "fwd_bwd_ms": fb / a.steps * 1e3, "steps": a.steps,
-                      "config": {"S": a.S, "N": a.N, "M": a.M, "D": a.D}, "losses": [round(x, 5) for x in losses],
-                      "gradnorm": float(out["gradnorm"]), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    dt = torch.tensor([(time.perf_counter() - t0) / a.steps, fb / a.steps], device="cuda")
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        step_ms, fb_ms = float(dt[0]) * 1e3, float(dt[1]) * 1e3
+        print(json.dumps({"metric": "vool_train_step_ms", "value": step_ms, "fwd_bwd_ms": fb_ms, "allreduce_clip_lamb_ms": step_ms - fb_ms,
+                          "steps_per_s_all_ranks": world / (step_ms / 1e3), "n_gpus": world, "steps": a.steps,
+                          "config": {"S": a.S, "N": a.N, "M": a.M, "D": a.D}, "losses": [round(x, 5) for x in losses],
+                          "gradnorm": float(out["gradnorm"]), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    if world > 1:
+        dist.destroy_process_group()
