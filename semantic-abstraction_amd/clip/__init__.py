@@ -218,11 +218,12 @@ class ClipWrapper:
         return cls.relevancy_device(images, w, kwargs["cropping_augmentations"], horizontal_flipping, positive_attn_only).cpu()
 
     @classmethod
-    def make_images(cls, img, augmentations: int, jittered_images=None) -> torch.Tensor:
-        """uint8 [1 + augmentations, H, W, 3] on the GPU: the image then its colour-jittered copies."""
+    def make_images(cls, img, augmentations: int, jittered_images=None, img_dev: torch.Tensor | None = None) -> torch.Tensor:
+        """uint8 [1 + augmentations, H, W, 3] on the GPU: the image then its colour-jittered copies (img_dev: the image already in HBM)."""
         assert type(img) == np.ndarray and img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        cls.check_initialized()
         dev = cls.device
-        base = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+        base = img_dev if img_dev is not None else torch.from_numpy(np.ascontiguousarray(img)).to(dev)
         if augmentations == 0:
             return base[None].contiguous()
         if jittered_images is not None:

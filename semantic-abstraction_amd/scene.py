@@ -78,12 +78,9 @@ class ScenePipeline:
         H, W = scene["depth"].shape
         L = int(w_text.shape[0])
         cfg = saliency_configs[self.config](H)
-        # ---- relevancy --------------------------------------------------------------------------------
-        if images_dev is None:
-            images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images)
-        maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
-                                            cfg["positive_attn_only"])                       # [L, H, W]
-        # ---- geometry ---------------------------------------------------------------------------------
+        # ---- geometry first: its compaction (nonzero) is the one host synchronisation of the scene, and here the GPU queue is still
+        # empty; placed after the relevancy stage (the reference's order) the host would sit behind 120 ms of queued ViT work and the GPU
+        # would then idle while the UNet launches are issued ---------------------------------------------------------------------------
         depth_dev = scene.get("depth_dev")
         if depth_dev is None:
             depth_dev = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(dev)
@@ -96,6 +93,11 @@ class ScenePipeline:
         rng = np.random.default_rng(seed)
         choice = torch.from_numpy(rng.integers(0, n_in, size=self.num_input_pts)).to(dev)     # np.random.choice with replacement
         sel = pix.index_select(0, choice).contiguous()
+        # ---- relevancy --------------------------------------------------------------------------------
+        if images_dev is None:
+            images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images, img_dev=scene.get("rgb_dev"))
+        maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
+                                            cfg["positive_attn_only"])                       # [L, H, W]
         feat = torch.empty(L, self.num_input_pts, dtype=torch.float32, device=dev)
         xyz_sub = torch.empty(self.num_input_pts, 3, dtype=torch.float32, device=dev)
         maps_c = maps.contiguous()
