@@ -451,7 +451,7 @@ template <bool F32, int C16_T0>      // brick depth 8 (fp16: 57.6 KB LDS) or 4 (
 __global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
     constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2, NTHR = 64 * C16_T0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* s_hi = reinterpret_cast<f16*>(smem);                       // [HALO][16]
+    f16* s_hi = reinterpret_cast<f16*>(smem);                       // [2 half-voxels][HALO][8]: the 16 consecutive-x voxels of a fragment read are 256 contiguous bytes
     f16* s_lo = s_hi + C16_HALO * 16;                               // exact mode only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -500,9 +500,9 @@ __global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
             h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
             if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
         }
-        if (v < C16_HALO) {
-            *reinterpret_cast<f16x8*>(s_hi + v * 16) = h0; *reinterpret_cast<f16x8*>(s_hi + v * 16 + 8) = h1;
-            if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 16) = l0; *reinterpret_cast<f16x8*>(s_lo + v * 16 + 8) = l1; }
+        if (v < C16_HALO) {                                          // two planes of 16-byte half-voxels: [channels 0-7][v], [channels 8-15][v]
+            *reinterpret_cast<f16x8*>(s_hi + v * 8) = h0; *reinterpret_cast<f16x8*>(s_hi + C16_HALO * 8 + v * 8) = h1;
+            if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 8) = l0; *reinterpret_cast<f16x8*>(s_lo + C16_HALO * 8 + v * 8) = l1; }
         }
     }
     // ---- weights: A operand (rows = cout) for all 14 k-steps, in registers ----
@@ -524,15 +524,15 @@ __global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
         for (int mi = 0; mi < 2; ++mi) {
             const int row = wid * 8 + pr * 2 + mi;                  // 0..63 = z * 8 + y
             rz[mi] = row >> 3; ry[mi] = row & 7;
-            lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 16 + half * 8;     // element offset of the centre tap
+            lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 8 + half * (C16_HALO * 8);   // element offset of the centre tap
         }
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
             // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
             const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
-            const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 16;
-            const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 16;
+            const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 8;
+            const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 8;
             const int off = tsel ? offb : offa;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
