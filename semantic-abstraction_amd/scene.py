@@ -73,34 +73,60 @@ class ScenePipeline:
     def run(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None, images_dev: torch.Tensor | None = None) -> SceneResult:
         """scene: dict(rgb uint8 [H, W, 3], depth fp32 [H, W], cam_intr, cam_pose [+ rgb_dev / depth_dev]);
         w_text fp32 [L, E] on the GPU (zero-shot weights of the labels)."""
+        return self.run_voxels(self.run_relevancy(scene, w_text, seed, jittered_images, images_dev))
+
+    def run_relevancy(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None, images_dev: torch.Tensor | None = None,
+                      geo_stream: torch.cuda.Stream | None = None, vit_stream: torch.cuda.Stream | None = None) -> dict:
+        """First half of a scene: geometry (point cloud, in-bounds compaction, seeded sub-sample) and the relevancy maps.  With streams
+        given, geometry runs on `geo_stream` (its host sync then waits for nothing else) and the ViT on `vit_stream`; the returned state
+        carries the events `run_voxels` waits for - this is what lets a caller overlap scene i's voxel stage with scene i + 1's ViT."""
         dev, net = self.dev, self.net
-        st = _lib.stream()
         H, W = scene["depth"].shape
-        L = int(w_text.shape[0])
         cfg = saliency_configs[self.config](H)
+        cur = torch.cuda.current_stream()
+        gs, vs = geo_stream or cur, vit_stream or cur
         # ---- geometry first: its compaction (nonzero) is the one host synchronisation of the scene, and here the GPU queue is still
         # empty; placed after the relevancy stage (the reference's order) the host would sit behind 120 ms of queued ViT work and the GPU
         # would then idle while the UNet launches are issued ---------------------------------------------------------------------------
-        depth_dev = scene.get("depth_dev")
-        if depth_dev is None:
-            depth_dev = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(dev)
-        bounds = np.array([net.vg.lower_corner, net.vg.upper_corner], np.float64)
-        xyz, mask = pointcloud_device(depth_dev, scene["cam_intr"], scene["cam_pose"], bounds)
-        pix = torch.nonzero(mask, as_tuple=False).view(-1)                                    # in-bounds pixel ids (compaction)
-        n_in = int(pix.numel())
-        if n_in == 0:
-            raise RuntimeError("no point of the depth image falls inside scene_bounds")
-        rng = np.random.default_rng(seed)
-        choice = torch.from_numpy(rng.integers(0, n_in, size=self.num_input_pts)).to(dev)     # np.random.choice with replacement
-        sel = pix.index_select(0, choice).contiguous()
+        with torch.cuda.stream(gs):
+            depth_dev = scene.get("depth_dev")
+            if depth_dev is None:
+                depth_dev = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(dev)
+            bounds = np.array([net.vg.lower_corner, net.vg.upper_corner], np.float64)
+            xyz, mask = pointcloud_device(depth_dev, scene["cam_intr"], scene["cam_pose"], bounds)
+            pix = torch.nonzero(mask, as_tuple=False).view(-1)                                # in-bounds pixel ids (compaction)
+            n_in = int(pix.numel())
+            if n_in == 0:
+                raise RuntimeError("no point of the depth image falls inside scene_bounds")
+            rng = np.random.default_rng(seed)
+            choice = torch.from_numpy(rng.integers(0, n_in, size=self.num_input_pts)).to(dev)  # np.random.choice with replacement
+            sel = pix.index_select(0, choice).contiguous()
+            geo_done = torch.cuda.Event()
+            geo_done.record(gs)
         # ---- relevancy --------------------------------------------------------------------------------
-        if images_dev is None:
-            images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images, img_dev=scene.get("rgb_dev"))
-        maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
-                                            cfg["positive_attn_only"])                       # [L, H, W]
+        with torch.cuda.stream(vs):
+            if images_dev is None:
+                images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images, img_dev=scene.get("rgb_dev"))
+            maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
+                                                cfg["positive_attn_only"])                   # [L, H, W]
+            maps_c = maps.contiguous()
+            vit_done = torch.cuda.Event()
+            vit_done.record(vs)
+        return dict(scene=scene, L=int(w_text.shape[0]), H=H, W=W, depth_dev=depth_dev, xyz=xyz, sel=sel, n_in=n_in, maps=maps, maps_c=maps_c,
+                    geo_done=geo_done, vit_done=vit_done, streams=(gs, vs))
+
+    def run_voxels(self, state: dict) -> SceneResult:
+        """Second half: per-point features, voxel inference, TSDF and the label volume, on the current stream."""
+        dev, net = self.dev, self.net
+        scene, L, H, W = state["scene"], state["L"], state["H"], state["W"]
+        depth_dev, xyz, sel, maps, maps_c, n_in = state["depth_dev"], state["xyz"], state["sel"], state["maps"], state["maps_c"], state["n_in"]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(state["geo_done"]); cur.wait_event(state["vit_done"])
+        for t in (xyz, sel, maps, maps_c, depth_dev):
+            t.record_stream(cur)                                                              # produced on other streams, read here
+        st = _lib.stream()
         feat = torch.empty(L, self.num_input_pts, dtype=torch.float32, device=dev)
         xyz_sub = torch.empty(self.num_input_pts, 3, dtype=torch.float32, device=dev)
-        maps_c = maps.contiguous()
         _lib.call("semabs_gather_point_features", _lib.ptr(maps_c), _lib.ptr(sel), _lib.ptr(xyz), L, H * W, self.num_input_pts, 50.0,
                   int(self.subtract_mean), _lib.ptr(feat), _lib.ptr(xyz_sub), st)
         # ---- voxel inference ----------------------------------------------------------------------------
