@@ -257,13 +257,26 @@ class ClipWrapper:
         max_ks = max(cls._coeffs.ksize) if cls._coeffs.ksize else 0
         tiles_dev = torch.from_numpy(np.concatenate([table, coef_ids[:, None]], axis=1).astype(np.int32)).to(dev).contiguous()
         passes = 2 if horizontal_flipping else 1
-        rel = [torch.zeros(L, N, g, g, dtype=torch.float32, device=dev) for _ in range(passes)]
         G, Kp = g * g, 3 * eng.p * eng.p
         t_lo, t_hi = (0, N) if tile_range is None else tile_range
+        # relevance of every (pass, tile) forward of this call, in issue order: pass p, tile t at column p * (t_hi - t_lo) + (t - t_lo),
+        # so that one ViT batch may span the flip boundary
+        rel_all = torch.zeros(L, passes * (t_hi - t_lo), g, g, dtype=torch.float32, device=dev)
         # Tile chunks are independent: alternate them over `n_streams` HIP streams (one workspace each) so one chunk's
         # memory-bound kernels and GEMM store tails overlap the other chunk's MFMA phases.
         main = torch.cuda.current_stream()
-        work = [(flip, t0) for flip in range(passes) for t0 in range(t_lo, t_hi, eng.chunk)]
+        # The (pass, tile) forwards form ONE list cut into chunks of `eng.chunk`: a single ragged batch at the very end instead of one
+        # per pass (the chunk size is tuned so that full batches have no ragged last wave of GEMM tiles).
+        n_per = t_hi - t_lo
+        work = []                                       # per chunk: list of (flip, first tile, count)
+        for v0 in range(0, passes * n_per, eng.chunk):
+            v1 = min(passes * n_per, v0 + eng.chunk)
+            segs = []
+            for flip in range(passes):
+                a, b = max(v0, flip * n_per), min(v1, (flip + 1) * n_per)
+                if a < b:
+                    segs.append((flip, t_lo + a - flip * n_per, b - a))
+            work.append(segs)
         ns = max(1, min(cls.n_streams, len(work)))
         if cls._streams is None or len(cls._streams) < ns:
             cls._streams = [torch.cuda.Stream() for _ in range(ns)]
@@ -271,29 +284,38 @@ class ClipWrapper:
         for i in range(ns):
             cls._streams[i].wait_stream(main)
         w_chunks = [w_text[l0:l0 + eng.max_labels].contiguous() for l0 in range(0, L, eng.max_labels)]
-        for i, (flip, t0) in enumerate(work):
+        for i, segs in enumerate(work):
             slot = i % ns
             with torch.cuda.stream(cls._streams[slot]):
                 eng.slot = slot
-                key = (slot, min(N, eng.chunk) * G, Kp)
+                key = (slot, min(passes * N, eng.chunk) * G, Kp)
                 if key not in cls._patches:
                     cls._patches = {k: v for k, v in cls._patches.items() if k[0] != slot}
                     cls._patches[key] = torch.empty(key[1], Kp, dtype=torch.float16, device=dev)
                 patches = cls._patches[key]
                 st = _lib.stream()
-                m = min(eng.chunk, t_hi - t0)
-                _lib.call("semabs_tile_patches", _lib.ptr(images), n_img, H, W, tiles_dev[t0:].data_ptr(), m, _lib.ptr(xmin_d),
-                          _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(cls._lut), _lib.ptr(patches), eng.p, flip, max_ks, st)
+                m = 0
+                for flip, t0, cnt in segs:
+                    _lib.call("semabs_tile_patches", _lib.ptr(images), n_img, H, W, tiles_dev[t0:].data_ptr(), cnt, _lib.ptr(xmin_d),
+                              _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(cls._lut), patches[m * G:].data_ptr(), eng.p, flip, max_ks, st)
+                    m += cnt
                 eng.embed(patches, m); eng.trunk(m); eng.head(m)
+                col0 = i * eng.chunk                            # the chunk's tiles are consecutive columns of rel_all
                 for li, wl in enumerate(w_chunks):
                     l0 = li * eng.max_labels
-                    eng.rollout(m, wl, positive_attn_only, rel[flip][l0:l0 + eng.max_labels], t0)
+                    eng.rollout(m, wl, positive_attn_only, rel_all[l0:l0 + eng.max_labels], col0)
         for i in range(ns):
             main.wait_stream(cls._streams[i])
         eng.slot = 0
-        for t in (images, tiles_dev, w_text, *rel, *w_chunks):
+        for t in (images, tiles_dev, w_text, rel_all, *w_chunks):
             for i in range(ns):
                 t.record_stream(cls._streams[i])
+        if tile_range is None:
+            rel = [rel_all[:, p * N:(p + 1) * N].contiguous() if passes > 1 else rel_all for p in range(passes)]
+        else:                                           # a shard: the other tiles' relevances stay zero (summed across ranks by the caller)
+            rel = [torch.zeros(L, N, g, g, dtype=torch.float32, device=dev) for _ in range(passes)]
+            for p in range(passes):
+                rel[p][:, t_lo:t_hi] = rel_all[:, p * n_per:(p + 1) * n_per]
         if return_tiles:
             return rel, table, scales
         return cls.aggregate_device(rel, scales, n_img, H, W)
