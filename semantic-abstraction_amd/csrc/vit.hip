@@ -101,7 +101,7 @@ extern "C" int semabs_embed_finish(float* x, const float* cls, const float* pos,
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int NKB, bool CAUSAL>   // number of 32-key blocks: TP = 32 * NKB
-__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4)) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int H,
+__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int H,
                                                    int ld, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = 32 * NKB;
@@ -141,54 +141,53 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4)) void k_attention(const f1
         f16x8 fq[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
-        f32x16 s[NKB];
+        // Two passes over the key blocks instead of keeping all NKB score blocks in registers (112 VGPRs at T = 197): pass 1 only finds the
+        // row maximum, pass 2 recomputes each score block (4 MFMAs - the matrix pipe is 13 % busy in this kernel), exponentiates, and feeds
+        // the un-normalised probabilities straight into P.V; O is scaled by 1 / sum at the end.  ~100 VGPRs -> two workgroups per CU.
+        auto scores = [&](int kb, f32x16& sc) {
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f16x8 fk = *reinterpret_cast<const f16x8*>(sK + kb * 4096 + koff[ks]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fq[ks], s[kb], 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fq[ks], sc, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every block's K reads (VGPR blow-up)
-        }
-        // s[kb][r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*hi, query = q)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            // only a block that reaches past T (or, for the causal text tower, past the query) needs masking
+            // sc[r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*hi, query = q); only a block that reaches past T (or, causal, past the query) needs masking
             if (CAUSAL || kb * 32 + 31 >= T) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    bool dead = key >= T || (CAUSAL && key > q);
-                    s[kb][r] = dead ? -INFINITY : s[kb][r];
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool dead = key >= T || (CAUSAL && key > q);
+                    sc[r] = dead ? -INFINITY : sc[r];
                 }
             }
+        };
+        float mx = -INFINITY;
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 sc;
+            scores(kb, sc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[kb][r] = __expf(s[kb][r] - mx); sum += s[kb][r]; }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
         f32x16 o[2];
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 sc;
+            scores(kb, sc);
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+            for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - mx); sum += sc[r]; }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 f16x8 p;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) p[j] = (f16)(s[kb][hf * 8 + j] * inv);
+                for (int j = 0; j < 8; ++j) p[j] = (f16)sc[hf * 8 + j];
                 const int kbase = kb * 32 + hf * 16 + 4 * hi;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
@@ -200,8 +199,14 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4)) void k_attention(const f1
                     fv[4] = v1[0]; fv[5] = v1[1]; fv[6] = v1[2]; fv[7] = v1[3];
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv, p, o[db], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= inv;
         // o[db][r] = O[query q][d = db*32 + (r&3) + 8*(r>>2) + 4*hi]
         if (q < T) {
             f16* orow = out + ((long)seq * T + q) * D + h * 64;
