@@ -499,7 +499,7 @@ extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, lo
 // =================================================================================================
 // Rollout (closed form of clip_gradcam.py:90-131 for the only contributing block):
 //   rel[l, i, j-1] = scale[l, i] / H * sum_h clampmin0?(A[i, h, j] * (V[i, j, h, :] . u[l, i, h, :])),  j = 1..T-1
-// One workgroup per tile i; u rows for all labels staged in LDS; thread = token j.
+// One workgroup per (tile i, group of 4 labels); that group's u rows staged in LDS; thread = token j.
 //   probs fp32 [n, H, T]; kv fp32 [n, T, 2D] (V at column offset D); u fp32 [L, n, D]; out fp32 [L, n_total, T-1]
 //   written at tile offset `tile0` (so chunks of tiles fill one [L, N, g, g] array).
 // =================================================================================================
@@ -508,52 +508,49 @@ __global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs
                                                  float* __restrict__ rel, int n, int T, int H, int L, int positive_only,
                                                  long n_total, long tile0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* su = reinterpret_cast<float*>(smem);            // [L][D]
+    float* su = reinterpret_cast<float*>(smem);            // [4][D]: this workgroup's group of 4 labels
     const int D = H * 64;
     const int i = blockIdx.x;
-    for (int c = threadIdx.x; c < L * D; c += blockDim.x) su[c] = u[((long)(c / D) * n + i) * D + (c % D)];
+    const int l0 = blockIdx.y * 4;                         // (tile, label group) per workgroup: n tiles alone would not even fill the CUs
+    const int nl = (L - l0 < 4) ? L - l0 : 4;
+    for (int c = threadIdx.x; c < nl * D; c += blockDim.x) su[c] = u[((long)(l0 + c / D) * n + i) * D + (c % D)];
+    for (int c = nl * D + threadIdx.x; c < 4 * D; c += blockDim.x) su[c] = 0.f;
     __syncthreads();
     for (int j = 1 + threadIdx.x; j < T; j += blockDim.x) {
         const float* vrow = kv + ((long)i * T + j) * 2 * D + D;
-        for (int l0 = 0; l0 < L; l0 += 4) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int h = 0; h < H; ++h) {
-                float dot[4] = {0.f, 0.f, 0.f, 0.f};
-                const float4* v4 = reinterpret_cast<const float4*>(vrow + h * 64);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < H; ++h) {
+            float dot[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4* v4 = reinterpret_cast<const float4*>(vrow + h * 64);
 #pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    float4 vv = v4[d];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (l0 + k < L) {
-                            const float4 uu = *reinterpret_cast<const float4*>(su + (l0 + k) * D + h * 64 + d * 4);
-                            dot[k] += vv.x * uu.x + vv.y * uu.y + vv.z * uu.z + vv.w * uu.w;
-                        }
-                    }
-                }
-                const float a = probs[((long)i * H + h) * T + j];
+            for (int d = 0; d < 16; ++d) {
+                float4 vv = v4[d];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float c = a * dot[k];
-                    acc[k] += positive_only ? fmaxf(c, 0.f) : c;
+                    const float4 uu = *reinterpret_cast<const float4*>(su + k * D + h * 64 + d * 4);
+                    dot[k] += vv.x * uu.x + vv.y * uu.y + vv.z * uu.z + vv.w * uu.w;
                 }
             }
+            const float a = probs[((long)i * H + h) * T + j];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (l0 + k < L)
-                    rel[((long)(l0 + k) * n_total + tile0 + i) * (T - 1) + (j - 1)] = acc[k] / H * scale[(long)(l0 + k) * n + i];
+            for (int k = 0; k < 4; ++k) {
+                float c = a * dot[k];
+                acc[k] += positive_only ? fmaxf(c, 0.f) : c;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nl)
+                rel[((long)(l0 + k) * n_total + tile0 + i) * (T - 1) + (j - 1)] = acc[k] / H * scale[(long)(l0 + k) * n + i];
     }
 }
 extern "C" int semabs_rollout(const float* probs, const float* kv, const float* u, const float* scale, float* rel, int n,
                               int T, int H, int L, int positive_only, long n_total, long tile0, void* stream) {
     if (n == 0 || L == 0) return SEMABS_OK;
     SEMABS_REQUIRE(probs && kv && u && scale && rel && n > 0 && T > 1 && H > 0, "semabs_rollout: bad args");
-    size_t lds = (size_t)L * H * 64 * 4;
-    SEMABS_REQUIRE(lds <= 160 * 1024, "semabs_rollout: too many labels per call (L * D * 4 bytes must fit LDS)");
-    static size_t set_for = 0;
-    if (lds > set_for) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_for = lds; }
-    hipLaunchKernelGGL(k_rollout, dim3(n), dim3(256), lds, (hipStream_t)stream, probs, kv, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
+    size_t lds = (size_t)4 * H * 64 * 4;
+    SEMABS_REQUIRE(lds <= 64 * 1024, "semabs_rollout: H * 64 * 16 bytes must fit the default LDS allocation");
+    hipLaunchKernelGGL(k_rollout, dim3(n, (L + 3) / 4), dim3(256), lds, (hipStream_t)stream, probs, kv, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
