@@ -145,8 +145,9 @@ class SemAbs3D:
             taps["point_feat"] = pf
         return unet.forward_cl(vol, taps=taps)
 
-    def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False) -> torch.Tensor:
-        """features [P, S, S, S, C]; query fp32 [P, M, 3] (or [M, 3] with shared=True) -> logits fp32 [P, M]."""
+    def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False, lattice=None) -> torch.Tensor:
+        """features [P, S, S, S, C]; query fp32 [P, M, 3] (or [M, 3] with shared=True) -> logits fp32 [P, M].
+        lattice=(G0, G1, G2): the M queries are a dense C-order lattice (e.g. `VirtualGrid.get_grid_points`): same results, faster walk."""
         dev = _lib.require_gpu()
         P = int(features_cl.shape[0])
         M = int(query.shape[-2])
@@ -156,7 +157,7 @@ class SemAbs3D:
         query = query.contiguous()
         _lib.call("semabs_decoder", _lib.ptr(features_cl), _lib.ptr(query), _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales),
                   _lib.iarr(self.vg.grid_shape), fp(d["w1"]), fp(d["b1"]), fp(d["w2"]), fp(d["b2"]), int(self.concat_xyz), P, M,
-                  0 if shared else M * 3, self.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
+                  0 if shared else M * 3, self.vol_feature_extractor.f32, _lib.ptr(out), None if lattice is None else _lib.iarr(lattice), _lib.stream())
         return out
 
     # ---- reference surface ---------------------------------------------------------------------------

@@ -131,7 +131,7 @@ class ScenePipeline:
                   int(self.subtract_mean), _lib.ptr(feat), _lib.ptr(xyz_sub), st)
         # ---- voxel inference ----------------------------------------------------------------------------
         features = net.feature_volume(xyz_sub, feat)
-        logits = net.decode(features, self.grid_points, shared=True)                          # [L, S^3]
+        logits = net.decode(features, self.grid_points, shared=True, lattice=net.vg.grid_shape)   # [L, S^3], queries = all voxel centres
         net.features_cl = features
         tsdf = labels = None
         if self.with_tsdf:

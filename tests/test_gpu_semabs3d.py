@@ -220,3 +220,21 @@ def test_unet128_vs_golden(golden, precision, tol):
     err = np.abs(y.reshape(-1)[g["si"]] - g["y_s"]).max()
     print(f"{precision}: unet128 Linf {err:.3e} (max|ref| {np.abs(g['y_s']).max():.3f})")
     assert err <= tol * np.abs(g["y_s"]).max()
+
+
+def test_decoder_lattice_walk_is_bit_identical():
+    """The lattice hint only changes the order in which the kernel visits the queries: same bits, same output layout."""
+    S, P = 32, 3
+    m = _model(S, "exact")
+    rng = np.random.default_rng(4)
+    feats = _cl(torch.from_numpy(rng.standard_normal((P, 16, S, S, S)).astype(np.float32))).cuda()
+    lo, hi = np.asarray(SCENE_BOUNDS[0], np.float32), np.asarray(SCENE_BOUNDS[1], np.float32)
+    g = np.stack(np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing="ij"), axis=-1).astype(np.float32)
+    pts = torch.from_numpy((g * ((hi - lo) / np.float32(S - 1)) + lo).reshape(-1, 3).astype(np.float32)).cuda()
+    plain = m.decode(feats, pts, shared=True)
+    fast = m.decode(feats, pts, shared=True, lattice=(S, S, S))
+    assert torch.equal(plain, fast)
+    per_label = pts[None].repeat(P, 1, 1).contiguous()
+    assert torch.equal(m.decode(feats, per_label, lattice=(S, S, S)), plain)
+    # a lattice whose dims do not tile (32, 2, 4) silently takes the plain walk
+    assert torch.equal(m.decode(feats, pts[: 30 * 32 * 32], shared=True, lattice=(30, 32, 32)), plain[:, : 30 * 32 * 32])
