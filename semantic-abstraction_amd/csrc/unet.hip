@@ -852,6 +852,154 @@ extern "C" int semabs_conv3d_gather(const void* x, const void* w_hi, const void*
     return conv_launch(a, act_f32, (hipStream_t)stream);
 }
 
+// -------------------------------------------------------------------------------------------------
+// ConvTranspose3d in TWO launches (output parity along axis 0) for volumes that tile into 4 x 8 x 16 input bricks (the three upper levels).  The eight parity-class
+// launches of the gather kernel read the input once per tap (27 x the tensor through L2) and write every output line in 64-byte halves;
+// here a workgroup (8 waves) stages the 5 x 9 x 17 input halo of 32 channels at a time in LDS (split fp16, bank-swizzled like
+// k_conv_brick) and produces four classes of its 8 x 16 x 32 output brick: wave = 4 input rows, 4 classes x 16 output channels in
+// registers (16 accumulators), weights streamed from L2.  y = skip + convT(x) + bias as before; Cout sliced by 16 over grid z.
+// -------------------------------------------------------------------------------------------------
+struct ConvTArgs {
+    const void* x; void* y; const f16* w_hi; const f16* w_lo; const float* bias; const void* skip;
+    long class_off[8];
+    int B, D0, D1, D2, Cin, Cout;
+};
+template <bool F32, int P0>                              // P0 = output parity along axis 0: two launches of four classes each (acc registers)
+__global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
+    constexpr int T0 = 4, T1 = 8, T2 = 16, H0 = T0 + 1, H1 = T1 + 1, H2 = T2 + 1, HALO = H0 * H1 * H2, NTHR = 512, CW = 32, CPV = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* s_hi = reinterpret_cast<f16*>(smem);               // [HALO][32], chunk-swizzled
+    f16* s_lo = s_hi + HALO * CW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vl = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y, cout0 = blockIdx.z * 16;
+    const int n2 = a.D2 / T2, n1 = a.D1 / T1;
+    int t = blockIdx.x;
+    const int t2 = t % n2; t /= n2;
+    const int t1 = t % n1; const int t0 = t / n1;
+    const int z0 = t0 * T0, y0 = t1 * T1, x0 = t2 * T2;
+    auto swz = [](int v, int chunk) { return chunk ^ ((v >> 2) & 3); };
+
+    f32x4 acc[4][4];                                        // [input row of this wave][parity class (p1, p2)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int rbase[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wid * 4 + r;                        // z * 8 + y of the input brick
+        rbase[r] = ((row >> 3) * H1 + (row & 7)) * H2 + vl;
+    }
+    const int nchunks = a.Cin / CW;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc) __syncthreads();
+        constexpr int NIT = (HALO * CPV + NTHR - 1) / NTHR;
+        const int c = tid % CPV;
+        const int ch = cc * CW + c * 8;
+        float raw[NIT][8];
+        bool inb[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int v = (tid + it * NTHR) / CPV;
+            const int hx = v % H2, hy = (v / H2) % H1, hz = v / (H2 * H1);
+            const int gz = z0 + hz, gy = y0 + hy, gx = x0 + hx;                 // halo on the high side only (taps reach m and m + 1)
+            inb[it] = v < HALO && gz < a.D0 && gy < a.D1 && gx < a.D2;
+            if (inb[it]) load8<F32>(a.x, ((((long)b * a.D0 + gz) * a.D1 + gy) * a.D2 + gx) * a.Cin + ch, raw[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int v = (tid + it * NTHR) / CPV;
+            f16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float val = inb[it] ? raw[it][j] : 0.f;
+                h[j] = (f16)val; if (F32) l[j] = (f16)(val - (float)h[j]);
+            }
+            if (v < HALO) {
+                const int off = v * CW + swz(v, c) * 8;
+                *reinterpret_cast<f16x8*>(s_hi + off) = h;
+                if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            constexpr int p0 = P0;
+            const int cls = P0 * 4 + c4, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
+            const int ntaps = (p0 + 1) * (p1 + 1) * (p2 + 1);
+            const long kp = (long)ntaps * a.Cin;                                // row stride of this class's weight matrix
+            const f16* wh_c = a.w_hi + a.class_off[cls];
+            const f16* wl_c = F32 ? a.w_lo + a.class_off[cls] : nullptr;
+            int tt = 0;
+#pragma unroll
+            for (int q0 = 0; q0 <= p0; ++q0)
+#pragma unroll
+                for (int q1 = 0; q1 <= p1; ++q1)
+#pragma unroll
+                    for (int q2 = 0; q2 <= p2; ++q2, ++tt) {
+                        const int d0 = p0 ? (q0 == 0 ? 1 : 0) : 0, d1 = p1 ? (q1 == 0 ? 1 : 0) : 0, d2 = p2 ? (q2 == 0 ? 1 : 0) : 0;
+                        const int voff = (d0 * H1 + d1) * H2 + d2;
+                        const long widx = (long)(cout0 + vl) * kp + (long)tt * a.Cin + cc * 32 + kg * 8;
+                        const f16x8 wh = *reinterpret_cast<const f16x8*>(wh_c + widx);
+                        f16x8 wl;
+                        if (F32) wl = *reinterpret_cast<const f16x8*>(wl_c + widx);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int v = rbase[r] + voff;
+                            const int off = v * CW + swz(v, kg) * 8;
+                            const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + off);
+                            acc[r][c4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[r][c4], 0, 0, 0);
+                            if (F32) {
+                                const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + off);
+                                acc[r][c4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[r][c4], 0, 0, 0);
+                                acc[r][c4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[r][c4], 0, 0, 0);
+                            }
+                        }
+                        if (tt & 1) __builtin_amdgcn_sched_barrier(0);          // keep the scheduler from hoisting all 9 / 18 taps' weight rows (spills)
+                    }
+        }
+    }
+    // acc[r][c4][e] = convT output at (2 z + P0, 2 y + p1, 2 (x0 + vl) + p2), channel cout0 + 4 kg + e
+    const int O1 = 2 * a.D1, O2 = 2 * a.D2;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cout0 + 4 * kg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wid * 4 + r;
+        const int z = z0 + (row >> 3), y = y0 + (row & 7), x = x0 + vl;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
+            const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
+            const long oidx = ovox * a.Cout + cout0 + 4 * kg;
+            float o[4] = {acc[r][c4][0] + bv.x, acc[r][c4][1] + bv.y, acc[r][c4][2] + bv.z, acc[r][c4][3] + bv.w};
+            if (a.skip) {
+                if (F32) { const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.skip) + oidx); o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
+                else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); o[0] += (float)q[0]; o[1] += (float)q[1]; o[2] += (float)q[2]; o[3] += (float)q[3]; }
+            }
+            if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
+            else { f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h; }
+        }
+    }
+}
+template <bool F32>
+static int convT_brick_launch(const ConvTArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)5 * 9 * 17 * 32 * 2 * (F32 ? 2 : 1);
+    static bool set = false;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convT_brick<F32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convT_brick<F32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set = true;
+    }
+    dim3 grid((a.D0 / 4) * (a.D1 / 8) * (a.D2 / 16), a.B, a.Cout / 16);
+    hipLaunchKernelGGL((k_convT_brick<F32, 0>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_convT_brick<F32, 1>), grid, dim3(512), lds, s, a);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // ConvTranspose3d k3 s2 p1 output_padding 1 (+bias) fused with the sum-joining skip: y = skip + convT(x) + bias.
 // x [B, D0, D1, D2, Cin] -> y [B, 2 D0, 2 D1, 2 D2, Cout].  One launch per output parity class (8 of them): output
 // o = 2 m + p takes input m (kernel index 1) when p = 0, inputs m + 1 (k = 0) and m (k = 2) when p = 1.
@@ -864,6 +1012,13 @@ extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const voi
     int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
     if (rc) return rc;
     SEMABS_REQUIRE(class_off && Cin % 32 == 0, "semabs_convtranspose3d: Cin must be a multiple of 32");
+    if (g_conv16_lds && D0 % 4 == 0 && D1 % 8 == 0 && D2 % 16 == 0) {           // one launch, input read once, all eight classes per brick
+        ConvTArgs ta;
+        ta.x = x; ta.y = y; ta.w_hi = (const f16*)w_hi; ta.w_lo = (const f16*)w_lo; ta.bias = bias; ta.skip = skip;
+        for (int c = 0; c < 8; ++c) ta.class_off[c] = class_off[c];
+        ta.B = B; ta.D0 = D0; ta.D1 = D1; ta.D2 = D2; ta.Cin = Cin; ta.Cout = Cout;
+        return act_f32 ? convT_brick_launch<true>(ta, (hipStream_t)stream) : convT_brick_launch<false>(ta, (hipStream_t)stream);
+    }
     for (int cls = 0; cls < 8; ++cls) {
         const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
         ConvArgs a;

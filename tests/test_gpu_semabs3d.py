@@ -238,3 +238,30 @@ def test_decoder_lattice_walk_is_bit_identical():
     assert torch.equal(m.decode(feats, per_label, lattice=(S, S, S)), plain)
     # a lattice whose dims do not tile (32, 2, 4) silently takes the plain walk
     assert torch.equal(m.decode(feats, pts[: 30 * 32 * 32], shared=True, lattice=(30, 32, 32)), plain[:, : 30 * 32 * 32])
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
+@pytest.mark.parametrize("cin,cout,dims,B", [(32, 16, (4, 8, 16), 2), (64, 32, (8, 8, 16), 1), (128, 64, (4, 16, 32), 1)])
+def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B):
+    """Input dims that tile into 4 x 8 x 16 bricks take the two-launch LDS-halo kernel: against torch and against the parity-class gather
+    launches (same arithmetic, different summation order across taps)."""
+    from semabs_amd import _lib
+    from semabs_amd.unet3d import _ConvT
+    rng = np.random.default_rng(cin + 1)
+    D0, D1, D2 = dims
+    x = torch.from_numpy(rng.standard_normal((B, cin, D0, D1, D2)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cin, cout, 3, 3, 3)) / np.sqrt(27 * cin / 8)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    skip = torch.from_numpy(rng.standard_normal((B, cout, 2 * D0, 2 * D1, 2 * D2)).astype(np.float32))
+    u = _unet(precision)
+    xd, sd_ = _cl(x).cuda().to(u.act_dtype), _cl(skip).cuda().to(u.act_dtype)
+    ref = sd_.float().cpu().permute(0, 4, 1, 2, 3) + F.conv_transpose3d(xd.float().cpu().permute(0, 4, 1, 2, 3), w, b, stride=2, padding=1,
+                                                                         output_padding=1)
+    ct = _ConvT(w, b, u.dev)
+    y_brick = u._up(xd, sd_, ct).float().cpu().permute(0, 4, 1, 2, 3)
+    _lib.call("semabs_conv_set_config", 0)
+    y_gather = u._up(xd, sd_, ct).float().cpu().permute(0, 4, 1, 2, 3)
+    _lib.call("semabs_conv_set_config", 1)
+    scale = max(1.0, ref.abs().max().item())
+    assert (y_brick - ref).abs().max().item() <= tol * scale
+    assert (y_brick - y_gather).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale
