@@ -447,152 +447,207 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #define C16_H1 (C16_T1 + 2)
 #define C16_H2 (C16_T2 + 2)
 
-template <bool F32, int C16_T0>      // brick depth 8 (fp16: 57.6 KB LDS) or 4 (exact: 69 KB) so that two workgroups share a CU
-__global__ __launch_bounds__(64 * C16_T0) void k_conv16_lds(ConvArgs a) {
-    constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2, NTHR = 64 * C16_T0;
+template <bool F32, int C16_T0>      // brick depth 8 (fp16: 2 x 57.6 KB LDS) or 4 (exact: 2 x 69 KB): one 8-wave workgroup per CU, two halo buffers
+__global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
+    constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2;
+    constexpr int NPROD = 256;                                      // producer threads (waves 4-7)
+    constexpr int NIT = (C16_HALO + NPROD - 1) / NPROD;
+    constexpr int BUF_EL = C16_HALO * 16 * (F32 ? 2 : 1);           // fp16 elements per halo buffer: hi planes, then lo planes (exact mode)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* s_hi = reinterpret_cast<f16*>(smem);                       // [2 half-voxels][HALO][8]: the 16 consecutive-x voxels of a fragment read are 256 contiguous bytes
-    f16* s_lo = s_hi + C16_HALO * 16;                               // exact mode only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vl = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.y;
-    const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1;
-    int t = blockIdx.x;
-    const int t2 = t % n2; t /= n2;
-    const int t1 = t % n1; const int t0 = t / n1;
-    const int z0 = t0 * C16_T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
-
-    // ---- phase 1: halo -> GroupNorm affine -> fp16 hi/lo -> LDS (zero padding AFTER the normalisation) ----
-    float gsc[16], gsh[16];
+    const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1, n0 = a.I0 / C16_T0;
+    const int per_vol = n0 * n1 * n2, total = a.B * per_vol;
     const bool has_gn = a.gn_scale != nullptr;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) { gsc[c] = has_gn ? a.gn_scale[b * 16 + c] : 1.f; gsh[c] = has_gn ? a.gn_shift[b * 16 + c] : 0.f; }
-    // All of this thread's halo loads are issued before the first one is consumed: written as "load, convert, store" per voxel the
-    // loop serialises into one HBM round trip per iteration (5 of them per brick) and the whole kernel becomes latency-bound.
-    constexpr int NIT = (C16_HALO + NTHR - 1) / NTHR;
-    float raw[NIT][16];
-    bool inb[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int v = tid + it * NTHR;
-        const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        inb[it] = v < C16_HALO && gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
-        if (inb[it]) {
-            const long idx = ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * 16;
-            float lo8[8], hi8[8];
-            load8<F32>(a.x, idx, lo8);
-            load8<F32>(a.x, idx + 8, hi8);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { raw[it][c] = lo8[c]; raw[it][8 + c] = hi8[c]; }
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int v = tid + it * NTHR;
-        float val[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) val[c] = inb[it] ? raw[it][c] * gsc[c] + gsh[c] : 0.f;
-        f16x8 h0, h1, l0, l1;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
-            if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
-        }
-        if (v < C16_HALO) {                                          // two planes of 16-byte half-voxels: [channels 0-7][v], [channels 8-15][v]
-            *reinterpret_cast<f16x8*>(s_hi + v * 8) = h0; *reinterpret_cast<f16x8*>(s_hi + C16_HALO * 8 + v * 8) = h1;
-            if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 8) = l0; *reinterpret_cast<f16x8*>(s_lo + C16_HALO * 8 + v * 8) = l1; }
-        }
-    }
-    // ---- weights: A operand (rows = cout) for all 14 k-steps, in registers ----
-    f16x8 wh[14], wl[14];
-#pragma unroll
-    for (int ks = 0; ks < 14; ++ks) {
-        const long widx = (long)vl * a.Kp + ks * 32 + kg * 8;
-        wh[ks] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
-        if (F32) wl[ks] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
-    }
-    __syncthreads();
+    // Wave specialisation.  The PMC profile of the plain form (every wave stages its brick, then computes it) showed the matrix pipe, the
+    // VALU (GroupNorm + fp16 hi/lo conversion of the halo) and LDS each ~28 % busy and never at the same time: two co-resident workgroups
+    // doing identical work fall into lockstep.  Here one persistent workgroup per CU splits the roles: waves 4-7 (one per SIMD) PRODUCE
+    // the halo of brick i + 1 into the second LDS buffer (HBM -> registers -> affine -> split -> LDS) while waves 0-3 (one per SIMD)
+    // CONSUME brick i on the matrix pipe; one barrier per brick.  VALU and MFMA now overlap on every SIMD by construction.
+    const bool producer = wid >= 4;
+    const int ptid = tid - 256;                                     // producer thread index (valid when producer)
 
-    // ---- phase 2: each wave takes 8 rows (16 voxels along x) of the brick, two at a time ----
-    const int half = kg & 1, tsel = kg >> 1;
-#pragma unroll 1
-    for (int pr = 0; pr < 4; ++pr) {
-        int rz[2], ry[2], lbase[2];
+    auto produce = [&](int brick, int buf) {
+        const int b = brick / per_vol; int t = brick - b * per_vol;
+        const int t2 = t % n2; t /= n2;
+        const int t1 = t % n1; const int t0 = t / n1;
+        const int z0 = t0 * C16_T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
+        f16* s_hi = reinterpret_cast<f16*>(smem) + buf * BUF_EL;
+        f16* s_lo = s_hi + C16_HALO * 16;
+        // two batches of loads (3 + 2 voxels per thread): all in flight at once would need 80 VGPRs next to the consumers' 112 weight
+        // registers (the allocation is the union of both roles); the producers have a whole MFMA phase of slack for the second round trip
+        constexpr int NB1 = (NIT + 1) / 2;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = wid * 8 + pr * 2 + mi;                  // 0..63 = z * 8 + y
-            rz[mi] = row >> 3; ry[mi] = row & 7;
-            lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 8 + half * (C16_HALO * 8);   // element offset of the centre tap
+        for (int base = 0; base < NIT; base += NB1) {
+            float raw[NB1][16];
+            bool inb[NB1];
+#pragma unroll
+            for (int k = 0; k < NB1; ++k) {
+                const int it = base + k;
+                const int v = ptid + it * NPROD;
+                const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+                inb[k] = it < NIT && v < C16_HALO && gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
+                if (inb[k]) {
+                    const long idx = ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * 16;
+                    float lo8[8], hi8[8];
+                    load8<F32>(a.x, idx, lo8);
+                    load8<F32>(a.x, idx + 8, hi8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { raw[k][c] = lo8[c]; raw[k][8 + c] = hi8[c]; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB1; ++k) {
+                const int it = base + k;
+                const int v = ptid + it * NPROD;
+                float val[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float sc = has_gn ? a.gn_scale[b * 16 + c] : 1.f, sh = has_gn ? a.gn_shift[b * 16 + c] : 0.f;   // uniform: scalar loads
+                    val[c] = inb[k] ? raw[k][c] * sc + sh : 0.f;    // zero padding AFTER the normalisation
+                }
+                f16x8 h0, h1, l0, l1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
+                    if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
+                }
+                if (it < NIT && v < C16_HALO) {                      // two planes of 16-byte half-voxels: [channels 0-7][v], [channels 8-15][v]
+                    *reinterpret_cast<f16x8*>(s_hi + v * 8) = h0; *reinterpret_cast<f16x8*>(s_hi + C16_HALO * 8 + v * 8) = h1;
+                    if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 8) = l0; *reinterpret_cast<f16x8*>(s_lo + C16_HALO * 8 + v * 8) = l1; }
+                }
+            }
         }
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    };
+
+    // consumers: weights (A operand, rows = cout) for all 14 k-steps live in registers
+    f16x8 wh[14], wl[14];
+    if (!producer) {
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
-            // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
-            const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
-            const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 8;
-            const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 8;
-            const int off = tsel ? offb : offa;
+            const long widx = (long)vl * a.Kp + ks * 32 + kg * 8;
+            wh[ks] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+            if (F32) wl[ks] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+        }
+    }
+    const int half = kg & 1, tsel = kg >> 1;
+    constexpr int ROWS_PER_WAVE = C16_T0 * 2;                        // 4 consumer waves share the brick's T0 * 8 rows
+
+    auto consume = [&](int brick, int buf) {
+        const int b = brick / per_vol; int t = brick - b * per_vol;
+        const int t2 = t % n2; t /= n2;
+        const int t1 = t % n1; const int t0 = t / n1;
+        const int z0 = t0 * C16_T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
+        const f16* s_hi = reinterpret_cast<const f16*>(smem) + buf * BUF_EL;
+        const f16* s_lo = s_hi + C16_HALO * 16;
+        constexpr int MR = 4;                                       // rows in flight per wave: 4 independent accumulator chains, and the
+#pragma unroll 1                                                    // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
+        for (int pr = 0; pr < ROWS_PER_WAVE / MR; ++pr) {
+            int rz[MR], ry[MR], lbase[MR];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + lbase[mi] + off);
-                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xh, acc[mi], 0, 0, 0);
+            for (int mi = 0; mi < MR; ++mi) {
+                const int row = wid * ROWS_PER_WAVE + pr * MR + mi; // z * 8 + y
+                rz[mi] = row >> 3; ry[mi] = row & 7;
+                lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 8 + half * (C16_HALO * 8);   // element offset of the centre tap
+            }
+            f32x4 acc[MR];
+#pragma unroll
+            for (int mi = 0; mi < MR; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f16x8 xh[2][MR], xl[2][MR];
+            auto frags = [&](int ks, int slot) {
+                // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
+                const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
+                const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 8;
+                const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 8;
+                const int off = tsel ? offb : offa;
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi) {
+                    xh[slot][mi] = *reinterpret_cast<const f16x8*>(s_hi + lbase[mi] + off);
+                    if (F32) xl[slot][mi] = *reinterpret_cast<const f16x8*>(s_lo + lbase[mi] + off);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 14; ++ks) {
+                if (ks + 1 < 14) frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xh[ks & 1][mi], acc[mi], 0, 0, 0);
                 if (F32) {
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + lbase[mi] + off);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], xh, acc[mi], 0, 0, 0);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xl, acc[mi], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], xh[ks & 1][mi], acc[mi], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xl[ks & 1][mi], acc[mi], 0, 0, 0);
                 }
             }
-        }
-        // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
+            // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const long ovox = (((long)b * a.I0 + (z0 + rz[mi])) * a.I1 + (y0 + ry[mi])) * a.I2 + (x0 + vl);
-            const long oidx = ovox * 16 + 4 * kg;
-            float o[4] = {acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
-            if (a.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + 4 * kg);
-                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-            }
-            if (a.resid) {
+            for (int mi = 0; mi < MR; ++mi) {
+                const long ovox = (((long)b * a.I0 + (z0 + rz[mi])) * a.I1 + (y0 + ry[mi])) * a.I2 + (x0 + vl);
+                const long oidx = ovox * 16 + 4 * kg;
+                float o[4] = {acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + 4 * kg);
+                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                }
+                if (a.resid) {
+                    if (F32) {
+                        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx);
+                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                    } else {
+                        const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oidx);
+                        o[0] += (float)r[0]; o[1] += (float)r[1]; o[2] += (float)r[2]; o[3] += (float)r[3];
+                    }
+                }
+                if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
                 if (F32) {
-                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx);
-                    o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
                 } else {
-                    const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oidx);
-                    o[0] += (float)r[0]; o[1] += (float)r[1]; o[2] += (float)r[2]; o[3] += (float)r[3];
+                    f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3];
+                    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
                 }
             }
-            if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
-            if (F32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-                f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3];
-                *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
-            }
         }
+    };
+
+    int brick = blockIdx.x;
+    if (producer && brick < total) produce(brick, 0);
+    __syncthreads();
+    int buf = 0;
+    for (; brick < total; brick += gridDim.x, buf ^= 1) {
+        const int next = brick + gridDim.x;
+        if (producer) { if (next < total) produce(next, buf ^ 1); }   // the other buffer: consumed one iteration ago, before the barrier
+        else consume(brick, buf);
+        __syncthreads();
     }
 }
 
 static int g_conv16_lds = 1;     // tuning / test hook: 0 = always use the generic gather kernel
 extern "C" int semabs_conv_set_config(int use_lds_brick) { g_conv16_lds = use_lds_brick; return SEMABS_OK; }
 
+static int semabs_num_cus() {
+    static int n = 0;
+    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
 static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
     if (f32) {
         constexpr int T0 = 4;
-        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2 * 2;
-        dim3 grid((a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B), block(64 * T0);
+        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2 * 2 * 2;       // hi + lo, two buffers
+        const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
+        long nb = semabs_num_cus(); if (nb > total) nb = total;
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<true, T0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-        hipLaunchKernelGGL((k_conv16_lds<true, T0>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((k_conv16_lds<true, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
     } else {
         constexpr int T0 = 8;
-        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2;
-        dim3 grid((a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B), block(64 * T0);
+        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2 * 2;           // two buffers
+        const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
+        long nb = semabs_num_cus(); if (nb > total) nb = total;
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<false, T0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-        hipLaunchKernelGGL((k_conv16_lds<false, T0>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((k_conv16_lds<false, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
     }
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
