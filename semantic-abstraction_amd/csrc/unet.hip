@@ -256,6 +256,8 @@ struct ConvArgs {
     int Cin, Cout, Kp;          // Kp = padded K (multiple of 32) = weight row stride
     int ntaps; int relu;
     int is;                     // input coordinate = m * is + td (1 except for the ConvTranspose data gradient)
+    int ksplit;                 // > 1: blockIdx.z takes a slice of the k-steps and adds its partial sum to y (fp32, pre-zeroed) with atomics;
+                                // bias / residual / ReLU are then applied by k_conv_finish
     signed char td0[28], td1[28], td2[28];   // tap offsets: input coordinate = m + td  (conv pad-1: -1..1; convT: 0/+1)
 };
 
@@ -387,13 +389,18 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             }
         }
     };
+    int ks_lo = 0, ks_hi = nsteps;
+    if (a.ksplit > 1) {
+        const int per = (nsteps + a.ksplit - 1) / a.ksplit;
+        ks_lo = blockIdx.z * per; ks_hi = ks_lo + per < nsteps ? ks_lo + per : nsteps;
+    }
     Raw R0, R1;
-    fetch(0, R0);
-    for (int ks = 0; ks < nsteps; ks += 2) {
-        if (ks + 1 < nsteps) fetch(ks + 1, R1);
+    if (ks_lo < ks_hi) fetch(ks_lo, R0);
+    for (int ks = ks_lo; ks < ks_hi; ks += 2) {
+        if (ks + 1 < ks_hi) fetch(ks + 1, R1);
         consume(ks, R0);
-        if (ks + 1 < nsteps) {
-            if (ks + 2 < nsteps) fetch(ks + 2, R0);
+        if (ks + 1 < ks_hi) {
+            if (ks + 2 < ks_hi) fetch(ks + 2, R0);
             consume(ks + 1, R1);
         }
     }
@@ -406,6 +413,12 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         for (int ni = 0; ni < NW; ++ni) {
             const int co = n0 + ni * 16 + 4 * kg;
             float o[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            if (F32 && a.ksplit > 1) {                             // split-K partial: plain sums, finished by k_conv_finish
+                float* yp = reinterpret_cast<float*>(a.y) + ovox * a.Cout + co;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(yp + e, o[e]);
+                continue;
+            }
             if (a.bias) {
                 const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
                 o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
@@ -830,8 +843,42 @@ static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
     return f32 ? conv_brick_launch_t<true, 32, 2, false>(a, s) : conv_brick_launch_t<false, 32, 2, false>(a, s);
 }
 
-static int conv_launch(const ConvArgs& a, int f32, hipStream_t s) {
+// split-K epilogue: y = act(y + bias + resid) in place, fp32 channels-last
+__global__ void k_conv_finish(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ resid, long n4, int C, int relu) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = *reinterpret_cast<float4*>(y + i * 4);
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % C); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (resid) { const float4 r = *reinterpret_cast<const float4*>(resid + i * 4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (relu == 2) { v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y; v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w; }
+    *reinterpret_cast<float4*>(y + i * 4) = v;
+}
+
+static int conv_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
+    ConvArgs a = a_in;
     const long Mtot = (long)a.B * a.M0 * a.M1 * a.M2;
+    // The deepest levels (8^3, 4^3 voxels x 256 / 512 channels) have so few voxels that even 16-channel output slices leave the k-loop
+    // (216 / 432 steps) as the only parallelism left - and every slice re-gathers the input.  In exact mode those launches split the
+    // k-steps over grid z instead (wide 64-channel slices, 4x less input traffic), accumulate with fp32 atomics into a zeroed output and
+    // apply bias / residual / ReLU in a second, tiny pass.
+    a.ksplit = 1;
+    if (f32 && a.os == 1 && a.Cout % 64 == 0 && a.Cin % 32 == 0 && a.ntaps == 27 && Mtot <= 16384) {
+        const long slices = semabs_cdiv(Mtot, 4 * 32) * (a.Cout / 64);
+        int ks = (int)(2048 / (slices > 0 ? slices : 1));
+        if (ks > 27) ks = 27;
+        if (ks >= 3) {
+            a.ksplit = ks;
+            if (hipMemsetAsync(a.y, 0, (size_t)Mtot * a.Cout * sizeof(float), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+            dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / 64, ks), block(256);
+            hipLaunchKernelGGL((k_conv<4, true, false>), grid, block, 0, s, a);
+            const long n4 = Mtot * a.Cout / 4;
+            hipLaunchKernelGGL(k_conv_finish, dim3(semabs_cdiv(n4, 256)), dim3(256), 0, s, reinterpret_cast<float*>(a.y), a.bias,
+                               reinterpret_cast<const float*>(a.resid), n4, a.Cout, a.relu);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
+    }
     // output channels per wave: 64 / 32 / 16.  Wide slices reuse each gathered input fragment more, but the deep UNet levels have only
     // a few thousand voxels: there the k-loop (up to 432 steps of dependent L2 weight loads) is latency-bound and the chip is filled
     // by slicing Cout finer instead (4^3 x 512 channels: 32 -> 128 workgroups).
