@@ -160,10 +160,12 @@ int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, co
 int semabs_maxpool3d(const void* x, void* y, int B, int D0, int D1, int D2, int C, int act_f32, void* stream);   /* unet3d.py:298 */
 /* ImplicitVolumetricDecoder: trilinear grid_sample (border, align_corners) + MLP    net.py:215-256
  * off3 / sc3 / shape3 / w1 / b1 / w2 / b2 are HOST arrays.  qgrid3 (host int[3] or NULL): the M queries of every label are a dense C-order
- * lattice of these dims (e.g. all voxel centres) - lets the kernel walk them in the volume's memory order; results and layout unchanged. */
+ * lattice of these dims (e.g. all voxel centres) - lets the kernel walk them in the volume's memory order; results and layout unchanged.
+ * final_w [16,16] / final_b [16] (host or NULL): vol is the activation in front of the UNet's final 1x1x1 conv (unet3d.py:584-586), which is
+ * then applied to the sampled features (it commutes with the interpolation). */
 int semabs_decoder(const void* vol, const float* query, const float* off3, const float* sc3, const int* shape3, const float* w1,
                    const float* b1, const float* w2, const float* b2, int concat_xyz, int P, long M, long q_stride_p, int vol_f32,
-                   float* out, const int* qgrid3, void* stream);
+                   float* out, const int* qgrid3, const float* final_w, const float* final_b, void* stream);
 
 /* SemAbsVOOL head: sample two 16-ch volumes (no concat), spatial sampler 35 -> 32 -> 64, cosine similarity with the
  * relation embedding / temperature                                    net.py:559-579, 215-256, 300-309

@@ -65,7 +65,7 @@ SIGNATURES = {
     "semabs_maxpool3d": [P, P, I, I, I, I, I, I, P],
     "semabs_vool_head": [P, P, P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), F, I, L, I, P, P],
     "semabs_lamb_step": [P, I, P, I, D, D, D, D, D, I, P, P, P],
-    "semabs_decoder": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, I, I, L, L, I, P, C.POINTER(I), P],
+    "semabs_decoder": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, I, I, L, L, I, P, C.POINTER(I), P, P, P],
     # training step (train.hip, unet.hip)
     "semabs_conv3d_gather": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],
     "semabs_wgrad": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],

@@ -1196,7 +1196,8 @@ struct DecArgs {
     float off[3], sc[3];
     int S0, S1, S2; int concat_xyz;
     float w1[16 * 19], b1[16], w2[16], b2;
-};
+    int has_final; float fw[16 * 16], fb[16];      // optional: the UNet's final 1x1x1 convolution applied to the SAMPLED features (it commutes
+};                                                 // with the trilinear interpolation), so its output volume never has to be written
 // LATTICE: the M queries of a label are a dense C-order lattice G0 x G1 x G2 (e.g. all voxel centres).  Query axis 0 is the point's x, which
 // the decoder maps to the volume's INNERMOST axis (net.py:221-239), so in query order consecutive threads walk the volume's slowest axis
 // (1 MB apart at 128^3, every lane its own cache lines: 2.4 ms per scene).  Here a workgroup takes a 32 x 2 x 4 tile of the lattice with the
@@ -1256,6 +1257,18 @@ __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, cons
 #pragma unroll
         for (int c = 0; c < 8; ++c) f[8 + c] += v[c] * w;
     }
+    if (a.has_final) {                                      // f <- W_final . f + b_final  (the corner weights of the in-range corners sum to 1)
+        float g[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float t = a.fb[j];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t += a.fw[j * 16 + c] * f[c];
+            g[j] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = g[j];
+    }
     float o = a.b2;
     const int din = a.concat_xyz ? 19 : 16;
 #pragma unroll
@@ -1283,9 +1296,12 @@ __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, cons
 // M points x 3; out fp32 [P, M].  w1 [16, 19 or 16], b1 [16], w2 [1, 16], b2 [1] host pointers (fp32).
 // qgrid3 (host int[3] or NULL): promise that every label's M queries form a dense C-order lattice of these dims (M = product) - only
 // changes the order in which the kernel walks them, never the results or their layout.
+// final_w [16, 16] / final_b [16] (host, or NULL): `vol` is the UNet's activation BEFORE its final 1x1x1 convolution; the decoder applies that
+// convolution to the sampled features instead (a linear map commutes with the interpolation) - saves writing and re-reading one volume.
 extern "C" int semabs_decoder(const void* vol, const float* query, const float* off3, const float* sc3, const int* shape3,
                               const float* w1, const float* b1, const float* w2, const float* b2, int concat_xyz, int P, long M,
-                              long q_stride_p, int vol_f32, float* out, const int* qgrid3, void* stream) {
+                              long q_stride_p, int vol_f32, float* out, const int* qgrid3, const float* final_w, const float* final_b,
+                              void* stream) {
     if (P == 0 || M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(vol && query && off3 && sc3 && shape3 && w1 && b1 && w2 && b2 && out, "semabs_decoder: null pointer");
     DecArgs a;
@@ -1295,6 +1311,12 @@ extern "C" int semabs_decoder(const void* vol, const float* query, const float* 
     for (int i = 0; i < 16 * din; ++i) a.w1[i] = w1[i];
     for (int i = 0; i < 16; ++i) { a.b1[i] = b1[i]; a.w2[i] = w2[i]; }
     a.b2 = b2[0];
+    a.has_final = final_w != nullptr;
+    if (final_w) {
+        SEMABS_REQUIRE(final_b, "semabs_decoder: final_w needs final_b");
+        for (int i = 0; i < 256; ++i) a.fw[i] = final_w[i];
+        for (int i = 0; i < 16; ++i) a.fb[i] = final_b[i];
+    }
     const bool lattice = qgrid3 && (long)qgrid3[0] * qgrid3[1] * qgrid3[2] == M && qgrid3[0] % 32 == 0 && qgrid3[1] % 2 == 0 && qgrid3[2] % 4 == 0 &&
                          (long)P * (M / 256) < (1L << 31);
     if (lattice) {

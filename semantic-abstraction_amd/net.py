@@ -106,6 +106,8 @@ class SemAbs3D:
         self._dec = {k: np.ascontiguousarray(sd[f"visual_sampler.mlp.{i}.{n}"].float().cpu().numpy().reshape(-1)) for k, (i, n) in
                      dict(w1=(0, "weight"), b1=(0, "bias"), w2=(2, "weight"), b2=(2, "bias")).items()}
         self.vol_feature_extractor.load_state_dict(sd, strict=strict, prefix="vol_feature_extractor.")
+        self._final = (np.ascontiguousarray(sd["vol_feature_extractor.final_conv.weight"].float().cpu().numpy().reshape(-1)),
+                       np.ascontiguousarray(sd["vol_feature_extractor.final_conv.bias"].float().cpu().numpy().reshape(-1)))
         if "steps" in sd:
             self.steps = sd["steps"].clone()
         self._sd = {k: v.detach().clone() for k, v in sd.items()}
@@ -121,8 +123,9 @@ class SemAbs3D:
         return self
 
     # ---- stages ------------------------------------------------------------------------------------
-    def feature_volume(self, xyz: torch.Tensor, feat: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
-        """xyz fp32 [N, 3], feat fp32 [P, N] (one scene, P label volumes) -> UNet features channels-last [P, S, S, S, C]."""
+    def feature_volume(self, xyz: torch.Tensor, feat: torch.Tensor, taps: dict | None = None, skip_final: bool = False) -> torch.Tensor:
+        """xyz fp32 [N, 3], feat fp32 [P, N] (one scene, P label volumes) -> UNet features channels-last [P, S, S, S, C].
+        skip_final: stop in front of the UNet's final 1x1x1 convolution (see `decode(pre_final=True)`)."""
         dev = _lib.require_gpu()
         P, N = int(feat.shape[0]), int(feat.shape[1])
         S0, S1, S2 = self.vg.grid_shape
@@ -143,11 +146,13 @@ class SemAbs3D:
         if taps is not None:
             taps["scatter"] = vol
             taps["point_feat"] = pf
-        return unet.forward_cl(vol, taps=taps)
+        return unet.forward_cl(vol, taps=taps, skip_final=skip_final)
 
-    def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False, lattice=None) -> torch.Tensor:
+    def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False, lattice=None, pre_final: bool = False) -> torch.Tensor:
         """features [P, S, S, S, C]; query fp32 [P, M, 3] (or [M, 3] with shared=True) -> logits fp32 [P, M].
-        lattice=(G0, G1, G2): the M queries are a dense C-order lattice (e.g. `VirtualGrid.get_grid_points`): same results, faster walk."""
+        lattice=(G0, G1, G2): the M queries are a dense C-order lattice (e.g. `VirtualGrid.get_grid_points`): same results, faster walk.
+        pre_final: `features_cl` is `feature_volume(..., skip_final=True)`, i.e. the activation in front of the UNet's final 1x1x1
+        convolution; that (linear) layer is applied to the sampled features inside the decoder kernel instead."""
         dev = _lib.require_gpu()
         P = int(features_cl.shape[0])
         M = int(query.shape[-2])
@@ -157,7 +162,8 @@ class SemAbs3D:
         query = query.contiguous()
         _lib.call("semabs_decoder", _lib.ptr(features_cl), _lib.ptr(query), _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales),
                   _lib.iarr(self.vg.grid_shape), fp(d["w1"]), fp(d["b1"]), fp(d["w2"]), fp(d["b2"]), int(self.concat_xyz), P, M,
-                  0 if shared else M * 3, self.vol_feature_extractor.f32, _lib.ptr(out), None if lattice is None else _lib.iarr(lattice), _lib.stream())
+                  0 if shared else M * 3, self.vol_feature_extractor.f32, _lib.ptr(out), None if lattice is None else _lib.iarr(lattice),
+                  fp(self._final[0]) if pre_final else None, fp(self._final[1]) if pre_final else None, _lib.stream())
         return out
 
     # ---- reference surface ---------------------------------------------------------------------------

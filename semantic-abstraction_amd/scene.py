@@ -45,13 +45,14 @@ class SceneResult:
 
 class ScenePipeline:
     def __init__(self, net: SemAbs3D, num_input_pts: int = 80000, config: str = "ours", subtract_mean: bool = True,
-                 with_tsdf: bool = True, cutoff: float = -3.0):
+                 with_tsdf: bool = True, cutoff: float = -3.0, fold_final_conv: bool = True):
         self.net = net
         self.num_input_pts = int(num_input_pts)
         self.config = config
         self.subtract_mean = subtract_mean
         self.with_tsdf = with_tsdf
         self.cutoff = cutoff
+        self.fold_final_conv = bool(fold_final_conv)
         self.dev = _lib.require_gpu()
         S0, S1, S2 = net.vg.grid_shape
         lc = np.asarray(net.vg.lower_corner, np.float32)
@@ -130,9 +131,11 @@ class ScenePipeline:
         _lib.call("semabs_gather_point_features", _lib.ptr(maps_c), _lib.ptr(sel), _lib.ptr(xyz), L, H * W, self.num_input_pts, 50.0,
                   int(self.subtract_mean), _lib.ptr(feat), _lib.ptr(xyz_sub), st)
         # ---- voxel inference ----------------------------------------------------------------------------
-        features = net.feature_volume(xyz_sub, feat)
-        logits = net.decode(features, self.grid_points, shared=True, lattice=net.vg.grid_shape)   # [L, S^3], queries = all voxel centres
-        net.features_cl = features
+        # the UNet's final 1x1x1 convolution is folded into the decoder (applied to the sampled features): its output volume - 2 GB written
+        # and read back at 128^3 x 16 labels - is never materialised on this path; SemAbs3D.forward keeps producing it
+        features = net.feature_volume(xyz_sub, feat, skip_final=self.fold_final_conv)
+        logits = net.decode(features, self.grid_points, shared=True, lattice=net.vg.grid_shape, pre_final=self.fold_final_conv)   # [L, S^3]
+        net.features_cl = None if self.fold_final_conv else features
         tsdf = labels = None
         if self.with_tsdf:
             S = net.vg.grid_shape[0]

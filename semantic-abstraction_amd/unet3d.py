@@ -170,8 +170,8 @@ class ResidualUNet3D:
         return y
 
     # ---- forward -----------------------------------------------------------------------------------
-    def forward_cl(self, x: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
-        """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]."""
+    def forward_cl(self, x: torch.Tensor, taps: dict | None = None, skip_final: bool = False) -> torch.Tensor:
+        """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]  (skip_final: the input of `final_conv`)."""
         assert self.final is not None, "load_state_dict first"
         assert x.dtype == self.act_dtype and x.is_contiguous()
         feats = []
@@ -187,6 +187,8 @@ class ResidualUNet3D:
             x = self._block(x, convs)
             if taps is not None:
                 taps[f"dec{i}"] = x
+        if skip_final:
+            return x
         return self._conv(x, self.final, relu=False, gn=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

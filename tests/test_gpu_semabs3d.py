@@ -265,3 +265,18 @@ def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B):
     scale = max(1.0, ref.abs().max().item())
     assert (y_brick - ref).abs().max().item() <= tol * scale
     assert (y_brick - y_gather).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale
+
+
+def test_decoder_folded_final_conv_matches_materialised():
+    """decode(feature_volume(skip_final=True), pre_final=True) == decode(feature_volume()): the final 1x1x1 conv commutes with the trilinear
+    interpolation; only fp32 summation order differs."""
+    S, N, M, P = 32, 3000, 2048, 2
+    m = _model(S, "exact")
+    xyz, feat, q = semabs_inputs(S, N, M, P, 11)
+    xyzd = torch.from_numpy(xyz[0]).cuda()
+    featd = torch.from_numpy(feat[0, :, :, 0]).cuda().contiguous()
+    qd = torch.from_numpy(q[0]).cuda()
+    full = m.decode(m.feature_volume(xyzd, featd), qd)
+    folded = m.decode(m.feature_volume(xyzd, featd, skip_final=True), qd, pre_final=True)
+    scale = float(full.abs().max())
+    assert float((full - folded).abs().max()) <= 2e-5 * scale and scale > 0
