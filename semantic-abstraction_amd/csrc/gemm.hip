@@ -6,13 +6,16 @@
 // Both operands are K-contiguous (torch Linear weight layout [N, K]); weights are fp16-exact because the
 // reference rounds them to fp16 (`convert_weights`, model_explainability.py:501-527).  fp32 accumulate.
 //
-// Structure (gfx950): block tile 256 x 256 x 64 with 8 waves (2 x 4, wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_f16
-// accumulators) for the big GEMMs, 128 x 128 x 64 with 4 waves for small M / N; operands go global -> LDS by
-// direct DMA (global_load_lds_dwordx4, double buffered, one barrier per K tile) - no VGPR round trip and no
-// ds_write traffic; LDS rows are 128 B with the 16-B chunk index XOR-swizzled by (row >> 1) & 7 (applied on the DMA
-// source address and on the read) so ds_read_b128 fragment reads are bank-conflict-free; the epilogue stages 64-row
-// slabs of each wave's fp32 tile through a private 16 KB LDS slice to emit 16-byte row-contiguous stores; block ids
-// are remapped so the blocks that share an A row-panel run on one XCD (private L2).
+// Two kernels (gfx950):
+//  * k_gemm8 (M >= 2048, N % 256 == 0, K >= 128 - every GEMM of the ViT trunk): 256 x 256 x 64 tile, 8 waves, four phases per K tile with one
+//    half-tile of direct-to-LDS DMA issued per phase and four half-tiles in flight across barriers, skewed wave rows, register-direct
+//    epilogue.  Described in full at its definition below.
+//  * k_gemm_f16 (everything else - small M, N % 256 != 0, K = 64): 128 x 128 x 64 (or 128 x 256 x 32) tile of 32x32x16 MFMAs, operands
+//    global -> LDS by direct DMA (global_load_lds_dwordx4) in a 2-3 stage ring with counted vmcnt + raw barriers, LDS rows XOR-swizzled
+//    (applied on the DMA source address and on the read) so ds_read_b128 fragment reads are bank-conflict-free, fragment ping-pong, and an
+//    epilogue that stages 32-row slabs of each wave's fp32 tile through a private 8 KB LDS slice to emit 16-byte row-contiguous stores.
+// Both: fused epilogues (bias / QuickGELU / fp32 residual read-modify-write / row-remap + addend), block ids remapped so the blocks that
+// share operand panels run on one XCD (private L2) with grouped rasterisation.
 #include "semabs_common.h"
 #include <type_traits>
 

@@ -16,6 +16,13 @@
 // B operand columns, so each lane ends up with 4 consecutive output channels of one voxel (8-byte coalesced store).
 // K order is (tap, cin); for Cin = 16 one MFMA k-step covers two taps, otherwise one tap x 32 input channels.
 // "exact" mode splits both operands into fp16 hi + lo and issues 3 MFMAs (hi*hi + lo*hi + hi*lo): ~fp32 accuracy.
+//
+// Convolution kernels by level of the 128^3 UNet (all share the ConvArgs contract and the [Cout, (tap, cin)] split weight matrices):
+//   k_conv16_lds    128^3 x 16 -> 16      persistent, wave-specialised (producer / consumer), LDS-double-buffered halo bricks
+//   k_conv_brick    64^3 .. 16^3           LDS halo bricks, input channels staged 32 at a time, Cout sliced over grid z
+//   k_convT_brick   ConvTranspose3d of the three upper levels, two launches (output parity along axis 0)
+//   k_conv          everything else: gather implicit GEMM (1x1x1, strided data gradients, deepest levels; split-K + k_conv_finish
+//                   for the 8^3 / 4^3 levels in exact mode)
 #include "semabs_common.h"
 
 // =================================================================================================
