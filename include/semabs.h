@@ -254,6 +254,20 @@ int semabs_cos_bce(const float* o, const float* rel, const float* label, const f
 int semabs_clip_grad_norm(const long long* chunks, int n_chunks, const long long* ptrs, int n_tensors, float max_norm, float extra_scale,
                           double* sq, void* stream);
 
+/* ============================ relevancy storage format (csrc/relio.hip) =================== */
+/* What sits between get_clip_saliency and the HDF5 file, and between the file and the network input (the container itself - gzip chunks,
+ * region references, file locks - is storage and out of scope). */
+
+/* maps fp32 [L, H, W] -> out fp32 [L + 1, h, w]: nearest-exact resize to the storage dims + the mean-over-labels map as the last row
+ *                                                                                              generate_relevancy.py:95-108 */
+int semabs_relevancy_pack(const float* maps, float* out, int L, int H, int W, int h, int w, void* stream);
+/* feats fp32 [L, E] -> out fp32 [L + 1, E]: append the mean row, L2-normalise every row               generate_relevancy.py:109-118 */
+int semabs_text_pack(const float* feats, float* out, int L, int E, void* stream);
+/* stored fp32 [R, h, w], rows int64 [P] (or NULL = rows 0..P-1), mean_map fp32 [h, w] (or NULL) -> out fp32 [P, H, W] =
+ * out_scale * bilinear(align_corners = False)(stored[rows] - mean_map)                                dataset.py:821-871 (x 50: :1053) */
+int semabs_relevancy_unpack(const float* stored, const long long* rows, const float* mean_map, float* out, int P, int h, int w, int H, int W,
+                            float out_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ LIB = os.path.join(OUT_DIR, "libsemabs_hip.so")
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
 # files whose integer outputs are bit-exact targets: no FMA contraction, IEEE division
-PER_FILE = {"geometry.hip": ["-ffp-contract=off"], "tiles.hip": ["-ffp-contract=off"]}
+PER_FILE = {"geometry.hip": ["-ffp-contract=off"], "tiles.hip": ["-ffp-contract=off"], "relio.hip": ["-ffp-contract=off"]}
 
 
 def hipcc() -> str:

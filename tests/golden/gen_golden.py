@@ -525,3 +525,33 @@ def g13_vool_train():
 
 if __name__ == "__main__" and "g13" in sys.argv[1:]:
     g13_vool_train()
+
+
+# ---- appended: relevancy storage format (G14): the reference's own expressions at generate_relevancy.py:95-118 and dataset.py:821-871 -----
+def g14_relevancy_io():
+    """`generate_saliency_helper` is a ray remote writing HDF5 and the loader reads it back; neither can run here (ray / h5py / dataset files
+    absent), so the golden executes the reference's tensor expressions verbatim on seeded inputs (they are plain torch calls)."""
+    rng = np.random.default_rng(140)
+    res = {}
+    for tag, (L, H, W, h, w) in {"a": (5, 96, 96, 40, 40), "b": (3, 120, 90, 64, 48), "c": (4, 60, 60, 128, 128)}.items():
+        config_saliency = torch.from_numpy((rng.standard_normal((L, H, W)) * 0.01).astype(np.float32))
+        text_label_features = torch.from_numpy(rng.standard_normal((L, 512)).astype(np.float32))
+        storage_dims = np.array([h, w])
+        # generate_relevancy.py:95-118
+        cs = torch.nn.functional.interpolate(config_saliency[:, None, :, :], size=tuple(storage_dims), mode="nearest-exact")[:, 0]
+        cs = torch.cat([cs, cs.mean(dim=0, keepdim=True)], dim=0)
+        tf = torch.cat([text_label_features, text_label_features.mean(dim=0, keepdim=True)], dim=0)
+        tf /= tf.norm(dim=-1, keepdim=True)
+        # dataset.py:821-832, 866-871, 1053
+        saliency_indices = np.array(sorted(rng.choice(L, size=max(1, L - 1), replace=False)))
+        patch = cs[saliency_indices].float()
+        patch -= cs[L].float().squeeze()
+        patch = torch.nn.functional.interpolate(patch[:, None, :, :], size=(H, W), mode="bilinear", align_corners=False)[:, 0]
+        res.update({f"{tag}_maps": config_saliency.numpy(), f"{tag}_feats": text_label_features.numpy(), f"{tag}_dims": np.asarray([L, H, W, h, w]),
+                    f"{tag}_stored": cs.numpy(), f"{tag}_tf": tf.numpy(), f"{tag}_rows": saliency_indices.astype(np.int64),
+                    f"{tag}_loaded50": (patch * 50).numpy()})
+    save("g14_relevancy_io", **res)
+
+
+if __name__ == "__main__" and "g14" in sys.argv[1:]:
+    g14_relevancy_io()
