@@ -268,6 +268,17 @@ int semabs_text_pack(const float* feats, float* out, int L, int E, void* stream)
 int semabs_relevancy_unpack(const float* stored, const long long* rows, const float* mean_map, float* out, int P, int h, int w, int H, int W,
                             float out_scale, void* stream);
 
+/* ============================ evaluation metrics (csrc/evalm.hip) ========================= */
+/* utils.voxelize_points (utils.py:617-665): flat int64 [BP, N] voxel indices (semabs_voxel_index), pred / label / ignore uint8 [BP, N] ->
+ * voxelised prediction / label / ignore uint8 [BP, nvox] (scatter-max semantics, empty voxels ignored); vol_scratch int32 [BP, nvox, 3] */
+int semabs_voxelize_eval(const long long* flat, const unsigned char* pred, const unsigned char* label, const unsigned char* ignore,
+                         int* vol_scratch, unsigned char* out_pred, unsigned char* out_label, unsigned char* out_ignore, long BP, long N,
+                         long nvox, void* stream);
+/* utils.prediction_analysis (utils.py:340-380): per row, over the non-ignored elements: counts uint64 [BP, 6] = (valid, positive labels,
+ * positive predictions, true positives, union, 0); the ratios are formed on the host from these exact counts */
+int semabs_prediction_counts(const unsigned char* pred, const unsigned char* label, const unsigned char* ignore, unsigned long long* counts,
+                             long BP, long M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

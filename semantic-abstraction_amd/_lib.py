@@ -87,6 +87,9 @@ SIGNATURES = {
     "semabs_relevancy_pack": [P, P, I, I, I, I, I, P],
     "semabs_text_pack": [P, P, I, I, P],
     "semabs_relevancy_unpack": [P, P, P, P, I, I, I, I, I, F, P],
+    # evalm.hip
+    "semabs_voxelize_eval": [P, P, P, P, P, P, P, P, L, L, L, P],
+    "semabs_prediction_counts": [P, P, P, P, L, L, P],
 }
 
 

@@ -555,3 +555,51 @@ def g14_relevancy_io():
 
 if __name__ == "__main__" and "g14" in sys.argv[1:]:
     g14_relevancy_io()
+
+
+# ---- appended: evaluation metrics (G15): the reference's voxelize_points / prediction_analysis / iou run on seeded inputs ------------------
+def g15_metrics():
+    """utils.py cannot be imported here (tensorboardX / transformers / dataset), so the three functions are compiled from its source,
+    unmodified except for the type annotations / decorators, with the reference's own VirtualGrid (torch_scatter stubbed)."""
+    import ast
+    net, _ = refimport.load_reference_net()
+    tree = ast.parse(open(os.path.join(refimport.REF, "utils.py")).read())
+    class _NumpyWithNAN:                                      # API drift: numpy 2 dropped the np.NAN alias the reference uses (utils.py:364,369)
+        NAN = float("nan")
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+    ns = {"torch": torch, "np": _NumpyWithNAN(), "VirtualGrid": net.VirtualGrid}
+    for name in ("iou", "prediction_analysis", "voxelize_points"):
+        fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+        fn.decorator_list, fn.returns = [], None
+        for a in fn.args.args:
+            a.annotation = None
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), f"utils.py:{name}", "exec"), ns)
+    rng = np.random.default_rng(150)
+    B, P, N, S = 2, 3, 6000, 32
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    xyz = (lo - 0.05 + (hi - lo + 0.1) * rng.random((B, P, N, 3))).astype(np.float32)
+    logits = rng.standard_normal((B, P, N)).astype(np.float32)
+    label = (rng.random((B, P, N)) < 0.3)
+    ignore = (rng.random((B, P, N)) < 0.1)
+    ignore[1, 2] = True                                       # one fully ignored pair: the NaN branches
+    pred = logits > 0.5
+    pred[0, 1] = False                                        # no positive prediction: precision NaN
+    vox = ns["voxelize_points"](prediction=torch.from_numpy(pred), label=torch.from_numpy(label), xyz_pts=torch.from_numpy(xyz), voxel_shape=(S, S, S),
+                                scene_bounds=torch.tensor(SCENE_BOUNDS), ignore_pts=torch.from_numpy(ignore), device="cpu")
+    pts = ns["prediction_analysis"](prediction=torch.from_numpy(pred), label=torch.from_numpy(label), ignore=torch.from_numpy(ignore))
+    vst = ns["prediction_analysis"](**vox)
+    res = {"meta": np.asarray([B, P, N, S]), "xyz": xyz, "pred": pred, "label": label, "ignore": ignore,
+           "vox_prediction": vox["prediction"].numpy(), "vox_label": vox["label"].numpy(), "vox_ignore": vox["ignore"].numpy(),
+           "iou_rows": ns["iou"](torch.from_numpy(pred), torch.from_numpy(label)).numpy()}
+    for k, v in pts.items():
+        res["point_" + k] = np.asarray(v, np.float64)
+    for k, v in vst.items():
+        res["voxel_" + k] = np.asarray(v, np.float64)
+    save("g15_metrics", **res)
+
+
+if __name__ == "__main__" and "g15" in sys.argv[1:]:
+    g15_metrics()
