@@ -279,6 +279,14 @@ int semabs_voxelize_eval(const long long* flat, const unsigned char* pred, const
 int semabs_prediction_counts(const unsigned char* pred, const unsigned char* label, const unsigned char* ignore, unsigned long long* counts,
                              long BP, long M, void* stream);
 
+/* ============================ timing helpers ============================================================== */
+/* The next semabs_gemm_f16 launch records its start / stop timestamps into these HIP events through the dispatch packet itself
+ * (hipExtLaunchKernelGGL): per-launch durations without barrier packets around the kernel.  Used by bench.py's roofline leg. */
+int semabs_gemm_time_next(void* start_event, void* stop_event);
+int semabs_event_create(void** ev);
+int semabs_event_destroy(void* ev);
+int semabs_event_elapsed_ms(void* start, void* stop, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

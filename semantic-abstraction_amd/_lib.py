@@ -90,6 +90,11 @@ SIGNATURES = {
     # evalm.hip
     "semabs_voxelize_eval": [P, P, P, P, P, P, P, P, L, L, L, P],
     "semabs_prediction_counts": [P, P, P, P, L, L, P],
+    # timing helpers
+    "semabs_gemm_time_next": [P, P],
+    "semabs_event_create": [C.POINTER(P)],
+    "semabs_event_destroy": [P],
+    "semabs_event_elapsed_ms": [P, P, C.POINTER(F)],
 }
 
 

@@ -27,16 +27,43 @@ EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP = 0, 1, 2, 3, 4
 
 
 class GemmTimer:
-    """Optional live timing of every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+    """Optional live timing of every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The events are filled
+    by the dispatch packet of the kernel itself (`semabs_gemm_time_next` -> hipExtLaunchKernelGGL), not recorded around it: no barrier
+    packets are inserted between consecutive kernels, so timing does not perturb the step being timed."""
 
     def __init__(self):
-        self.records = []          # (start_event, stop_event, flops)
+        self.records = []          # (start_event, stop_event, flops); raw hipEvent_t handles
+        self._free = []
+
+    def _pair(self):
+        import ctypes as C
+        if self._free:
+            return self._free.pop()
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.call("semabs_event_create", C.byref(a))
+        _lib.call("semabs_event_create", C.byref(b))
+        return a, b
 
     def summary(self):
+        import ctypes as C
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        ms, tmp = 0.0, C.c_float()
+        for a, b, _ in self.records:
+            _lib.call("semabs_event_elapsed_ms", a, b, C.byref(tmp))
+            ms += tmp.value
         fl = sum(f for _, _, f in self.records)
-        return dict(launches=len(self.records), total_ms=ms, flops=fl)
+        out = dict(launches=len(self.records), total_ms=ms, flops=fl)
+        self._free.extend((a, b) for a, b, _ in self.records)
+        self.records = []
+        return out
+
+    def __del__(self):
+        try:
+            for a, b in self._free + [(x, y) for x, y, _ in self.records]:
+                _lib.call("semabs_event_destroy", a)
+                _lib.call("semabs_event_destroy", b)
+        except Exception:
+            pass
 
 
 GEMM_TIMER: "GemmTimer | None" = None
@@ -45,12 +72,10 @@ GEMM_TIMER: "GemmTimer | None" = None
 def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):
     t = GEMM_TIMER
     if t is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend, rowmap)
-    if t is not None:
-        e1.record()
+        e0, e1 = t._pair()
+        _lib.call("semabs_gemm_time_next", e0, e1)
         t.records.append((e0, e1, 2.0 * M * N * K))
+    _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend, rowmap)
 
 
 def _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):

@@ -17,6 +17,7 @@
 // Both: fused epilogues (bias / QuickGELU / fp32 residual read-modify-write / row-remap + addend), block ids remapped so the blocks that
 // share operand panels run on one XCD (private L2) with grouped rasterisation.
 #include "semabs_common.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 #define BK 64   // K granularity required by the ABI (both K-tile sizes divide it)
@@ -229,6 +230,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
     }
 }
 
+// Optional per-launch timing: the NEXT GEMM launch records its start / stop timestamps into these HIP events through the dispatch packet
+// itself (hipExtLaunchKernelGGL) - no extra barrier packets around the kernel, unlike hipEventRecord before and after it.
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+extern "C" int semabs_gemm_time_next(void* start_event, void* stop_event) {
+    g_ev_start = (hipEvent_t)start_event; g_ev_stop = (hipEvent_t)stop_event;
+    return SEMABS_OK;
+}
+template <typename Kern>
+static inline void gemm_dispatch(Kern kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const GemmArgs& g) {
+    if (g_ev_start && g_ev_stop) {
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_ev_start, g_ev_stop, 0, g);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, g);
+    }
+}
+
 static int g_group_m = 8;
 static int g_ablate = 0;
 static int g_force_cfg = 0;     // 0 = heuristic, 1 = 128x128 / 4 waves, 2 = 256x256 / 8 waves (tuning / tests)
@@ -254,7 +272,7 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
     g.ablate = g_ablate;
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
-    hipLaunchKernelGGL((k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>), dim3(g.n_blocks), dim3(64 * WGM * WGN), LDS, s, g);
+    gemm_dispatch(k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>, dim3(g.n_blocks), dim3(64 * WGM * WGN), LDS, s, g);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -521,7 +539,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s) {
     g.ablate = g_ablate;
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
-    hipLaunchKernelGGL((k_gemm8<EPI>), dim3(g.n_blocks), dim3(512), LDS, s, g);
+    gemm_dispatch(k_gemm8<EPI>, dim3(g.n_blocks), dim3(512), LDS, s, g);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -24,3 +24,21 @@ extern "C" int semabs_device_info(char* name, int name_len, int* cu_count, long 
     if (hbm_bytes) *hbm_bytes = (long long)p.totalGlobalMem;
     return SEMABS_OK;
 }
+
+// HIP event helpers for the per-launch GEMM timing of bench.py (events with timing enabled; see semabs_gemm_time_next)
+extern "C" int semabs_event_create(void** ev) {
+    SEMABS_REQUIRE(ev, "semabs_event_create: null pointer");
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { semabs_set_error("hipEventCreate failed"); return SEMABS_EHIP; }
+    *ev = (void*)e;
+    return SEMABS_OK;
+}
+extern "C" int semabs_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+    return SEMABS_OK;
+}
+extern "C" int semabs_event_elapsed_ms(void* start, void* stop, float* ms) {
+    SEMABS_REQUIRE(start && stop && ms, "semabs_event_elapsed_ms: null pointer");
+    if (hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) { semabs_set_error("hipEventElapsedTime failed"); return SEMABS_EHIP; }
+    return SEMABS_OK;
+}
