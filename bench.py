@@ -85,6 +85,7 @@ def main():
                     "output tiles for N = 768 / 2304 / 3072, i.e. 1.99 / 5.98 / 7.97 waves of the 256 CUs (no ragged last wave)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over (2 = +4%% scenes/s, but "
                     "overlapping kernels blur the per-launch HIP-event timing the roofline leg relies on)")
+    ap.add_argument("--cu-split", action="store_true", help="with --streams N: give each stream its own 1/N of every XCD's CUs (CU-masked streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,6 +113,7 @@ def main():
     n_scenes = args.steps + args.warmup
     from semabs_amd.clip import ClipWrapper, saliency_configs
     ClipWrapper.n_streams = max(1, args.streams)
+    ClipWrapper.cu_partition = bool(args.cu_split)
     cfg = saliency_configs["ours"](IMG)
     scenes = [pipe.upload(synth_scene(IMG, IMG, seed=1000 * rank + i)) for i in range(n_scenes)]      # RGB-D frames resident in HBM
 

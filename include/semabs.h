@@ -287,6 +287,13 @@ int semabs_event_create(void** ev);
 int semabs_event_destroy(void* ev);
 int semabs_event_elapsed_ms(void* start, void* stop, float* ms);
 
+/* CU-partitioned streams: kernels of such a stream only run on the CUs named in `mask` (bit i = CU i, driver numbering).  ClipWrapper runs
+ * two tile-chunk pipelines side by side on disjoint halves of the chip with them.  semabs_probe_placement reports where the workgroups of a
+ * stream land: out int32[n_blocks,2] = (XCC id, HW_ID register). */
+int semabs_stream_create_cumask(void** stream, const uint32_t* mask, int n_words);
+int semabs_stream_destroy(void* stream);
+int semabs_probe_placement(int* out, int n_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

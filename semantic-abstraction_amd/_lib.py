@@ -95,6 +95,9 @@ SIGNATURES = {
     "semabs_event_create": [C.POINTER(P)],
     "semabs_event_destroy": [P],
     "semabs_event_elapsed_ms": [P, P, C.POINTER(F)],
+    "semabs_stream_create_cumask": [C.POINTER(P), C.POINTER(C.c_uint32), I],
+    "semabs_stream_destroy": [P],
+    "semabs_probe_placement": [P, I, P],
 }
 
 

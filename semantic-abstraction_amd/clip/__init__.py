@@ -115,6 +115,7 @@ class ClipWrapper:
     _lut = None
     _rng = np.random.default_rng(0)
     n_streams = 2                       # HIP streams the independent tile chunks are pipelined over
+    cu_partition = False                # True: each stream owns a disjoint 1/n_streams of every XCD's compute units
     _streams = None
     _patches = {}
     state_dict_provider = None          # callable(clip_model_type) -> state dict; set by tests / bench
@@ -279,7 +280,7 @@ class ClipWrapper:
             work.append(segs)
         ns = max(1, min(cls.n_streams, len(work)))
         if cls._streams is None or len(cls._streams) < ns:
-            cls._streams = [torch.cuda.Stream() for _ in range(ns)]
+            cls._streams = cls._make_streams(ns)
             cls._patches = {}
         for i in range(ns):
             cls._streams[i].wait_stream(main)
@@ -319,6 +320,25 @@ class ClipWrapper:
         if return_tiles:
             return rel, table, scales
         return cls.aggregate_device(rel, scales, n_img, H, W)
+
+    @classmethod
+    def _make_streams(cls, ns: int):
+        """`ns` HIP streams for the tile-chunk pipelines.  With `cu_partition` each stream is created with a CU mask: mask bit i is CU
+        i // 8 of XCD i % 8 (probed: tools/cumask_probe.py), so bits [k * 256 / ns, (k + 1) * 256 / ns) give stream k the same share of
+        every XCD and workgroup b of its kernels still runs on XCD b % 8 (the kernels' XCD-aware tile order stays valid)."""
+        if not cls.cu_partition or ns == 1:
+            return [torch.cuda.Stream() for _ in range(ns)]
+        import ctypes as C
+        n_cu = torch.cuda.get_device_properties(cls.device).multi_processor_count
+        out = []
+        for k in range(ns):
+            words = [0] * ((n_cu + 31) // 32)
+            for b in range(k * n_cu // ns, (k + 1) * n_cu // ns):
+                words[b // 32] |= 1 << (b % 32)
+            h = C.c_void_p()
+            _lib.call("semabs_stream_create_cumask", C.byref(h), (C.c_uint32 * len(words))(*words), len(words))
+            out.append(torch.cuda.ExternalStream(h.value, device=cls.device))
+        return out
 
     @classmethod
     def aggregate_device(cls, rel, scales: np.ndarray, n_img: int, H: int, W: int) -> torch.Tensor:
