@@ -472,7 +472,12 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2;
     constexpr int NPROD = 256;                                      // producer threads (waves 4-7)
     constexpr int NIT = (C16_HALO + NPROD - 1) / NPROD;
-    constexpr int BUF_EL = C16_HALO * 16 * (F32 ? 2 : 1);           // fp16 elements per halo buffer: hi planes, then lo planes (exact mode)
+    // One plane = the 16-byte half-voxels (channels 0-7 or 8-15) of the whole halo.  Its size is rounded up to a multiple of 256 B: a
+    // ds_read_b128 is served in lane groups such as {0-3, 12-15, 20-27}, i.e. voxels 0-3 / 12-15 of plane 0 together with voxels 4-11 of
+    // plane 1 - the group covers all 64 banks exactly once only if the plane offset is = 0 mod 256 B (unpadded it is 128 mod 256: 2-way
+    // conflicts on every fragment read, SQ_LDS_BANK_CONFLICT = 46 % of the LDS-active cycles).
+    constexpr int PLANE = (C16_HALO * 8 + 127) / 128 * 128;         // fp16 elements
+    constexpr int BUF_EL = PLANE * 2 * (F32 ? 2 : 1);               // fp16 elements per halo buffer: hi planes, then lo planes (exact mode)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -494,65 +499,83 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         const int t1 = t % n1; const int t0 = t / n1;
         const int z0 = t0 * C16_T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
         f16* s_hi = reinterpret_cast<f16*>(smem) + buf * BUF_EL;
-        f16* s_lo = s_hi + C16_HALO * 16;
-        // two batches of loads (3 + 2 voxels per thread): all in flight at once would need 80 VGPRs next to the consumers' 112 weight
-        // registers (the allocation is the union of both roles); the producers have a whole MFMA phase of slack for the second round trip
-        constexpr int NB1 = (NIT + 1) / 2;
+        f16* s_lo = s_hi + PLANE * 2;
+        // task = (halo voxel, 8-channel half).  Eight consecutive lanes take eight consecutive voxels of ONE half, the next eight lanes the
+        // other half of the same voxels: a wave's loads still cover whole 64-byte voxels, its ds_write_b128 lane groups (8 x 8 lanes) write
+        // 128 contiguous bytes of one plane, and a thread keeps ONE channel half for all of its tasks, so the GroupNorm scale / shift of its
+        // 8 channels are fetched once per brick (indexing them per element made the compiler emit 32 dependent broadcast loads per voxel).
+        const int hsel = (ptid >> 3) & 1;
+        const int vsub = (ptid & 7) + ((ptid >> 4) << 3);          // 0 .. 127
+        float gs[8], gh[8];
+        if (has_gn) {
+            const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + b * 16 + hsel * 8);
+            const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + b * 16 + hsel * 8);
+            const float4 s0 = ps[0], s1 = ps[1], h0 = pt[0], h1 = pt[1];
+            gs[0] = s0.x; gs[1] = s0.y; gs[2] = s0.z; gs[3] = s0.w; gs[4] = s1.x; gs[5] = s1.y; gs[6] = s1.z; gs[7] = s1.w;
+            gh[0] = h0.x; gh[1] = h0.y; gh[2] = h0.z; gh[3] = h0.w; gh[4] = h1.x; gh[5] = h1.y; gh[6] = h1.z; gh[7] = h1.w;
+        } else {
 #pragma unroll
-        for (int base = 0; base < NIT; base += NB1) {
-            float raw[NB1][16];
-            bool inb[NB1];
+            for (int j = 0; j < 8; ++j) { gs[j] = 1.f; gh[j] = 0.f; }
+        }
+        // Every halo load of the brick is issued before the first one is used (NT x 8 VGPRs; the producer loop below is a separate branch
+        // of the kernel, so these registers overlap the consumers' 112 weight registers).  Out-of-volume taps read a clamped (valid)
+        // address and are zeroed afterwards: no divergent branches around the loads.  Addresses = brick base (scalar, 64-bit) + a 32-bit
+        // per-lane element offset.
+        constexpr int NT = (C16_HALO + 127) / 128;                  // tasks per thread
+        const float* xb = reinterpret_cast<const float*>(a.x) + (size_t)b * a.I0 * a.I1 * a.I2 * 16;
+        const f16* xbh = reinterpret_cast<const f16*>(a.x) + (size_t)b * a.I0 * a.I1 * a.I2 * 16;
+        float raw[NT][8];
+        bool inb[NT];
 #pragma unroll
-            for (int k = 0; k < NB1; ++k) {
-                const int it = base + k;
-                const int v = ptid + it * NPROD;
-                const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
-                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-                inb[k] = it < NIT && v < C16_HALO && gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
-                if (inb[k]) {
-                    const long idx = ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * 16;
-                    float lo8[8], hi8[8];
-                    load8<F32>(a.x, idx, lo8);
-                    load8<F32>(a.x, idx + 8, hi8);
+        for (int k = 0; k < NT; ++k) {
+            const int v = min(vsub + k * 128, C16_HALO - 1);
+            const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            inb[k] = gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
+            const int cz = min(max(gz, 0), a.I0 - 1), cy = min(max(gy, 0), a.I1 - 1), cx = min(max(gx, 0), a.I2 - 1);
+            const unsigned eo = (unsigned)(((cz * a.I1 + cy) * a.I2 + cx) * 16 + hsel * 8);      // < 2^31 elements per volume (checked on the host)
+            {
+                if (F32) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(xb + eo), q1 = *reinterpret_cast<const float4*>(xb + eo + 4);
+                    raw[k][0] = q0.x; raw[k][1] = q0.y; raw[k][2] = q0.z; raw[k][3] = q0.w; raw[k][4] = q1.x; raw[k][5] = q1.y; raw[k][6] = q1.z; raw[k][7] = q1.w;
+                } else {
+                    const f16x8 q = *reinterpret_cast<const f16x8*>(xbh + eo);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) { raw[k][c] = lo8[c]; raw[k][8 + c] = hi8[c]; }
+                    for (int c = 0; c < 8; ++c) raw[k][c] = (float)q[c];
                 }
             }
+        }
 #pragma unroll
-            for (int k = 0; k < NB1; ++k) {
-                const int it = base + k;
-                const int v = ptid + it * NPROD;
-                float val[16];
+        for (int k = 0; k < NT; ++k) {
+            const int v = vsub + k * 128;
+            f16x8 h, l;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const float sc = has_gn ? a.gn_scale[b * 16 + c] : 1.f, sh = has_gn ? a.gn_shift[b * 16 + c] : 0.f;   // uniform: scalar loads
-                    val[c] = inb[k] ? raw[k][c] * sc + sh : 0.f;    // zero padding AFTER the normalisation
-                }
-                f16x8 h0, h1, l0, l1;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    h0[c] = (f16)val[c]; h1[c] = (f16)val[8 + c];
-                    if (F32) { l0[c] = (f16)(val[c] - (float)h0[c]); l1[c] = (f16)(val[8 + c] - (float)h1[c]); }
-                }
-                if (it < NIT && v < C16_HALO) {                      // two planes of 16-byte half-voxels: [channels 0-7][v], [channels 8-15][v]
-                    *reinterpret_cast<f16x8*>(s_hi + v * 8) = h0; *reinterpret_cast<f16x8*>(s_hi + C16_HALO * 8 + v * 8) = h1;
-                    if (F32) { *reinterpret_cast<f16x8*>(s_lo + v * 8) = l0; *reinterpret_cast<f16x8*>(s_lo + C16_HALO * 8 + v * 8) = l1; }
-                }
+            for (int c = 0; c < 8; ++c) {
+                const float val = inb[k] ? raw[k][c] * gs[c] + gh[c] : 0.f;          // zero padding AFTER the normalisation
+                h[c] = (f16)val;
+                if (F32) l[c] = (f16)(val - (float)h[c]);
+            }
+            if (v < C16_HALO) {                                     // two planes of 16-byte half-voxels: [channels 0-7][v], [channels 8-15][v]
+                *reinterpret_cast<f16x8*>(s_hi + hsel * PLANE + v * 8) = h;
+                if (F32) *reinterpret_cast<f16x8*>(s_lo + hsel * PLANE + v * 8) = l;
             }
         }
     };
 
     // consumers: weights (A operand, rows = cout) for all 14 k-steps live in registers
     f16x8 wh[14], wl[14];
-    if (!producer) {
+    auto load_weights = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
             const long widx = (long)vl * a.Kp + ks * 32 + kg * 8;
             wh[ks] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
             if (F32) wl[ks] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
         }
-    }
+    };
     const int half = kg & 1, tsel = kg >> 1;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * kg);
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
     constexpr int ROWS_PER_WAVE = C16_T0 * 2;                        // 4 consumer waves share the brick's T0 * 8 rows
 
     auto consume = [&](int brick, int buf) {
@@ -561,7 +584,8 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         const int t1 = t % n1; const int t0 = t / n1;
         const int z0 = t0 * C16_T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
         const f16* s_hi = reinterpret_cast<const f16*>(smem) + buf * BUF_EL;
-        const f16* s_lo = s_hi + C16_HALO * 16;
+        const f16* s_lo = s_hi + PLANE * 2;
+        const size_t vol_off = (size_t)b * a.I0 * a.I1 * a.I2 * 16;
         constexpr int MR = 4;                                       // rows in flight per wave: 4 independent accumulator chains, and the
 #pragma unroll 1                                                    // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
         for (int pr = 0; pr < ROWS_PER_WAVE / MR; ++pr) {
@@ -570,91 +594,123 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
             for (int mi = 0; mi < MR; ++mi) {
                 const int row = wid * ROWS_PER_WAVE + pr * MR + mi; // z * 8 + y
                 rz[mi] = row >> 3; ry[mi] = row & 7;
-                lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 8 + half * (C16_HALO * 8);   // element offset of the centre tap
+                lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 8 + half * PLANE;   // element offset of the centre tap
             }
             f32x4 acc[MR];
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // Output offsets and the residual rows are fetched now: the loads have the whole k-loop (~2 700 cycles) to arrive, and the epilogue
+            // after the last MFMA is a dozen branch-free instructions per row (the matrix pipe idles while it runs).
+            unsigned ooff[MR];                                      // element offset inside volume b; < 2^31 (checked on the host)
+            f32x4 res[MR];
+#pragma unroll
+            for (int mi = 0; mi < MR; ++mi) {
+                ooff[mi] = (unsigned)((((z0 + rz[mi]) * a.I1 + (y0 + ry[mi])) * a.I2 + (x0 + vl)) * 16 + 4 * kg);
+                res[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (a.resid) {
+#pragma unroll
+                for (int mi = 0; mi < MR; ++mi) {
+                    if (F32) res[mi] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.resid) + vol_off + ooff[mi]);
+                    else {
+                        const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + vol_off + ooff[mi]);
+                        res[mi] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                    }
+                }
+            }
+            // Fragment double buffer: the 2 x MR fragments of k-step ks + 1 are requested before the 3 x MR MFMAs of k-step ks (~190 cycles of
+            // cover for the LDS round trip); within a k-step the MFMAs go round the MR accumulators, so dependent MFMAs are MR issues apart.
+            // The sched_barrier keeps the compiler from sinking the requests next to their first use (it did: MFMA busy 45 %).
             f16x8 xh[2][MR], xl[2][MR];
-            auto frags = [&](int ks, int slot) {
+            auto tap_off = [&](int ks) {
                 // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
                 const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
                 const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 8;
                 const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 8;
-                const int off = tsel ? offb : offa;
-#pragma unroll
-                for (int mi = 0; mi < MR; ++mi) {
-                    xh[slot][mi] = *reinterpret_cast<const f16x8*>(s_hi + lbase[mi] + off);
-                    if (F32) xl[slot][mi] = *reinterpret_cast<const f16x8*>(s_lo + lbase[mi] + off);
-                }
+                return tsel ? offb : offa;
             };
-            frags(0, 0);
+            // request j of a k-step: j < MR -> hi fragment of row j, else lo fragment of row j - MR
+            auto request = [&](int ks, int j) {
+                const int slot = ks & 1, off = tap_off(ks);
+                if (j < MR) xh[slot][j] = *reinterpret_cast<const f16x8*>(s_hi + lbase[j] + off);
+                else xl[slot][j - MR] = *reinterpret_cast<const f16x8*>(s_lo + lbase[j - MR] + off);
+            };
+            constexpr int NREQ = (F32 ? 2 : 1) * MR, NMFMA = (F32 ? 3 : 1) * MR;
+#pragma unroll
+            for (int j = 0; j < NREQ; ++j) request(0, j);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 14; ++ks) {
-                if (ks + 1 < 14) frags(ks + 1, (ks + 1) & 1);
+                // MFMA i of the k-step: i / MR = 0: wh . xh, 1: wl . xh, 2: wh . xl (exact mode); they go round the MR accumulators, so dependent
+                // MFMAs are MR issues apart.  Request j of k-step ks + 1 is issued right after MFMA j: its issue slot hides under the matrix
+                // pipe, and every fragment has a full k-step (~190 cycles) to arrive.  The sched_barriers pin this order (left alone the
+                // compiler merges the two fragment buffers and issues the requests next to their first use: MFMA busy 45 %).
 #pragma unroll
-                for (int mi = 0; mi < MR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xh[ks & 1][mi], acc[mi], 0, 0, 0);
-                if (F32) {
-#pragma unroll
-                    for (int mi = 0; mi < MR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks], xh[ks & 1][mi], acc[mi], 0, 0, 0);
-#pragma unroll
-                    for (int mi = 0; mi < MR; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks], xl[ks & 1][mi], acc[mi], 0, 0, 0);
+                for (int i = 0; i < NMFMA; ++i) {
+                    const int mi = i % MR, kind = i / MR;
+                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kind == 1 ? wl[ks] : wh[ks], kind == 2 ? xl[ks & 1][mi] : xh[ks & 1][mi], acc[mi], 0, 0, 0);
+                    if (i < NREQ && ks + 1 < 14) request(ks + 1, i);
+                    if (i < NREQ) __builtin_amdgcn_sched_barrier(0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (a.ksplit == 4) { if (acc[0][0] != 1234.5f) continue; }
             // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
-                const long ovox = (((long)b * a.I0 + (z0 + rz[mi])) * a.I1 + (y0 + ry[mi])) * a.I2 + (x0 + vl);
-                const long oidx = ovox * 16 + 4 * kg;
-                float o[4] = {acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
-                if (a.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + 4 * kg);
-                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-                }
-                if (a.resid) {
-                    if (F32) {
-                        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx);
-                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-                    } else {
-                        const f16x4 r = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oidx);
-                        o[0] += (float)r[0]; o[1] += (float)r[1]; o[2] += (float)r[2]; o[3] += (float)r[3];
-                    }
-                }
-                if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[mi][e] + bias4[e] + res[mi][e], relu_floor);
                 if (F32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + vol_off + ooff[mi]) = make_float4(o[0], o[1], o[2], o[3]);
                 } else {
                     f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3];
-                    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
+                    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + vol_off + ooff[mi]) = h;
                 }
             }
         }
     };
 
-    int brick = blockIdx.x;
-    if (producer && brick < total) produce(brick, 0);
-    __syncthreads();
-    int buf = 0;
-    for (; brick < total; brick += gridDim.x, buf ^= 1) {
-        const int next = brick + gridDim.x;
-        if (producer) { if (next < total) produce(next, buf ^ 1); }   // the other buffer: consumed one iteration ago, before the barrier
-        else consume(brick, buf);
-        __syncthreads();
+    // Two role loops with the same barrier count (one per brick + one for the first halo).  They are separate branches so that the register
+    // allocation of each role only carries its own live values (the weights are not live in the producer loop).
+    // The barriers only order LDS traffic (halo buffers); __syncthreads() would also wait for the consumers' global stores to complete
+    // (vmcnt(0)) once per brick.
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if (producer) {
+        int brick = blockIdx.x;
+        if (brick < total) produce(brick, 0);
+        lds_barrier();
+        int buf = 0;
+        for (; brick < total; brick += gridDim.x, buf ^= 1) {
+            const int next = brick + gridDim.x;
+            if (next < total && a.ksplit != 2 && a.ksplit < 4) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
+            lds_barrier();
+        }
+    } else {
+        load_weights();
+        lds_barrier();
+        int buf = 0;
+        for (int brick = blockIdx.x; brick < total; brick += gridDim.x, buf ^= 1) {
+            if (a.ksplit != 1) consume(brick, buf);   // ablation: 4 = no epilogue, 5 = no fragment reads, 6 = neither
+            lds_barrier();
+        }
     }
 }
 
 static int g_conv16_lds = 1;     // tuning / test hook: 0 = always use the generic gather kernel
-extern "C" int semabs_conv_set_config(int use_lds_brick) { g_conv16_lds = use_lds_brick; return SEMABS_OK; }
+static int g_conv16_ablate = 0;
+extern "C" int semabs_conv_set_config(int use_lds_brick) { g_conv16_lds = use_lds_brick & 1; g_conv16_ablate = use_lds_brick >> 1; return SEMABS_OK; }
 
 static int semabs_num_cus() {
     static int n = 0;
     if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
     return n;
 }
-static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
+static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
+    ConvArgs a = a_in; a.ksplit = g_conv16_ablate;
     if (f32) {
         constexpr int T0 = 4;
-        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2 * 2 * 2;       // hi + lo, two buffers
+        const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2 * 2;   // two half-voxel planes (256-B padded), hi + lo, two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
         long nb = semabs_num_cus(); if (nb > total) nb = total;
         static bool set = false;
@@ -662,7 +718,7 @@ static int conv16_lds_launch(const ConvArgs& a, int f32, hipStream_t s) {
         hipLaunchKernelGGL((k_conv16_lds<true, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
     } else {
         constexpr int T0 = 8;
-        const size_t lds = (size_t)(T0 + 2) * C16_H1 * C16_H2 * 16 * 2 * 2;           // two buffers
+        const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2;       // two half-voxel planes (256-B padded), two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
         long nb = semabs_num_cus(); if (nb > total) nb = total;
         static bool set = false;
@@ -934,7 +990,7 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
         for (int kh = 0; kh < ksize; ++kh)
             for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
     SEMABS_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && ksize == 1), "semabs_conv3d: relu must be 0, 1, or 2 (LeakyReLU, ksize 1 only)");
-    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
+    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31))
         return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
     if (g_conv16_lds && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
         return conv_brick_launch(a, act_f32, (hipStream_t)stream);
