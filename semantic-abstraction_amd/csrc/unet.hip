@@ -744,8 +744,13 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     constexpr int CPV = CW / 8;                             // 16-byte chunks per staged voxel
     constexpr int NSTEPS = CW == 32 ? 27 : 14;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* s_hi = reinterpret_cast<f16*>(smem);               // [HALO][CW], chunk-swizzled
-    f16* s_lo = s_hi + HALO * CW;                           // exact mode only
+    // LDS layout: one plane per 8-channel chunk, [CPV][PLANE] 16-byte half-voxels, plane size a multiple of 256 B.  A ds_read_b128 is served
+    // in lane groups such as {0-3, 12-15, 20-27} = voxels 0-3 / 12-15 of chunk kg and voxels 4-11 of chunk kg ^ 1: with the planes a
+    // multiple of 256 B apart those are 16 distinct 16-byte slots of the 64 banks for any start voxel (the former [voxel][chunk ^ f(voxel)]
+    // swizzle assumed contiguous 16-lane groups: SQ_LDS_BANK_CONFLICT was 42 % of the LDS-active cycles).
+    constexpr int PLANE = (HALO * 8 + 127) / 128 * 128;    // fp16 elements
+    f16* s_hi = reinterpret_cast<f16*>(smem);
+    f16* s_lo = s_hi + PLANE * CPV;                         // exact mode only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vl = lane & 15, kg = lane >> 4;
@@ -756,7 +761,6 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     const int t2 = t % n2; t /= n2;
     const int t1 = t % n1; const int t0 = t / n1;
     const int z0 = t0 * T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
-    auto swz = [](int v, int chunk) { return CW == 32 ? (chunk ^ ((v >> 2) & 3)) : (chunk ^ ((v >> 3) & 1)); };
     const bool has_gn = a.gn_scale != nullptr;
 
     f32x4 acc[4][NB];
@@ -775,10 +779,14 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                            // every wave is done reading the previous channel chunk
         // ---- halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
-        // NTHR % CPV == 0, so a thread keeps the same 8-channel chunk c for all of its tasks: one GroupNorm scale / shift fetch, and all
-        // of its halo loads in flight together (see k_conv16_lds: one round trip per iteration otherwise)
-        constexpr int NIT = (HALO * CPV + NTHR - 1) / NTHR;
-        const int c = tid % CPV;
+        // Eight consecutive lanes = eight consecutive halo voxels of ONE chunk, the next eight lanes the next chunk of the same voxels: a wave's
+        // loads still cover whole voxels, each 8-lane ds_write_b128 group writes 128 contiguous bytes of one plane.  A thread keeps its chunk
+        // for all of its tasks (one GroupNorm scale / shift fetch); all of its halo loads are in flight together; out-of-volume taps read a
+        // clamped address and are zeroed afterwards (no divergent branches around the loads).
+        constexpr int VPI = NTHR / CPV;                     // halo voxels staged per iteration
+        constexpr int NIT = (HALO + VPI - 1) / VPI;
+        const int c = (tid >> 3) % CPV;
+        const int vsub = (tid & 7) + ((tid / (8 * CPV)) << 3);
         const int ch = cc * CW + c * 8;
         float gs[8], gh[8];
         if (has_gn) {
@@ -795,15 +803,16 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
         bool inb[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int v = (tid + it * NTHR) / CPV;
+            const int v = min(vsub + it * VPI, HALO - 1);
             const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            inb[it] = v < HALO && gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
-            if (inb[it]) load8<F32>(a.x, ((((long)b * a.I0 + gz) * a.I1 + gy) * a.I2 + gx) * Cin + ch, raw[it]);
+            inb[it] = gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
+            const int cz = min(max(gz, 0), a.I0 - 1), cy = min(max(gy, 0), a.I1 - 1), cx = min(max(gx, 0), a.I2 - 1);
+            load8<F32>(a.x, ((((long)b * a.I0 + cz) * a.I1 + cy) * a.I2 + cx) * Cin + ch, raw[it]);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int v = (tid + it * NTHR) / CPV;
+            const int v = vsub + it * VPI;
             f16x8 h, l;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
                 h[j] = (f16)val; if (F32) l[j] = (f16)(val - (float)h[j]);
             }
             if (v < HALO) {
-                const int off = v * CW + swz(v, c) * 8;
+                const int off = c * PLANE + v * 8;
                 *reinterpret_cast<f16x8*>(s_hi + off) = h;
                 if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
             }
@@ -843,8 +852,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int v = rbase[r] + voff;
-                const int off = v * CW + swz(v, chunk) * 8;
+                const int off = chunk * PLANE + (rbase[r] + voff) * 8;
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + off);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh, acc[r][nb], 0, 0, 0);
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
 
 template <bool F32, int CW, int NB, bool ONE>
 static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)6 * C16_H1 * C16_H2 * CW * 2 * (F32 ? 2 : 1);
+    const size_t lds = (size_t)((6 * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * (CW / 8) * 2 * (F32 ? 2 : 1);      // CW / 8 planes (256-B padded), hi (+ lo), fp16
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     dim3 grid((a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B, a.Cout / (NB * 16));
