@@ -150,6 +150,12 @@ int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta
 int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                   const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                   int act_f32, void* stream);
+/* Same convolution, and the GroupNorm statistics of its OUTPUT for the next layer: out_sums fp64 [B, out_groups, 2] (sum, sum of squares
+ * per group; zero-filled by the caller) -> semabs_gn_finalize.  Fused into the epilogue at the 128^3 x 16-channel level (saves one full
+ * read of the tensor per GroupNorm, unet3d.py:66-79), a statistics pass over y elsewhere. */
+int semabs_conv3d_stats(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                        const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
+                        int act_f32, double* out_sums, int out_groups, void* stream);
 /* tuning / test hook: 1 (default) = Cin = Cout = 16 3^3 convolutions on bricks that are multiples of 8 x 8 x 16 use the
  * LDS-halo kernel, 0 = always the generic gather kernel */
 int semabs_conv_set_config(int use_lds_brick);

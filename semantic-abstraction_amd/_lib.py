@@ -60,6 +60,7 @@ SIGNATURES = {
     "semabs_gn_stats": [P, P, I, L, I, I, I, P],
     "semabs_gn_finalize": [P, P, P, P, P, I, I, I, L, F, P],
     "semabs_conv3d": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "semabs_conv3d_stats": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
     "semabs_conv_set_config": [I],
     "semabs_convtranspose3d": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P],
     "semabs_maxpool3d": [P, P, I, I, I, I, I, I, P],

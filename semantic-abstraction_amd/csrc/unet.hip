@@ -266,6 +266,7 @@ struct ConvArgs {
     int ksplit;                 // > 1: blockIdx.z takes a slice of the k-steps and adds its partial sum to y (fp32, pre-zeroed) with atomics;
                                 // bias / residual / ReLU are then applied by k_conv_finish
     signed char td0[28], td1[28], td2[28];   // tap offsets: input coordinate = m + td  (conv pad-1: -1..1; convT: 0/+1)
+    double* stats;              // optional (k_conv16_lds): fp64 [B, 8, 2] sum / sum of squares of the OUTPUT per GroupNorm group, accumulated
 };
 
 template <bool F32>
@@ -576,6 +577,23 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * kg);
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    // Fused GroupNorm statistics of the output (8 groups of 2 channels): a lane's four output channels 4 kg .. 4 kg + 3 are the groups 2 kg
+    // and 2 kg + 1.  fp32 partial sums per 4-row group, fp64 running sums per wave while the volume index stays the same, then a 16-lane
+    // reduction and one fp64 atomic per (group, moment) per wave per volume.
+    double st[4] = {0.0, 0.0, 0.0, 0.0};                            // sum / sum of squares of group 2 kg, then of group 2 kg + 1
+    int st_b = -1;
+    auto flush_stats = [&]() {
+        if (st_b >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = st[j];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+                if (vl == 0) atomicAdd(a.stats + ((long)st_b * 8 + 2 * kg + (j >> 1)) * 2 + (j & 1), v);
+                st[j] = 0.0;
+            }
+        }
+    };
     constexpr int ROWS_PER_WAVE = C16_T0 * 2;                        // 4 consumer waves share the brick's T0 * 8 rows
 
     auto consume = [&](int brick, int buf) {
@@ -586,6 +604,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         const f16* s_hi = reinterpret_cast<const f16*>(smem) + buf * BUF_EL;
         const f16* s_lo = s_hi + PLANE * 2;
         const size_t vol_off = (size_t)b * a.I0 * a.I1 * a.I2 * 16;
+        if (a.stats && b != st_b) { flush_stats(); st_b = b; }
         constexpr int MR = 4;                                       // rows in flight per wave: 4 independent accumulator chains, and the
 #pragma unroll 1                                                    // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
         for (int pr = 0; pr < ROWS_PER_WAVE / MR; ++pr) {
@@ -656,17 +675,28 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
             }
             if (a.ksplit == 4) { if (acc[0][0] != 1234.5f) continue; }
             // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[mi][e] + bias4[e] + res[mi][e], relu_floor);
+                if (!F32) {                                          // statistics of the values as stored
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (float)(f16)o[e];
+                }
+                ps[0] += o[0] + o[1]; ps[1] += o[0] * o[0] + o[1] * o[1];
+                ps[2] += o[2] + o[3]; ps[3] += o[2] * o[2] + o[3] * o[3];
                 if (F32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + vol_off + ooff[mi]) = make_float4(o[0], o[1], o[2], o[3]);
                 } else {
                     f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3];
                     *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + vol_off + ooff[mi]) = h;
                 }
+            }
+            if (a.stats) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[j] += (double)ps[j];
             }
         }
     };
@@ -691,9 +721,10 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         lds_barrier();
         int buf = 0;
         for (int brick = blockIdx.x; brick < total; brick += gridDim.x, buf ^= 1) {
-            if (a.ksplit != 1) consume(brick, buf);   // ablation: 4 = no epilogue, 5 = no fragment reads, 6 = neither
+            if (a.ksplit != 1) consume(brick, buf);   // ablation: 4 = no epilogue
             lds_barrier();
         }
+        if (a.stats) flush_stats();
     }
 }
 
@@ -979,9 +1010,12 @@ static int conv_common_checks(const void* x, const void* w_hi, const void* w_lo,
 // act_f32).  w_hi / w_lo fp16 [Cout, Kp], k index = ((kd*3 + kh)*3 + kw) * Cin + cin, Kp = K rounded up to 32.
 // gn_scale / gn_shift fp32 [B, Cin] (null = no GroupNorm in front); bias fp32 [Cout] or null; resid like y or null.
 // relu: 0 none, 1 ReLU, 2 LeakyReLU(0.01) (generic kernel only: ksize 1, i.e. the MLP layers of the training step).
-extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
-                             const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
-                             int relu, int act_f32, void* stream) {
+// out_sums (optional): fp64 [B, out_groups, 2], ZERO-FILLED by the caller; receives the GroupNorm statistics (sum, sum of squares per group)
+// of the output y - fused into the convolution's epilogue where the kernel supports it (the 128^3 x 16-channel level), otherwise by a
+// statistics pass over y on the same stream.
+static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                       const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
+                       int relu, int act_f32, double* out_sums, int out_groups, void* stream) {
     if (B == 0) return SEMABS_OK;
     int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
     if (rc) return rc;
@@ -993,16 +1027,35 @@ extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, 
     a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.ntaps = ksize * ksize * ksize;
     a.Kp = ((a.ntaps * Cin + 31) / 32) * 32;
+    a.stats = nullptr;
     int t = 0;
     for (int kd = 0; kd < ksize; ++kd)
         for (int kh = 0; kh < ksize; ++kh)
             for (int kw = 0; kw < ksize; ++kw, ++t) { a.td0[t] = kd - ksize / 2; a.td1[t] = kh - ksize / 2; a.td2[t] = kw - ksize / 2; }
     SEMABS_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && ksize == 1), "semabs_conv3d: relu must be 0, 1, or 2 (LeakyReLU, ksize 1 only)");
-    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31))
-        return conv16_lds_launch(a, act_f32, (hipStream_t)stream);
-    if (g_conv16_lds && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0)
-        return conv_brick_launch(a, act_f32, (hipStream_t)stream);
-    return conv_launch(a, act_f32, (hipStream_t)stream);
+    SEMABS_REQUIRE(!out_sums || (out_groups > 0 && Cout % out_groups == 0), "semabs_conv3d_stats: Cout must be a multiple of out_groups");
+    bool fused = false;
+    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31)) {
+        if (out_sums && out_groups == 8) { a.stats = out_sums; fused = true; }
+        rc = conv16_lds_launch(a, act_f32, (hipStream_t)stream);
+    } else if (g_conv16_lds && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0) {
+        rc = conv_brick_launch(a, act_f32, (hipStream_t)stream);
+    } else {
+        rc = conv_launch(a, act_f32, (hipStream_t)stream);
+    }
+    if (rc == SEMABS_OK && out_sums && !fused) rc = semabs_gn_stats(y, out_sums, B, (long)D0 * D1 * D2, Cout, out_groups, act_f32, stream);
+    return rc;
+}
+extern "C" int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                             const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
+                             int relu, int act_f32, void* stream) {
+    return conv3d_impl(x, w_hi, w_lo, y, gn_scale, gn_shift, bias, resid, B, D0, D1, D2, Cin, Cout, ksize, relu, act_f32, nullptr, 0, stream);
+}
+extern "C" int semabs_conv3d_stats(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                                   const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
+                                   int relu, int act_f32, double* out_sums, int out_groups, void* stream) {
+    SEMABS_REQUIRE(out_sums, "semabs_conv3d_stats: out_sums is null");
+    return conv3d_impl(x, w_hi, w_lo, y, gn_scale, gn_shift, bias, resid, B, D0, D1, D2, Cin, Cout, ksize, relu, act_f32, out_sums, out_groups, stream);
 }
 
 // General gather convolution (used for the data gradients of training): y[b, m, :] = sum_taps W_tap . x[b, m * in_stride + td_tap, :]
@@ -1018,7 +1071,7 @@ extern "C" int semabs_conv3d_gather(const void* x, const void* w_hi, const void*
     ConvArgs a;
     SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gather: in_scale and in_shift go together");
     a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
-    a.bias = nullptr; a.resid = nullptr; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
+    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
     a.M0 = M0; a.M1 = M1; a.M2 = M2; a.os = 1; a.is = in_stride; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
     a.ntaps = ntaps; a.Kp = ((ntaps * Cin + 31) / 32) * 32;
     for (int t = 0; t < ntaps; ++t) { a.td0[t] = taps[t * 3]; a.td1[t] = taps[t * 3 + 1]; a.td2[t] = taps[t * 3 + 2]; }
@@ -1196,7 +1249,7 @@ extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const voi
         const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
         ConvArgs a;
         a.x = x; a.y = y; a.w_hi = (const f16*)w_hi + class_off[cls]; a.w_lo = w_lo ? (const f16*)w_lo + class_off[cls] : nullptr;
-        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip;
+        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip; a.stats = nullptr;
         a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = 2 * D0; a.O1 = 2 * D1; a.O2 = 2 * D2;
         a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.is = 1; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
         int t = 0;

@@ -130,30 +130,39 @@ class ResidualUNet3D:
         return self
 
     # ---- kernels -----------------------------------------------------------------------------------
-    def _gn(self, x, conv: _Conv):
+    def _gn(self, x, conv: _Conv, sums=None):
+        """GroupNorm scale / shift [B, C] of `conv`'s input x; `sums` = statistics already produced by the kernel that wrote x."""
         B, nvox, Cc = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], x.shape[4]
         G = conv.groups
-        sums = torch.zeros(B, G, 2, dtype=torch.float64, device=self.dev)
         st = _lib.stream()
-        _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, self.f32, st)
+        if sums is None:
+            sums = torch.zeros(B, G, 2, dtype=torch.float64, device=self.dev)
+            _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, self.f32, st)
         scale = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
         shift = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
         _lib.call("semabs_gn_finalize", _lib.ptr(sums), _lib.ptr(conv.gn_w), _lib.ptr(conv.gn_b), _lib.ptr(scale), _lib.ptr(shift),
                   B, Cc, G, nvox, 1e-5, st)
         return scale, shift
 
-    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None):
+    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None, in_sums=None, out_groups=0):
+        """out_groups > 0: also return the GroupNorm statistics of the output (fp64 [B, out_groups, 2]) for the next layer."""
         B, D0, D1, D2, _ = x.shape
         y = torch.empty(B, D0, D1, D2, conv.cout, dtype=self.act_dtype, device=self.dev)
-        scale, shift = self._gn(x, conv) if gn else (None, None)
-        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
-                  _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32, _lib.stream())
+        scale, shift = self._gn(x, conv, in_sums) if gn else (None, None)
+        args = (_lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
+                _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32)
+        if out_groups:
+            sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
+            _lib.call("semabs_conv3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
+            return y, sums
+        _lib.call("semabs_conv3d", *args, _lib.stream())
         return y
 
     def _block(self, x, convs):
-        out1 = self._conv(x, convs[0], relu=True)
-        out2 = self._conv(out1, convs[1], relu=True)
-        return self._conv(out2, convs[2], relu=True, resid=out1)          # conv3 (no ReLU) + residual, then ReLU
+        # conv1 / conv2 hand the statistics of their outputs to the GroupNorm of conv2 / conv3 (fused into the epilogue where supported)
+        out1, s1 = self._conv(x, convs[0], relu=True, out_groups=convs[1].groups)
+        out2, s2 = self._conv(out1, convs[1], relu=True, in_sums=s1, out_groups=convs[2].groups)
+        return self._conv(out2, convs[2], relu=True, resid=out1, in_sums=s2)          # conv3 (no ReLU) + residual, then ReLU
 
     def _pool(self, x):
         B, D0, D1, D2, Cc = x.shape

@@ -280,3 +280,27 @@ def test_decoder_folded_final_conv_matches_materialised():
     folded = m.decode(m.feature_volume(xyzd, featd, skip_final=True), qd, pre_final=True)
     scale = float(full.abs().max())
     assert float((full - folded).abs().max()) <= 2e-5 * scale and scale > 0
+
+
+@pytest.mark.parametrize("precision", ["exact", "fp16"])
+@pytest.mark.parametrize("cin,cout,dims,B", [(16, 16, (16, 24, 32), 3), (16, 16, (8, 8, 16), 1), (16, 32, (8, 8, 16), 2), (32, 64, (3, 5, 6), 2)])
+def test_conv3d_output_statistics(precision, cin, cout, dims, B):
+    """semabs_conv3d_stats: the GroupNorm statistics of the output handed to the next layer - fused into the level-0 kernel's epilogue
+    (Cin = Cout = 16 on 8 x 8 x 16 bricks), a statistics pass elsewhere - equal the sums of the stored output, and the output itself
+    is the plain semabs_conv3d result."""
+    from semabs_amd.unet3d import _Conv
+    rng = np.random.default_rng(cin * 7 + cout)
+    u = _unet(precision)
+    x = _cl(torch.from_numpy(rng.standard_normal((B, cin, *dims)).astype(np.float32)) * 1.5 + 0.3).cuda().to(u.act_dtype)
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+    gw = torch.from_numpy((1 + 0.2 * rng.standard_normal(cin)).astype(np.float32))
+    gb = torch.from_numpy((0.2 * rng.standard_normal(cin)).astype(np.float32))
+    res = _cl(torch.from_numpy(rng.standard_normal((B, cout, *dims)).astype(np.float32))).cuda().to(u.act_dtype)
+    conv = _Conv(w, gw, gb, None, 8, u.dev)
+    y0 = u._conv(x, conv, relu=True, resid=res)
+    y, sums = u._conv(x, conv, relu=True, resid=res, out_groups=8)
+    # (not bit-equal: the input statistics of each call are reduced with floating-point atomics, so the GroupNorm affine may differ by an ulp)
+    assert (y.float() - y0.float()).abs().max().item() <= (1e-5 if precision == "exact" else 4e-3) * float(y0.float().abs().max())
+    yd = y.double().reshape(B, -1, 8, cout // 8)                       # [B, voxels, group, channel in group]
+    want = torch.stack([yd.sum(dim=(1, 3)), (yd * yd).sum(dim=(1, 3))], dim=-1)
+    np.testing.assert_allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=1e-6 * float(want.abs().max()))

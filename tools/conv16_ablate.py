@@ -35,3 +35,14 @@ e0.record()
 for _ in range(5): run_res()
 e1.record(); torch.cuda.synchronize()
 print(f"{'full, with residual':36s} {e0.elapsed_time(e1) / 5:7.3f} ms", flush=True)
+sums = torch.zeros(P, 8, 2, dtype=torch.float64, device="cuda")
+def run_stats():
+    _lib.call("semabs_conv3d_stats", _lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
+              None, None, P, S, S, S, 16, 16, 3, 1, 1, _lib.ptr(sums), 8, _lib.stream())
+for fn, label in ((run, "full"), (run_stats, "full + fused output statistics"), (run, "full"), (run_stats, "full + fused output statistics")):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{label:36s} {e0.elapsed_time(e1) / 5:7.3f} ms", flush=True)
