@@ -112,6 +112,11 @@ int semabs_gemm_set_config(int cfg);
 /* LayerNorm (fp32 statistics)                                        model_explainability.py:188-194 */
 int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D, float eps,
                      int out_f32, long ld_in, void* stream);
+/* Residual add fused into the LayerNorm pass: x fp32 [M, D] += delta fp16 [M, D] (in place), out fp16 [M, D] = LayerNorm(x); out NULL = the
+ * addition only.  ResidualAttentionBlock.forward's `x = x + ...; ln_2(x)` (model_explainability.py:232-255) with the read-modify-write of
+ * the residual stream taken out of the GEMM epilogue. */
+int semabs_add_layernorm(float* x, const void* delta, const float* gamma, const float* beta, void* out, long M, int D, float eps,
+                         void* stream);
 /* class token rows: x[n, 0, :] = class_embedding + pos[0, :]          model_explainability.py:329-343 */
 int semabs_embed_finish(float* x, const float* cls, const float* pos, int n, int T, int D, void* stream);
 /* fused multi-head attention, head_dim 64, T <= 224                  auxiliary.py:260-340 (q pre-scaled) */

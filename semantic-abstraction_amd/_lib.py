@@ -43,6 +43,7 @@ SIGNATURES = {
     "semabs_gemm_set_config": [I],
     # vit.hip
     "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
+    "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],
     "semabs_embed_finish": [P, P, P, I, I, I, P],
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
     "semabs_attention_cls": [P, P, P, P, I, I, I, I, P],

@@ -54,6 +54,67 @@ __global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float
     }
 }
 
+// Residual add fused into the LayerNorm pass: x[row, :] += delta[row, :] (fp16 GEMM output), x written back, out = fp16 LayerNorm(x).
+// The fp32 read-modify-write of the residual stream leaves the GEMM epilogue (where it serialises with the MFMA work of the tile: the
+// out-proj GEMM spent 37 of its 80 us there) for this streaming kernel, which already reads the row.
+template <int VPL>
+__global__ void k_add_layernorm(float* __restrict__ x, const f16* __restrict__ delta, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, f16* __restrict__ out, long M, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D = 256 * VPL;
+    float* xr = x + row * D;
+    const f16* dr = delta + row * D;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        v[i] = *reinterpret_cast<const float4*>(xr + c0);
+        const f16x4 d = *reinterpret_cast<const f16x4*>(dr + c0);
+        v[i].x += (float)d[0]; v[i].y += (float)d[1]; v[i].z += (float)d[2]; v[i].w += (float)d[3];
+        *reinterpret_cast<float4*>(xr + c0) = v[i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (!out) return;                                               // add only (uniform)
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+        float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+        f16x4 h;
+        h[0] = (f16)((v[i].x - mean) * rstd * gm.x + bt.x); h[1] = (f16)((v[i].y - mean) * rstd * gm.y + bt.y);
+        h[2] = (f16)((v[i].z - mean) * rstd * gm.z + bt.z); h[3] = (f16)((v[i].w - mean) * rstd * gm.w + bt.w);
+        *reinterpret_cast<f16x4*>(out + row * D + c0) = h;
+    }
+}
+// x fp32 [M, D] += delta fp16 [M, D] in place; out fp16 [M, D] = LayerNorm(x) (out = NULL: the addition only)
+extern "C" int semabs_add_layernorm(float* x, const void* delta, const float* gamma, const float* beta, void* out, long M, int D,
+                                    float eps, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && delta && M > 0 && (!out || (gamma && beta)), "semabs_add_layernorm: bad args");
+    SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024, "semabs_add_layernorm: D must be 256..1024 step 256");
+    dim3 grid(semabs_cdiv(M, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(k_add_layernorm<1>, grid, block, 0, s, x, (const f16*)delta, gamma, beta, (f16*)out, M, eps); break;
+        case 2: hipLaunchKernelGGL(k_add_layernorm<2>, grid, block, 0, s, x, (const f16*)delta, gamma, beta, (f16*)out, M, eps); break;
+        case 3: hipLaunchKernelGGL(k_add_layernorm<3>, grid, block, 0, s, x, (const f16*)delta, gamma, beta, (f16*)out, M, eps); break;
+        case 4: hipLaunchKernelGGL(k_add_layernorm<4>, grid, block, 0, s, x, (const f16*)delta, gamma, beta, (f16*)out, M, eps); break;
+    }
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // x fp32 rows (stride ld_in elements) -> out [M, D] dense, fp16 (out_f32 = 0) or fp32 (1; may alias x when ld_in == D)
 extern "C" int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D,
                                 float eps, int out_f32, long ld_in, void* stream) {

@@ -291,3 +291,22 @@ def test_public_get_clip_saliency_with_text_tower(golden):
     with pytest.raises(AssertionError):
         CW.get_clip_saliency(img=img.astype(np.float32), text_labels=labels, prompts=[DEFAULT_PROMPT], **saliency_configs["chefer_et_al"](96))
     CW.tokenizer = None
+
+
+def test_add_layernorm():
+    """x += delta (fp16) in place, then LayerNorm -> fp16; out = NULL adds only."""
+    from semabs_amd.clip.vit import add_layernorm
+    rng = np.random.default_rng(5)
+    M, D = 333, 768
+    x = torch.from_numpy(rng.standard_normal((M, D)).astype(np.float32) * 3 + 0.5)
+    d = torch.from_numpy(rng.standard_normal((M, D)).astype(np.float32)).half()
+    w = torch.from_numpy((1 + 0.1 * rng.standard_normal(D)).astype(np.float32))
+    b = torch.from_numpy((0.1 * rng.standard_normal(D)).astype(np.float32))
+    xs = x + d.float()
+    ref = torch.nn.functional.layer_norm(xs, (D,), w, b, 1e-5)
+    xd, out = x.cuda(), torch.empty(M, D, dtype=torch.float16, device="cuda")
+    add_layernorm(xd, d.cuda(), w.cuda(), b.cuda(), out, M, D)
+    assert torch.equal(xd.cpu(), xs)
+    np.testing.assert_allclose(out.cpu().float().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
+    add_layernorm(xd, d.cuda(), None, None, None, M, D)
+    assert torch.equal(xd.cpu(), xs + d.float())
