@@ -205,9 +205,9 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         // Two passes over the key blocks instead of keeping all NKB score blocks in registers (112 VGPRs at T = 197): pass 1 only finds the
         // row maximum, pass 2 recomputes each score block (4 MFMAs - the matrix pipe is 13 % busy in this kernel), exponentiates, and feeds
         // the un-normalised probabilities straight into P.V; O is scaled by 1 / sum at the end.  ~100 VGPRs -> two workgroups per CU.
-        auto scores = [&](int kb, f32x16& sc) {
+        auto scores = [&](int kb, f32x16& sc, float init) {      // init = 0 (pass 1) or -max (pass 2: the MFMA accumulator does the subtraction)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sc[r] = init;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f16x8 fk = *reinterpret_cast<const f16x8*>(sK + kb * 4096 + koff[ks]);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 sc;
-            scores(kb, sc);
+            scores(kb, sc, 0.f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
         }
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 sc;
-            scores(kb, sc);
+            scores(kb, sc, -mx);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - mx); sum += sc[r]; }
+            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] * 1.44269504088896340736f); sum += sc[r]; }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 f16x8 p;
