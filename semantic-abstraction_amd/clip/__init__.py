@@ -219,8 +219,10 @@ class ClipWrapper:
         return cls.relevancy_device(images, w, kwargs["cropping_augmentations"], horizontal_flipping, positive_attn_only).cpu()
 
     @classmethod
-    def make_images(cls, img, augmentations: int, jittered_images=None, img_dev: torch.Tensor | None = None) -> torch.Tensor:
-        """uint8 [1 + augmentations, H, W, 3] on the GPU: the image then its colour-jittered copies (img_dev: the image already in HBM)."""
+    def make_images(cls, img, augmentations: int, jittered_images=None, img_dev: torch.Tensor | None = None, seed: int | None = None) -> torch.Tensor:
+        """uint8 [1 + augmentations, H, W, 3] on the GPU: the image then its colour-jittered copies (img_dev: the image already in HBM).
+        seed: draw the jitter parameters from np.random.default_rng(seed) instead of the wrapper's running generator - ranks that share
+        one scene (tile sharding) must jitter identically."""
         assert type(img) == np.ndarray and img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
         cls.check_initialized()
         dev = cls.device
@@ -233,9 +235,10 @@ class ClipWrapper:
         out = base[None].repeat(augmentations + 1, 1, 1, 1).contiguous()
         scratch = torch.zeros(1, dtype=torch.int64, device=dev)
         H, W = img.shape[:2]
+        rng = cls._rng if seed is None else np.random.default_rng(seed)
         for k in range(1, augmentations + 1):
-            order = cls._rng.permutation(4)
-            f = [cls._rng.uniform(0.4, 1.6), cls._rng.uniform(0.4, 1.6), cls._rng.uniform(0.4, 1.6), cls._rng.uniform(-0.1, 0.1)]
+            order = rng.permutation(4)
+            f = [rng.uniform(0.4, 1.6), rng.uniform(0.4, 1.6), rng.uniform(0.4, 1.6), rng.uniform(-0.1, 0.1)]
             _lib.call("semabs_color_jitter", out[k].data_ptr(), H, W, _lib.iarr(order), _lib.farr(f), _lib.ptr(scratch), _lib.stream())
         return out
 

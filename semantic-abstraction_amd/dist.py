@@ -18,6 +18,13 @@ import torch
 import torch.distributed as dist
 
 
+def rank_world() -> Tuple[int, int]:
+    """(rank, world size) of the default process group; (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous balanced slice [lo, hi) of n items for `rank` (first n % world ranks get one extra)."""
     q, r = divmod(n, world)
@@ -43,6 +50,11 @@ def gather_results(local: torch.Tensor) -> torch.Tensor:
     """All-gather equally shaped per-rank results along a new leading dim (label / scene shards -> rank 0 and all)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local[None]
+    if local.is_cuda and dist.get_backend() == "gloo":                  # gloo has no device all_gather (tests on one GPU): stage through the host
+        host = local.detach().cpu().contiguous()
+        out = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, host)
+        return torch.stack(out, dim=0).to(local.device)
     out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(out, local.contiguous())
     return torch.stack(out, dim=0)

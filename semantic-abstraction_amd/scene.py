@@ -22,7 +22,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .clip import ClipWrapper, saliency_configs
+from . import dist as sdist
+from .clip import ClipWrapper, plan_tiles, saliency_configs
 from .fusion import TSDFVolume
 from .net import SemAbs3D
 from .point_cloud import check_pts_in_frustum, pointcloud_device
@@ -76,8 +77,16 @@ class ScenePipeline:
         w_text fp32 [L, E] on the GPU (zero-shot weights of the labels)."""
         return self.run_voxels(self.run_relevancy(scene, w_text, seed, jittered_images, images_dev))
 
+    def run_sharded(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None) -> SceneResult:
+        """ONE scene split over the ranks of the default process group - the single-scene latency mode of SURVEY.md 8(e), next to the
+        scene-sharded throughput mode `bench.py` measures.  Relevancy is tile-sharded: every rank runs a contiguous slice of the tile
+        forwards for all labels and one all-reduce(sum) of the per-tile relevances (RCCL) completes them everywhere (the aggregation is
+        then replicated - it is cheap and deterministic).  Voxel inference is label-sharded: each rank runs the UNet / decoder on its
+        slice of the label volumes and the logits are all-gathered.  Geometry is replicated.  World size 1 degenerates to `run`."""
+        return self.run_voxels(self.run_relevancy(scene, w_text, seed, jittered_images, shard_tiles=True), shard_labels=True)
+
     def run_relevancy(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None, images_dev: torch.Tensor | None = None,
-                      geo_stream: torch.cuda.Stream | None = None, vit_stream: torch.cuda.Stream | None = None) -> dict:
+                      geo_stream: torch.cuda.Stream | None = None, vit_stream: torch.cuda.Stream | None = None, shard_tiles: bool = False) -> dict:
         """First half of a scene: geometry (point cloud, in-bounds compaction, seeded sub-sample) and the relevancy maps.  With streams
         given, geometry runs on `geo_stream` (its host sync then waits for nothing else) and the ViT on `vit_stream`; the returned state
         carries the events `run_voxels` waits for - this is what lets a caller overlap scene i's voxel stage with scene i + 1's ViT."""
@@ -107,17 +116,28 @@ class ScenePipeline:
         # ---- relevancy --------------------------------------------------------------------------------
         with torch.cuda.stream(vs):
             if images_dev is None:
-                images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images, img_dev=scene.get("rgb_dev"))
-            maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
-                                                cfg["positive_attn_only"])                   # [L, H, W]
+                images_dev = ClipWrapper.make_images(scene["rgb"], cfg["augmentations"], jittered_images, img_dev=scene.get("rgb_dev"), seed=seed)
+            rank, world = sdist.rank_world()
+            if shard_tiles and world > 1:
+                n_img = int(images_dev.shape[0])
+                table, _ = plan_tiles(H, W, n_img, cfg["cropping_augmentations"])
+                rel, _, scales = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
+                                                              cfg["positive_attn_only"], tile_range=sdist.shard_range(len(table), rank, world),
+                                                              return_tiles=True)
+                rel = sdist.allreduce_tile_relevance(rel)
+                maps = ClipWrapper.aggregate_device(rel, scales, n_img, H, W)
+            else:
+                maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
+                                                    cfg["positive_attn_only"])               # [L, H, W]
             maps_c = maps.contiguous()
             vit_done = torch.cuda.Event()
             vit_done.record(vs)
         return dict(scene=scene, L=int(w_text.shape[0]), H=H, W=W, depth_dev=depth_dev, xyz=xyz, sel=sel, n_in=n_in, maps=maps, maps_c=maps_c,
                     geo_done=geo_done, vit_done=vit_done, streams=(gs, vs))
 
-    def run_voxels(self, state: dict) -> SceneResult:
-        """Second half: per-point features, voxel inference, TSDF and the label volume, on the current stream."""
+    def run_voxels(self, state: dict, shard_labels: bool = False) -> SceneResult:
+        """Second half: per-point features, voxel inference, TSDF and the label volume, on the current stream.
+        shard_labels: each rank infers a contiguous slice of the label volumes, the logits are all-gathered."""
         dev, net = self.dev, self.net
         scene, L, H, W = state["scene"], state["L"], state["H"], state["W"]
         depth_dev, xyz, sel, maps, maps_c, n_in = state["depth_dev"], state["xyz"], state["sel"], state["maps"], state["maps_c"], state["n_in"]
@@ -133,9 +153,20 @@ class ScenePipeline:
         # ---- voxel inference ----------------------------------------------------------------------------
         # the UNet's final 1x1x1 convolution is folded into the decoder (applied to the sampled features): its output volume - 2 GB written
         # and read back at 128^3 x 16 labels - is never materialised on this path; SemAbs3D.forward keeps producing it
-        features = net.feature_volume(xyz_sub, feat, skip_final=self.fold_final_conv)
-        logits = net.decode(features, self.grid_points, shared=True, lattice=net.vg.grid_shape, pre_final=self.fold_final_conv)   # [L, S^3]
-        net.features_cl = None if self.fold_final_conv else features
+        rank, world = sdist.rank_world()
+        if shard_labels and world > 1:
+            per = (L + world - 1) // world                                                    # equal slices (the last one padded) for all_gather
+            l0, l1 = min(L, rank * per), min(L, (rank + 1) * per)
+            part = torch.zeros(per, self.grid_points.shape[0], dtype=torch.float32, device=dev)
+            if l1 > l0:
+                f_r = net.feature_volume(xyz_sub, feat[l0:l1].contiguous(), skip_final=self.fold_final_conv)
+                part[:l1 - l0] = net.decode(f_r, self.grid_points, shared=True, lattice=net.vg.grid_shape, pre_final=self.fold_final_conv)
+            logits = sdist.gather_results(part).reshape(world * per, -1)[:L].contiguous()
+            net.features_cl = None
+        else:
+            features = net.feature_volume(xyz_sub, feat, skip_final=self.fold_final_conv)
+            logits = net.decode(features, self.grid_points, shared=True, lattice=net.vg.grid_shape, pre_final=self.fold_final_conv)   # [L, S^3]
+            net.features_cl = None if self.fold_final_conv else features
         tsdf = labels = None
         if self.with_tsdf:
             S = net.vg.grid_shape[0]

@@ -8,13 +8,14 @@ gradient buffer per step (semabs_amd.dist.allreduce_flat_gradients); rank 0 prin
 """
 import argparse
 import json
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import semabs_amd  # noqa: E402,F401
 from semabs_amd.synth import SCENE_BOUNDS  # noqa: E402
 from semabs_amd.train import RELATIONS, VOOLTrainer  # noqa: E402
