@@ -267,6 +267,7 @@ struct ConvArgs {
                                 // bias / residual / ReLU are then applied by k_conv_finish
     signed char td0[28], td1[28], td2[28];   // tap offsets: input coordinate = m + td  (conv pad-1: -1..1; convT: 0/+1)
     double* stats;              // optional (k_conv16_lds): fp64 [B, 8, 2] sum / sum of squares of the OUTPUT per GroupNorm group, accumulated
+    int ablate;                 // tuning only (k_conv16_lds, tools/conv16_ablate.py): 1 producers only, 2 consumers only, 4 consumers without epilogue
 };
 
 template <bool F32>
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (a.ksplit == 4) { if (acc[0][0] != 1234.5f) continue; }
+            if (a.ablate == 4) { if (acc[0][0] != 1234.5f) continue; }
             // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
             float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         int buf = 0;
         for (; brick < total; brick += gridDim.x, buf ^= 1) {
             const int next = brick + gridDim.x;
-            if (next < total && a.ksplit != 2 && a.ksplit < 4) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
+            if (next < total && a.ablate != 2 && a.ablate < 4) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
             lds_barrier();
         }
     } else {
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         lds_barrier();
         int buf = 0;
         for (int brick = blockIdx.x; brick < total; brick += gridDim.x, buf ^= 1) {
-            if (a.ksplit != 1) consume(brick, buf);   // ablation: 4 = no epilogue
+            if (a.ablate != 1) consume(brick, buf);
             lds_barrier();
         }
         if (a.stats) flush_stats();
@@ -738,7 +739,7 @@ static int semabs_num_cus() {
     return n;
 }
 static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
-    ConvArgs a = a_in; a.ksplit = g_conv16_ablate;
+    ConvArgs a = a_in; a.ablate = g_conv16_ablate;
     if (f32) {
         constexpr int T0 = 4;
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2 * 2;   // two half-voxel planes (256-B padded), hi + lo, two buffers; fp16
@@ -1027,7 +1028,7 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
     a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.ntaps = ksize * ksize * ksize;
     a.Kp = ((a.ntaps * Cin + 31) / 32) * 32;
-    a.stats = nullptr;
+    a.stats = nullptr; a.ablate = 0;
     int t = 0;
     for (int kd = 0; kd < ksize; ++kd)
         for (int kh = 0; kh < ksize; ++kh)
@@ -1071,7 +1072,7 @@ extern "C" int semabs_conv3d_gather(const void* x, const void* w_hi, const void*
     ConvArgs a;
     SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gather: in_scale and in_shift go together");
     a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
-    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
+    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.ablate = 0; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
     a.M0 = M0; a.M1 = M1; a.M2 = M2; a.os = 1; a.is = in_stride; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
     a.ntaps = ntaps; a.Kp = ((ntaps * Cin + 31) / 32) * 32;
     for (int t = 0; t < ntaps; ++t) { a.td0[t] = taps[t * 3]; a.td1[t] = taps[t * 3 + 1]; a.td2[t] = taps[t * 3 + 2]; }
@@ -1249,7 +1250,7 @@ extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const voi
         const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
         ConvArgs a;
         a.x = x; a.y = y; a.w_hi = (const f16*)w_hi + class_off[cls]; a.w_lo = w_lo ? (const f16*)w_lo + class_off[cls] : nullptr;
-        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip; a.stats = nullptr;
+        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip; a.stats = nullptr; a.ablate = 0;
         a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = 2 * D0; a.O1 = 2 * D1; a.O2 = 2 * D2;
         a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.is = 1; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
         int t = 0;
