@@ -19,3 +19,26 @@ for i in range(1, 4):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     print(f"scene {i}: issue relevancy {1e3*(t1-t0):.1f} ms, issue voxels {1e3*(t2-t1):.1f} ms, then wait for the GPU {1e3*(t3-t2):.1f} ms, total {1e3*(t3-t0):.1f} ms")
+
+# pure host cost: the same Python path with every C-ABI launch replaced by a no-op (allocations and torch ops still run)
+from semabs_amd import _lib
+real_call = _lib.call
+n_calls = [0]
+def fake(name, *a):
+    n_calls[0] += 1
+_lib.call = fake
+import semabs_amd.clip.vit as _v, semabs_amd.clip as _c, semabs_amd.unet3d as _u, semabs_amd.net as _n, semabs_amd.scene as _s
+for mod in (_v, _c, _u, _n, _s):
+    if hasattr(mod, "_lib"):
+        mod._lib.call = fake
+torch.cuda.synchronize()
+for i in range(1, 4):
+    n_calls[0] = 0
+    t0 = time.perf_counter()
+    try:
+        pipe.run(scenes[i], w_text, seed=i)
+    except Exception as e:
+        print("dry run stopped:", type(e).__name__, str(e)[:80])
+    torch.cuda.synchronize()
+    print(f"dry run {i}: host {1e3 * (time.perf_counter() - t0):.1f} ms for {n_calls[0]} C-ABI calls")
+_lib.call = real_call
