@@ -554,6 +554,7 @@ static int launch(const GemmArgs& g, hipStream_t s) {
     if (big && g_force_cfg == 4) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU
     if (big && g_force_cfg == 5) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);
     if (g_force_cfg == 6) return launch_cfg<EPI, 128, 128, 32, 2, 2, 3>(g, s);               // 4 waves, 48 KB: 3 blocks / CU
+    if (big && g_force_cfg == 7) return launch_cfg<EPI, 256, 128, 32, 2, 2, 3>(g, s);      // 4 waves, 128 x 64 wave tiles, 72 KB: 2 blocks / CU
     if (big) return launch_cfg<EPI, 256, 256, 32, 2, 4, 4>(g, s);
     return launch_cfg<EPI, 128, 128, 64, 2, 2, 2>(g, s);
 }
