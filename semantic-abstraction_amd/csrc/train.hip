@@ -36,26 +36,33 @@ struct WgradArgs {
     signed char td0[28], td1[28], td2[28];
 };
 
+template <int TA>                     // a thread owns TA x 4 outputs: workgroup tile = (16 TA) x 64 of dW; TA = 4 -> two 16-byte LDS reads feed 16 FMAs
 __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
-    __shared__ float sA[32][16];
+    __shared__ __attribute__((aligned(16))) float sA[32][16 * TA];
     __shared__ __attribute__((aligned(16))) float sB[32][64];
     const int t = threadIdx.x;
-    const int ca0 = blockIdx.y * 16, n0 = blockIdx.z * 64;
+    const int ca0 = blockIdx.y * 16 * TA, n0 = blockIdx.z * 64;
     const int N = a.ntaps * a.Cx;
     const long R = (long)a.B * a.M0 * a.M1 * a.M2;
     const long r_begin = (long)blockIdx.x * a.rows_per_block;
     long r_end = r_begin + a.rows_per_block; if (r_end > R) r_end = R;
-    const int ca = t & 15, ng = t >> 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long rb = r_begin; rb < r_end; rb += 32) {
-        // stage A: 32 rows x 16 channels (2 per thread)
+    const int cg = t & 15, ng = t >> 4;
+    float acc[TA][4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = t + k * 256, rr = e >> 4, c = e & 15;
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+    // register double buffer: the global loads of row batch i + 1 are in flight while batch i is multiplied out of LDS (with a load ->
+    // LDS -> barrier -> FMA -> barrier loop every batch paid a full memory round trip: the 8^3 / 4^3 levels were latency-bound)
+    float ra[2 * TA];
+    float4 rx[2];
+    auto fetch = [&](long rb) {
+#pragma unroll
+        for (int k = 0; k < 2 * TA; ++k) {
+            const int e = t + k * 256, rr = e / (16 * TA), c = e % (16 * TA);
             const long row = rb + rr;
-            sA[rr][c] = (row < r_end) ? a.A[row * a.Ca + ca0 + c] : 0.f;
+            ra[k] = (row < r_end) ? a.A[row * a.Ca + ca0 + c] : 0.f;
         }
-        // stage gathered X: 32 rows x 64 columns as 16 float4 per row (2 float4 per thread)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e = t + k * 256, rr = e >> 4, q = e & 15;
@@ -78,26 +85,46 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
                     }
                 }
             }
-            *reinterpret_cast<float4*>(&sB[rr][q * 4]) = v;
+            rx[k] = v;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (long rb = r_begin; rb < r_end; rb += 32) {
+#pragma unroll
+        for (int k = 0; k < 2 * TA; ++k) {
+            const int e = t + k * 256;
+            sA[e / (16 * TA)][e % (16 * TA)] = ra[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = t + k * 256;
+            *reinterpret_cast<float4*>(&sB[e >> 4][(e & 15) * 4]) = rx[k];
         }
         __syncthreads();
+        if (rb + 32 < r_end) fetch(rb + 32);
 #pragma unroll 8
         for (int rr = 0; rr < 32; ++rr) {
-            const float av = sA[rr][ca];
+            float av[TA];
+            if (TA == 4) { const float4 q = *reinterpret_cast<const float4*>(&sA[rr][cg * 4]); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+            else if (TA == 2) { const float2 q = *reinterpret_cast<const float2*>(&sA[rr][cg * 2]); av[0] = q.x; av[1] = q.y; }
+            else av[0] = sA[rr][cg];
             const float4 bv = *reinterpret_cast<const float4*>(&sB[rr][ng * 4]);
-            acc[0] += av * bv.x; acc[1] += av * bv.y; acc[2] += av * bv.z; acc[3] += av * bv.w;
+#pragma unroll
+            for (int i = 0; i < TA; ++i) { acc[i][0] += av[i] * bv.x; acc[i][1] += av[i] * bv.y; acc[i][2] += av[i] * bv.z; acc[i][3] += av[i] * bv.w; }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int n = n0 + ng * 4 + k;
-        if (n < N) {
-            const int tap = n / a.Cx, cx = n - tap * a.Cx;
-            const long idx = a.tap_minor ? ((long)(ca0 + ca) * a.Cx + cx) * a.ntaps + tap : (long)(ca0 + ca) * N + n;
-            atomicAdd(&a.dW[idx], acc[k]);
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = n0 + ng * 4 + k, ca = ca0 + cg * TA + i;
+            if (n < N) {
+                const int tap = n / a.Cx, cx = n - tap * a.Cx;
+                const long idx = a.tap_minor ? ((long)ca * a.Cx + cx) * a.ntaps + tap : (long)ca * N + n;
+                atomicAdd(&a.dW[idx], acc[i][k]);
+            }
         }
-    }
 }
 
 // dW fp32 is ACCUMULATED into: [Ca, ntaps, Cx] (tap_minor = 0, the forward kernels' K order) or [Ca, Cx, ntaps] (tap_minor = 1, the
@@ -115,14 +142,18 @@ extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scal
     a.tap_minor = tap_minor;
     for (int i = 0; i < ntaps; ++i) { a.td0[i] = taps[i * 3]; a.td1[i] = taps[i * 3 + 1]; a.td2[i] = taps[i * 3 + 2]; }
     const long R = (long)B * M0 * M1 * M2;
-    const int ytiles = Ca / 16, ztiles = semabs_cdiv((long)ntaps * Cx, 64);
+    const int TA = (Ca % 64 == 0) ? 4 : (Ca % 32 == 0 ? 2 : 1);
+    const int ytiles = Ca / (16 * TA), ztiles = semabs_cdiv((long)ntaps * Cx, 64);
     // enough row chunks to fill the chip a few times over, but at least 1024 rows each (keeps the atomic traffic small)
     long target_blocks = 4096 / ((long)ytiles * ztiles); if (target_blocks < 1) target_blocks = 1;
+    if (target_blocks > 1024) target_blocks = 1024;      // a single-tile output (linear layers, 1x1x1 convolution): every row chunk adds to the same addresses
     long rpb = (R + target_blocks - 1) / target_blocks; if (rpb < 1024) rpb = 1024;
     rpb = (rpb + 31) / 32 * 32;
     a.rows_per_block = rpb;
     dim3 grid(semabs_cdiv(R, rpb), ytiles, ztiles);
-    hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (TA == 4) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (TA == 2) hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
