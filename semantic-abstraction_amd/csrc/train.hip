@@ -695,7 +695,11 @@ extern "C" int semabs_clip_grad_norm(const long long* chunks, int n_chunks, cons
 #define WG_T2 16
 #define WG_H0 (WG_T0 + 2)
 #define WG_H1 (WG_T1 + 2)
-#define WG_XROW 32                           // elements per (z, y, channel) row of the X halo: x = -1 .. 16 sit at 7 .. 24
+#define WG_XROW 24                           // element stride of the (z, y, channel) rows of the X halo: x = -1 .. 16 sit at 7 .. 24 of a row, i.e. a
+                                             // row's last two slots are the (never used) first two of the next row.  48 B = 3 x 16 B: the 16 channel
+                                             // rows of a fragment read land in 16 different 16-byte slots of the 64 banks (at 64 B they shared 4)
+#define WG_AYROW (16 * WG_T2 + 8)            // element stride of a (z, y) block of dZ rows: the + 16 B puts the two y rows of a lane group in
+                                             // different slots
 #define WG_NTHR 576
 struct Wgrad16Args {
     const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* s2; float* dW;
@@ -713,8 +717,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XH_EL = WG_H0 * WG_H1 * 16 * WG_XROW;            // elements in one X plane (hi or lo)
-    constexpr int A_EL = WG_T0 * WG_T1 * 16 * WG_T2;
+    constexpr int XH_EL = WG_H0 * WG_H1 * 16 * WG_XROW + 8;        // elements in one X plane (hi or lo); + 8: the last row's tail
+    constexpr int A_EL = WG_T0 * WG_T1 * WG_AYROW;
     unsigned short* sXh = reinterpret_cast<unsigned short*>(smem);
     unsigned short* sXl = sXh + XH_EL;
     unsigned short* sAh = sXl + XH_EL;
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const float4 w = p[q]; v[e][4 * q] = w.x * s_in; v[e][4 * q + 1] = w.y * s_in; v[e][4 * q + 2] = w.z * s_in; v[e][4 * q + 3] = w.w * s_in; }
             }
-            const int rowbase = ((zz * WG_T1 + yy) * 16) * WG_T2 + 2 * px;
+            const int rowbase = (zz * WG_T1 + yy) * WG_AYROW + 2 * px;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 unsigned int lo;
@@ -791,8 +795,11 @@ __global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
         // ---- 16 k-steps of 32 voxels (2 rows x 16 x): A = dZ[ca][vox], B = X[vox + tap][cx] ----
 #pragma unroll 2
         for (int ks = 0; ks < 16; ++ks) {
-            const int zz = ks >> 2, yy = (ks & 3) * 2 + (kg >> 1), xg = kg & 1;
-            const int aoff = ((zz * WG_T1 + yy) * 16 + i16) * WG_T2 + xg * 8;
+            // lane group kg -> (y row, x half) = (kg & 1, kg >> 1): the ds_read_b128 lane groups pair kg 0 with kg 1 (and 2 with 3), i.e. two
+            // y rows of the same x half - with the strides above every group of 16 lanes covers 16 distinct 16-byte bank slots (before:
+            // SQ_LDS_BANK_CONFLICT = 73 % of the LDS-active cycles, and LDS was the busiest unit of the kernel)
+            const int zz = ks >> 2, yy = (ks & 3) * 2 + (kg & 1), xg = kg >> 1;
+            const int aoff = (zz * WG_T1 + yy) * WG_AYROW + i16 * WG_T2 + xg * 8;
             const f16x8 ah = *reinterpret_cast<const f16x8*>(sAh + aoff);
             const f16x8 al = *reinterpret_cast<const f16x8*>(sAl + aoff);
             const int boff = (((zz + 1 + dz) * WG_H1 + (yy + 1 + dy)) * 16 + i16) * WG_XROW + 8 + xg * 8;
@@ -854,7 +861,7 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_conv3: gn_scale and gn_shift go together");
     Wgrad16Args a;
     a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx; a.tap_minor = tap_minor;
-    const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + WG_T0 * WG_T1 * 16 * WG_T2) * 2 * 2;
+    const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + 8 + WG_T0 * WG_T1 * WG_AYROW) * 2 * 2;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nbricks = B * (D0 / WG_T0) * (D1 / WG_T1) * (D2 / WG_T2);
