@@ -75,7 +75,8 @@ int semabs_resize_coeffs(int in_size, int out_size, int* xmin, int* kk, int kmax
  *                                          CLIP/clip/__init__.py:254-281, 171-173; model_explainability.py:325-328
  * images uint8 [n_img, H, W, 3]; tiles int32 [n_tiles, 5] = (image, row0, col0, tile_size, coef_id);
  * coef_xmin int32 [n_sizes, 224], coef_kk int32 [n_sizes, 224, 24], coef_ksize int32 [n_sizes]; lut fp16 [3, 256]
- * = fp16((u/255 - mean_c)/std_c); patches fp16 [n_tiles * g*g, 3*p*p] (g = 224/p), column = c*p*p + iy*p + ix. */
+ * = fp16((u/255 - mean_c)/std_c); patches fp16 [n_tiles * g*g, 3*p*p] (g = 224/p), column = c*p*p + iy*p + ix.
+ * flip 0 = as is, 1 = mirrored (the flip pass, __init__.py:171-173), 2 = both from one resampling: patches fp16 [2, n_tiles * g*g, 3*p*p]. */
 int semabs_tile_patches(const unsigned char* images, int n_img, int H, int W, const int* tiles, int n_tiles,
                         const int* coef_xmin, const int* coef_kk, const int* coef_ksize, const void* lut, void* patches,
                         int patch, int flip, int max_ksize, void* stream);

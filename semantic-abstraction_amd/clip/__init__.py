@@ -284,7 +284,16 @@ class ClipWrapper:
         ns = max(1, min(cls.n_streams, len(work)))
         if cls._streams is None or len(cls._streams) < ns:
             cls._streams = cls._make_streams(ns)
-            cls._patches = {}
+        # Patch matrix of EVERY (pass, tile) forward of this call, in issue order (737 MB at the BASELINE shape): each tile is resampled
+        # once and written as is and mirrored (the flip pass differs only in the output column), in one launch of 14 workgroups per tile
+        # instead of one launch per chunk and pass; a chunk's GEMM A operand is a row slice of it.
+        key = (passes * n_per * G, Kp)
+        if cls._patches.get("key") != key:
+            cls._patches = {"key": key, "buf": torch.empty(key[0], Kp, dtype=torch.float16, device=dev)}
+        patches_all = cls._patches["buf"]
+        if n_per > 0:
+            _lib.call("semabs_tile_patches", _lib.ptr(images), n_img, H, W, tiles_dev[t_lo:].data_ptr(), n_per, _lib.ptr(xmin_d),
+                      _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(cls._lut), _lib.ptr(patches_all), eng.p, 2 if passes == 2 else 0, max_ks, _lib.stream())
         for i in range(ns):
             cls._streams[i].wait_stream(main)
         w_chunks = [w_text[l0:l0 + eng.max_labels].contiguous() for l0 in range(0, L, eng.max_labels)]
@@ -292,17 +301,9 @@ class ClipWrapper:
             slot = i % ns
             with torch.cuda.stream(cls._streams[slot]):
                 eng.slot = slot
-                key = (slot, min(passes * N, eng.chunk) * G, Kp)
-                if key not in cls._patches:
-                    cls._patches = {k: v for k, v in cls._patches.items() if k[0] != slot}
-                    cls._patches[key] = torch.empty(key[1], Kp, dtype=torch.float16, device=dev)
-                patches = cls._patches[key]
-                st = _lib.stream()
-                m = 0
-                for flip, t0, cnt in segs:
-                    _lib.call("semabs_tile_patches", _lib.ptr(images), n_img, H, W, tiles_dev[t0:].data_ptr(), cnt, _lib.ptr(xmin_d),
-                              _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(cls._lut), patches[m * G:].data_ptr(), eng.p, flip, max_ks, st)
-                    m += cnt
+                m = sum(cnt for _, _, cnt in segs)
+                v0 = i * eng.chunk                              # first (pass, tile) forward of the chunk = row v0 * G of the patch matrix
+                patches = patches_all[v0 * G:(v0 + m) * G]
                 eng.embed(patches, m); eng.trunk(m); eng.head(m)
                 col0 = i * eng.chunk                            # the chunk's tiles are consecutive columns of rel_all
                 for li, wl in enumerate(w_chunks):
@@ -311,7 +312,7 @@ class ClipWrapper:
         for i in range(ns):
             main.wait_stream(cls._streams[i])
         eng.slot = 0
-        for t in (images, tiles_dev, w_text, rel_all, *w_chunks):
+        for t in (images, tiles_dev, w_text, rel_all, patches_all, *w_chunks):
             for i in range(ns):
                 t.record_stream(cls._streams[i])
         if tile_range is None:

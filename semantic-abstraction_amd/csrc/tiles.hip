@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_tile_patches(const unsigned char* __res
                                                       const int* __restrict__ tiles, const int* __restrict__ coef_xmin,
                                                       const int* __restrict__ coef_kk, const int* __restrict__ coef_ksize,
                                                       const f16* __restrict__ lut, f16* __restrict__ patches, int p,
-                                                      int flip) {
+                                                      int flip, int n_tiles) {
     __shared__ unsigned char sh[MAX_IN_ROWS][OUT_RES][3];
     __shared__ int s_xmin[OUT_RES];
     const int t = blockIdx.x, band = blockIdx.y, tid = threadIdx.x;
@@ -137,10 +137,17 @@ __global__ __launch_bounds__(256) void k_tile_patches(const unsigned char* __res
             a0 >>= PRECISION_BITS; a1 >>= PRECISION_BITS; a2 >>= PRECISION_BITS;
             v0 = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0); v1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1); v2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
         }
-        const int xo = flip ? (OUT_RES - 1 - x) : x;
-        const int py = y / p, iy = y - py * p, px = xo / p, ix = xo - px * p;
-        f16* dst = patches + ((long)t * g * g + py * g + px) * Kp + iy * p + ix;
-        dst[0] = lut[v0]; dst[pp] = lut[256 + v1]; dst[2 * pp] = lut[512 + v2];
+        const f16 o0 = lut[v0], o1 = lut[256 + v1], o2 = lut[512 + v2];
+        const int py = y / p, iy = y - py * p;
+        // flip = 2: the resampled tile is written twice, as is into patches[0 .. n_tiles) and mirrored into patches[n_tiles .. 2 n_tiles)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (flip != 2 && f != flip) continue;
+            const int xo = f ? (OUT_RES - 1 - x) : x;
+            const int px = xo / p, ix = xo - px * p;
+            f16* dst = patches + ((long)((flip == 2 && f) ? t + n_tiles : t) * g * g + py * g + px) * Kp + iy * p + ix;
+            dst[0] = o0; dst[pp] = o1; dst[2 * pp] = o2;
+        }
     }
 }
 
@@ -150,12 +157,13 @@ extern "C" int semabs_tile_patches(const unsigned char* images, int n_img, int H
     if (n_tiles == 0) return SEMABS_OK;
     SEMABS_REQUIRE(images && tiles_dev && coef_xmin && coef_kk && coef_ksize && lut && patches, "semabs_tile_patches: null pointer");
     SEMABS_REQUIRE(n_img > 0 && H > 0 && W > 0 && (patch == 16 || patch == 32 || patch == 14), "semabs_tile_patches: bad shape / patch size");
+    SEMABS_REQUIRE(flip >= 0 && flip <= 2, "semabs_tile_patches: flip must be 0 (as is), 1 (mirrored) or 2 (both: patches holds 2 n_tiles tiles)");
     SEMABS_REQUIRE(OUT_RES % patch == 0, "semabs_tile_patches: patch must divide 224");
     // a 16-row band touches at most 16 * scale + ksize input rows; ksize = 2 ceil(2 scale) + 1
     SEMABS_REQUIRE(max_ksize <= KMAX && (max_ksize - 1) / 4.0 * BAND + max_ksize + 2 <= MAX_IN_ROWS,
                    "semabs_tile_patches: tile_size / 224 too large for the LDS band (tile_size must be <= ~490)");
     hipLaunchKernelGGL(k_tile_patches, dim3(n_tiles, OUT_RES / BAND), dim3(256), 0, (hipStream_t)stream, images, H, W, tiles_dev,
-                       coef_xmin, coef_kk, coef_ksize, (const f16*)lut, (f16*)patches, patch, flip);
+                       coef_xmin, coef_kk, coef_ksize, (const f16*)lut, (f16*)patches, patch, flip, n_tiles);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
