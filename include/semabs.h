@@ -163,8 +163,8 @@ int semabs_conv3d_stats(const void* x, const void* w_hi, const void* w_lo, void*
                         const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                         int act_f32, double* out_sums, int out_groups, void* stream);
 /* tuning / test hook: bit 0: 1 (default) = Cin = Cout = 16 3^3 convolutions on bricks that are multiples of 8 x 8 x 16 use the
- * LDS-halo kernel, 0 = always the generic gather kernel; bits 1.. = role ablation of that kernel for tools/conv16_ablate.py
- * (wrong results; 0 in every product path) */
+ * LDS-halo kernel, 0 = always the generic gather kernel; bits 1-3 = role ablation of that kernel for tools/conv16_ablate.py
+ * (wrong results; 0 in every product path); bit 8 = point MLP on fp32 FMAs instead of the matrix pipe (tools/point_mlp_time.py) */
 int semabs_conv_set_config(int use_lds_brick);
 /* ConvTranspose3d k3 s2 p1 (output_size = skip size) + bias + sum joining          unet3d.py:428-440, 385-396 */
 int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off /*host*/, void* y,

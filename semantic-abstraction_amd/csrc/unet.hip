@@ -25,6 +25,8 @@
 //                   for the 8^3 / 4^3 levels in exact mode)
 #include "semabs_common.h"
 
+static int semabs_num_cus();
+
 // =================================================================================================
 // Point MLP: (xyz | feat) 4 -> H -> H -> C, LeakyReLU(0.01); fp32 FMAs, weights in LDS, one thread per (label, point)
 // =================================================================================================
@@ -86,6 +88,133 @@ __global__ __launch_bounds__(256, 2) void k_point_mlp(const float* __restrict__ 
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same MLP on the matrix pipe (exact mode: operands split into fp16 hi + lo, 3 MFMAs per product, fp32 accumulate).  A wave owns 64
+// points (4 tiles of 16 = MFMA columns) and never leaves its registers between the layers:
+//   layer 1 (4 -> 128) is computed on the VALU directly in the B-operand layout of layer 2 (lane (point, kg) produces the 8 channels
+//   ks * 32 + kg * 8 .. + 7 of k-step ks);
+//   layer 2 (128 -> 128): W2 hi / lo are the A operand from LDS (rows 288 B apart: conflict-free ds_read_b128 for the real lane groups),
+//   32 accumulators [8 output tiles][4 point tiles];
+//   layer 3 (128 -> 16) takes its B operand straight from those accumulators: a lane holds channels 16 ot + 4 kg + r, so k-step ks' is
+//   DEFINED as the channels {16 (2 ks') + 4 kg + e, 16 (2 ks' + 1) + 4 kg + e : e < 4} and W3 is staged in LDS in that k order.
+// 48.5 GFLOP per scene: 1.45 ms on fp32 FMAs -> matrix pipe.
+// -------------------------------------------------------------------------------------------------
+#define PM_ROW 144                              // fp16 elements per W2 row in LDS (128 + 16 pad = 288 B)
+__global__ __launch_bounds__(512) void k_point_mlp_mfma(const float* __restrict__ xyz, const float* __restrict__ feat,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const float* __restrict__ w3, const float* __restrict__ b3,
+                                                        float* __restrict__ out, int P, long N) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* sw2h = reinterpret_cast<f16*>(smem);              // [128][PM_ROW]
+    f16* sw2l = sw2h + 128 * PM_ROW;
+    f16* sw3h = sw2l + 128 * PM_ROW;                        // [4 ks'][4 kg][16 m][8]: the A fragment of layer 3, ready to load
+    f16* sw3l = sw3h + 4 * 4 * 16 * 8;
+    float* sw1 = reinterpret_cast<float*>(sw3l + 4 * 4 * 16 * 8);   // [128][4]
+    float* sb1 = sw1 + 128 * 4;                             // [128]
+    float* sb2 = sb1 + 128;                                 // [128]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 128 * 128; i += 512) {
+        const int r = i >> 7, c = i & 127;
+        const float v = w2[i];
+        const f16 h = (f16)v;
+        sw2h[r * PM_ROW + c] = h; sw2l[r * PM_ROW + c] = (f16)(v - (float)h);
+    }
+    for (int i = tid; i < 4 * 4 * 16 * 8; i += 512) {
+        const int e = i & 7, m = (i >> 3) & 15, kg = (i >> 7) & 3, ks = i >> 9;
+        const int ch = (e < 4) ? (2 * ks) * 16 + 4 * kg + e : (2 * ks + 1) * 16 + 4 * kg + (e - 4);
+        const float v = w3[m * 128 + ch];
+        const f16 h = (f16)v;
+        sw3h[i] = h; sw3l[i] = (f16)(v - (float)h);
+    }
+    for (int i = tid; i < 128 * 4; i += 512) sw1[i] = w1[i];
+    for (int i = tid; i < 128; i += 512) { sb1[i] = b1[i]; sb2[i] = b2[i]; }
+    __syncthreads();
+    const int lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
+    const int wave = (int)blockIdx.x * 8 + (tid >> 6), n_waves = (int)gridDim.x * 8;
+    const long total = (long)P * N;
+    const f32x4 b3v = *reinterpret_cast<const f32x4*>(b3 + 4 * kg);
+    for (long g0 = (long)wave * 64; g0 < total; g0 += (long)n_waves * 64) {
+        float px[4], py[4], pz[4], pf[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            long r = g0 + pt * 16 + l15; if (r > total - 1) r = total - 1;
+            const long n = r % N;
+            px[pt] = xyz[n * 3]; py[pt] = xyz[n * 3 + 1]; pz[pt] = xyz[n * 3 + 2]; pf[pt] = feat[r];
+        }
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ot][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            // layer 1 for the 8 channels this lane feeds into k-step ks, for its 4 points
+            f16x8 bh[4], bl[4];
+            const int c0 = ks * 32 + kg * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 w = *reinterpret_cast<const float4*>(sw1 + (c0 + e) * 4);
+                const float bb = sb1[c0 + e];
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    float v = bb + w.x * px[pt] + w.y * py[pt] + w.z * pz[pt] + w.w * pf[pt];
+                    v = v > 0.f ? v : 0.01f * v;
+                    const f16 h = (f16)v;
+                    bh[pt][e] = h; bl[pt][e] = (f16)(v - (float)h);
+                }
+            }
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) {
+                const int aoff = (ot * 16 + l15) * PM_ROW + ks * 32 + kg * 8;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(sw2h + aoff);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(sw2l + aoff);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ot][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[pt], acc[ot][pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ot][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[pt], acc[ot][pt], 0, 0, 0);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ot][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[pt], acc[ot][pt], 0, 0, 0);
+            }
+        }
+        // layer 2 epilogue (bias, LeakyReLU) and layer 3, k-step ks' = output tiles (2 ks', 2 ks' + 1)
+        f32x4 o[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) o[pt] = b3v;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(sb2 + (2 * ks) * 16 + 4 * kg);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(sb2 + (2 * ks + 1) * 16 + 4 * kg);
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(sw3h + ((ks * 4 + kg) * 16 + l15) * 8);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(sw3l + ((ks * 4 + kg) * 16 + l15) * 8);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                f16x8 hh, hl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[2 * ks][pt][e] + ba[e];
+                    v = v > 0.f ? v : 0.01f * v;
+                    f16 h = (f16)v; hh[e] = h; hl[e] = (f16)(v - (float)h);
+                    v = acc[2 * ks + 1][pt][e] + bb[e];
+                    v = v > 0.f ? v : 0.01f * v;
+                    h = (f16)v; hh[4 + e] = h; hl[4 + e] = (f16)(v - (float)h);
+                }
+                o[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, o[pt], 0, 0, 0);
+                o[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, o[pt], 0, 0, 0);
+                o[pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, o[pt], 0, 0, 0);
+            }
+        }
+        // o[pt][r] = out[point g0 + 16 pt + l15][channel 4 kg + r]
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const long r = g0 + pt * 16 + l15;
+            if (r < total) *reinterpret_cast<f32x4*>(out + r * 16 + 4 * kg) = o[pt];
+        }
+    }
+}
+
+static int g_point_mlp_mfma = 1;     // tuning / test hook (semabs_conv_set_config bit 8 clears it): 0 = the fp32 FMA kernel
+
 // xyz fp32 [N, 3] (shared by the P label volumes), feat fp32 [P, N] -> out fp32 [P, N, 16]
 extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* w3, const float* b3, float* out, int P, long N, int hidden,
@@ -93,6 +222,16 @@ extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float
     if (P == 0 || N == 0) return SEMABS_OK;
     SEMABS_REQUIRE(xyz && feat && w1 && b1 && w2 && b2 && w3 && b3 && out, "semabs_point_mlp: null pointer");
     SEMABS_REQUIRE(hidden == 128 && cout == 16, "semabs_point_mlp: built for hidden 128 -> 16 channels (net.py:358-367 defaults)");
+    if (g_point_mlp_mfma) {
+        const size_t lds2 = (size_t)(2 * 128 * PM_ROW + 2 * 4 * 4 * 16 * 8) * 2 + (size_t)(128 * 4 + 2 * 128) * 4;
+        static bool set2 = false;
+        if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); set2 = true; }
+        const long groups = ((long)P * N + 63) / 64;
+        long grid2 = (groups + 7) / 8; if (grid2 > semabs_num_cus()) grid2 = semabs_num_cus();
+        hipLaunchKernelGGL(k_point_mlp_mfma, dim3((unsigned)grid2), dim3(512), lds2, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
     size_t lds = (size_t)(128 * 128 + 16 * 128 + 128 * 4 + 2 * 128 + 16) * 4;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp<128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
@@ -731,7 +870,10 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
 
 static int g_conv16_lds = 1;     // tuning / test hook: 0 = always use the generic gather kernel
 static int g_conv16_ablate = 0;
-extern "C" int semabs_conv_set_config(int use_lds_brick) { g_conv16_lds = use_lds_brick & 1; g_conv16_ablate = use_lds_brick >> 1; return SEMABS_OK; }
+extern "C" int semabs_conv_set_config(int use_lds_brick) {
+    g_conv16_lds = use_lds_brick & 1; g_conv16_ablate = (use_lds_brick >> 1) & 7; g_point_mlp_mfma = !(use_lds_brick & 256);
+    return SEMABS_OK;
+}
 
 static int semabs_num_cus() {
     static int n = 0;
