@@ -397,7 +397,7 @@ class VOOLTrainer:
         x4 = torch.cat([xyz.unsqueeze(0).expand(P, N, 3), feat.unsqueeze(-1)], dim=-1).reshape(P * N, 4).contiguous()
         h1 = self._linear(x4, p[cn + "0.weight"], p[cn + "0.bias"], 1)
         h2 = self._linear_mfma(h1, p[cn + "2.weight"], p[cn + "2.bias"], 1)
-        pf = self._linear(h2, p[cn + "4.weight"], p[cn + "4.bias"], 0)                   # [P*N, C]
+        pf = self._linear_mfma(h2, p[cn + "4.weight"], p[cn + "4.bias"], 0)              # [P*N, C]
         flat = self.vg.flat_idxs(xyz)
         vol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
         head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
@@ -412,7 +412,7 @@ class VOOLTrainer:
         w1p = torch.zeros(32, 36, dtype=torch.float32, device=dev)
         w1p[:, :35] = p[ss + "0.weight"]
         h = self._linear(f, w1p, p[ss + "0.bias"], 1)
-        o = self._linear(h, p[ss + "2.weight"], p[ss + "2.bias"], 0)
+        o = self._linear_mfma(h, p[ss + "2.weight"], p[ss + "2.bias"], 0)
         rel = torch.stack([p["relation_embeddings." + n] for n in rel_names], dim=0).contiguous()
         dO = torch.empty_like(o)
         drel = torch.zeros(D, self.E, dtype=torch.float32, device=dev)
@@ -423,7 +423,7 @@ class VOOLTrainer:
             g["relation_embeddings." + n].add_(drel[d])
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
         u._colsum(dO, g[ss + "2.bias"])
-        dh = u._ew(self._linear(dO, p[ss + "2.weight"].t().contiguous(), None, 0), h, 1)
+        dh = u._ew(self._linear_mfma(dO, p[ss + "2.weight"].t().contiguous(), None, 0, grad_in=True), h, 1)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
@@ -438,7 +438,7 @@ class VOOLTrainer:
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
-        dh2 = u._ew(self._linear(dpf, p[cn + "4.weight"].t().contiguous(), None, 0), h2, 1)
+        dh2 = u._ew(self._linear_mfma(dpf, p[cn + "4.weight"].t().contiguous(), None, 0, grad_in=True), h2, 1)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
         dh1 = u._ew(self._linear_mfma(dh2, p[cn + "2.weight"].t().contiguous(), None, 0, grad_in=True), h1, 1)
