@@ -170,6 +170,11 @@ int semabs_conv_set_config(int use_lds_brick);
 int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off /*host*/, void* y,
                            const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout, int act_f32,
                            void* stream);
+/* Same, plus the GroupNorm statistics of the output (sum / sum of squares per group, fp64 [B, out_groups, 2], zero-filled by the caller) for
+ * the decoder block that follows (unet3d.py:66-79): fused into the brick kernel's epilogue for 8 groups, a statistics pass otherwise. */
+int semabs_convtranspose3d_stats(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y, const float* bias,
+                                 const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout, int act_f32, double* out_sums,
+                                 int out_groups, void* stream);
 int semabs_maxpool3d(const void* x, void* y, int B, int D0, int D1, int D2, int C, int act_f32, void* stream);   /* unet3d.py:298 */
 /* ImplicitVolumetricDecoder: trilinear grid_sample (border, align_corners) + MLP    net.py:215-256
  * off3 / sc3 / shape3 / w1 / b1 / w2 / b2 are HOST arrays.  qgrid3 (host int[3] or NULL): the M queries of every label are a dense C-order

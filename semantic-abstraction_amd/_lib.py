@@ -64,6 +64,7 @@ SIGNATURES = {
     "semabs_conv3d_stats": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
     "semabs_conv_set_config": [I],
     "semabs_convtranspose3d": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P],
+    "semabs_convtranspose3d_stats": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P, I, P],
     "semabs_maxpool3d": [P, P, I, I, I, I, I, I, P],
     "semabs_vool_head": [P, P, P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), F, I, L, I, P, P],
     "semabs_lamb_step": [P, I, P, I, D, D, D, D, D, I, P, P, P],

@@ -1232,6 +1232,7 @@ struct ConvTArgs {
     const void* x; void* y; const f16* w_hi; const f16* w_lo; const float* bias; const void* skip;
     long class_off[8];
     int B, D0, D1, D2, Cin, Cout;
+    double* stats;              // optional: fp64 [B, 8, 2] GroupNorm statistics (8 groups) of the output (after bias and skip), accumulated
 };
 template <bool F32, int P0>                              // P0 = output parity along axis 0: two launches of four classes each (acc registers)
 __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
@@ -1334,6 +1335,16 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
     const int O1 = 2 * a.D1, O2 = 2 * a.D2;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cout0 + 4 * kg);
+    // fused GroupNorm statistics of the output: a lane's channels 4 kg, 4 kg + 1 | 4 kg + 2, 4 kg + 3 are two halves that each lie inside one
+    // of the 8 groups (Cout / 8 >= 2 channels per group); fp32 per lane -> 16-lane reduction -> LDS float atomics per group of this
+    // 16-channel slice -> one fp64 atomic per (group, moment) per workgroup
+    float* s_stat = reinterpret_cast<float*>(smem);         // [8 local groups][2]
+    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
+    if (a.stats) {
+        __syncthreads();                                    // every wave is done with the operand tiles
+        if (tid < 16) s_stat[tid] = 0.f;
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = wid * 4 + r;
@@ -1349,8 +1360,30 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
                 else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); o[0] += (float)q[0]; o[1] += (float)q[1]; o[2] += (float)q[2]; o[3] += (float)q[3]; }
             }
             if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
-            else { f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h; }
+            else {
+                f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (float)h[e];                  // statistics of the values as stored
+            }
+            st_s[0] += o[0] + o[1]; st_q[0] += o[0] * o[0] + o[1] * o[1];
+            st_s[1] += o[2] + o[3]; st_q[1] += o[2] * o[2] + o[3] * o[3];
         }
+    }
+    if (a.stats) {
+        const int cg = a.Cout / 8;                          // channels per group
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            float vs = st_s[hf], vq = st_q[hf];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { vs += __shfl_xor(vs, m, 64); vq += __shfl_xor(vq, m, 64); }
+            if (vl == 0) {
+                const int gl = (cg >= 16) ? 0 : (4 * kg + 2 * hf) / cg;          // group index local to this 16-channel slice
+                atomicAdd(&s_stat[gl * 2], vs); atomicAdd(&s_stat[gl * 2 + 1], vq);
+            }
+        }
+        __syncthreads();
+        const int ngl = (cg >= 16) ? 1 : 16 / cg;
+        if (tid < ngl * 2) atomicAdd(a.stats + ((long)b * 8 + cout0 / cg + (tid >> 1)) * 2 + (tid & 1), (double)s_stat[tid]);
     }
 }
 template <bool F32>
@@ -1374,9 +1407,9 @@ static int convT_brick_launch(const ConvTArgs& a, hipStream_t s) {
 // o = 2 m + p takes input m (kernel index 1) when p = 0, inputs m + 1 (k = 0) and m (k = 2) when p = 1.
 // w_hi / w_lo: 8 matrices, class c = p0*4 + p1*2 + p2 at offset class_off[c] (elements), each [Cout, ntaps_c * Cin]
 // with tap order (t0, t1, t2) over each dimension's candidate list above.
-extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y,
-                                      const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout,
-                                      int act_f32, void* stream) {
+static int convT_impl(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y,
+                      const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout,
+                      int act_f32, double* out_sums, int out_groups, void* stream) {
     if (B == 0) return SEMABS_OK;
     int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
     if (rc) return rc;
@@ -1386,7 +1419,11 @@ extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const voi
         ta.x = x; ta.y = y; ta.w_hi = (const f16*)w_hi; ta.w_lo = (const f16*)w_lo; ta.bias = bias; ta.skip = skip;
         for (int c = 0; c < 8; ++c) ta.class_off[c] = class_off[c];
         ta.B = B; ta.D0 = D0; ta.D1 = D1; ta.D2 = D2; ta.Cin = Cin; ta.Cout = Cout;
-        return act_f32 ? convT_brick_launch<true>(ta, (hipStream_t)stream) : convT_brick_launch<false>(ta, (hipStream_t)stream);
+        const bool fused = out_sums && out_groups == 8 && Cout % 16 == 0;
+        ta.stats = fused ? out_sums : nullptr;
+        rc = act_f32 ? convT_brick_launch<true>(ta, (hipStream_t)stream) : convT_brick_launch<false>(ta, (hipStream_t)stream);
+        if (rc == SEMABS_OK && out_sums && !fused) rc = semabs_gn_stats(y, out_sums, B, 8L * D0 * D1 * D2, Cout, out_groups, act_f32, stream);
+        return rc;
     }
     for (int cls = 0; cls < 8; ++cls) {
         const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
@@ -1406,7 +1443,21 @@ extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const voi
         rc = conv_launch(a, act_f32, (hipStream_t)stream);
         if (rc) return rc;
     }
+    if (out_sums) return semabs_gn_stats(y, out_sums, B, 8L * D0 * D1 * D2, Cout, out_groups, act_f32, stream);
     return SEMABS_OK;
+}
+extern "C" int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y,
+                                      const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout,
+                                      int act_f32, void* stream) {
+    return convT_impl(x, w_hi, w_lo, class_off, y, bias, skip, B, D0, D1, D2, Cin, Cout, act_f32, nullptr, 0, stream);
+}
+// + the GroupNorm statistics of the output (fp64 [B, out_groups, 2], zero-filled by the caller) for the block that follows: fused into the
+// brick kernel's epilogue for 8 groups, a statistics pass over y otherwise
+extern "C" int semabs_convtranspose3d_stats(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y,
+                                            const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout,
+                                            int act_f32, double* out_sums, int out_groups, void* stream) {
+    SEMABS_REQUIRE(out_sums && out_groups > 0 && Cout % out_groups == 0, "semabs_convtranspose3d_stats: bad out_sums / out_groups");
+    return convT_impl(x, w_hi, w_lo, class_off, y, bias, skip, B, D0, D1, D2, Cin, Cout, act_f32, out_sums, out_groups, stream);
 }
 
 // =================================================================================================

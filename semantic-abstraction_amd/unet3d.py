@@ -158,9 +158,10 @@ class ResidualUNet3D:
         _lib.call("semabs_conv3d", *args, _lib.stream())
         return y
 
-    def _block(self, x, convs):
-        # conv1 / conv2 hand the statistics of their outputs to the GroupNorm of conv2 / conv3 (fused into the epilogue where supported)
-        out1, s1 = self._conv(x, convs[0], relu=True, out_groups=convs[1].groups)
+    def _block(self, x, convs, in_sums=None):
+        # conv1 / conv2 hand the statistics of their outputs to the GroupNorm of conv2 / conv3 (fused into the epilogue where supported);
+        # in_sums: the statistics of x when its producer already has them (the transposed convolution of a decoder level)
+        out1, s1 = self._conv(x, convs[0], relu=True, in_sums=in_sums, out_groups=convs[1].groups)
         out2, s2 = self._conv(out1, convs[1], relu=True, in_sums=s1, out_groups=convs[2].groups)
         return self._conv(out2, convs[2], relu=True, resid=out1, in_sums=s2)          # conv3 (no ReLU) + residual, then ReLU
 
@@ -170,12 +171,18 @@ class ResidualUNet3D:
         _lib.call("semabs_maxpool3d", _lib.ptr(x), _lib.ptr(y), B, D0, D1, D2, Cc, self.f32, _lib.stream())
         return y
 
-    def _up(self, x, skip, ct: _ConvT):
+    def _up(self, x, skip, ct: _ConvT, out_groups=0):
+        """ConvTranspose3d(k3, s2) + skip; out_groups > 0: also the GroupNorm statistics of the result for the block that follows."""
         B, D0, D1, D2, _ = x.shape
         assert tuple(skip.shape) == (B, 2 * D0, 2 * D1, 2 * D2, ct.cout)
         y = torch.empty_like(skip)
-        _lib.call("semabs_convtranspose3d", _lib.ptr(x), _lib.ptr(ct.w_hi), _lib.ptr(ct.w_lo), ct.class_off, _lib.ptr(y),
-                  _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32, _lib.stream())
+        args = (_lib.ptr(x), _lib.ptr(ct.w_hi), _lib.ptr(ct.w_lo), ct.class_off, _lib.ptr(y),
+                _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32)
+        if out_groups:
+            sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
+            _lib.call("semabs_convtranspose3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
+            return y, sums
+        _lib.call("semabs_convtranspose3d", *args, _lib.stream())
         return y
 
     # ---- forward -----------------------------------------------------------------------------------
@@ -192,8 +199,8 @@ class ResidualUNet3D:
                 taps[f"enc{i}"] = x
             feats.insert(0, x)
         for i, (skip, (ct, convs)) in enumerate(zip(feats[1:], self.dec)):
-            x = self._up(x, skip, ct)
-            x = self._block(x, convs)
+            x, sums = self._up(x, skip, ct, out_groups=convs[0].groups)
+            x = self._block(x, convs, in_sums=sums)
             if taps is not None:
                 taps[f"dec{i}"] = x
         if skip_final:

@@ -304,3 +304,24 @@ def test_conv3d_output_statistics(precision, cin, cout, dims, B):
     yd = y.double().reshape(B, -1, 8, cout // 8)                       # [B, voxels, group, channel in group]
     want = torch.stack([yd.sum(dim=(1, 3)), (yd * yd).sum(dim=(1, 3))], dim=-1)
     np.testing.assert_allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=2e-6, atol=1e-6 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["exact", "fp16"])
+@pytest.mark.parametrize("cin,cout,dims,B", [(32, 16, (4, 8, 16), 2), (64, 32, (4, 8, 16), 1), (256, 128, (4, 8, 16), 1), (32, 16, (3, 4, 5), 2)])
+def test_convtranspose3d_output_statistics(precision, cin, cout, dims, B):
+    """semabs_convtranspose3d_stats: GroupNorm statistics of (ConvTranspose3d + skip) fused into the brick kernel's epilogue (last case:
+    the per-class fallback + a statistics pass) equal the sums of the stored output."""
+    from semabs_amd.unet3d import _ConvT
+    rng = np.random.default_rng(cin + cout)
+    u = _unet(precision)
+    x = _cl(torch.from_numpy(rng.standard_normal((B, cin, *dims)).astype(np.float32))).cuda().to(u.act_dtype)
+    w = torch.from_numpy((rng.standard_normal((cin, cout, 3, 3, 3)) / np.sqrt(27 * cin / 8)).astype(np.float32))
+    bias = torch.from_numpy((0.1 * rng.standard_normal(cout)).astype(np.float32))
+    skip = _cl(torch.from_numpy(rng.standard_normal((B, cout, *[2 * d for d in dims])).astype(np.float32))).cuda().to(u.act_dtype)
+    ct = _ConvT(w, bias, u.dev)
+    y0 = u._up(x, skip, ct)
+    y, sums = u._up(x, skip, ct, out_groups=8)
+    assert torch.equal(y, y0)
+    yd = y.double().reshape(B, -1, 8, cout // 8)
+    want = torch.stack([yd.sum(dim=(1, 3)), (yd * yd).sum(dim=(1, 3))], dim=-1)
+    np.testing.assert_allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=2e-6 * float(want.abs().max()))
