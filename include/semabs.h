@@ -148,6 +148,10 @@ int semabs_point_mlp(const float* xyz, const float* feat, const float* w1, const
  * deterministic, sums in point order; vol zero-filled and head filled with -1 by the caller. */
 int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
                         long nvox, int vol_f32, void* stream);
+/* Same, plus the GroupNorm statistics (8 groups, fp64 [P, 8, 2], zero-filled by the caller) of the scattered volume for the first UNet block
+ * (unet3d.py:66-79): summed over the occupied voxels while they are written.  C must be 16. */
+int semabs_scatter_mean_stats(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
+                              long nvox, int vol_f32, double* out_sums, void* stream);
 /* GroupNorm statistics / affine                                       unet3d.py:66-79 (nn.GroupNorm) */
 int semabs_gn_stats(const void* x, double* sums, int B, long nvox, int C, int G, int x_f32, void* stream);
 int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta, float* scale, float* shift, int B, int C,

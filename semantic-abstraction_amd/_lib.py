@@ -58,6 +58,7 @@ SIGNATURES = {
     # unet.hip
     "semabs_point_mlp": [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     "semabs_scatter_mean": [P, P, P, P, P, I, L, I, L, I, P],
+    "semabs_scatter_mean_stats": [P, P, P, P, P, I, L, I, L, I, P, P],
     "semabs_gn_stats": [P, P, I, L, I, I, I, P],
     "semabs_gn_finalize": [P, P, P, P, P, I, I, I, L, F, P],
     "semabs_conv3d": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],

@@ -256,12 +256,17 @@ __global__ void k_scatter_link(const long long* __restrict__ flat, long N, int* 
 #define SCATTER_MAXLIST 32
 template <typename TOut>
 __global__ void k_scatter_mean(const long long* __restrict__ flat, const float* __restrict__ feat, const int* __restrict__ head,
-                               const int* __restrict__ next, TOut* __restrict__ vol, int P, long N, int C, long nvox) {
+                               const int* __restrict__ next, TOut* __restrict__ vol, int P, long N, int C, long nvox, double* __restrict__ stats) {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)P * N) return;
+    const bool in_range = t < (long)P * N;
+    if (!in_range) t = (long)P * N - 1;
     const long p = t % N; const int b = (int)(t / N);
     const long v = flat[p];
-    if (head[v] != (int)p) return;                  // one worker per occupied voxel (and label)
+    const bool worker = in_range && head[v] == (int)p;     // one worker per occupied voxel (and label)
+    // `stats` (optional, C == 16): GroupNorm statistics (8 groups of 2 channels) of the volume being written - empty voxels add nothing, so
+    // the sums over the workers' voxels are the sums over the dense volume.  A wave reduces its workers' sums and issues 16 fp64 atomics.
+    float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (worker) {
     int ids[SCATTER_MAXLIST]; int cnt = 0; int total = 0;
     for (int q = (int)p; q >= 0; q = next[q]) {
         if (cnt < SCATTER_MAXLIST) ids[cnt++] = q;
@@ -282,22 +287,54 @@ __global__ void k_scatter_mean(const long long* __restrict__ flat, const float* 
         } else {                                    // very crowded voxel: list order (last-bit differences only)
             for (int q = (int)p; q >= 0; q = next[q]) s += feat[((long)b * N + q) * C + c];
         }
-        vol[((long)b * nvox + v) * C + c] = (TOut)(s / denom);
+        const TOut o = (TOut)(s / denom);
+        vol[((long)b * nvox + v) * C + c] = o;
+        if (stats && c < 16) { const float of = (float)o; gs[c >> 1] += of; gq[c >> 1] += of * of; }
+    }
+    }
+    if (stats) {                                            // uniform
+        if (__ballot(worker) != 0) {
+            const int bw = __builtin_amdgcn_readfirstlane(b);       // a wave may straddle two labels only if N % 64 != 0: then per-lane atomics
+            const bool uniform_b = __ballot(b != bw) == 0;
+            if (uniform_b) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    float a = gs[g], q = gq[g];
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); q += __shfl_xor(q, m, 64); }
+                    if ((threadIdx.x & 63) == 0) { atomicAdd(stats + ((long)bw * 8 + g) * 2, (double)a); atomicAdd(stats + ((long)bw * 8 + g) * 2 + 1, (double)q); }
+                }
+            } else if (worker) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) { atomicAdd(stats + ((long)b * 8 + g) * 2, (double)gs[g]); atomicAdd(stats + ((long)b * 8 + g) * 2 + 1, (double)gq[g]); }
+            }
+        }
     }
 }
 
 // flat int64 [N]; feat fp32 [P, N, C]; vol [P, nvox, C] (fp16 or fp32), must be zero-filled by the caller;
 // head int32 [nvox] filled with -1 by the caller; next int32 [N] scratch.
-extern "C" int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
-                                   long nvox, int vol_f32, void* stream) {
+static int scatter_mean_impl(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
+                             long nvox, int vol_f32, double* stats, void* stream) {
     if (P == 0 || N == 0) return SEMABS_OK;
     SEMABS_REQUIRE(flat && feat && head && next && vol && C > 0 && nvox > 0, "semabs_scatter_mean: bad args");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_scatter_link, dim3(semabs_cdiv(N, 256)), dim3(256), 0, s, flat, N, head, next);
-    if (vol_f32) hipLaunchKernelGGL(k_scatter_mean<float>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (float*)vol, P, N, C, nvox);
-    else hipLaunchKernelGGL(k_scatter_mean<f16>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (f16*)vol, P, N, C, nvox);
+    if (vol_f32) hipLaunchKernelGGL(k_scatter_mean<float>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (float*)vol, P, N, C, nvox, stats);
+    else hipLaunchKernelGGL(k_scatter_mean<f16>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (f16*)vol, P, N, C, nvox, stats);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
+}
+extern "C" int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
+                                   long nvox, int vol_f32, void* stream) {
+    return scatter_mean_impl(flat, feat, head, next, vol, P, N, C, nvox, vol_f32, nullptr, stream);
+}
+// + the GroupNorm statistics (8 groups; sum / sum of squares, fp64 [P, 8, 2], zero-filled by the caller) of the scattered volume for the first
+// UNet block: only occupied voxels contribute, so the 2 GB dense volume is not read back for them.  C must be 16.
+extern "C" int semabs_scatter_mean_stats(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
+                                         long nvox, int vol_f32, double* out_sums, void* stream) {
+    SEMABS_REQUIRE(out_sums && C == 16, "semabs_scatter_mean_stats: needs out_sums and C == 16");
+    return scatter_mean_impl(flat, feat, head, next, vol, P, N, C, nvox, vol_f32, out_sums, stream);
 }
 
 // =================================================================================================

@@ -141,12 +141,18 @@ class SemAbs3D:
         vol = torch.zeros(P, S0, S1, S2, self.C, dtype=unet.act_dtype, device=dev)
         head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
         nxt = torch.empty(N, dtype=torch.int32, device=dev)
-        _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
-                  unet.f32, st)
+        sums = None
+        if self.C == 16 and unet.in_channels == 16 and unet.enc[0][0].groups == 8:     # statistics for the first GroupNorm come out of the scatter
+            sums = torch.zeros(P, 8, 2, dtype=torch.float64, device=dev)
+            _lib.call("semabs_scatter_mean_stats", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
+                      unet.f32, _lib.ptr(sums), st)
+        else:
+            _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
+                      unet.f32, st)
         if taps is not None:
             taps["scatter"] = vol
             taps["point_feat"] = pf
-        return unet.forward_cl(vol, taps=taps, skip_final=skip_final)
+        return unet.forward_cl(vol, taps=taps, skip_final=skip_final, in_sums=sums)
 
     def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False, lattice=None, pre_final: bool = False) -> torch.Tensor:
         """features [P, S, S, S, C]; query fp32 [P, M, 3] (or [M, 3] with shared=True) -> logits fp32 [P, M].

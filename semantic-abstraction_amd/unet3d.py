@@ -186,15 +186,16 @@ class ResidualUNet3D:
         return y
 
     # ---- forward -----------------------------------------------------------------------------------
-    def forward_cl(self, x: torch.Tensor, taps: dict | None = None, skip_final: bool = False) -> torch.Tensor:
-        """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]  (skip_final: the input of `final_conv`)."""
+    def forward_cl(self, x: torch.Tensor, taps: dict | None = None, skip_final: bool = False, in_sums=None) -> torch.Tensor:
+        """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]  (skip_final: the input of `final_conv`;
+        in_sums: GroupNorm statistics of x, fp64 [B, groups, 2], when its producer already has them)."""
         assert self.final is not None, "load_state_dict first"
         assert x.dtype == self.act_dtype and x.is_contiguous()
         feats = []
         for i, convs in enumerate(self.enc):
             if i > 0:
                 x = self._pool(x)
-            x = self._block(x, convs)
+            x = self._block(x, convs, in_sums=in_sums if i == 0 else None)
             if taps is not None:
                 taps[f"enc{i}"] = x
             feats.insert(0, x)

@@ -325,3 +325,32 @@ def test_convtranspose3d_output_statistics(precision, cin, cout, dims, B):
     yd = y.double().reshape(B, -1, 8, cout // 8)
     want = torch.stack([yd.sum(dim=(1, 3)), (yd * yd).sum(dim=(1, 3))], dim=-1)
     np.testing.assert_allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=2e-6 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("vol_f32", [1, 0])
+def test_scatter_mean_statistics(vol_f32):
+    """semabs_scatter_mean_stats: same volume as semabs_scatter_mean, and the GroupNorm statistics of the dense volume summed over the
+    occupied voxels only (N not a multiple of 64: waves that straddle two label volumes take the per-lane path)."""
+    from semabs_amd import _lib
+    rng = np.random.default_rng(9)
+    P, N, C, S = 3, 1000, 16, 12
+    nvox = S ** 3
+    flat = torch.from_numpy(rng.integers(0, nvox, size=N).astype(np.int64)).cuda()
+    feat = torch.from_numpy(rng.standard_normal((P, N, C)).astype(np.float32)).cuda()
+    dt = torch.float32 if vol_f32 else torch.float16
+    vols = []
+    for with_stats in (False, True):
+        vol = torch.zeros(P, nvox, C, dtype=dt, device="cuda")
+        head = torch.full((nvox,), -1, dtype=torch.int32, device="cuda")
+        nxt = torch.empty(N, dtype=torch.int32, device="cuda")
+        if with_stats:
+            sums = torch.zeros(P, 8, 2, dtype=torch.float64, device="cuda")
+            _lib.call("semabs_scatter_mean_stats", _lib.ptr(flat), _lib.ptr(feat), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, C, nvox, vol_f32,
+                      _lib.ptr(sums), _lib.stream())
+        else:
+            _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(feat), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, C, nvox, vol_f32, _lib.stream())
+        vols.append(vol)
+    assert torch.equal(vols[0], vols[1])
+    vd = vols[1].double().reshape(P, nvox, 8, 2)
+    want = torch.stack([vd.sum(dim=(1, 3)), (vd * vd).sum(dim=(1, 3))], dim=-1)
+    np.testing.assert_allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=2e-6 * float(want.abs().max()))
