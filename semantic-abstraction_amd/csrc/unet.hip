@@ -460,14 +460,19 @@ __device__ __forceinline__ void load8(const void* base, long idx, float (&v)[8])
 }
 
 // NW = 16-channel output blocks per wave (1, 2, 4); MW = 2 voxel blocks of 16 per wave; 4 waves per workgroup.
-template <int NW, bool F32, bool CIN16>
+// LDSW (the deep levels, NW = 4): the four waves of a workgroup share their output-channel tiles, i.e. their weight fragments - 8 KB per
+// k-step that each of them used to pull through the vector L1 on its own (the kernel is bound by L1 bandwidth there: 12 KB of operands per
+// wave per 24 MFMAs).  Wave w loads tile w, parks it in a double-buffered LDS slab, and all four read the k-step's four tiles from there.
+template <int NW, bool F32, bool CIN16, bool LDSW = false>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     constexpr int MW = 2;
+    static_assert(!LDSW || (NW == 4 && !CIN16), "LDSW: four waves x four output-channel tiles");
+    __shared__ __attribute__((aligned(16))) f16x8 s_w[LDSW ? 2 : 1][LDSW ? 4 : 1][2][LDSW ? 64 : 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int vl = lane & 15, kg = lane >> 4;
     const long Mtot = (long)a.B * a.M0 * a.M1 * a.M2;
     const long mbase = ((long)blockIdx.x * 4 + wid) * (MW * 16);
-    if (mbase >= Mtot) return;
+    if (!LDSW && mbase >= Mtot) return;                    // (LDSW: every wave takes part in the barriers; its voxels are masked by vok)
     const int n0 = blockIdx.y * (NW * 16);
     const bool has_gn = a.gn_scale != nullptr;
 
@@ -524,10 +529,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         }
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
-            const long widx = (long)(n0 + ni * 16 + vl) * a.Kp + ks * 32 + kg * 8;
+            if (LDSW && ni != 0) continue;                  // this wave's own tile only (tile wid), kept in slot 0
+            const long widx = (long)(n0 + (LDSW ? wid : ni) * 16 + vl) * a.Kp + ks * 32 + kg * 8;
             R.wh[ni] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
             if (F32) R.wl[ni] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
         }
+    };
+    auto park = [&](int ks, Raw& R) {                       // LDSW: this wave's tile of k-step ks -> LDS, then the workgroup barrier
+        s_w[ks & 1][wid][0][lane] = R.wh[0];
+        if (F32) s_w[ks & 1][wid][1][lane] = R.wl[0];
+        __syncthreads();
     };
     auto consume = [&](int ks, Raw& R) {
         int c0 = 0;
@@ -563,13 +574,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         }
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
+            const f16x8 wh = LDSW ? s_w[ks & 1][ni][0][lane] : R.wh[ni];
+            f16x8 wl;
+            if (F32) wl = LDSW ? s_w[ks & 1][ni][1][lane] : R.wl[ni];
 #pragma unroll
-            for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.wh[ni], xh[mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < MW; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[mi], acc[mi][ni], 0, 0, 0);
             if (F32) {
 #pragma unroll
                 for (int mi = 0; mi < MW; ++mi) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.wl[ni], xh[mi], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.wh[ni], xl[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[mi], acc[mi][ni], 0, 0, 0);
                 }
             }
         }
@@ -581,6 +595,21 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     }
     Raw R0, R1;
     if (ks_lo < ks_hi) fetch(ks_lo, R0);
+    if (LDSW) {
+        // k-step ks: its four weight tiles are in slab ks & 1 (parked one step earlier); the loads of k-step ks + 1 are in flight during the
+        // MFMAs and are parked into the other slab afterwards - that slab was last read in step ks - 1, before the previous barrier.
+        if (ks_lo < ks_hi) park(ks_lo, R0);
+        for (int ks = ks_lo; ks < ks_hi; ks += 2) {
+            if (ks + 1 < ks_hi) fetch(ks + 1, R1);
+            consume(ks, R0);
+            if (ks + 1 < ks_hi) {
+                park(ks + 1, R1);
+                if (ks + 2 < ks_hi) fetch(ks + 2, R0);
+                consume(ks + 1, R1);
+                if (ks + 2 < ks_hi) park(ks + 2, R0);
+            }
+        }
+    } else
     for (int ks = ks_lo; ks < ks_hi; ks += 2) {
         if (ks + 1 < ks_hi) fetch(ks + 1, R1);
         consume(ks, R0);
@@ -1153,7 +1182,7 @@ static int conv_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
             a.ksplit = ks;
             if (hipMemsetAsync(a.y, 0, (size_t)Mtot * a.Cout * sizeof(float), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
             dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / 64, ks), block(256);
-            hipLaunchKernelGGL((k_conv<4, true, false>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_conv<4, true, false, true>), grid, block, 0, s, a);
             const long n4 = Mtot * a.Cout / 4;
             hipLaunchKernelGGL(k_conv_finish, dim3(semabs_cdiv(n4, 256)), dim3(256), 0, s, reinterpret_cast<float*>(a.y), a.bias,
                                reinterpret_cast<const float*>(a.resid), n4, a.Cout, a.relu);
@@ -1170,7 +1199,11 @@ static int conv_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
     const bool c16 = a.Cin == 16;
 #define CONV_GO(NW_, F_, C_) hipLaunchKernelGGL((k_conv<NW_, F_, C_>), grid, block, 0, s, a)
 #define CONV_NW(F_, C_) { if (nw == 4) CONV_GO(4, F_, C_); else if (nw == 2) CONV_GO(2, F_, C_); else CONV_GO(1, F_, C_); }
-    if (f32) { if (c16) CONV_NW(true, true) else CONV_NW(true, false) }
+    if (nw == 4 && !c16) {                                  // four waves x four shared weight tiles: weights through LDS
+        if (f32) hipLaunchKernelGGL((k_conv<4, true, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_conv<4, false, false, true>), grid, block, 0, s, a);
+    }
+    else if (f32) { if (c16) CONV_NW(true, true) else CONV_NW(true, false) }
     else { if (c16) CONV_NW(false, true) else CONV_NW(false, false) }
 #undef CONV_NW
 #undef CONV_GO
