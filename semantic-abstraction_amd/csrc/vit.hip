@@ -202,10 +202,9 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         f16x8 fq[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
-        // Two passes over the key blocks instead of keeping all NKB score blocks in registers (112 VGPRs at T = 197): pass 1 only finds the
-        // row maximum, pass 2 recomputes each score block (4 MFMAs - the matrix pipe is 13 % busy in this kernel), exponentiates, and feeds
-        // the un-normalised probabilities straight into P.V; O is scaled by 1 / sum at the end.  ~100 VGPRs -> two workgroups per CU.
-        auto scores = [&](int kb, f32x16& sc, float init) {      // init = 0 (pass 1) or -max (pass 2: the MFMA accumulator does the subtraction)
+        // One score block (4 MFMAs) at a time instead of keeping all NKB blocks in registers (112 VGPRs at T = 197): exponentiate, feed the
+        // un-normalised probabilities straight into P.V; O is scaled by 1 / sum at the end.  ~100 VGPRs -> two workgroups per CU.
+        auto scores = [&](int kb, f32x16& sc, float init) {      // init = -(reference maximum): the MFMA accumulator does the subtraction
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = init;
 #pragma unroll
@@ -223,15 +222,12 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
                 }
             }
         };
-        float mx = -INFINITY;
-#pragma unroll 1
-        for (int kb = 0; kb < NKB; ++kb) {
-            f32x16 sc;
-            scores(kb, sc, 0.f);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // Single pass with a LAZY running maximum: block kb's scores come out of the MFMA already shifted by the current reference m (the
+        // accumulator starts at -m); m is only raised - and O and the running sum rescaled - when some query of the wave sees a score more
+        // than 8 above it, i.e. almost never after the first block (un-normalised probabilities up to e^8 = 2981 are exact enough in fp16
+        // and the accumulations are fp32; the final 1 / sum removes the reference).  Saves the separate max pass: 28 of the 84 MFMAs and
+        // 28 of the K fragment reads per query block.
+        float mref = 0.f;                                   // per query (the two lanes of a query keep the same value)
         float sum = 0.f;
         f32x16 o[2];
 #pragma unroll
@@ -241,7 +237,24 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 #pragma unroll 1
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 sc;
-            scores(kb, sc, -mx);
+            scores(kb, sc, -mref);
+            float bm = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, sc[r]);
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const bool raise = kb == 0 || bm > 8.f;          // first block: adopt its maximum as the reference
+            if (__ballot(raise) != 0) {                      // wave-uniform branch
+                const float d = raise ? bm : 0.f;            // (a fully masked block cannot occur: key 0 is always live)
+                const float alpha = __builtin_amdgcn_exp2f(-d * 1.44269504088896340736f);
+                mref += d;
+                sum *= alpha;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] -= d;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] * 1.44269504088896340736f); sum += sc[r]; }
 #pragma unroll

@@ -310,3 +310,27 @@ def test_add_layernorm():
     np.testing.assert_allclose(out.cpu().float().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3)
     add_layernorm(xd, d.cuda(), None, None, None, M, D)
     assert torch.equal(xd.cpu(), xs + d.float())
+
+
+@pytest.mark.parametrize("T,H,causal", [(197, 2, 0), (128, 2, 1), (77, 1, 1)])
+def test_attention_rising_scores(T, H, causal):
+    """The single-pass softmax keeps a lazy reference maximum and rescales only when a key block exceeds it by more than 8: here the scores
+    grow steeply along the keys (and span > 60 per row), so every later block raises the reference and the rescaling path runs."""
+    from semabs_amd import _lib
+    rng = np.random.default_rng(T + 7)
+    n, D = 2, H * 64
+    qkv = _rand16(rng, n, T, 3 * D).float()
+    ramp = torch.linspace(0.0, 1.0, T)[None, :, None]
+    qkv[..., :D] = 0.25 * qkv[..., :D] + 1.0                               # queries: a common positive component ...
+    qkv[..., D:2 * D] = 0.25 * qkv[..., D:2 * D] + ramp                    # ... that the keys pick up more and more strongly -> scores rise to ~64
+    qkv = qkv.half()
+    out = torch.zeros(n, T, D, dtype=torch.float16, device="cuda")
+    qkv_d = qkv.cuda()
+    _lib.call("semabs_attention", _lib.ptr(qkv_d), _lib.ptr(out), None, n, T, H, 64, 3 * D, causal, _lib.stream())
+    q, k, v = (t.double().view(n, T, H, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+    s = q @ k.transpose(-1, -2)
+    assert float(s.max() - s.min()) > 40.0
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu_(1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n, T, D)
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
