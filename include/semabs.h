@@ -123,8 +123,9 @@ int semabs_embed_finish(float* x, const float* cls, const float* pos, int n, int
 /* fused multi-head attention, head_dim 64, T <= 224                  auxiliary.py:260-340 (q pre-scaled) */
 int semabs_attention(const void* qkv, void* out, const void* reserved, int n_seq, int T, int H, int head_dim, int ld,
                      int causal, void* stream);
-/* last block, CLS query only; keeps the softmax row (the hooked attn_probs, auxiliary.py:330-335) */
-int semabs_attention_cls(const float* q, const float* kv, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
+/* last block, CLS query only; keeps the softmax row (the hooked attn_probs, auxiliary.py:330-335).  q fp32 [n, D], k fp32 [n, T, D] (the
+ * scores stay fp32), v fp16 [n, T, D] (it only enters averaged: o, and the rollout's V . u dots) */
+int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
 int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
 int semabs_quickgelu(const float* fc, void* act, long n, void* stream);                 /* model_explainability.py:197-199 */
 /* logits = 100 f/|f| . w_l and d logit / d f, rows normalised to max-abs 1            clip_gradcam.py:62-67 */
@@ -133,7 +134,7 @@ int semabs_ln_bwd(const float* x, const float* gamma, const float* gy, const flo
                   long M, int D, int n_x, long ld_x, float eps, void* stream);
 int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, void* stream);
 /* closed form of ClipGradcam.interpret for the only contributing block             clip_gradcam.py:70-132 */
-int semabs_rollout(const float* probs, const float* kv, const float* u, const float* scale, float* rel, int n, int T, int H,
+int semabs_rollout(const float* probs, const void* v /* fp16 [n, T, D] */, const float* u, const float* scale, float* rel, int n, int T, int H,
                    int L, int positive_only, long n_total, long tile0, void* stream);
 /* text tower glue                                                    model_explainability.py:469-482; clip_gradcam.py:24-27 */
 int semabs_gather_text(const long long* tokens, const float* emb, const float* pos, float* x, int B, int T, int D, void* stream);

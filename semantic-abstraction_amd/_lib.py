@@ -46,7 +46,7 @@ SIGNATURES = {
     "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],
     "semabs_embed_finish": [P, P, P, I, I, I, P],
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
-    "semabs_attention_cls": [P, P, P, P, I, I, I, I, P],
+    "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, P],
     "semabs_rows_gather": [P, P, L, I, L, L, P],
     "semabs_quickgelu": [P, P, L, P],
     "semabs_logit_grad": [P, P, I, I, I, P, P, P, P],

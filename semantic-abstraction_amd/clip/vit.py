@@ -180,7 +180,7 @@ class VisionRollout:
             R = Lm * n
             self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), delta=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
-                kv32=e32(n * T, 2 * D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
+                k32=e32(n * T, D), v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
                 h2c=e16(n, D), fc=e32(n, 4 * D), actc=e16(n, 4 * D), x2c=e32(n, D), yc=e16(n, D), feat=e32(n, E),
                 logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, D),
                 dact=e32(R, 4 * D), dfc=e16(R, 4 * D), dh2=e32(R, D), g1h=e16(R, D), u=e32(R, D),
@@ -234,18 +234,21 @@ class VisionRollout:
             add_layernorm(x, delta, None, None, None, M, D)            # the last block's MLP delta
 
     def head(self, n: int):
-        """last block for the CLS token + ln_post + proj -> ws['feat'] [n, E]; keeps probs / kv32 / x1c / fc / x2c."""
+        """last block for the CLS token + ln_post + proj -> ws['feat'] [n, E]; keeps probs / v16 / x1c / fc / x2c."""
         ws = self._workspace()
         T, D, H, E = self.T, self.D, self.H, self.E
         b = self.blocks[-1]
         x, h = ws["x"], ws["h"]
         st = _lib.stream()
         layernorm(x, b.ln1_w, b.ln1_b, h, n * T, D)
-        # K | V for every token (fp32 out: they feed the kept softmax row and the rollout directly)
-        gemm(h, b.w_in[D:], ws["kv32"], b.b_in[D:], n * T, 2 * D, D, D, D, 2 * D, EPI_F32)
+        # K and V for every token.  K in fp32: it feeds the kept softmax row directly.  V in fp16 like every other block's: it only enters
+        # through averages (the CLS output, itself stored in fp16, and the rollout's 64-long V . u dots), where its rounding is ~6e-5
+        # relative - and it is read five times (CLS attention + four label groups of the rollout), so its width is bandwidth
+        gemm(h, b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, D, D, D, D, EPI_F32)
+        gemm(h, b.w_in[2 * D:], ws["v16"], b.b_in[2 * D:], n * T, D, D, D, D, D, EPI_F16)
         # Q for the CLS rows only (row stride T * D)
         gemm(h, b.w_in[:D], ws["q32"], b.b_in[:D], n, D, D, T * D, D, D, EPI_F32)
-        _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["kv32"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
+        _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["k32"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
                   n, T, H, 64, st)
         _lib.call("semabs_rows_gather", _lib.ptr(x), _lib.ptr(ws["x1c"]), n, D, T * D, 0, st)
         gemm(ws["o_cls"], b.w_o, ws["x1c"], b.b_o, n, D, D, D, D, D, EPI_RESID_F32)
@@ -277,7 +280,7 @@ class VisionRollout:
         _lib.call("semabs_ln_bwd", _lib.ptr(ws["x1c"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh2"]), _lib.ptr(ws["dx2"]),
                   None, _lib.ptr(ws["g1h"]), R, D, n, D, 1e-5, st)
         gemm(ws["g1h"], b.w_o_t, ws["u"], None, R, D, D, D, D, D, EPI_F32)
-        _lib.call("semabs_rollout", _lib.ptr(ws["probs"]), _lib.ptr(ws["kv32"]), _lib.ptr(ws["u"]), _lib.ptr(ws["scale"]),
+        _lib.call("semabs_rollout", _lib.ptr(ws["probs"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["u"]), _lib.ptr(ws["scale"]),
                   _lib.ptr(rel_out), n, T, H, L, int(positive_attn_only), int(rel_out.shape[1]), int(tile0), st)
 
     def gradcam_patches(self, patches: torch.Tensor, n: int, w_text: torch.Tensor, positive_attn_only: bool,

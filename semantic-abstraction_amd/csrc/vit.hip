@@ -336,7 +336,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved
 //   q fp32 [n, D] (scaled), kv fp32 [n, T, 2D] (k | v)  ->  probs fp32 [n, H, T] (kept for the rollout),
 //   o fp16 [n, D] (input of out_proj)
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__ q, const float* __restrict__ kv,
+__global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__ q, const float* __restrict__ kmat, const f16* __restrict__ vmat,
                                                        float* __restrict__ probs, f16* __restrict__ o, int n, int T, int H) {
     __shared__ float sp[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__
     const int D = H * 64;
     const int i = (int)(wh / H), h = (int)(wh % H);
     const float* qr = q + (long)i * D + h * 64;
-    const float* kb = kv + (long)i * T * 2 * D + h * 64;
+    const float* kb = kmat + (long)i * T * D + h * 64;
     float sc[4];
     float mx = -INFINITY;
 #pragma unroll
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__
         int j = t * 64 + lane;
         float acc = -INFINITY;
         if (j < T) {
-            const float4* kr = reinterpret_cast<const float4*>(kb + (long)j * 2 * D);
+            const float4* kr = reinterpret_cast<const float4*>(kb + (long)j * D);
             const float4* q4 = reinterpret_cast<const float4*>(qr);
             acc = 0.f;
 #pragma unroll
@@ -380,18 +380,18 @@ __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    const float* vb = kb + D + lane;       // lane = d
+    const f16* vb = vmat + (long)i * T * D + h * 64 + lane;       // lane = d
     float acc = 0.f;
-    for (int j = 0; j < T; ++j) acc += sp[w][j] * vb[(long)j * 2 * D];
+    for (int j = 0; j < T; ++j) acc += sp[w][j] * (float)vb[(long)j * D];
     o[(long)i * D + h * 64 + lane] = (f16)acc;
 }
 
-extern "C" int semabs_attention_cls(const float* q, const float* kv, float* probs, void* o, int n, int T, int H,
+extern "C" int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H,
                                     int head_dim, void* stream) {
     if (n == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(q && kv && probs && o && n > 0, "semabs_attention_cls: bad args");
+    SEMABS_REQUIRE(q && k && v && probs && o && n > 0, "semabs_attention_cls: bad args");
     SEMABS_REQUIRE(head_dim == 64 && T <= 256 && T > 0, "semabs_attention_cls: head_dim 64, T <= 256");
-    hipLaunchKernelGGL(k_attention_cls, dim3(semabs_cdiv((long)n * H, 4)), dim3(256), 0, (hipStream_t)stream, q, kv, probs,
+    hipLaunchKernelGGL(k_attention_cls, dim3(semabs_cdiv((long)n * H, 4)), dim3(256), 0, (hipStream_t)stream, q, k, (const f16*)v, probs,
                        (f16*)o, n, T, H);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
@@ -574,10 +574,10 @@ extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, lo
 // Rollout (closed form of clip_gradcam.py:90-131 for the only contributing block):
 //   rel[l, i, j-1] = scale[l, i] / H * sum_h clampmin0?(A[i, h, j] * (V[i, j, h, :] . u[l, i, h, :])),  j = 1..T-1
 // One workgroup per (tile i, group of 4 labels); that group's u rows staged in LDS; thread = token j.
-//   probs fp32 [n, H, T]; kv fp32 [n, T, 2D] (V at column offset D); u fp32 [L, n, D]; out fp32 [L, n_total, T-1]
+//   probs fp32 [n, H, T]; v fp16 [n, T, D] (the last block's V); u fp32 [L, n, D]; out fp32 [L, n_total, T-1]
 //   written at tile offset `tile0` (so chunks of tiles fill one [L, N, g, g] array).
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs, const float* __restrict__ kv,
+__global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs, const f16* __restrict__ vmat,
                                                  const float* __restrict__ u, const float* __restrict__ scale,
                                                  float* __restrict__ rel, int n, int T, int H, int L, int positive_only,
                                                  long n_total, long tile0) {
@@ -591,18 +591,23 @@ __global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs
     for (int c = nl * D + threadIdx.x; c < 4 * D; c += blockDim.x) su[c] = 0.f;
     __syncthreads();
     for (int j = 1 + threadIdx.x; j < T; j += blockDim.x) {
-        const float* vrow = kv + ((long)i * T + j) * 2 * D + D;
+        const f16* vrow = vmat + ((long)i * T + j) * D;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int h = 0; h < H; ++h) {
             float dot[4] = {0.f, 0.f, 0.f, 0.f};
-            const float4* v4 = reinterpret_cast<const float4*>(vrow + h * 64);
+            const f16x8* v8 = reinterpret_cast<const f16x8*>(vrow + h * 64);
 #pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                float4 vv = v4[d];
+            for (int d = 0; d < 8; ++d) {
+                const f16x8 vh = v8[d];
+                float vv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = (float)vh[e];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float4 uu = *reinterpret_cast<const float4*>(su + k * D + h * 64 + d * 4);
-                    dot[k] += vv.x * uu.x + vv.y * uu.y + vv.z * uu.z + vv.w * uu.w;
+                    const float4 u0 = *reinterpret_cast<const float4*>(su + k * D + h * 64 + d * 8);
+                    const float4 u1 = *reinterpret_cast<const float4*>(su + k * D + h * 64 + d * 8 + 4);
+                    dot[k] += vv[0] * u0.x + vv[1] * u0.y + vv[2] * u0.z + vv[3] * u0.w;
+                    dot[k] += vv[4] * u1.x + vv[5] * u1.y + vv[6] * u1.z + vv[7] * u1.w;
                 }
             }
             const float a = probs[((long)i * H + h) * T + j];
@@ -618,13 +623,13 @@ __global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs
                 rel[((long)(l0 + k) * n_total + tile0 + i) * (T - 1) + (j - 1)] = acc[k] / H * scale[(long)(l0 + k) * n + i];
     }
 }
-extern "C" int semabs_rollout(const float* probs, const float* kv, const float* u, const float* scale, float* rel, int n,
+extern "C" int semabs_rollout(const float* probs, const void* v, const float* u, const float* scale, float* rel, int n,
                               int T, int H, int L, int positive_only, long n_total, long tile0, void* stream) {
     if (n == 0 || L == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(probs && kv && u && scale && rel && n > 0 && T > 1 && H > 0, "semabs_rollout: bad args");
+    SEMABS_REQUIRE(probs && v && u && scale && rel && n > 0 && T > 1 && H > 0, "semabs_rollout: bad args");
     size_t lds = (size_t)4 * H * 64 * 4;
     SEMABS_REQUIRE(lds <= 64 * 1024, "semabs_rollout: H * 64 * 16 bytes must fit the default LDS allocation");
-    hipLaunchKernelGGL(k_rollout, dim3(n, (L + 3) / 4), dim3(256), lds, (hipStream_t)stream, probs, kv, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
+    hipLaunchKernelGGL(k_rollout, dim3(n, (L + 3) / 4), dim3(256), lds, (hipStream_t)stream, probs, (const f16*)v, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
