@@ -83,8 +83,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default=ARCH)
     ap.add_argument("--precision", default="exact", choices=["exact", "fp16"], help="UNet arithmetic (see DESIGN.md)")
-    ap.add_argument("--chunk", type=int, default=220, help="tiles per ViT batch: 220 x 197 rows = 170 row panels of 256 -> 510 / 1530 / 2040 "
-                    "output tiles for N = 768 / 2304 / 3072, i.e. 1.99 / 5.98 / 7.97 waves of the 256 CUs (no ragged last wave)")
+    ap.add_argument("--chunk", type=int, default=2448, help="tile forwards per ViT batch.  2448 = the whole scene in one batch (11 GB of activations of "
+                    "the 288 GB): the GEMMs run 22 / 66 / 88 waves of tiles deep, so launch, prologue and last-wave effects are amortised - "
+                    "901 vs 853 TFLOP/s and 136.7 vs 142.7 ms per scene against 220 (which was tuned to have no ragged last wave: 1.99 / "
+                    "5.98 / 7.97 waves); 663 / 1224: 139 ms.  The maps are bit-identical for every chunk size (tools/chunk_equiv.py)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over (2 = +4%% scenes/s, but "
                     "overlapping kernels blur the per-launch HIP-event timing the roofline leg relies on)")
     ap.add_argument("--cu-split", action="store_true", help="with --streams N: give each stream its own 1/N of every XCD's CUs (CU-masked streams)")
