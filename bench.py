@@ -11,8 +11,7 @@ volumes of 128^3, implicit decoder at the 128^3 voxel centres, TSDF integration 
 (scene sharding, no data-path collective) -> weak scaling; value = all scenes / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the fp16 MFMA GEMM, timed
-live inside the timed region with HIP events carried by the launches' own dispatch packets - a uniform 1-in-5 sample of
-the launches by default, `--time-every 1` for all of them) and `cpu_baseline` (the oracle on the host cores, bounded
+live inside the timed region with HIP events carried by the launches' own dispatch packets) and `cpu_baseline` (the oracle on the host cores, bounded
 sample, N = 1).
 """
 from __future__ import annotations
@@ -87,12 +86,13 @@ def main():
                     "the 288 GB): the GEMMs run 22 / 66 / 88 waves of tiles deep, so launch, prologue and last-wave effects are amortised - "
                     "901 vs 853 TFLOP/s and 136.7 vs 142.7 ms per scene against 220 (which was tuned to have no ragged last wave: 1.99 / "
                     "5.98 / 7.97 waves); 663 / 1224: 139 ms.  The maps are bit-identical for every chunk size (tools/chunk_equiv.py)")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over (2 = +4%% scenes/s, but "
-                    "overlapping kernels blur the per-launch HIP-event timing the roofline leg relies on)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over when --chunk cuts the scene into several "
+                    "batches (2 = +4%% scenes/s at --chunk 220, but overlapping kernels blur the per-launch timing of the roofline leg)")
     ap.add_argument("--cu-split", action="store_true", help="with --streams N: give each stream its own 1/N of every XCD's CUs (CU-masked streams)")
-    ap.add_argument("--time-every", type=int, default=5, help="roofline leg: attach timing events to one GEMM launch in n of the timed region (chosen by a hash of the launch "
-                    "index, so the sample is uniform over shapes and positions); 1 = every launch, which costs 1.9 %% of scenes/s - "
-                    "every dispatch packet then carries a completion signal")
+    ap.add_argument("--time-every", type=int, default=1, help="roofline leg: attach timing events to one GEMM launch in n of the timed region (chosen by a "
+                    "hash of the launch index).  1 = every launch: free with one ViT batch per scene (~60 launches); with small batches "
+                    "(--chunk 220: 660 launches per scene) it costs 1.9 %% of scenes/s - every dispatch packet then carries a completion signal - "
+                    "and 5 gives the same TFLOP/s figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -175,7 +175,8 @@ def main():
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
             "roofline": {"kernel": "fp16 GEMM: k_gemm8 (large shapes) + k_gemm_f16 (small), all epilogues", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "launches": gs["launches"], "launches_in_timed_region": gs["seen"],
-                         "sampling": f"1 in {args.time_every} GEMM launches of the timed region (hashed launch index) carries start / stop events",
+                         "sampling": ("every GEMM launch of the timed region carries start / stop events" if args.time_every == 1 else
+                                      f"1 in {args.time_every} GEMM launches of the timed region (hashed launch index) carries start / stop events"),
                          "avg_launch_us": gs["total_ms"] * 1e3 / max(1, gs["launches"]),
                          "gemm_share_of_step": gs["total_ms"] * 1e-3 * gs["seen"] / max(1, gs["launches"]) / dt if world == 1 else None},
         }
