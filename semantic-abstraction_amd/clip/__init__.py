@@ -121,7 +121,7 @@ class ClipWrapper:
     state_dict_provider = None          # callable(clip_model_type) -> state dict; set by tests / bench
 
     # ---- initialisation ----------------------------------------------------------------------------
-    def __init__(self, clip_model_type, device=None, state_dict=None, chunk_tiles=256, max_labels=32, **kwargs):
+    def __init__(self, clip_model_type, device=None, state_dict=None, chunk_tiles=2448, max_labels=32, **kwargs):
         dev = _lib.require_gpu()
         if state_dict is None:
             state_dict = ClipWrapper._load_checkpoint(clip_model_type)

@@ -141,7 +141,7 @@ class _BlockWeights:
 class VisionRollout:
     """ViT-B image tower + last-block rollout for chunks of tiles."""
 
-    def __init__(self, state_dict, heads: int = 12, chunk_tiles: int = 256, max_labels: int = 16):
+    def __init__(self, state_dict, heads: int = 12, chunk_tiles: int = 2448, max_labels: int = 16):
         dev = self.dev = _lib.require_gpu()
         sd = state_dict
         w = sd["visual.conv1.weight"]
@@ -167,13 +167,21 @@ class VisionRollout:
         self.chunk = int(chunk_tiles)
         self.max_labels = int(max_labels)
         self._wss = {}
+        self._cap = {}           # tiles the workspace of each slot is sized for
         self.delta_residual = DELTA_RESIDUAL
         self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
+    def _reserve(self, n: int):
+        """Size the active workspace for batches of up to n tiles (allocated on first use, re-allocated only to grow: a large `chunk_tiles`
+        costs nothing until a batch that large arrives)."""
+        if self._cap.get(self.slot, 0) < n:
+            self._cap[self.slot] = int(n)
+            self._wss.pop(self.slot, None)
+
     def _workspace(self):
         if self.slot not in self._wss:
-            n, T, D, Lm, E = self.chunk, self.T, self.D, self.max_labels, self.E
+            n, T, D, Lm, E = self._cap.get(self.slot) or self.chunk, self.T, self.D, self.max_labels, self.E
             dev = self.dev
             e16 = lambda *s: torch.empty(*s, dtype=torch.float16, device=dev)
             e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -190,6 +198,8 @@ class VisionRollout:
     # ---- forward ---------------------------------------------------------------------------------
     def embed(self, patches: torch.Tensor, n: int):
         """patches fp16 [n * g*g, 3 p p] -> ws['x'] = ln_pre(cat(cls, conv) + pos)  [n * T, D] fp32."""
+        assert n <= self.chunk
+        self._reserve(n)
         ws = self._workspace()
         T, D, G = self.T, self.D, self.g * self.g
         x = ws["x"]

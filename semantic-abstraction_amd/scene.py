@@ -191,7 +191,7 @@ class ScenePipeline:
         return self._frustum_cache[key]
 
 
-def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 256,
+def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 2448,
                   max_labels: int = 16, voxel: int = 128, text_tower: bool = True, **pipe_kwargs) -> ScenePipeline:
     """Seeded random-init weights of the released architectures (no checkpoints / network here)."""
     from .weights import make_clip_state_dict, make_semabs3d_state_dict
