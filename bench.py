@@ -88,7 +88,6 @@ def main():
                     "5.98 / 7.97 waves); 663 / 1224: 139 ms.  The maps are bit-identical for every chunk size (tools/chunk_equiv.py)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the tile chunks are pipelined over when --chunk cuts the scene into several "
                     "batches (2 = +4%% scenes/s at --chunk 220, but overlapping kernels blur the per-launch timing of the roofline leg)")
-    ap.add_argument("--cu-split", action="store_true", help="with --streams N: give each stream its own 1/N of every XCD's CUs (CU-masked streams)")
     ap.add_argument("--time-every", type=int, default=1, help="roofline leg: attach timing events to one GEMM launch in n of the timed region (chosen by a "
                     "hash of the launch index).  1 = every launch: free with one ViT batch per scene (~60 launches); with small batches "
                     "(--chunk 220: 660 launches per scene) it costs 1.9 %% of scenes/s - every dispatch packet then carries a completion signal - "
@@ -96,18 +95,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL), exactly as the driver would
+        # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...), and hand back its exit code.
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run plainly and let bench.py spawn the ranks)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from semabs_amd.clip import vit as vitmod
     from semabs_amd.scene import build_default
@@ -120,7 +135,6 @@ def main():
     n_scenes = args.steps + args.warmup
     from semabs_amd.clip import ClipWrapper, saliency_configs
     ClipWrapper.n_streams = max(1, args.streams)
-    ClipWrapper.cu_partition = bool(args.cu_split)
     cfg = saliency_configs["ours"](IMG)
     scenes = [pipe.upload(synth_scene(IMG, IMG, seed=1000 * rank + i)) for i in range(n_scenes)]      # RGB-D frames resident in HBM
 

@@ -105,8 +105,13 @@ int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, con
 int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
                     long lda, int ldb, long ldc, int epi, const int* rowmap3, void* stream);
 
-/* tuning hook: 0 = heuristic tile choice, 1 = force 128x128 / 4 waves, 2 = force 256x256 / 8 waves (when N % 256 == 0) */
-int semabs_gemm_set_config(int cfg);
+/* Same contraction with per-call launch options (the library keeps no process-global launch state):
+ * kernel: 0 = heuristic, 1 = the 128x128 ring kernel, 2 = the 256x256 phased kernel (needs N % 256 == 0, K >= 128);
+ * start_event / stop_event: optional hipEvent_t pair filled by the launch's own dispatch packet (both or neither) - how bench.py times
+ * the GEMM launches of the timed region without inserting barrier packets around them. */
+int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
+                       long lda, int ldb, long ldc, int epi, const int* rowmap3, int kernel, void* start_event, void* stop_event,
+                       void* stream);
 
 /* ============================ transformer pieces (csrc/vit.hip) ========================================= */
 
@@ -145,6 +150,9 @@ int semabs_text_finish(const float* e, float* w, int C, int P, int E, void* stre
 /* SemAbs3D.pts_feat_extractor: (xyz | feat) 4 -> 128 -> 128 -> 16, LeakyReLU(0.01)   net.py:358-367, 395-404 */
 int semabs_point_mlp(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2, const float* b2,
                      const float* w3, const float* b3, float* out, int P, long N, int hidden, int cout, void* stream);
+/* the same MLP on fp32 FMAs instead of the matrix pipe: the cross-check of the MFMA kernel (tests) */
+int semabs_point_mlp_fma(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* w3, const float* b3, float* out, int P, long N, int hidden, int cout, void* stream);
 /* VirtualGrid.scatter_points, reduce = MEAN (the reference ignores reduce_method)     net.py:185-201
  * deterministic, sums in point order; vol zero-filled and head filled with -1 by the caller. */
 int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
@@ -157,7 +165,9 @@ int semabs_scatter_mean_stats(const long long* flat, const float* feat, int* hea
 int semabs_gn_stats(const void* x, double* sums, int B, long nvox, int C, int G, int x_f32, void* stream);
 int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta, float* scale, float* shift, int B, int C,
                        int G, long nvox, float eps, void* stream);
-/* [GroupNorm ->] Conv3d k in {1, 3} pad k/2 [+ bias] [+ residual] [-> ReLU], channels-last   unet3d.py:16-17, 98-128, 247-259, 579 */
+/* [GroupNorm ->] Conv3d k in {1, 3} pad k/2 [+ bias] [+ residual] [-> ReLU], channels-last   unet3d.py:16-17, 98-128, 247-259, 579
+ * act_f32 (here and in the ConvTranspose3d entry points) is a flag word: bit 0 = fp32 activations ("exact" mode), bit 8 = run the generic
+ * gather kernel even where an LDS-brick kernel exists (per-call cross-check for tests; results agree to rounding). */
 int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                   const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                   int act_f32, void* stream);
@@ -167,10 +177,6 @@ int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, co
 int semabs_conv3d_stats(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                         const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                         int act_f32, double* out_sums, int out_groups, void* stream);
-/* tuning / test hook: bit 0: 1 (default) = Cin = Cout = 16 3^3 convolutions on bricks that are multiples of 8 x 8 x 16 use the
- * LDS-halo kernel, 0 = always the generic gather kernel; bits 1-3 = role ablation of that kernel for tools/conv16_ablate.py
- * (wrong results; 0 in every product path); bit 8 = point MLP on fp32 FMAs instead of the matrix pipe (tools/point_mlp_time.py) */
-int semabs_conv_set_config(int use_lds_brick);
 /* ConvTranspose3d k3 s2 p1 (output_size = skip size) + bias + sum joining          unet3d.py:428-440, 385-396 */
 int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off /*host*/, void* y,
                            const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout, int act_f32,
@@ -303,19 +309,11 @@ int semabs_prediction_counts(const unsigned char* pred, const unsigned char* lab
                              long BP, long M, void* stream);
 
 /* ============================ timing helpers ============================================================== */
-/* The next semabs_gemm_f16 launch records its start / stop timestamps into these HIP events through the dispatch packet itself
- * (hipExtLaunchKernelGGL): per-launch durations without barrier packets around the kernel.  Used by bench.py's roofline leg. */
-int semabs_gemm_time_next(void* start_event, void* stop_event);
+/* HIP events (timing enabled) for semabs_gemm_f16_ex's start_event / stop_event: the launch records its start / stop timestamps through the
+ * dispatch packet itself (hipExtLaunchKernelGGL) - per-launch durations without barrier packets around the kernel (bench.py's roofline leg). */
 int semabs_event_create(void** ev);
 int semabs_event_destroy(void* ev);
 int semabs_event_elapsed_ms(void* start, void* stop, float* ms);
-
-/* CU-partitioned streams: kernels of such a stream only run on the CUs named in `mask` (bit i = CU i, driver numbering).  ClipWrapper runs
- * two tile-chunk pipelines side by side on disjoint halves of the chip with them.  semabs_probe_placement reports where the workgroups of a
- * stream land: out int32[n_blocks,2] = (XCC id, HW_ID register). */
-int semabs_stream_create_cumask(void** stream, const uint32_t* mask, int n_words);
-int semabs_stream_destroy(void* stream);
-int semabs_probe_placement(int* out, int n_blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsemabs_hip.so")
+if os.environ.get("SEMABS_TUNE_LIB") == "1":        # tools/ only: the -DSEMABS_TUNING build of the same sources (build.py --tuning)
+    LIB_PATH = os.path.join(_HERE, "lib", "libsemabs_hip_tune.so")
 
 _lib = None
 
@@ -40,7 +42,7 @@ SIGNATURES = {
     "semabs_color_jitter": [P, I, I, C.POINTER(I), C.POINTER(F), P, P],
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
-    "semabs_gemm_set_config": [I],
+    "semabs_gemm_f16_ex": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), I, P, P, P],
     # vit.hip
     "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
     "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],
@@ -57,13 +59,13 @@ SIGNATURES = {
     "semabs_text_finish": [P, P, I, I, I, P],
     # unet.hip
     "semabs_point_mlp": [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
+    "semabs_point_mlp_fma": [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     "semabs_scatter_mean": [P, P, P, P, P, I, L, I, L, I, P],
     "semabs_scatter_mean_stats": [P, P, P, P, P, I, L, I, L, I, P, P],
     "semabs_gn_stats": [P, P, I, L, I, I, I, P],
     "semabs_gn_finalize": [P, P, P, P, P, I, I, I, L, F, P],
     "semabs_conv3d": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "semabs_conv3d_stats": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
-    "semabs_conv_set_config": [I],
     "semabs_convtranspose3d": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P],
     "semabs_convtranspose3d_stats": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P, I, P],
     "semabs_maxpool3d": [P, P, I, I, I, I, I, I, P],
@@ -95,14 +97,13 @@ SIGNATURES = {
     "semabs_voxelize_eval": [P, P, P, P, P, P, P, P, L, L, L, P],
     "semabs_prediction_counts": [P, P, P, P, L, L, P],
     # timing helpers
-    "semabs_gemm_time_next": [P, P],
     "semabs_event_create": [C.POINTER(P)],
     "semabs_event_destroy": [P],
     "semabs_event_elapsed_ms": [P, P, C.POINTER(F)],
-    "semabs_stream_create_cumask": [C.POINTER(P), C.POINTER(C.c_uint32), I],
-    "semabs_stream_destroy": [P],
-    "semabs_probe_placement": [P, I, P],
 }
+
+
+TUNING_SIGNATURES = {"semabs_gemm_tune": [I, C.c_longlong], "semabs_conv_tune": [I]}
 
 
 def lib():
@@ -121,6 +122,11 @@ def lib():
             fn = getattr(h, name)
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        for name, argtypes in TUNING_SIGNATURES.items():        # present in the tuning build only
+            if hasattr(h, name):
+                fn = getattr(h, name)
+                fn.argtypes = argtypes
+                fn.restype = C.c_int
         h.semabs_last_error.restype = C.c_char_p
         _lib = h
     return _lib

@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libsemabs_hip.so")
+TUNE_LIB = os.path.join(OUT_DIR, "libsemabs_hip_tune.so")
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
 # files whose integer outputs are bit-exact targets: no FMA contraction, IEEE division
@@ -40,7 +41,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, tuning: bool = False) -> str:
+    """tuning=True: the same sources with -DSEMABS_TUNING -> lib/libsemabs_hip_tune.so (ablation switches, alternative tile configurations,
+    per-workgroup traces; used by tools/ only, selected with SEMABS_TUNE_LIB=1).  The production library carries none of it."""
+    if tuning:
+        return _build(force, verbose, "libsemabs_hip_tune.so", "_tune.o", ["-DSEMABS_TUNING"])
+    return _build(force, verbose, "libsemabs_hip.so", ".o", [])
+
+
+def _build(force, verbose, libname, osuffix, extra) -> str:
+    LIB = os.path.join(OUT_DIR, libname)
     os.makedirs(OUT_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     cc = hipcc()
@@ -48,10 +58,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
     for f in sources():
         src = os.path.join(CSRC, f)
-        obj = os.path.join(OUT_DIR, f.replace(".hip", ".o"))
+        obj = os.path.join(OUT_DIR, f.replace(".hip", osuffix))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append((f, [cc, "-c", src, "-o", obj] + COMMON + PER_FILE.get(f, [])))
+            jobs.append((f, [cc, "-c", src, "-o", obj] + COMMON + extra + PER_FILE.get(f, [])))
 
     def run(job):
         name, cmd = job
@@ -78,4 +88,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

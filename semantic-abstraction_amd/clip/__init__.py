@@ -114,8 +114,7 @@ class ClipWrapper:
     _coeffs: Optional[_ResizeCoeffs] = None
     _lut = None
     _rng = np.random.default_rng(0)
-    n_streams = 2                       # HIP streams the independent tile chunks are pipelined over
-    cu_partition = False                # True: each stream owns a disjoint 1/n_streams of every XCD's compute units
+    n_streams = 1                       # HIP streams the independent tile chunks are pipelined over (when a scene is cut into several batches)
     _streams = None
     _patches = {}
     state_dict_provider = None          # callable(clip_model_type) -> state dict; set by tests / bench
@@ -246,8 +245,8 @@ class ClipWrapper:
     def relevancy_device(cls, images: torch.Tensor, w_text: torch.Tensor, cropping_augmentations, horizontal_flipping: bool,
                          positive_attn_only: bool, tile_range=None, return_tiles: bool = False):
         """images uint8 [n_img, H, W, 3] (GPU), w_text fp32 [L, E] (GPU) -> fp32 [L, H, W] on the GPU.
-        tile_range=(t0, t1): only run the ViT on that slice of the tile table (multi-GPU tile sharding); the caller
-        then sums the per-rank tile relevances before aggregation."""
+        tile_range=(t0, t1): only run the ViT on that slice of the tile table (multi-GPU tile sharding); with return_tiles the result is
+        this rank's slice [L, t1 - t0, g, g] per pass, which the caller all-gathers (`dist.allgather_tile_relevance`) before aggregation."""
         cls.check_initialized()
         eng = cls.engine
         dev = cls.device
@@ -317,32 +316,15 @@ class ClipWrapper:
                 t.record_stream(cls._streams[i])
         if tile_range is None:
             rel = [rel_all[:, p * N:(p + 1) * N].contiguous() if passes > 1 else rel_all for p in range(passes)]
-        else:                                           # a shard: the other tiles' relevances stay zero (summed across ranks by the caller)
-            rel = [torch.zeros(L, N, g, g, dtype=torch.float32, device=dev) for _ in range(passes)]
-            for p in range(passes):
-                rel[p][:, t_lo:t_hi] = rel_all[:, p * n_per:(p + 1) * n_per]
+        else:                                           # a shard: only this rank's tile slice [L, t_hi - t_lo, g, g] per pass (all-gathered by the caller)
+            rel = [rel_all[:, p * n_per:(p + 1) * n_per].contiguous() for p in range(passes)]
         if return_tiles:
             return rel, table, scales
         return cls.aggregate_device(rel, scales, n_img, H, W)
 
     @classmethod
     def _make_streams(cls, ns: int):
-        """`ns` HIP streams for the tile-chunk pipelines.  With `cu_partition` each stream is created with a CU mask: mask bit i is CU
-        i // 8 of XCD i % 8 (probed: tools/cumask_probe.py), so bits [k * 256 / ns, (k + 1) * 256 / ns) give stream k the same share of
-        every XCD and workgroup b of its kernels still runs on XCD b % 8 (the kernels' XCD-aware tile order stays valid)."""
-        if not cls.cu_partition or ns == 1:
-            return [torch.cuda.Stream() for _ in range(ns)]
-        import ctypes as C
-        n_cu = torch.cuda.get_device_properties(cls.device).multi_processor_count
-        out = []
-        for k in range(ns):
-            words = [0] * ((n_cu + 31) // 32)
-            for b in range(k * n_cu // ns, (k + 1) * n_cu // ns):
-                words[b // 32] |= 1 << (b % 32)
-            h = C.c_void_p()
-            _lib.call("semabs_stream_create_cumask", C.byref(h), (C.c_uint32 * len(words))(*words), len(words))
-            out.append(torch.cuda.ExternalStream(h.value, device=cls.device))
-        return out
+        return [torch.cuda.Stream() for _ in range(ns)]
 
     @classmethod
     def aggregate_device(cls, rel, scales: np.ndarray, n_img: int, H: int, W: int) -> torch.Tensor:

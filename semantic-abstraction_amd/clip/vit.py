@@ -30,7 +30,7 @@ EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP = 0, 1, 2, 3, 4
 
 class GemmTimer:
     """Optional live timing of every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The events are filled
-    by the dispatch packet of the kernel itself (`semabs_gemm_time_next` -> hipExtLaunchKernelGGL), not recorded around it: no barrier
+    by the dispatch packet of the kernel itself (`semabs_gemm_f16_ex(..., start_event, stop_event)` -> hipExtLaunchKernelGGL), not recorded around it: no barrier
     packets are inserted between consecutive kernels, so timing does not perturb the step being timed."""
 
     def __init__(self, every: int = 1):
@@ -78,20 +78,21 @@ GEMM_TIMER: "GemmTimer | None" = None
 DELTA_RESIDUAL = os.environ.get("SEMABS_DELTA_RESIDUAL", "0") == "1"
 
 
-def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):
+def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, kernel=0):
+    """kernel: 0 = the library's heuristic, 1 = ring kernel, 2 = phased 256 x 256 kernel (per call; tests pin a path with it)."""
     t = GEMM_TIMER
+    e0 = e1 = None
     if t is not None:
         t.seen += 1
-    if t is not None and (t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0):     # hashed: no phase lock with the launch pattern
-        e0, e1 = t._pair()
-        _lib.call("semabs_gemm_time_next", e0, e1)
-        t.records.append((e0, e1, 2.0 * M * N * K))
-    _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend, rowmap)
+        if t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0:     # hashed: no phase lock with the launch pattern
+            e0, e1 = t._pair()
+            t.records.append((e0, e1, 2.0 * M * N * K))
+    _lib.call("semabs_gemm_f16_ex", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
+              int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, int(kernel), e0, e1,
+              _lib.stream())
 
 
-def _gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None):
-    _lib.call("semabs_gemm_f16", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
-              int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, _lib.stream())
+_gemm = gemm
 
 
 def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5):

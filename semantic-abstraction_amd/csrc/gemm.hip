@@ -28,8 +28,19 @@ struct GemmArgs {
     long M; int N, K; long lda; int ldb; long ldc;
     int g_in, g_out, g_off;     // EPI_ROWMAP_ADD_F32: out row = (m / g_in) * g_out + g_off + m % g_in
     int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
-    int ablate;     // tuning only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
+#ifdef SEMABS_TUNING
+    int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
+    int stagger;    // tuning build only: first-wave start stagger in units of 64 shader clocks (0 = off)
+    unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
+#endif
 };
+// Ablation switches exist only in the tuning build (build.py --tuning -> libsemabs_hip_tune.so, used by tools/); in the production library
+// GEMM_ABL() is the constant false and every ablation branch is compiled out of the hot loops.
+#ifdef SEMABS_TUNING
+#define GEMM_ABL(bit) ((g.ablate & (bit)) != 0)
+#else
+#define GEMM_ABL(bit) (false)
+#endif
 
 // LDS tile rows hold BKT fp16 of K (128 B for BKT = 64, 64 B for BKT = 32); the 16-byte chunk index is XOR-ed with a
 // function of the row chosen so that every 16-lane group of a ds_read_b128 fragment read hits 16 distinct 16-byte
@@ -130,23 +141,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
         for (int j = 0; j < TN; ++j) fb[which][j] = *reinterpret_cast<const f16x8*>(sb + swz_off<BKT>(wn * WTN + j * 32 + frow, ks * 2 + fk));
     };
     load_frags(0, 0, 0);
-    if (g.ablate & 2) load_frags(1, 0, 1);
+    if GEMM_ABL(2) load_frags(1, 0, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + STAGES - 1 < nk && !(g.ablate & 1)) stage(kt + STAGES - 1);  // buffer last read in iteration kt - 1 (reads retired before its barrier)
+        if (kt + STAGES - 1 < nk && !GEMM_ABL(1)) stage(kt + STAGES - 1);  // buffer last read in iteration kt - 1 (reads retired before its barrier)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < KS) {
-                if (!(g.ablate & 2)) load_frags(nxt, kt, ks + 1);
-            } else if (g.ablate & 4) {
-                if (kt + 1 < nk && !(g.ablate & 2)) load_frags(nxt, kt + 1, 0);
+                if (!GEMM_ABL(2)) load_frags(nxt, kt, ks + 1);
+            } else if GEMM_ABL(4) {
+                if (kt + 1 < nk && !GEMM_ABL(2)) load_frags(nxt, kt + 1, 0);
             } else {
                 // tile kt + 1 must have landed for every wave before anyone reads it; later tiles stay in flight
                 if (kt + STAGES - 1 < nk) wait_vmcnt<(STAGES - 2) * PPW>();
                 else wait_vmcnt<0>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (kt + 1 < nk && !(g.ablate & 2)) load_frags(nxt, kt + 1, 0);
+                if (kt + 1 < nk && !GEMM_ABL(2)) load_frags(nxt, kt + 1, 0);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
     __builtin_amdgcn_s_barrier();                          // every wave is done with the operand tiles before they become epilogue scratch
 
     // ---- epilogue: per wave, 32-row slabs of its tile through a private 8 KB LDS slice -> 16-byte row accesses ----
-    if ((g.ablate & 8) && acc[0][0][0] != 12345.678f) return;
+    if (GEMM_ABL(8) && acc[0][0][0] != 12345.678f) return;
     float* st = reinterpret_cast<float*>(smem + wid * 8192);
     const int cchunk = lane & 15;          // 4 floats
     const int ncol = n0 + wn * WTN + cchunk * 4;
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
                     if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));   // 1-ulp rcp << fp16 rounding of the result
                     h[e] = (f16)v[e];
                 }
-                if ((g.ablate & 16) && v[0] != 12345.678f) continue;
+                if (GEMM_ABL(16) && v[0] != 12345.678f) continue;
                 *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(g.C) + m * g.ldc + ncol8) = h;
             }
         } else {
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
             if (m >= g.M) continue;
             float4 v = *reinterpret_cast<const float4*>(st + row * 64 + cchunk * 4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if ((g.ablate & 16) && v.x != 12345.678f) continue;
+            if (GEMM_ABL(16) && v.x != 12345.678f) continue;
             if (EPI == EPI_BIAS_RESID_F32) {
                 float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
                 float4 o = *p;
@@ -230,35 +241,42 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
     }
 }
 
-// Optional per-launch timing: the NEXT GEMM launch records its start / stop timestamps into these HIP events through the dispatch packet
-// itself (hipExtLaunchKernelGGL) - no extra barrier packets around the kernel, unlike hipEventRecord before and after it.
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-extern "C" int semabs_gemm_time_next(void* start_event, void* stop_event) {
-    g_ev_start = (hipEvent_t)start_event; g_ev_stop = (hipEvent_t)stop_event;
-    return SEMABS_OK;
-}
-template <typename Kern>
-static inline void gemm_dispatch(Kern kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const GemmArgs& g) {
-    if (g_ev_start && g_ev_stop) {
-        hipExtLaunchKernelGGL(kernel, grid, block, lds, s, g_ev_start, g_ev_stop, 0, g);
-        g_ev_start = g_ev_stop = nullptr;
-    } else {
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, g);
-    }
-}
+// Per-call launch options (no process-global state: the library is re-entrant per stream).
+//   kernel      : 0 = heuristic, 1 = the 128 x 128 ring kernel, 2 = the 256 x 256 phased kernel (when the shape allows it)
+//   ev_start/stop: optional HIP events filled by the launch's own dispatch packet (hipExtLaunchKernelGGL) - no extra barrier packets
+//                  around the kernel, unlike hipEventRecord before and after it
+struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
 
-static int g_group_m = 8;
-static int g_ablate = 0;
-static int g_force_cfg = 0;     // 0 = heuristic, 1 = 128x128 / 4 waves, 2 = 256x256 / 8 waves (tuning / tests)
-extern "C" int semabs_gemm_set_config(int cfg) {
-    if (cfg >= 1000) { g_ablate = cfg - 1000; return SEMABS_OK; }
-    if (cfg >= 100) { g_group_m = cfg - 100; if (g_group_m < 1) g_group_m = 1; }     // 100 + GROUP_M: rasterisation group (tuning)
-    else g_force_cfg = cfg;
+#ifdef SEMABS_TUNING
+// tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
+static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0, g_stagger = 0;
+static unsigned long long* g_trace = nullptr;
+extern "C" int semabs_gemm_tune(int key, long long value) {
+    switch (key) {
+        case 0: g_force_cfg = (int)value; break;     // alternative ring-kernel tile configurations (see launch())
+        case 1: g_group_m = value < 1 ? 1 : (int)value; break;
+        case 2: g_ablate = (int)value; break;
+        case 3: g_stagger = (int)value; break;
+        case 4: g_trace = (unsigned long long*)value; break;
+        default: return SEMABS_EINVAL;
+    }
     return SEMABS_OK;
+}
+#define GEMM_GROUP_M g_group_m
+#define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).stagger = g_stagger; (g).trace = g_trace; } while (0)
+#else
+#define GEMM_GROUP_M 8
+#define GEMM_TUNE_ARGS(g) do { } while (0)
+#endif
+
+template <typename Kern>
+static inline void gemm_dispatch(Kern kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const GemmArgs& g, const GemmOpts& o) {
+    if (o.ev_start && o.ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, o.ev_start, o.ev_stop, 0, g);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, g);
 }
 
 template <int EPI, int BM, int BN, int BKT, int WGM, int WGN, int STAGES>
-static int launch_cfg(GemmArgs g, hipStream_t s) {
+static int launch_cfg(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     constexpr int LDS = STAGES * (BM + BN) * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -268,11 +286,11 @@ static int launch_cfg(GemmArgs g, hipStream_t s) {
     g.n_tiles_n = g.N / BN;
     long mt = (g.M + BM - 1) / BM;
     g.n_tiles_m = (int)mt;
-    g.group_m = g_group_m;
-    g.ablate = g_ablate;
+    g.group_m = GEMM_GROUP_M;
+    GEMM_TUNE_ARGS(g);
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
-    gemm_dispatch(k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>, dim3(g.n_blocks), dim3(64 * WGM * WGN), LDS, s, g);
+    gemm_dispatch(k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>, dim3(g.n_blocks), dim3(64 * WGM * WGN), LDS, s, g, o);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -322,6 +340,15 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     }
     const long m0 = (long)tm * 256;
     const int n0 = tn * 256;
+#ifdef SEMABS_TUNING
+    // experiment: stagger the first wave of workgroups (one per CU) so that the CUs' epilogues do not all hit HBM at the same time
+    if (g.stagger > 0 && blockIdx.x < 256) {
+        const int d = g.stagger * (int)((blockIdx.x >> 3) & 31) / 32;
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned long long t_start = 0, t_main = 0;
+    if (g.trace) t_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- DMA sources: thread -> (row = j * 64 + tid / 8, 16-byte chunk position tid % 8) of every half-tile, j = 0, 1 ----
     const int srow = tid >> 3, scp = tid & 7;
@@ -429,21 +456,21 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     if (wr == 1) __builtin_amdgcn_s_barrier();              // skew the second wave row by one barrier
     for (int t = 0; t < nk; ++t) {
         const int par = t & 1;
-        const bool s1 = t + 1 < nk && !(g.ablate & 1), s2 = t + 2 < nk && !(g.ablate & 1);
+        const bool s1 = t + 1 < nk && !GEMM_ABL(1), s2 = t + 2 < nk && !GEMM_ABL(1);
         // phase 0: quadrant (A0, B0)
-        if (!(g.ablate & 2) || t == 0) { read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par); }
+        if (!GEMM_ABL(2) || t == 0) { read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par); }
         if (s1) stage_b(1, t + 1);
         GEMM8_SYNC(s1);
         mma(0, 0);
         GEMM8_END();
         // phase 1: quadrant (A0, B1)
-        if (!(g.ablate & 2) || t == 0) read_b(1, par);
+        if (!GEMM_ABL(2) || t == 0) read_b(1, par);
         if (s1) stage_a(1, t + 1);
         GEMM8_SYNC(s1);
         mma(0, 1);
         GEMM8_END();
         // phase 2: quadrant (A1, B1)
-        if (!(g.ablate & 2) || t == 0) read_a(1, par);
+        if (!GEMM_ABL(2) || t == 0) read_a(1, par);
         if (s2) stage_a(0, t + 2);
         GEMM8_SYNC(s2);
         mma(1, 1);
@@ -462,7 +489,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     // Interior tiles (all 256 rows valid - every tile but the last row panel) take a branch-free path: per-row guards would put
     // every store in its own basic block, each opening with a conservative s_waitcnt vmcnt(0) that also waits for the previous
     // STORE (gfx9 counts stores in vmcnt) and serialises the whole tail.
-    if (g.ablate & 8) { if (acc[0][0][0][0][0] != 12345.678f) return; }
+#ifdef SEMABS_TUNING
+    if (g.trace) t_main = __builtin_amdgcn_s_memrealtime();
+#endif
+    if GEMM_ABL(8) { if (acc[0][0][0][0][0] != 12345.678f) return; }
     auto epilogue = [&](auto checked) {
         constexpr bool CHECK = decltype(checked)::value;
 #pragma unroll
@@ -525,51 +555,69 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         }
     };
     if (m0 + 256 <= g.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
+#ifdef SEMABS_TUNING
+    if (g.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* t = g.trace + (size_t)blockIdx.x * 4;
+            t[0] = t_start; t[1] = t_main; t[2] = t_end; t[3] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+#endif
 }
 
 template <int EPI>
-static int launch_gemm8(GemmArgs g, hipStream_t s) {
+static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     constexpr int LDS = 2 * 4 * 16384;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     g.n_tiles_n = g.N / 256;
     const long mt = (g.M + 255) / 256;
     g.n_tiles_m = (int)mt;
-    g.group_m = g_group_m;
-    g.ablate = g_ablate;
+    g.group_m = GEMM_GROUP_M;
+    GEMM_TUNE_ARGS(g);
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
-    gemm_dispatch(k_gemm8<EPI>, dim3(g.n_blocks), dim3(512), LDS, s, g);
+    gemm_dispatch(k_gemm8<EPI>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
 
 template <int EPI>
-static int launch(const GemmArgs& g, hipStream_t s) {
-    const bool big_ok = g.N % 256 == 0;
-    const bool big = g_force_cfg >= 2 ? big_ok : (g_force_cfg == 1 ? false : (big_ok && g.M >= 2048));
-    if (big && (g_force_cfg == 0 || g_force_cfg == 8) && g.K >= 128) return launch_gemm8<EPI>(g, s);   // default: 256 x 256 x 64 phased kernel
-    if (big && g_force_cfg == 0) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);      // K = 64: one K tile, nothing to pipeline
-    if (big && g_force_cfg == 3) return launch_cfg<EPI, 256, 256, 32, 4, 4, 4>(g, s);      // 16 waves, 64 x 64 wave tiles
-    if (big && g_force_cfg == 4) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU
-    if (big && g_force_cfg == 5) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s);
-    if (g_force_cfg == 6) return launch_cfg<EPI, 128, 128, 32, 2, 2, 3>(g, s);               // 4 waves, 48 KB: 3 blocks / CU
-    if (big && g_force_cfg == 7) return launch_cfg<EPI, 256, 128, 32, 2, 2, 3>(g, s);      // 4 waves, 128 x 64 wave tiles, 72 KB: 2 blocks / CU
-    if (big) return launch_cfg<EPI, 256, 256, 32, 2, 4, 4>(g, s);
-    return launch_cfg<EPI, 128, 128, 64, 2, 2, 2>(g, s);
+static int launch(const GemmArgs& g, hipStream_t s, const GemmOpts& o) {
+    const bool big_ok = g.N % 256 == 0 && g.K >= 128;                   // what the phased kernel can run
+#ifdef SEMABS_TUNING
+    if (g_force_cfg == 3 && g.N % 256 == 0) return launch_cfg<EPI, 256, 256, 32, 4, 4, 4>(g, s, o);      // 16 waves, 64 x 64 wave tiles
+    if (g_force_cfg == 4 && g.N % 256 == 0) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s, o);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU
+    if (g_force_cfg == 5 && g.N % 256 == 0) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s, o);
+    if (g_force_cfg == 6) return launch_cfg<EPI, 128, 128, 32, 2, 2, 3>(g, s, o);                         // 4 waves, 48 KB: 3 blocks / CU
+    if (g_force_cfg == 7 && g.N % 256 == 0) return launch_cfg<EPI, 256, 128, 32, 2, 2, 3>(g, s, o);      // 4 waves, 128 x 64 wave tiles, 72 KB: 2 blocks / CU
+    if (g_force_cfg == 9 && g.N % 256 == 0) return launch_cfg<EPI, 256, 256, 32, 2, 4, 4>(g, s, o);
+#endif
+    const bool big = o.kernel == 2 ? big_ok : (o.kernel == 1 ? false : (big_ok && g.M >= 2048));
+    if (big) return launch_gemm8<EPI>(g, s, o);                                              // 256 x 256 x 64 phased kernel
+    if (o.kernel == 0 && g.N % 256 == 0 && g.M >= 2048) return launch_cfg<EPI, 128, 256, 32, 2, 4, 3>(g, s, o);      // K = 64: one K tile, nothing to pipeline
+    return launch_cfg<EPI, 128, 128, 64, 2, 2, 2>(g, s, o);
 }
 
 // C ABI.  A fp16 [M, K] (row stride lda elements), B fp16 [N, K] (row stride ldb), C per `epi`:
 //   0 fp16 = acc + bias        1 fp16 = quickgelu(acc + bias)      2 fp32 += acc + bias (in place)
 //   3 fp32 = acc + bias        4 fp32 row-remapped store + addend  (rowmap = {g_in, g_out, g_off})
 // bias fp32 [N] or NULL.  Requires N % 128 == 0, K % 64 == 0, 16-byte aligned rows.
-extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend,
-                               long M, int N, int K, long lda, int ldb, long ldc, int epi, const int* rowmap3,
-                               void* stream) {
+extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias, const float* addend,
+                                  long M, int N, int K, long lda, int ldb, long ldc, int epi, const int* rowmap3,
+                                  int kernel, void* start_event, void* stop_event, void* stream) {
     SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16: null operand");
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (epi > 1 || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
+    SEMABS_REQUIRE(kernel >= 0 && kernel <= 2, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased)");
+    SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -579,14 +627,21 @@ extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const floa
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
     g.n_tiles_n = 0; g.n_blocks = 0;
+    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
-        case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s);
-        case EPI_BIAS_GELU_F16: return launch<EPI_BIAS_GELU_F16>(g, s);
-        case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(g, s);
-        case EPI_BIAS_F32: return launch<EPI_BIAS_F32>(g, s);
-        case EPI_ROWMAP_ADD_F32: return launch<EPI_ROWMAP_ADD_F32>(g, s);
+        case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s, o);
+        case EPI_BIAS_GELU_F16: return launch<EPI_BIAS_GELU_F16>(g, s, o);
+        case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(g, s, o);
+        case EPI_BIAS_F32: return launch<EPI_BIAS_F32>(g, s, o);
+        case EPI_ROWMAP_ADD_F32: return launch<EPI_ROWMAP_ADD_F32>(g, s, o);
     }
     semabs_set_error("semabs_gemm_f16: unknown epilogue");
     return SEMABS_EINVAL;
+}
+
+extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend,
+                               long M, int N, int K, long lda, int ldb, long ldc, int epi, const int* rowmap3,
+                               void* stream) {
+    return semabs_gemm_f16_ex(A, B, C, bias, addend, M, N, K, lda, ldb, ldc, epi, rowmap3, 0, nullptr, nullptr, stream);
 }

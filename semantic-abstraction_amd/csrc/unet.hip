@@ -213,8 +213,6 @@ __global__ __launch_bounds__(512) void k_point_mlp_mfma(const float* __restrict_
     }
 }
 
-static int g_point_mlp_mfma = 1;     // tuning / test hook (semabs_conv_set_config bit 8 clears it): 0 = the fp32 FMA kernel
-
 // xyz fp32 [N, 3] (shared by the P label volumes), feat fp32 [P, N] -> out fp32 [P, N, 16]
 extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2,
                                 const float* b2, const float* w3, const float* b3, float* out, int P, long N, int hidden,
@@ -222,16 +220,23 @@ extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float
     if (P == 0 || N == 0) return SEMABS_OK;
     SEMABS_REQUIRE(xyz && feat && w1 && b1 && w2 && b2 && w3 && b3 && out, "semabs_point_mlp: null pointer");
     SEMABS_REQUIRE(hidden == 128 && cout == 16, "semabs_point_mlp: built for hidden 128 -> 16 channels (net.py:358-367 defaults)");
-    if (g_point_mlp_mfma) {
-        const size_t lds2 = (size_t)(2 * 128 * PM_ROW + 2 * 4 * 4 * 16 * 8) * 2 + (size_t)(128 * 4 + 2 * 128) * 4;
-        static bool set2 = false;
-        if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); set2 = true; }
-        const long groups = ((long)P * N + 63) / 64;
-        long grid2 = (groups + 7) / 8; if (grid2 > semabs_num_cus()) grid2 = semabs_num_cus();
-        hipLaunchKernelGGL(k_point_mlp_mfma, dim3((unsigned)grid2), dim3(512), lds2, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
-        SEMABS_CHECK_LAUNCH();
-        return SEMABS_OK;
-    }
+    const size_t lds2 = (size_t)(2 * 128 * PM_ROW + 2 * 4 * 4 * 16 * 8) * 2 + (size_t)(128 * 4 + 2 * 128) * 4;
+    static bool set2 = false;
+    if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); set2 = true; }
+    const long groups = ((long)P * N + 63) / 64;
+    long grid2 = (groups + 7) / 8; if (grid2 > semabs_num_cus()) grid2 = semabs_num_cus();
+    hipLaunchKernelGGL(k_point_mlp_mfma, dim3((unsigned)grid2), dim3(512), lds2, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// The same MLP on fp32 FMAs (no matrix pipe): the cross-check of the MFMA kernel in tests/ (its own entry point - no process-global switch).
+extern "C" int semabs_point_mlp_fma(const float* xyz, const float* feat, const float* w1, const float* b1, const float* w2,
+                                    const float* b2, const float* w3, const float* b3, float* out, int P, long N, int hidden,
+                                    int cout, void* stream) {
+    if (P == 0 || N == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(xyz && feat && w1 && b1 && w2 && b2 && w3 && b3 && out, "semabs_point_mlp_fma: null pointer");
+    SEMABS_REQUIRE(hidden == 128 && cout == 16, "semabs_point_mlp_fma: built for hidden 128 -> 16 channels (net.py:358-367 defaults)");
     size_t lds = (size_t)(128 * 128 + 16 * 128 + 128 * 4 + 2 * 128 + 16) * 4;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp<128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
@@ -429,6 +434,11 @@ extern "C" int semabs_gn_finalize(const double* sums, const float* gamma, const 
 // =================================================================================================
 // Implicit-GEMM convolution family
 // =================================================================================================
+#ifdef SEMABS_TUNING
+#define CONV16_ABL(c) (c)
+#else
+#define CONV16_ABL(c) false
+#endif
 struct ConvArgs {
     const void* x; void* y; const f16* w_hi; const f16* w_lo;
     const float* gn_scale; const float* gn_shift; const float* bias; const void* resid;
@@ -879,7 +889,9 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef SEMABS_TUNING
             if (a.ablate == 4) { if (acc[0][0] != 1234.5f) continue; }
+#endif
             // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
             float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -919,7 +931,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         int buf = 0;
         for (; brick < total; brick += gridDim.x, buf ^= 1) {
             const int next = brick + gridDim.x;
-            if (next < total && a.ablate != 2 && a.ablate < 4) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
+            if (next < total && !CONV16_ABL(a.ablate == 2 || a.ablate >= 4)) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
             lds_barrier();
         }
     } else {
@@ -927,19 +939,20 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         lds_barrier();
         int buf = 0;
         for (int brick = blockIdx.x; brick < total; brick += gridDim.x, buf ^= 1) {
-            if (a.ablate != 1) consume(brick, buf);
+            if (!CONV16_ABL(a.ablate == 1)) consume(brick, buf);
             lds_barrier();
         }
         if (a.stats) flush_stats();
     }
 }
 
-static int g_conv16_lds = 1;     // tuning / test hook: 0 = always use the generic gather kernel
-static int g_conv16_ablate = 0;
-extern "C" int semabs_conv_set_config(int use_lds_brick) {
-    g_conv16_lds = use_lds_brick & 1; g_conv16_ablate = (use_lds_brick >> 1) & 7; g_point_mlp_mfma = !(use_lds_brick & 256);
-    return SEMABS_OK;
-}
+// `act_f32` of the convolution entry points is a flag word: bit 0 = fp32 activations ("exact" mode), bit 8 (SEMABS_CONV_GENERIC) = run
+// the generic gather kernel even where a brick kernel exists - the per-call cross-check used by tests/ (no process-global switch).
+#define SEMABS_CONV_GENERIC 256
+#ifdef SEMABS_TUNING
+static int g_conv16_ablate = 0;      // tools/conv16_ablate.py, tuning build only (libsemabs_hip_tune.so)
+extern "C" int semabs_conv_tune(int ablate) { g_conv16_ablate = ablate & 7; return SEMABS_OK; }
+#endif
 
 static int semabs_num_cus() {
     static int n = 0;
@@ -947,7 +960,10 @@ static int semabs_num_cus() {
     return n;
 }
 static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
-    ConvArgs a = a_in; a.ablate = g_conv16_ablate;
+    ConvArgs a = a_in;
+#ifdef SEMABS_TUNING
+    a.ablate = g_conv16_ablate;
+#endif
     if (f32) {
         constexpr int T0 = 4;
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2 * 2;   // two half-voxel planes (256-B padded), hi + lo, two buffers; fp16
@@ -1228,8 +1244,10 @@ static int conv_common_checks(const void* x, const void* w_hi, const void* w_lo,
 // statistics pass over y on the same stream.
 static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                        const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
-                       int relu, int act_f32, double* out_sums, int out_groups, void* stream) {
+                       int relu, int act_flags, double* out_sums, int out_groups, void* stream) {
     if (B == 0) return SEMABS_OK;
+    const int act_f32 = act_flags & 1;
+    const bool bricks = !(act_flags & SEMABS_CONV_GENERIC);
     int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
     if (rc) return rc;
     SEMABS_REQUIRE(ksize == 1 || ksize == 3, "semabs_conv3d: kernel size must be 1 or 3");
@@ -1248,10 +1266,10 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
     SEMABS_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && ksize == 1), "semabs_conv3d: relu must be 0, 1, or 2 (LeakyReLU, ksize 1 only)");
     SEMABS_REQUIRE(!out_sums || (out_groups > 0 && Cout % out_groups == 0), "semabs_conv3d_stats: Cout must be a multiple of out_groups");
     bool fused = false;
-    if (g_conv16_lds && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31)) {
+    if (bricks && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31)) {
         if (out_sums && out_groups == 8) { a.stats = out_sums; fused = true; }
         rc = conv16_lds_launch(a, act_f32, (hipStream_t)stream);
-    } else if (g_conv16_lds && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0) {
+    } else if (bricks && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0) {
         rc = conv_brick_launch(a, act_f32, (hipStream_t)stream);
     } else {
         rc = conv_launch(a, act_f32, (hipStream_t)stream);
@@ -1479,12 +1497,14 @@ static int convT_brick_launch(const ConvTArgs& a, hipStream_t s) {
 // with tap order (t0, t1, t2) over each dimension's candidate list above.
 static int convT_impl(const void* x, const void* w_hi, const void* w_lo, const long* class_off, void* y,
                       const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout,
-                      int act_f32, double* out_sums, int out_groups, void* stream) {
+                      int act_flags, double* out_sums, int out_groups, void* stream) {
     if (B == 0) return SEMABS_OK;
+    const int act_f32 = act_flags & 1;
+    const bool bricks = !(act_flags & SEMABS_CONV_GENERIC);
     int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
     if (rc) return rc;
     SEMABS_REQUIRE(class_off && Cin % 32 == 0, "semabs_convtranspose3d: Cin must be a multiple of 32");
-    if (g_conv16_lds && D0 % 4 == 0 && D1 % 8 == 0 && D2 % 16 == 0) {           // one launch, input read once, all eight classes per brick
+    if (bricks && D0 % 4 == 0 && D1 % 8 == 0 && D2 % 16 == 0) {           // one launch, input read once, all eight classes per brick
         ConvTArgs ta;
         ta.x = x; ta.y = y; ta.w_hi = (const f16*)w_hi; ta.w_lo = (const f16*)w_lo; ta.bias = bias; ta.skip = skip;
         for (int c = 0; c < 8; ++c) ta.class_off[c] = class_off[c];

@@ -5,9 +5,9 @@ The path shards three ways, none of which needs a collective on
   * scene sharding   (config 4: 64 scenes over 8 GPUs)        - ranks own disjoint scenes; results stay on the rank or
                                                                  are gathered once at the end (`gather_results`).
   * tile sharding    (single-scene latency)                    - each rank runs a contiguous slice of the (tile, flip)
-                                                                 forwards for all labels and the per-tile relevances
-                                                                 [L, N, g, g] are summed with ONE all-reduce (disjoint
-                                                                 supports, so the sum is exact) before aggregation.
+                                                                 forwards for all labels; ONE all-gather of the per-rank
+                                                                 slices of the per-tile relevances [L, N, g, g] completes
+                                                                 them on every rank before aggregation.
   * label sharding   (voxel inference)                         - 16 label volumes / 8 GPUs = 2 each; logits all-gathered.
 """
 from __future__ import annotations
@@ -37,27 +37,46 @@ def shard_list(items: Sequence, rank: int, world: int) -> List:
     return list(items[lo:hi])
 
 
-def allreduce_tile_relevance(rel: List[torch.Tensor]) -> List[torch.Tensor]:
-    """Tile sharding: every rank filled only its slice of rel[pass][L, N, g, g] (zeros elsewhere); one all-reduce(sum)
-    per pass reconstructs the full tensor on every rank (RCCL over xGMI: 2 x 15 MB at the BASELINE shape)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        for r in rel:
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    return rel
+def _all_gather_list(local: torch.Tensor) -> List[torch.Tensor]:
+    """dist.all_gather of equally shaped tensors; gloo has no device collectives, so CUDA tensors are staged through the host there
+    (the CPU / single-GPU tests); with "nccl" (= RCCL) the device buffers go over xGMI directly."""
+    world = dist.get_world_size()
+    if local.is_cuda and dist.get_backend() == "gloo":
+        host = local.detach().cpu().contiguous()
+        out = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(out, host)
+        return [o.to(local.device) for o in out]
+    out = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(out, local.contiguous())
+    return out
+
+
+def allgather_tile_relevance(rel_local: List[torch.Tensor], n_tiles: int) -> List[torch.Tensor]:
+    """Tile sharding: rank r computed rel_local[pass] = [L, hi_r - lo_r, g, g] for its contiguous slice `shard_range(n_tiles, r, world)`
+    of the tile table.  ONE all-gather of the (padded-to-equal) slices of all passes completes [L, n_tiles, g, g] per pass on every rank:
+    each rank sends only what it computed (1 / world of the 2 x 15 MB at the BASELINE shape) - the zero-padded all-reduce this replaces sent
+    the full tensors and added zeros."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rel_local
+    rank, world = dist.get_rank(), dist.get_world_size()
+    passes = len(rel_local)
+    L, g = int(rel_local[0].shape[0]), int(rel_local[0].shape[2])
+    ranges = [shard_range(n_tiles, r, world) for r in range(world)]
+    pad = max(hi - lo for lo, hi in ranges)
+    lo, hi = ranges[rank]
+    assert all(int(r.shape[1]) == hi - lo for r in rel_local), "rel_local must hold exactly this rank's tile slice"
+    send = torch.zeros(passes, L, pad, g, g, dtype=rel_local[0].dtype, device=rel_local[0].device)
+    for p in range(passes):
+        send[p, :, : hi - lo] = rel_local[p]
+    parts = _all_gather_list(send)
+    return [torch.cat([parts[r][p, :, : ranges[r][1] - ranges[r][0]] for r in range(world)], dim=1).contiguous() for p in range(passes)]
 
 
 def gather_results(local: torch.Tensor) -> torch.Tensor:
     """All-gather equally shaped per-rank results along a new leading dim (label / scene shards -> rank 0 and all)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local[None]
-    if local.is_cuda and dist.get_backend() == "gloo":                  # gloo has no device all_gather (tests on one GPU): stage through the host
-        host = local.detach().cpu().contiguous()
-        out = [torch.empty_like(host) for _ in range(dist.get_world_size())]
-        dist.all_gather(out, host)
-        return torch.stack(out, dim=0).to(local.device)
-    out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, local.contiguous())
-    return torch.stack(out, dim=0)
+    return torch.stack(_all_gather_list(local), dim=0)
 
 
 def allreduce_flat_gradients(flat: torch.Tensor, n_flags: int = 0) -> Tuple[float, torch.Tensor | None]:

@@ -80,7 +80,7 @@ class ScenePipeline:
     def run_sharded(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None) -> SceneResult:
         """ONE scene split over the ranks of the default process group - the single-scene latency mode of SURVEY.md 8(e), next to the
         scene-sharded throughput mode `bench.py` measures.  Relevancy is tile-sharded: every rank runs a contiguous slice of the tile
-        forwards for all labels and one all-reduce(sum) of the per-tile relevances (RCCL) completes them everywhere (the aggregation is
+        forwards for all labels and one all-gather of the per-rank slices of the per-tile relevances (RCCL) completes them everywhere (the aggregation is
         then replicated - it is cheap and deterministic).  Voxel inference is label-sharded: each rank runs the UNet / decoder on its
         slice of the label volumes and the logits are all-gathered.  Geometry is replicated.  World size 1 degenerates to `run`."""
         return self.run_voxels(self.run_relevancy(scene, w_text, seed, jittered_images, shard_tiles=True), shard_labels=True)
@@ -124,7 +124,7 @@ class ScenePipeline:
                 rel, _, scales = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],
                                                               cfg["positive_attn_only"], tile_range=sdist.shard_range(len(table), rank, world),
                                                               return_tiles=True)
-                rel = sdist.allreduce_tile_relevance(rel)
+                rel = sdist.allgather_tile_relevance(rel, len(table))
                 maps = ClipWrapper.aggregate_device(rel, scales, n_img, H, W)
             else:
                 maps = ClipWrapper.relevancy_device(images_dev, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"],

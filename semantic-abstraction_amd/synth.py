@@ -56,3 +56,17 @@ def synth_scene(H: int = 480, W: int = 480, seed: int = 0) -> dict:
     s, c = np.sin(0.3), np.cos(0.3)
     pose = np.array([[0.0, -s, c, -2.05570605], [-1.0, 0.0, 0.0, -0.2], [0.0, -c, -s, 1.90137071], [0.0, 0.0, 0.0, 1.0]])
     return dict(rgb=rgb, depth=depth, cam_intr=K, cam_pose=pose)
+
+
+def synth_jitter(img: np.ndarray, k: int) -> np.ndarray:
+    """Deterministic stand-in for one draw of the reference's ColorJitter (`CLIP/clip/__init__.py:55-57,246-247` is random):
+    per-channel gain, brightness offset and a gamma curve chosen by `k`.  Parity fixtures inject these images on both sides
+    (reference: `ClipWrapper.jittering_transforms`; here: `jittered_images=`), so the augmentation path - 6 images, 2 448
+    forwards at 480 x 480 - is exercised with identical pixels."""
+    rng = np.random.default_rng(777 + k)
+    gain = rng.uniform(0.7, 1.3, size=3)
+    off = rng.uniform(-20, 20)
+    gamma = rng.uniform(0.7, 1.4)
+    x = img.astype(np.float64) / 255.0
+    x = np.clip(x, 0, 1) ** gamma * gain[None, None, :] + off / 255.0
+    return np.clip(np.round(x * 255.0), 0, 255).astype(np.uint8)

@@ -144,13 +144,14 @@ class ResidualUNet3D:
                   B, Cc, G, nvox, 1e-5, st)
         return scale, shift
 
-    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None, in_sums=None, out_groups=0):
-        """out_groups > 0: also return the GroupNorm statistics of the output (fp64 [B, out_groups, 2]) for the next layer."""
+    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None, in_sums=None, out_groups=0, generic=False):
+        """out_groups > 0: also return the GroupNorm statistics of the output (fp64 [B, out_groups, 2]) for the next layer.
+        generic: run the generic gather kernel even where an LDS-brick kernel exists (bit 8 of the flag word; per-call cross-check for tests)."""
         B, D0, D1, D2, _ = x.shape
         y = torch.empty(B, D0, D1, D2, conv.cout, dtype=self.act_dtype, device=self.dev)
         scale, shift = self._gn(x, conv, in_sums) if gn else (None, None)
         args = (_lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
-                _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32)
+                _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32 | (256 if generic else 0))
         if out_groups:
             sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
             _lib.call("semabs_conv3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
@@ -171,13 +172,13 @@ class ResidualUNet3D:
         _lib.call("semabs_maxpool3d", _lib.ptr(x), _lib.ptr(y), B, D0, D1, D2, Cc, self.f32, _lib.stream())
         return y
 
-    def _up(self, x, skip, ct: _ConvT, out_groups=0):
+    def _up(self, x, skip, ct: _ConvT, out_groups=0, generic=False):
         """ConvTranspose3d(k3, s2) + skip; out_groups > 0: also the GroupNorm statistics of the result for the block that follows."""
         B, D0, D1, D2, _ = x.shape
         assert tuple(skip.shape) == (B, 2 * D0, 2 * D1, 2 * D2, ct.cout)
         y = torch.empty_like(skip)
         args = (_lib.ptr(x), _lib.ptr(ct.w_hi), _lib.ptr(ct.w_lo), ct.class_off, _lib.ptr(y),
-                _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32)
+                _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32 | (256 if generic else 0))
         if out_groups:
             sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
             _lib.call("semabs_convtranspose3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())

@@ -603,3 +603,40 @@ def g15_metrics():
 
 if __name__ == "__main__" and "g15" in sys.argv[1:]:
     g15_metrics()
+
+
+# ---- appended (round 2): the headline relevancy shape, run through the unmodified reference ---------------------------
+def g16_headline(which=("aug0", "aug5")):
+    """ClipWrapper.get_clip_saliency at the BASELINE shape: 480 x 480, ViT-B/16, 16 labels, "ours" (CLIP/clip/__init__.py:103-236).
+    aug0: augmentations=0 (1 image, 408 forwards).  aug5: the 5 augmented copies are injected (`synth_jitter`, the same pixels on
+    both sides) through `ClipWrapper.jittering_transforms` -> 6 images, 2 448 forwards, the benchmarked workload.
+    Stored per run: the [::4, ::4] subsample of the fp32 maps, 8 full rows, per-label max / sum / sha256."""
+    from semabs_amd.weights import DEFAULT_LABELS
+    from semabs_amd.synth import synth_jitter
+    rc = refimport.load_reference_clip("ViT-B/16", seed=0)
+    W = rc.ClipWrapper
+    labels = list(DEFAULT_LABELS[:16])
+    img = synth_rgb(480, 480, seed=0)
+    for tag in which:
+        cfg = dict(rc.saliency_configs["ours"](480))
+        if tag == "aug0":
+            cfg["augmentations"] = 0
+        else:
+            from PIL import Image
+            queue = [Image.fromarray(synth_jitter(img, k)) for k in range(cfg["augmentations"])]
+            it = iter(queue)
+            W.jittering_transforms = lambda pil: next(it)
+        t = time.time()
+        maps, feats = W.get_clip_saliency(img=img, text_labels=labels, prompts=[DEFAULT_PROMPT], **cfg)
+        dt = time.time() - t
+        m = maps.numpy()
+        print(f"    headline/{tag}: {dt:.1f}s on {os.cpu_count()} cores  max|map| {np.abs(m).max():.5g}", flush=True)
+        rows = np.asarray([0, 61, 122, 183, 244, 305, 366, 479])
+        save(f"g16_headline_{tag}", sub=m[:, ::4, ::4].copy(), rows_idx=rows, rows=m[:, rows, :].copy(),
+             absmax=np.abs(m).reshape(16, -1).max(1), sums=m.astype(np.float64).reshape(16, -1).sum(1),
+             sha=np.stack([digest(m[l]) for l in range(16)]), text=feats.numpy(), labels=np.asarray(labels),
+             seconds=np.float64(dt), cores=np.int64(os.cpu_count()))
+
+
+if __name__ == "__main__" and any(a.startswith("g16") for a in sys.argv[1:]):
+    g16_headline(tuple(a.split(":")[1] for a in sys.argv[1:] if a.startswith("g16:")) or ("aug0", "aug5"))

@@ -66,13 +66,13 @@ def test_label_chunking_injected_augmentations_and_tile_sharding():
     with torch.no_grad():
         ref = orl.relevancy_maps(sd, [img, jit], w.cpu().T.contiguous(), **cfg).numpy()
     _check(maps.cpu().numpy(), ref)
-    # tile sharding: two "ranks" run disjoint tile slices; summed per-tile relevances aggregate to the same maps
+    # tile sharding: two "ranks" run disjoint tile slices; their concatenated per-tile relevances aggregate to the same maps
     rel_full, table, scales = CW.relevancy_device(images, w, cfg["cropping_augmentations"], True, True, return_tiles=True)
     parts = []
     for r in range(2):
         parts.append(CW.relevancy_device(images, w, cfg["cropping_augmentations"], True, True, tile_range=shard_range(len(table), r, 2),
                                          return_tiles=True)[0])
-    summed = [parts[0][p] + parts[1][p] for p in range(2)]
+    summed = [torch.cat([parts[0][p], parts[1][p]], dim=1).contiguous() for p in range(2)]
     assert all(torch.equal(a, b) for a, b in zip(summed, rel_full))
     assert torch.equal(CW.aggregate_device(summed, scales, 2, H, H), maps)
 

@@ -1,0 +1,137 @@
+"""GPU: the two fp16 MFMA GEMM kernels pinned per call (`semabs_gemm_f16_ex(kernel=...)`) against an fp64 product of the same fp16 operands.
+
+* kernel 2 = `k_gemm8`, the phased 256 x 256 x 64 kernel that runs every large contraction of the ViT trunk (60 % of a scene): all five
+  epilogues, M exactly one row panel / with a ragged last panel / the 256-tile batch size, N in {768, 2304, 3072}, K in {128, 768, 3072},
+  strided A and B (lda > K: the K|V weight slices and the CLS-row gather use it), the row-remapped epilogue of the patch embedding;
+* kernel 1 = `k_gemm_f16`, the ring kernel, on the same problems; the two must agree with each other to fp32 summation-order noise.
+
+Tolerances (stated per output type): fp32 outputs 1e-5 of max|ref| (fp32 accumulation of exact fp16 products: measured ~1e-6);
+fp16 outputs 5e-4 of max|ref| + 1e-3 relative (one fp16 rounding of the result = 2^-11)."""
+import numpy as np
+import pytest
+import torch
+
+import semabs_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP = 0, 1, 2, 3, 4
+
+
+def _operands(M, N, K, lda, ldb, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    A = torch.randn(M, lda, device="cuda", generator=g).half()
+    B = (torch.randn(N, ldb, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A[:, :K].double() @ B[:, :K].double().T + bias.double()            # asymmetric operands: catches transposes
+    return A, B, bias, ref
+
+
+def _check32(got, ref, what):
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max())
+    assert err <= 1e-5 * scale, f"{what}: max err {err:.3e} vs max|ref| {scale:.3e}"
+
+
+def _check16(got, ref, what):
+    scale = float(ref.abs().max())
+    d = (got.double() - ref).abs()
+    bad = d > (5e-4 * scale + 1e-3 * ref.abs())
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements off, max err {float(d.max()):.3e} vs max|ref| {scale:.3e}"
+
+
+SHAPES = [(2048, 768, 768), (2381, 768, 768), (2381, 2304, 768), (2381, 3072, 768), (2381, 768, 3072), (2049, 768, 128),
+          (50432, 2304, 768), (50432, 768, 3072), (256, 768, 768), (300, 3072, 768)]
+
+
+@pytest.mark.parametrize("kernel", [2, 1])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_kernels_all_epilogues(kernel, M, N, K):
+    from semabs_amd.clip.vit import gemm
+    A, B, bias, ref = _operands(M, N, K, K, K, seed=M + N + K)
+    tag = f"kernel {kernel} {M}x{N}x{K}"
+    c32 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    gemm(A, B, c32, bias, M, N, K, K, K, N, EPI_F32, kernel=kernel)
+    _check32(c32, ref, tag + " f32")
+    gemm(A, B, c32, None, M, N, K, K, K, N, EPI_F32, kernel=kernel)                    # no bias
+    _check32(c32, ref - bias.double(), tag + " f32 no bias")
+    c16 = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+    gemm(A, B, c16, bias, M, N, K, K, K, N, EPI_F16, kernel=kernel)
+    _check16(c16, ref, tag + " f16")
+    gemm(A, B, c16, bias, M, N, K, K, K, N, EPI_GELU_F16, kernel=kernel)
+    _check16(c16, ref * torch.sigmoid(1.702 * ref), tag + " gelu")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    c = res.clone()
+    gemm(A, B, c, bias, M, N, K, K, K, N, EPI_RESID_F32, kernel=kernel)
+    _check32(c, ref + res.double(), tag + " residual")
+    # rows past M must not be touched (ragged last row panel): the output buffer carries a guard band
+    guard = torch.full((M + 256, N), 7.0, dtype=torch.float32, device="cuda")
+    gemm(A, B, guard, bias, M, N, K, K, K, N, EPI_F32, kernel=kernel)
+    assert bool((guard[M:] == 7.0).all()), tag + ": wrote past row M"
+
+
+@pytest.mark.parametrize("kernel", [2, 1])
+def test_gemm_strided_operands_and_slices(kernel):
+    """lda / ldb > K and a row slice of B (the last block's K|V weights are rows D..3D of in_proj_weight; its CLS rows are a strided A)."""
+    from semabs_amd.clip.vit import gemm
+    M, N, K, lda, ldb = 2300, 768, 768, 3 * 768, 768 + 64
+    A, Bfull, _, _ = _operands(M, 3 * N, K, lda, ldb, seed=11)
+    bias_full = torch.randn(3 * N, device="cuda")
+    B = Bfull[N:2 * N]                                                          # contiguous row slice, row stride ldb
+    bias = bias_full[N:2 * N].contiguous()
+    ref = A[:, :K].double() @ B[:, :K].double().T + bias.double()
+    c = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    gemm(A, B, c, bias, M, N, K, lda, ldb, N, EPI_F32, kernel=kernel)
+    _check32(c, ref, f"kernel {kernel} strided")
+    # strided C (ldc > N): a column block of a wider fp16 buffer
+    wide = torch.full((M, 3 * N), 3.0, dtype=torch.float16, device="cuda")
+    cview = wide[:, N:2 * N]
+    from semabs_amd import _lib
+    _lib.call("semabs_gemm_f16_ex", A.data_ptr(), B.data_ptr(), cview.data_ptr(), bias.data_ptr(), None, M, N, K, lda, ldb, 3 * N, EPI_F16, None,
+              kernel, None, None, _lib.stream())
+    _check16(wide[:, N:2 * N], ref, f"kernel {kernel} strided C")
+    assert bool((wide[:, :N] == 3.0).all()) and bool((wide[:, 2 * N:] == 3.0).all())
+
+
+@pytest.mark.parametrize("kernel", [2, 1])
+def test_gemm_rowmap_epilogue(kernel):
+    """epi 4: out row = (m / g_in) * g_out + g_off + m % g_in, plus addend[g_off + m % g_in] - the patch embedding writes token rows 1..T-1 of
+    every tile and adds the positional embedding (model_explainability.py:325-343)."""
+    from semabs_amd.clip.vit import gemm
+    n, G, T, N, K = 11, 196, 197, 768, 768
+    A, B, _, _ = _operands(n * G, N, K, K, K, seed=3)
+    pos = torch.randn(T, N, device="cuda")
+    out = torch.full((n * T, N), -7.0, dtype=torch.float32, device="cuda")
+    gemm(A, B, out, None, n * G, N, K, K, K, N, EPI_ROWMAP, addend=pos, rowmap=(G, T, 1), kernel=kernel)
+    ref = (A.double() @ B.double().T).view(n, G, N) + pos[1:].double()
+    got = out.view(n, T, N)
+    _check32(got[:, 1:], ref, f"kernel {kernel} rowmap")
+    assert bool((got[:, 0] == -7.0).all())                                       # class-token rows are left to semabs_embed_finish
+
+
+def test_gemm_kernels_agree_and_heuristic_picks_the_phased_kernel():
+    """Both kernels compute the same sums (fp32 accumulation order differs); the heuristic (kernel 0) must give exactly the phased kernel's
+    result for a trunk-sized problem and exactly the ring kernel's for a small one."""
+    from semabs_amd.clip.vit import gemm
+    for (M, N, K), same_as in (((4925, 2304, 768), 2), ((591, 2304, 768), 1)):
+        A, B, bias, ref = _operands(M, N, K, K, K, seed=5)
+        outs = {}
+        for kernel in (0, 1, 2):
+            c = torch.empty(M, N, dtype=torch.float32, device="cuda")
+            gemm(A, B, c, bias, M, N, K, K, K, N, EPI_F32, kernel=kernel)
+            outs[kernel] = c
+        assert torch.equal(outs[0], outs[same_as])
+        assert float((outs[1] - outs[2]).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_gemm_ex_rejects_bad_options():
+    from semabs_amd import _lib
+    h = _lib.lib()
+    a = torch.zeros(256, 128, dtype=torch.float16, device="cuda")
+    c = torch.zeros(256, 128, dtype=torch.float32, device="cuda")
+    rc = h.semabs_gemm_f16_ex(a.data_ptr(), a.data_ptr(), c.data_ptr(), None, None, 256, 128, 128, 128, 128, 128, 3, None, 5, None, None, None)
+    assert rc == -1 and b"kernel must be" in h.semabs_last_error()
+    ev = torch.cuda.Event(enable_timing=True)
+    rc = h.semabs_gemm_f16_ex(a.data_ptr(), a.data_ptr(), c.data_ptr(), None, None, 256, 128, 128, 128, 128, 128, 3, None, 0, 1, None, None)
+    assert rc == -1 and b"go together" in h.semabs_last_error()

@@ -71,11 +71,8 @@ def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid):
     if resid:
         ref = ref + rd.float().cpu().permute(0, 4, 1, 2, 3)
     ref = F.relu(ref)
-    _lib.call("semabs_conv_set_config", 1)
     y_lds = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
-    _lib.call("semabs_conv_set_config", 0)
-    y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
-    _lib.call("semabs_conv_set_config", 1)
+    y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
     assert (y_lds - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (y_lds - ref).abs().max().item()
     assert (y_lds - y_gen).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item())
 
@@ -205,6 +202,10 @@ def test_point_mlp():
     _lib.call("semabs_point_mlp", _lib.ptr(xyz_d), _lib.ptr(feat_d), _lib.ptr(w["w1"]), _lib.ptr(w["b1"]), _lib.ptr(w["w2"]),
               _lib.ptr(w["b2"]), _lib.ptr(w["w3"]), _lib.ptr(w["b3"]), _lib.ptr(pf), P, N, 128, 16, _lib.stream())
     np.testing.assert_allclose(pf.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    pf2 = torch.empty_like(pf)                      # the fp32 FMA kernel (its own entry point) against the same oracle
+    _lib.call("semabs_point_mlp_fma", _lib.ptr(xyz_d), _lib.ptr(feat_d), _lib.ptr(w["w1"]), _lib.ptr(w["b1"]), _lib.ptr(w["w2"]),
+              _lib.ptr(w["b2"]), _lib.ptr(w["w3"]), _lib.ptr(w["b3"]), _lib.ptr(pf2), P, N, 128, 16, _lib.stream())
+    np.testing.assert_allclose(pf2.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 3e-4), ("fp16", 3e-2)])
@@ -259,9 +260,7 @@ def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B):
                                                                          output_padding=1)
     ct = _ConvT(w, b, u.dev)
     y_brick = u._up(xd, sd_, ct).float().cpu().permute(0, 4, 1, 2, 3)
-    _lib.call("semabs_conv_set_config", 0)
-    y_gather = u._up(xd, sd_, ct).float().cpu().permute(0, 4, 1, 2, 3)
-    _lib.call("semabs_conv_set_config", 1)
+    y_gather = u._up(xd, sd_, ct, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
     scale = max(1.0, ref.abs().max().item())
     assert (y_brick - ref).abs().max().item() <= tol * scale
     assert (y_brick - y_gather).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale

@@ -1,6 +1,6 @@
 """One scene split over two ranks (tile-sharded relevancy + label-sharded voxel inference) equals the single-rank result.
 Two processes share the one GPU of the test box, so the process group is gloo (RCCL refuses two ranks on one device); the code path is the
-one `nccl` takes on a multi-GPU node: ClipWrapper.relevancy_device(tile_range=...) -> all-reduce -> aggregate, per-rank label slices ->
+one `nccl` takes on a multi-GPU node: ClipWrapper.relevancy_device(tile_range=...) -> all-gather -> aggregate, per-rank label slices ->
 all-gather."""
 import os
 
@@ -58,7 +58,7 @@ def test_two_rank_scene_equals_single_rank():
     for p in procs:
         p.join(timeout=120)
     for rank, maps, logits, labels in got:
-        # a tile's relevance does not depend on the other tiles of its batch, and the all-reduce adds zeros; what differs is which GEMM
+        # a tile's relevance does not depend on the other tiles of its batch, and the all-gather only moves it; what differs is which GEMM
         # kernel a (smaller) batch selects, i.e. the fp32 summation order inside the MFMAs, seen through the fp16 canvases of the
         # aggregation (measured 1.2e-4 of the maximum = 6e-7 absolute; the bar of the path is 1e-3 absolute)
         assert np.abs(maps - ref_maps).max() <= 5e-4 * np.abs(ref_maps).max(), (rank, np.abs(maps - ref_maps).max(), np.abs(ref_maps).max())

@@ -92,15 +92,14 @@ def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import semabs_amd  # noqa: F401
-    from semabs_amd.dist import allreduce_flat_gradients, allreduce_tile_relevance, gather_results, shard_range
+    from semabs_amd.dist import allgather_tile_relevance, allreduce_flat_gradients, gather_results, shard_range
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    L, N, g = 3, 10, 2
+    L, N, g = 3, 11, 2                                                        # 11 tiles: ranks hold 6 and 5 (padded slices)
     full = torch.arange(L * N * g * g, dtype=torch.float32).view(L, N, g, g)
     lo, hi = shard_range(N, rank, world)
-    mine = torch.zeros_like(full)
-    mine[:, lo:hi] = full[:, lo:hi]                                           # this rank's tile slice
-    rel = allreduce_tile_relevance([mine])
-    ok1 = torch.equal(rel[0], full)
+    mine = full[:, lo:hi].contiguous()                                        # this rank's tile slice (10 tiles over 2 ranks; 3 ranks: ragged)
+    rel = allgather_tile_relevance([mine, 2 * mine], N)                       # two passes (flip) travel in one collective
+    ok1 = torch.equal(rel[0], full) and torch.equal(rel[1], 2 * full)
     gathered = gather_results(torch.full((2, 4), float(rank)))               # e.g. 2 label volumes per rank
     ok2 = gathered.shape == (world, 2, 4) and all(float(gathered[r, 0, 0]) == r for r in range(world))
     # training: one flat all-reduce of gradients + usage flags (rank 0 used relation 0, rank 1 relation 2; relation 1 unused everywhere)

@@ -1,0 +1,95 @@
+"""Tuning aid (SEMABS_TUNE_LIB=1 -> libsemabs_hip_tune.so): per-shape TFLOP/s of the ViT trunk GEMMs at the benchmark batch (M = 2448 * 197),
+ablations, first-wave stagger sweep, and per-workgroup {start, main-loop end, end} traces.   python tools/gemm_probe.py [what ...]"""
+import json, os, sys
+os.environ.setdefault("SEMABS_TUNE_LIB", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import semabs_amd  # noqa
+from semabs_amd import _lib
+from semabs_amd.clip.vit import gemm
+
+M = int(os.environ.get("PROBE_M", 2448 * 197))
+SHAPES = [("qkv", 2304, 768, 0), ("out", 768, 768, 2), ("fc", 3072, 768, 1), ("proj", 768, 3072, 2), ("kv32", 768, 768, 3)]
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "gemm_probe")
+os.makedirs(OUT, exist_ok=True)
+tune = lambda k, v: _lib.call("semabs_gemm_tune", k, v)
+bufs = {}
+
+
+def operands(n, k, epi):
+    key = (n, k, epi)
+    if key not in bufs:
+        g = torch.Generator(device="cuda").manual_seed(n * 7 + k)
+        A = torch.randn(M, k, device="cuda", generator=g).half()
+        B = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+        bias = torch.randn(n, device="cuda", generator=g)
+        C = torch.zeros(M, n, device="cuda", dtype=torch.float16 if epi in (0, 1) else torch.float32)
+        bufs[key] = (A, B, bias, C)
+    return bufs[key]
+
+
+def time_shape(n, k, epi, reps=6):
+    A, B, bias, C = operands(n, k, epi)
+    for _ in range(2):
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return ms, 2.0 * M * n * k / ms / 1e9
+
+
+def line(label):
+    res = {}
+    for name, n, k, epi in SHAPES:
+        ms, tf = time_shape(n, k, epi)
+        res[name] = (round(ms * 1e3, 1), round(tf))
+    print(f"{label:34s} " + "  ".join(f"{nm} {v[0]:7.1f}us {v[1]:5d}TF" for nm, v in res.items()), flush=True)
+    return res
+
+
+what = sys.argv[1:] or ["base", "ablate", "stagger", "trace"]
+log = {}
+if "base" in what:
+    log["base"] = line("baseline")
+if "ablate" in what:
+    for ab, label in [(8, "no epilogue"), (1, "no in-loop DMA"), (2, "no in-loop ds_read"), (3, "MFMA + barriers"), (11, "MFMA + barriers, no epilogue"), (9, "no DMA, no epilogue"), (10, "no ds_read, no epilogue")]:
+        tune(2, ab)
+        log[f"ablate{ab}"] = line(label)
+    tune(2, 0)
+if "stagger" in what:
+    for st in (0, 100, 200, 400, 800, 1200, 1600):
+        tune(3, st)
+        log[f"stagger{st}"] = line(f"stagger {st} x 64 clk")
+    tune(3, 0)
+if "trace" in what:
+    for st in (0, 400):
+        tune(3, st)
+        for name, n, k, epi in SHAPES[:4]:
+            A, B, bias, C = operands(n, k, epi)
+            nb = ((M + 255) // 256) * (n // 256)
+            tr = torch.zeros(nb, 4, dtype=torch.int64, device="cuda")
+            gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+            torch.cuda.synchronize()
+            tune(4, tr.data_ptr())
+            gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+            torch.cuda.synchronize()
+            tune(4, 0)
+            t = tr.cpu().numpy()
+            np.save(os.path.join(OUT, f"trace_{name}_st{st}.npy"), t)
+            t0 = t[:, 0].min()
+            start, main, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0     # us (100 MHz)
+            total = end.max()
+            mainloop, epi_t = main - start, end - main
+            # how many workgroups are in their epilogue at the same time (sampled every 1 us)
+            ts = np.arange(0, total, 1.0)
+            in_epi = np.array([((main <= x) & (end > x)).sum() for x in ts])
+            in_main = np.array([((start <= x) & (main > x)).sum() for x in ts])
+            print(f"trace {name} stagger {st}: total {total:.0f}us  blocks {nb}  main loop mean {mainloop.mean():.1f} (p10 {np.percentile(mainloop,10):.1f} p90 {np.percentile(mainloop,90):.1f})  "
+                  f"epilogue mean {epi_t.mean():.1f} (p10 {np.percentile(epi_t,10):.1f} p90 {np.percentile(epi_t,90):.1f})  "
+                  f"concurrent epilogues mean {in_epi.mean():.0f} max {in_epi.max()} p90 {np.percentile(in_epi,90):.0f}  main mean {in_main.mean():.0f}", flush=True)
+    tune(3, 0)
+json.dump(log, open(os.path.join(OUT, "probe.json"), "w"))
