@@ -12,7 +12,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsemabs_hip.so")
-if os.environ.get("SEMABS_TUNE_LIB") == "1":        # tools/ only: the -DSEMABS_TUNING build of the same sources (build.py --tuning)
+if os.environ.get("SEMABS_LIB_PATH"):                # debugging: an explicit build of the same sources
+    LIB_PATH = os.environ["SEMABS_LIB_PATH"]
+elif os.environ.get("SEMABS_TUNE_LIB") == "1":        # tools/ only: the -DSEMABS_TUNING build of the same sources (build.py --tuning)
     LIB_PATH = os.path.join(_HERE, "lib", "libsemabs_hip_tune.so")
 
 _lib = None

@@ -30,7 +30,6 @@ struct GemmArgs {
     int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
-    int stagger;    // tuning build only: first-wave start stagger in units of 64 shader clocks (0 = off)
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
 #endif
 };
@@ -249,21 +248,20 @@ struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
-static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0, g_stagger = 0;
+static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0;
 static unsigned long long* g_trace = nullptr;
 extern "C" int semabs_gemm_tune(int key, long long value) {
     switch (key) {
         case 0: g_force_cfg = (int)value; break;     // alternative ring-kernel tile configurations (see launch())
         case 1: g_group_m = value < 1 ? 1 : (int)value; break;
         case 2: g_ablate = (int)value; break;
-        case 3: g_stagger = (int)value; break;
         case 4: g_trace = (unsigned long long*)value; break;
         default: return SEMABS_EINVAL;
     }
     return SEMABS_OK;
 }
 #define GEMM_GROUP_M g_group_m
-#define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).stagger = g_stagger; (g).trace = g_trace; } while (0)
+#define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).trace = g_trace; } while (0)
 #else
 #define GEMM_GROUP_M 8
 #define GEMM_TUNE_ARGS(g) do { } while (0)
@@ -316,73 +314,79 @@ static int launch_cfg(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 __device__ __forceinline__ int swzA8(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int swzB8(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }
 
+// Buffer addressing (raw buffers, stride 0): address = 48-bit base in a scalar resource descriptor + 32-bit per-lane byte offset + scalar
+// byte offset.  One VGPR per lane serves every access of a tile - no 64-bit vector address arithmetic in the hot loop or the epilogue - and
+// accesses past `bytes` are dropped by the hardware (loads return 0, stores are discarded), which is how the ragged last row panel is
+// handled: no per-row guards anywhere.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p, long bytes) {
+    const int n = bytes > 0x7fffffffL ? 0x7fffffff : (bytes < 0 ? 0 : (int)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
+    constexpr bool OUT16 = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
+    constexpr int ES = OUT16 ? 2 : 4;                       // bytes per output element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int l15 = lane & 15, kg = lane >> 4;
 
-    int b = blockIdx.x;
-    {
-        const int nb = g.n_blocks, q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    int tm, tn;
-    {
+    // block id -> output tile.  XCD-aware bijective remap (hardware places block b on XCD b % 8) + grouped rasterisation, as in k_gemm_f16.
+    auto tile_of = [&](int vb, long& m0, int& n0) {
+        int b;
+        {
+            const int nb = g.n_blocks, q = nb >> 3, r = nb & 7, xcd = vb & 7, k = vb >> 3;
+            b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        }
         const int per_group = g.group_m * g.n_tiles_n, gid = b / per_group, first_m = gid * g.group_m;
         const int gsz = (g.n_tiles_m - first_m < g.group_m) ? g.n_tiles_m - first_m : g.group_m;
         const int r = b - gid * per_group;
-        tm = first_m + r % gsz; tn = r / gsz;
-    }
-    const long m0 = (long)tm * 256;
-    const int n0 = tn * 256;
-#ifdef SEMABS_TUNING
-    // experiment: stagger the first wave of workgroups (one per CU) so that the CUs' epilogues do not all hit HBM at the same time
-    if (g.stagger > 0 && blockIdx.x < 256) {
-        const int d = g.stagger * (int)((blockIdx.x >> 3) & 31) / 32;
-        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    unsigned long long t_start = 0, t_main = 0;
-    if (g.trace) t_start = __builtin_amdgcn_s_memrealtime();
-#endif
+        m0 = (long)(first_m + r % gsz) * 256;
+        n0 = (r / gsz) * 256;
+    };
 
     // ---- DMA sources: thread -> (row = j * 64 + tid / 8, 16-byte chunk position tid % 8) of every half-tile, j = 0, 1 ----
     const int srow = tid >> 3, scp = tid & 7;
-    long aoff[2][2];                                        // [half][j] element offsets into A (rows clamped for the M tail)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = j * 64 + srow;
-            long am = m0 + h * 128 + row; if (am > g.M - 1) am = g.M - 1;
-            aoff[h][j] = am * g.lda + ((swzA8(row, scp) - row * 128) >> 1);
-        }
-    int boff[2];                                            // [j]; the half adds 128 * ldb
+    unsigned aoff[2], boff[2];                              // [j] byte offsets from the tile's first row; the half-tile / K tile add scalar offsets
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = j * 64 + srow;
-        boff[j] = row * g.ldb + ((swzB8(row, scp) - row * 128) >> 1);
+        aoff[j] = (unsigned)(row * (int)g.lda * 2 + (swzA8(row, scp) - row * 128));
+        boff[j] = (unsigned)(row * g.ldb * 2 + (swzB8(row, scp) - row * 128));
     }
-    const f16* Bblk = g.B + (long)n0 * g.ldb;
+    const unsigned a_half = (unsigned)(128 * (int)g.lda * 2), b_half = (unsigned)(128 * g.ldb * 2);
+    __amdgpu_buffer_rsrc_t rA, rB;                          // per tile: rows past M read as zeros (they only feed output rows that are never stored)
+    auto set_tile = [&](long m0, int n0) {
+        const long rows = g.M - m0 < 256 ? g.M - m0 : 256;
+        rA = gemm_rsrc(g.A + m0 * g.lda, ((rows - 1) * g.lda + g.K) * 2);
+        rB = gemm_rsrc(g.B + (long)n0 * g.ldb, (255L * g.ldb + g.K) * 2);
+    };
     auto stage_a = [&](int h, int kt) {
         char* dst = smem + (kt & 1) * BUFSZ + (h ? OFF_A1 : OFF_A0) + wid * 1024;
+        const unsigned soff = (unsigned)kt * 128 + (h ? a_half : 0u);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + aoff[h][j] + (long)kt * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, aoff[j], soff, 0, 0);
     };
     auto stage_b = [&](int h, int kt) {
         char* dst = smem + (kt & 1) * BUFSZ + (h ? OFF_B1 : OFF_B0) + wid * 1024;
-        const f16* src = Bblk + (long)h * 128 * g.ldb + (long)kt * 64;
+        const unsigned soff = (unsigned)kt * 128 + (h ? b_half : 0u);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + boff[j]),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, boff[j], soff, 0, 0);
     };
+    auto prologue = [&]() { stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1); };
 
     // ---- fragment read offsets (bytes within a half-tile) ----
     int offA[2], offB[2][2];
@@ -398,14 +402,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         }
     }
     f32x4 acc[2][4][2][2];                                  // [A half][row tile][B half][col tile]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f16x8 fa[4][2], fb[2][2][2];                            // fa[row tile][kk] (A0 then A1 reuse it); fb[B half][col tile][kk]
 
     auto read_a = [&](int h, int par) {
@@ -449,8 +445,169 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                       \
     } while (0)
 
+    // ---- epilogue: registers -> wave-private LDS transpose -> row-contiguous 16-byte accesses ----
+    // After the MFMAs a lane holds, per 16 x 16 tile pair, 8 consecutive columns of ONE row (lane l15 = row, kg = column group).  Stored
+    // straight from registers, the 16 lanes of a quarter wave hit 16 different rows: the texture-address unit then handles about one lane per
+    // clock (measured: 16 B / clk / CU - 4-5 us per fp16 tile, 16-20 us per fp32 read-modify-write tile = as long as the K = 768 main loop,
+    // with the later waves queueing behind the earlier ones).  So every (B half, A half) pass of a wave - 64 rows x 32 columns - goes
+    // through 4 / 8 KB of the wave's own 16 KB slice of the (now idle) operand buffers and comes back with consecutive lanes on consecutive
+    // 16-byte chunks of a row (4 lanes = a 64-byte fp16 row segment, 8 lanes = a 128-byte fp32 one): quad-coalesced dwordx4 accesses at the
+    // full 64 B / clk.  No workgroup barrier: a wave only reads what it wrote (LDS is in-order per wave); the rows' 16-byte chunks are
+    // XOR-swizzled so that neither the row-per-lane writes nor the row-contiguous reads conflict.  The residual tile of the fp32
+    // read-modify-write is loaded in the same coalesced layout, one pass ahead.
+    // Output addressing: one resource descriptor per (tile, wave) whose extent ends with the last valid row - accesses of the ragged last row
+    // panel fall off it - plus a per-lane byte offset and a scalar offset per pass / instruction.
+    auto epilogue = [&](const long m0, const int n0) {
+        constexpr int ROWB = OUT16 ? 64 : 128;              // bytes of a pass row (32 columns)
+        constexpr int LPR = ROWB / 16;                      // lanes (16-byte chunks) per row in the coalesced layout: 4 / 8
+        constexpr int RPI = 64 / LPR;                       // rows per wave instruction: 16 / 8
+        constexpr int NIT = 64 / RPI;                       // instructions per pass: 4 / 8
+        constexpr int PASSB = 64 * ROWB;                    // 4 / 8 KB; two passes alternate inside the wave's 16 KB
+        char* const ep = smem + wid * 16384;
+        float bia[2][8];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int ncol = n0 + hb * 128 + wc * 32 + kg * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bia[hb][e] = 0.f;
+            if (g.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
+                bia[hb][0] = b0.x; bia[hb][1] = b0.y; bia[hb][2] = b0.z; bia[hb][3] = b0.w; bia[hb][4] = b1.x; bia[hb][5] = b1.y; bia[hb][6] = b1.z; bia[hb][7] = b1.w;
+            }
+        }
+        // register layout -> LDS (row = i * 16 + l15; this lane's 8 columns = chunk kg (fp16) / chunks 2 kg, 2 kg + 1 (fp32))
+        const int wswz = OUT16 ? ((l15 >> 1) & 3) : (l15 & 7);
+        // Scheduling fences around the LDS stores are load-bearing.  Left to itself the compiler interleaved the next values' VALU work with
+        // the 16-byte LDS stores and re-used a store's first data VGPR five VALU instructions after the ds_write_b128 that sources it; with
+        // the other wave row hammering the LDS at the same time, the last lane of each quad then stored the NEW register value
+        // (non-deterministic, ~1e-4 of the fp16 outputs wrong; fp32 untouched only because its registers happened not to be re-used).  The
+        // documented hazard (VALU write of the data of a > 64-bit store: 1-2 wait states) is what the compiler pads for; back-to-back wide
+        // stores evidently keep reading their operands for longer.  So: all values of a pass first, fence, then the stores, fence - the
+        // stores' operands are only overwritten by the NEXT pass, after this pass's LDS reads have returned.
+        auto lds_write = [&](int pass) {
+            const int hb = pass >> 1, ha = pass & 1;
+            char* buf = ep + (pass & 1) * PASSB;
+            f32x4 w[4][OUT16 ? 1 : 2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[hb][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][4 + e]; }
+                if constexpr (OUT16) {
+                    f16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+                        h[e] = (f16)v[e];
+                    }
+                    w[i][0] = __builtin_bit_cast(f32x4, h);                       // same access type as lds_read (no type-based reordering)
+                } else {
+                    w[i][0] = f32x4{v[0], v[1], v[2], v[3]};
+                    w[i][OUT16 ? 0 : 1] = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                char* row = buf + (i * 16 + l15) * ROWB;
+                if constexpr (OUT16) {
+                    *reinterpret_cast<f32x4*>(row + ((kg ^ wswz) << 4)) = w[i][0];
+                } else {
+                    *reinterpret_cast<f32x4*>(row + (((2 * kg) ^ wswz) << 4)) = w[i][0];
+                    *reinterpret_cast<f32x4*>(row + (((2 * kg + 1) ^ wswz) << 4)) = w[i][OUT16 ? 0 : 1];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // coalesced layout: instruction `it` of a pass covers rows it * RPI + lane / LPR, this lane's chunk = lane % LPR
+        const int crow = lane / LPR, cchunk = lane % LPR;
+        auto lds_read = [&](int pass, int it) {
+            const int row = it * RPI + crow;
+            const int rswz = OUT16 ? ((row >> 1) & 3) : (row & 7);
+            return *reinterpret_cast<const f32x4*>(ep + (pass & 1) * PASSB + row * ROWB + ((cchunk ^ rswz) << 4));
+        };
+        const long mw = m0 + wr * 64;                       // first row of this wave's 64-row strip of A half 0 (half 1: + 128)
+        const unsigned ldcb = (unsigned)g.ldc * ES;         // output row pitch in bytes
+        if constexpr (EPI == EPI_ROWMAP_ADD_F32) {
+            // out row = (m / g_in) * g_out + g_off + m % g_in: a per-lane row map, still monotonic in m - the descriptor starts at the strip's
+            // first output row and ends after the output row of the last valid m
+            const long grp0 = mw / g.g_in; const long orow0 = grp0 * g.g_out + g.g_off + (mw - grp0 * g.g_in);
+            const long mlast = g.M - 1; const long grpl = mlast / g.g_in; const long orowl = grpl * g.g_out + g.g_off + (mlast - grpl * g.g_in);
+            const __amdgpu_buffer_rsrc_t rC = gemm_rsrc(reinterpret_cast<const float*>(g.C) + orow0 * g.ldc + (n0 + wc * 32),
+                                                        (orowl - orow0) * (long)ldcb + (long)(g.N - n0 - wc * 32) * ES);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int hb = pass >> 1, ha = pass & 1;
+                lds_write(pass);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const long m = mw + ha * 128 + it * RPI + crow;
+                    const long grp = m / g.g_in; const int within = (int)(m - grp * g.g_in);
+                    const long orow = grp * g.g_out + g.g_off + within;
+                    f32x4 v = lds_read(pass, it);
+                    if (g.addend) {
+                        const float4 a = *reinterpret_cast<const float4*>(g.addend + (long)(g.g_off + within) * g.N + (n0 + hb * 128 + wc * 32 + cchunk * 4));
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                    }
+                    buf_store4(rC, (unsigned)(orow - orow0) * ldcb + (unsigned)(cchunk * 16), (unsigned)(hb * 128 * ES), v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const long rows = g.M - mw;                     // valid rows from the strip's first row on (may be <= 0: nothing is stored)
+            const __amdgpu_buffer_rsrc_t rC = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * ES,
+                                                        rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * ES : 0);
+            const unsigned voff = (unsigned)crow * ldcb + (unsigned)(cchunk * 16);
+            auto soff_of = [&](int pass, int it) { return (unsigned)((pass & 1) * 128 + it * RPI) * ldcb + (unsigned)((pass >> 1) * 128 * ES); };
+            if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                f32x4 res[2][NIT];
+                auto issue = [&](int pass) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) res[pass & 1][it] = buf_load4(rC, voff, soff_of(pass, it));
+                };
+                issue(0);
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    lds_write(pass);
+                    if (pass + 1 < 4) issue(pass + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const f32x4 v = lds_read(pass, it);
+                        const f32x4 o = res[pass & 1][it];
+                        buf_store4(rC, voff, soff_of(pass, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    lds_write(pass);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) buf_store4(rC, voff, soff_of(pass, it), lds_read(pass, it));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
-    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1);
+    long m0; int n0;
+    tile_of(blockIdx.x, m0, n0);
+    set_tile(m0, n0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef SEMABS_TUNING
+    unsigned long long t_start = 0, t_main = 0;
+    if (g.trace) t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    prologue();
     wait_vmcnt<8>();                                        // A0(0), B0(0) have landed (this wave's share)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();              // skew the second wave row by one barrier
@@ -482,93 +639,29 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         GEMM8_END();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();              // balance the skew barrier
-#undef GEMM8_SYNC
-#undef GEMM8_END
-
-    // ---- epilogue straight from registers: lane = row m (l15), 8 consecutive columns n = nb + kg * 8 + (jt * 4 + r) ----
-    // Interior tiles (all 256 rows valid - every tile but the last row panel) take a branch-free path: per-row guards would put
-    // every store in its own basic block, each opening with a conservative s_waitcnt vmcnt(0) that also waits for the previous
-    // STORE (gfx9 counts stores in vmcnt) and serialises the whole tail.
+    // Every DMA has been waited for (vmcnt(0) in the last K tile's phases): the epilogue's ordinary loads (bias, residual) never share the
+    // vmcnt queue with LDS-DMA loads.  That matters: counted vmcnt waits assume in-order return, and on gfx950 an ordinary load issued
+    // BEHIND outstanding LDS-DMA loads was observed to be reported complete too early (a persistent variant that issued the next tile's
+    // first half-tiles before the epilogue returned garbage in lanes 12-15 of the first bias fragment, non-deterministically).
 #ifdef SEMABS_TUNING
     if (g.trace) t_main = __builtin_amdgcn_s_memrealtime();
 #endif
-    if GEMM_ABL(8) { if (acc[0][0][0][0][0] != 12345.678f) return; }
-    auto epilogue = [&](auto checked) {
-        constexpr bool CHECK = decltype(checked)::value;
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int ncol = n0 + hb * 128 + wc * 32 + kg * 8;
-            float bia[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (g.bias) {
-                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
-                bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w; bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
-            }
-#pragma unroll
-            for (int ha = 0; ha < 2; ++ha) {
-                // fp32 residual read-modify-write: issue the four rows' loads together (32 VGPRs), then add and store
-                float4 res[4][2];
-                if (EPI == EPI_BIAS_RESID_F32) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const long m = m0 + ha * 128 + wr * 64 + i * 16 + l15;
-                        if (CHECK && m >= g.M) { res[i][0] = res[i][1] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-                        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.C) + m * g.ldc + ncol);
-                        res[i][0] = p[0]; res[i][1] = p[1];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long m = m0 + ha * 128 + wr * 64 + i * 16 + l15;
-                    if (CHECK && m >= g.M) continue;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[4 + e]; }
-                    if (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-                        f16x8 h;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
-                            h[e] = (f16)v[e];
-                        }
-                        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(g.C) + m * g.ldc + ncol) = h;
-                    } else if (EPI == EPI_BIAS_RESID_F32) {
-                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
-                        const float4 o0 = res[i][0], o1 = res[i][1];
-                        p[0] = make_float4(o0.x + v[0], o0.y + v[1], o0.z + v[2], o0.w + v[3]);
-                        p[1] = make_float4(o1.x + v[4], o1.y + v[5], o1.z + v[6], o1.w + v[7]);
-                    } else if (EPI == EPI_BIAS_F32) {
-                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + ncol);
-                        p[0] = make_float4(v[0], v[1], v[2], v[3]); p[1] = make_float4(v[4], v[5], v[6], v[7]);
-                    } else {
-                        const long grp = m / g.g_in; const int within = (int)(m - grp * g.g_in);
-                        const long orow = grp * g.g_out + g.g_off + within;
-                        if (g.addend) {
-                            const float4* ap = reinterpret_cast<const float4*>(g.addend + (long)(g.g_off + within) * g.N + ncol);
-                            const float4 a0 = ap[0], a1 = ap[1];
-                            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-                        }
-                        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + orow * g.ldc + ncol);
-                        p[0] = make_float4(v[0], v[1], v[2], v[3]); p[1] = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                }
-            }
-        }
-    };
-    if (m0 + 256 <= g.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
+    if (!GEMM_ABL(8)) epilogue(m0, n0);
 #ifdef SEMABS_TUNING
     if (g.trace) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            unsigned hw;
+            unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* t = g.trace + (size_t)blockIdx.x * 4;
-            t[0] = t_start; t[1] = t_main; t[2] = t_end; t[3] = ((unsigned long long)xcc << 32) | hw;
+            unsigned long long* tr = g.trace + (size_t)blockIdx.x * 4;
+            tr[0] = t_start; tr[1] = t_main; tr[2] = t_end; tr[3] = ((unsigned long long)xcc << 32) | hw;
         }
     }
 #endif
+#undef GEMM8_SYNC
+#undef GEMM8_END
 }
 
 template <int EPI>
@@ -590,7 +683,8 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s, const GemmOpts& o) {
-    const bool big_ok = g.N % 256 == 0 && g.K >= 128;                   // what the phased kernel can run
+    // what the phased kernel can run (its buffer addressing keeps per-tile byte offsets in 32 bits)
+    const bool big_ok = g.N % 256 == 0 && g.K >= 128 && g.lda < (1L << 20) && g.ldb < (1 << 20) && g.ldc < (1L << 20);
 #ifdef SEMABS_TUNING
     if (g_force_cfg == 3 && g.N % 256 == 0) return launch_cfg<EPI, 256, 256, 32, 4, 4, 4>(g, s, o);      // 16 waves, 64 x 64 wave tiles
     if (g_force_cfg == 4 && g.N % 256 == 0) return launch_cfg<EPI, 256, 128, 32, 4, 2, 3>(g, s, o);      // 8 waves, 64 x 64 wave tiles, 2 blocks / CU

@@ -8,8 +8,9 @@ the fp32 maps, 8 full rows, per-label max / sum, and the reference's zero-shot t
 not needed on the GPU box).
 
 Both ViT batch sizes are exercised: chunk_tiles = 2448 (what bench.py times: ONE 482 256-row batch, ragged last wave of GEMM tiles, 11 GB
-workspace) and 220.  Tolerance: RELATIVE L-infinity = max|ours - ref| / max|ref| per run; measured on MI355X 1.1e-3 ... 1.3e-3 (fp16 MFMA operands
-against the reference's fp32 CPU arithmetic; the reference's own fp16 canvases quantise at 2^-11 relative per add), asserted at 3 x that."""
+workspace) and 220.  Tolerance: RELATIVE L-infinity = max|ours - ref| / max|ref| per run; measured on MI355X 6.0e-4 (aug0) and 9.0e-4 (aug5) (fp16 MFMA operands
+against the reference's fp32 CPU arithmetic; the reference's own fp16 canvases quantise at 2^-11 = 4.9e-4 relative per add), i.e. 2.9e-6 /
+2.2e-6 absolute; asserted at 3 x the larger.  Worst single label relative to its own maximum: 9.4e-4 / 1.06e-3."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +20,7 @@ from semabs_amd.synth import synth_jitter, synth_rgb
 
 pytestmark = pytest.mark.gpu
 
-REL_LINF_BOUND = 4e-3          # 3 x the measured relative L-infinity (see the module docstring); BASELINE bar: 1e-3 ABSOLUTE on maps whose max is 4.8e-3
+REL_LINF_BOUND = 2.7e-3        # 3 x the measured relative L-infinity (see the module docstring); BASELINE bar: 1e-3 ABSOLUTE on maps whose max is 4.8e-3
 
 
 @pytest.fixture(scope="module")
@@ -66,8 +67,8 @@ def test_headline_maps_vs_reference(golden, wrapper, tag):
         print(f"headline {tag} chunk {chunk}: abs L-inf {max(e_sub, e_rows):.3e}  relative L-inf {rel:.3e}  worst per-label relative {per_label:.3e}  "
               f"map-sum relative {sums:.3e}  (max|ref| {ref_max:.3e})")
         assert rel <= REL_LINF_BOUND, rel
-        assert per_label <= 1.5 * REL_LINF_BOUND, per_label
-        assert max(e_sub, e_rows) <= 1e-3                                  # BASELINE.json's absolute bar
+        assert per_label <= 3.2e-3, per_label                              # 3 x the measured worst per-label value
+        assert max(e_sub, e_rows) <= 1e-5                                  # absolute: 3 x the measured 2.9e-6 (BASELINE.json's bar is 1e-3)
         res[chunk] = m
     # the maps must not depend on the ViT batch size (same kernels, same per-row arithmetic; was tools/chunk_equiv.py)
     assert np.array_equal(res[2448], res[220]), float(np.abs(res[2448] - res[220]).max())

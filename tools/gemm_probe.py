@@ -51,45 +51,40 @@ def line(label):
     return res
 
 
-what = sys.argv[1:] or ["base", "ablate", "stagger", "trace"]
+what = sys.argv[1:] or ["base", "ablate", "trace"]
 log = {}
 if "base" in what:
-    log["base"] = line("baseline")
+    for rep in range(2):
+        log[f"base_{rep}"] = line(f"baseline (rep {rep})")
 if "ablate" in what:
     for ab, label in [(8, "no epilogue"), (1, "no in-loop DMA"), (2, "no in-loop ds_read"), (3, "MFMA + barriers"), (11, "MFMA + barriers, no epilogue"), (9, "no DMA, no epilogue"), (10, "no ds_read, no epilogue")]:
         tune(2, ab)
         log[f"ablate{ab}"] = line(label)
     tune(2, 0)
-if "stagger" in what:
-    for st in (0, 100, 200, 400, 800, 1200, 1600):
-        tune(3, st)
-        log[f"stagger{st}"] = line(f"stagger {st} x 64 clk")
-    tune(3, 0)
 if "trace" in what:
-    for st in (0, 400):
-        tune(3, st)
-        for name, n, k, epi in SHAPES[:4]:
-            A, B, bias, C = operands(n, k, epi)
-            nb = ((M + 255) // 256) * (n // 256)
-            tr = torch.zeros(nb, 4, dtype=torch.int64, device="cuda")
-            gemm(A, B, C, bias, M, n, k, k, k, n, epi)
-            torch.cuda.synchronize()
-            tune(4, tr.data_ptr())
-            gemm(A, B, C, bias, M, n, k, k, k, n, epi)
-            torch.cuda.synchronize()
-            tune(4, 0)
-            t = tr.cpu().numpy()
-            np.save(os.path.join(OUT, f"trace_{name}_st{st}.npy"), t)
-            t0 = t[:, 0].min()
-            start, main, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0     # us (100 MHz)
-            total = end.max()
-            mainloop, epi_t = main - start, end - main
-            # how many workgroups are in their epilogue at the same time (sampled every 1 us)
-            ts = np.arange(0, total, 1.0)
-            in_epi = np.array([((main <= x) & (end > x)).sum() for x in ts])
-            in_main = np.array([((start <= x) & (main > x)).sum() for x in ts])
-            print(f"trace {name} stagger {st}: total {total:.0f}us  blocks {nb}  main loop mean {mainloop.mean():.1f} (p10 {np.percentile(mainloop,10):.1f} p90 {np.percentile(mainloop,90):.1f})  "
-                  f"epilogue mean {epi_t.mean():.1f} (p10 {np.percentile(epi_t,10):.1f} p90 {np.percentile(epi_t,90):.1f})  "
-                  f"concurrent epilogues mean {in_epi.mean():.0f} max {in_epi.max()} p90 {np.percentile(in_epi,90):.0f}  main mean {in_main.mean():.0f}", flush=True)
-    tune(3, 0)
+    for name, n, k, epi in SHAPES[:4]:
+        A, B, bias, C = operands(n, k, epi)
+        nb = ((M + 255) // 256) * (n // 256)
+        tr = torch.zeros(nb, 4, dtype=torch.int64, device="cuda")
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+        torch.cuda.synchronize()
+        tune(4, tr.data_ptr())
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+        torch.cuda.synchronize()
+        tune(4, 0)
+        t = tr.cpu().numpy()
+        np.save(os.path.join(OUT, f"trace_{name}.npy"), t)
+        t0 = t[:, 0].min()
+        start, main, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0     # us (100 MHz)
+        total = end.max()
+        hw = t[:, 3]; hwid = hw & 0xffffffff; xcc = hw >> 32
+        cuid = (xcc << 16) | ((hwid >> 8) & 0xf) | (((hwid >> 12) & 1) << 4) | (((hwid >> 13) & 7) << 5)
+        gaps = []
+        for c in np.unique(cuid):
+            idx = np.where(cuid == c)[0]
+            o = idx[np.argsort(start[idx])]
+            gaps += list(start[o][1:] - end[o][:-1])
+        gaps = np.asarray(gaps)
+        print(f"trace {name}: total {total:.0f}us  tiles {nb}  CUs {len(np.unique(cuid))}  main loop mean {(main - start).mean():.1f}  epilogue (to stores complete) mean {(end - main).mean():.1f}  "
+              f"gap to next tile mean {gaps.mean():.2f} p90 {np.percentile(gaps, 90):.2f}  per-tile period {total / (nb / 256):.1f}", flush=True)
 json.dump(log, open(os.path.join(OUT, "probe.json"), "w"))
