@@ -37,42 +37,129 @@ FLOPS_PER_TILE = {"ViT-B/16": 35.127e9, "ViT-B/32": 8.818e9}      # SURVEY.md §
 PEAK_F16_TFLOPS = 2500.0                                          # dense MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(arch, n_labels, tiles_sample=16):
-    """Oracle ("port" of the reference's CPU path) timed on this host: bounded sample, scaled to one scene."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _median3(fn, reps=3):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def cpu_baseline(arch, n_labels, tiles_sample=64):
+    """Oracle ("port" of the reference's CPU path, oracle/) timed on this host's cores: EVERY stage of one scene on a bounded sample of the
+    same workload (same synthetic scene family, "ours" config, same arch / label count / grid), median of 3 per stage, scaled to one scene.
+    The oracle restates the reference's arithmetic (torch-CPU fp32, analytic rollout instead of L autograd passes - i.e. it is FASTER than the
+    reference's own CPU path, which took 720 s for the relevancy stage of this scene on the 8 cores of the build container)."""
+    from oracle import geometry as og
     from oracle import relevancy as orl
+    from oracle import scene as osc
     from oracle import semabs3d as os3
-    from semabs_amd.synth import synth_rgb
+    from semabs_amd.synth import SCENE_BOUNDS, synth_scene
     from semabs_amd.weights import make_clip_state_dict, make_semabs3d_state_dict
-    threads = min(os.cpu_count() or 1, 64)
+    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     sd = make_clip_state_dict(arch, 0, text_tower=False)
     nsd = make_semabs3d_state_dict(seed=3)
     rng = np.random.default_rng(0)
     w = torch.from_numpy(rng.standard_normal((512, n_labels)).astype(np.float32))
-    img = synth_rgb(IMG, IMG, 1)
+    sc = synth_scene(IMG, IMG, seed=1)
     cfg = orl.saliency_configs["ours"](IMG)
-    table = orl.tile_table(IMG, IMG, 1, cfg["cropping_augmentations"])
+    table = orl.tile_table(IMG, IMG, 1, cfg["cropping_augmentations"])                    # 204 tiles of one image
     pick = table[np.linspace(0, len(table) - 1, tiles_sample).astype(int)]
-    t0 = time.time()
-    tiles = orl.make_tile_images([img], pick)
-    t_pre = time.time() - t0
+    st = {}
+    st["tiles_preprocess"] = _median3(lambda: orl.make_tile_images([sc["rgb"]], pick)) / tiles_sample * 1224
+    tiles = orl.make_tile_images([sc["rgb"]], pick)
     with torch.no_grad():
-        orl.gradcam_tiles(sd, tiles[:2], w, True)                                   # warm-up
-        t0 = time.time()
-        orl.gradcam_tiles(sd, tiles, w, True)
-        t_vit = time.time() - t0
-        x = torch.zeros(1, 16, VOXEL, VOXEL, VOXEL)
-        x[0, :, ::5, ::7, ::3] = 1.0
-        t0 = time.time()
-        os3.unet_forward(nsd, x, 6)
-        t_unet = time.time() - t0
-    n_fwd = 2448
-    scene_s = (t_pre / tiles_sample) * 1224 + (t_vit / tiles_sample) * n_fwd + t_unet * n_labels
-    return {"value": 1.0 / scene_s, "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": f"{tiles_sample} of 2448 tile forwards ({arch}, {n_labels} labels, analytic rollout) + 1 of {n_labels} "
-                      f"128^3 UNet volumes, torch-CPU fp32 oracle, scaled to one scene "
-                      f"(pre {t_pre:.2f}s, vit {t_vit:.2f}s, unet {t_unet:.2f}s); aggregation/decoder not included",
-            "scene_seconds_estimate": scene_s}
+        orl.gradcam_tiles(sd, tiles[:2], w, True)                                         # warm-up
+        st["vit_rollout"] = _median3(lambda: [orl.gradcam_tiles(sd, tiles[i:i + 32], w, True) for i in range(0, tiles_sample, 32)]) / tiles_sample * 2448
+        # aggregation of one image's tiles (both flip passes already averaged), x 6 images
+        rel = torch.from_numpy(rng.standard_normal((n_labels, len(table), 14 if "16" in arch else 7, 14 if "16" in arch else 7)).astype(np.float32) * 1e-3)
+        st["aggregate"] = _median3(lambda: orl.aggregate(rel, table, IMG, IMG, tile_sizes=[a["tile_size"] for a in cfg["cropping_augmentations"]]), reps=1) * 6
+        # geometry: unprojection, bounds, voxel indices, frustum of the lattice, TSDF
+        def geometry():
+            pts = og.get_pointcloud(sc["depth"], sc["cam_intr"], sc["cam_pose"]).astype(np.float32)
+            m = og.filter_pts_bounds(pts, np.asarray(SCENE_BOUNDS, np.float64))
+            og.flatten_idxs(og.points_grid_idxs(pts[m], SCENE_BOUNDS, (VOXEL,) * 3), (VOXEL,) * 3)
+        st["geometry"] = _median3(geometry)
+        q = osc.grid_points(SCENE_BOUNDS, VOXEL)
+        def tsdf_frustum():
+            lo, hi = np.asarray(SCENE_BOUNDS[0], np.float64), np.asarray(SCENE_BOUNDS[1], np.float64)
+            tv = og.TSDFVolume(np.stack([lo, hi], axis=1), (hi[0] - lo[0]) / VOXEL)
+            tv.integrate(sc["rgb"], sc["depth"], sc["cam_intr"], sc["cam_pose"])
+            og.check_pts_in_frustum(q.astype(np.float64), (IMG, IMG), sc["cam_pose"], sc["cam_intr"])
+        st["tsdf_frustum"] = _median3(tsdf_frustum, reps=1)
+        # voxel stage for ONE label volume, x n_labels: point MLP + scatter-mean, UNet, decoder at the 128^3 lattice
+        pts = og.get_pointcloud(sc["depth"], sc["cam_intr"], sc["cam_pose"]).astype(np.float32)
+        pts = pts[og.filter_pts_bounds(pts, np.asarray(SCENE_BOUNDS, np.float64))]
+        xyz = torch.from_numpy(pts[rng.integers(0, len(pts), size=80000)])[None]
+        feat = torch.from_numpy(rng.standard_normal((1, 80000, 1)).astype(np.float32))
+        st["point_mlp_scatter"] = _median3(lambda: os3.scatter_mean(xyz, os3.point_mlp(nsd, xyz, feat), SCENE_BOUNDS, (VOXEL,) * 3)) * n_labels
+        vol = os3.scatter_mean(xyz, os3.point_mlp(nsd, xyz, feat), SCENE_BOUNDS, (VOXEL,) * 3)
+        feats = [None]
+        def unet():
+            feats[0] = os3.unet_forward(nsd, vol, 6)
+        st["unet"] = _median3(unet) * n_labels
+        st["decoder"] = _median3(lambda: os3.decoder(nsd, feats[0], torch.from_numpy(q)[None], SCENE_BOUNDS, (VOXEL,) * 3, True), reps=1) * n_labels
+    scene_s = float(sum(st.values()))
+    return {"value": 1.0 / scene_s, "unit": "scenes/s", "cores": threads, "cpu_model": _cpu_model(), "kind": "port",
+            "sample": f"per stage, median of 3, scaled to one scene: {tiles_sample} of 2448 tile forwards + {tiles_sample} of 1224 tile "
+                      f"preprocessings ({arch}, {n_labels} labels, analytic rollout), 1 of 6 images' aggregation, full geometry / TSDF / frustum, "
+                      f"1 of {n_labels} label volumes through point MLP + scatter, the 128^3 UNet and the decoder; torch-CPU fp32 oracle",
+            "scene_seconds_estimate": scene_s, "stage_seconds_per_scene": {k: round(v, 3) for k, v in st.items()},
+            "reference_cpu_measured": "the unmodified reference's get_clip_saliency for this scene shape (6 images, 2448 forwards): 720 s on the 8 "
+                                      "cores of the build container (tests/golden/g16_headline_aug5.npz: seconds, cores)"}
+
+
+def parity_report(pipe, arch, precision):
+    """Outside the timed region, rank 0 / N = 1: the benchmarked kernels against the committed REFERENCE goldens (tests/golden/: outputs of the
+    unmodified reference run in the build container) - the headline relevancy maps on the benchmarked workload itself (6 images, 2 448 tile
+    forwards, one ViT batch), the 128^3 UNet of the voxel stage, and the bit-exact voxel indices."""
+    import hashlib
+    from semabs_amd.clip import ClipWrapper, saliency_configs
+    from semabs_amd.synth import SCENE_BOUNDS, synth_jitter, synth_rgb, synth_scene
+    gdir = os.path.join(ROOT, "tests", "golden")
+    out = {"source": "tests/golden g16 (get_clip_saliency 480x480 / 16 labels / ViT-B/16 'ours', 5 injected augmentations), g10 (ResidualUNet3D 128^3), "
+                     "g8 (get_pointcloud + VirtualGrid indices 480x480 / 128^3) - produced by the unmodified reference"}
+    if arch == "ViT-B/16":
+        g = np.load(os.path.join(gdir, "g16_headline_aug5.npz"))
+        img = synth_rgb(IMG, IMG, seed=0)
+        cfg = saliency_configs["ours"](IMG)
+        images = ClipWrapper.make_images(img, cfg["augmentations"], jittered_images=[synth_jitter(img, k) for k in range(cfg["augmentations"])])
+        maps = ClipWrapper.relevancy_device(images, torch.from_numpy(g["text"]).cuda().contiguous(), cfg["cropping_augmentations"],
+                                            cfg["horizontal_flipping"], cfg["positive_attn_only"]).cpu().numpy()
+        err = max(float(np.abs(maps[:, ::4, ::4] - g["sub"]).max()), float(np.abs(maps[:, g["rows_idx"], :] - g["rows"]).max()))
+        out["relevancy_map_abs_linf"] = err
+        out["relevancy_map_rel_linf"] = err / float(g["absmax"].max())
+    g = np.load(os.path.join(gdir, "g10_unet128.npz"))
+    rng = np.random.default_rng(int(g["meta"][0]))
+    x = np.zeros((1, 16, 128, 128, 128), np.float32)
+    occ = rng.random((128, 128, 128)) < 0.03
+    x[0][:, occ] = rng.standard_normal((16, int(occ.sum()))).astype(np.float32)
+    if VOXEL == 128 and int(g["meta"][1]) == 3:                     # the pipeline's UNet carries exactly the golden's weights (net seed 3)
+        y = pipe.net.vol_feature_extractor.forward(torch.from_numpy(x)).cpu().numpy()
+        out["unet128_feature_abs_linf"] = float(np.abs(y.reshape(-1)[g["si"]] - g["y_s"]).max())
+        out["unet128_feature_rel_linf"] = out["unet128_feature_abs_linf"] / float(np.abs(g["y_s"]).max())
+        out["unet_precision"] = precision
+    g = np.load(os.path.join(gdir, "g8_geometry.npz"))
+    from semabs_amd.point_cloud import pointcloud_device
+    sc = synth_scene(480, 480, seed=5)
+    xyz, _ = pointcloud_device(torch.from_numpy(sc["depth"]).cuda(), sc["cam_intr"], sc["cam_pose"], np.array(SCENE_BOUNDS))
+    flat = pipe.net.vg.flat_idxs(xyz).cpu().numpy().astype(np.int64)
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(flat).tobytes()).digest(), dtype=np.uint8)
+    out["voxel_indices_bit_exact"] = bool(VOXEL == 128 and np.array_equal(sha, g["480_flat_sha"]))
+    return out
 
 
 def main():
@@ -93,6 +180,7 @@ def main():
                     "(--chunk 220: 660 launches per scene) it costs 1.9 %% of scenes/s - every dispatch packet then carries a completion signal - "
                     "and 5 gives the same TFLOP/s figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (reference goldens, outside the timed region)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -170,13 +258,18 @@ def main():
     value = total_scenes / dt
     if rank == 0:
         ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12 if gs["total_ms"] > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "gemm_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM bytes per GEMM launch: PMC counters cannot be read from inside the process that is being timed (rocprofv3 owns them and
+        # serialises the kernels), so this figure is IMPORTED from the committed counter run of this same command and labelled as such
+        traffic, traffic_src = None, None
+        for name in ("r02_gemm_pmc.json", "gemm_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    traffic_src = f"imported from profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x 2 per the gfx950 correction), not measured in this run"
+                    break
+                except Exception:
+                    traffic = None
         out = {
             "metric": "scenes/sec (relevancy+3D-UNet infer), 480x480x16-label x128^3",
             "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,12 +281,19 @@ def main():
                        "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
             "roofline": {"kernel": "fp16 GEMM: k_gemm8 (large shapes) + k_gemm_f16 (small), all epilogues", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "launches": gs["launches"], "launches_in_timed_region": gs["seen"],
+                         "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"], "launches_in_timed_region": gs["seen"],
                          "sampling": ("every GEMM launch of the timed region carries start / stop events" if args.time_every == 1 else
                                       f"1 in {args.time_every} GEMM launches of the timed region (hashed launch index) carries start / stop events"),
                          "avg_launch_us": gs["total_ms"] * 1e3 / max(1, gs["launches"]),
                          "gemm_share_of_step": gs["total_ms"] * 1e-3 * gs["seen"] / max(1, gs["launches"]) / dt if world == 1 else None},
         }
+        out["timed_region"] = ("per scene, everything from the uint8 frame + fp32 depth resident in HBM to the label volume: colour jitter, tiling, "
+                               "ViT + rollout, aggregation, unprojection + compaction + sub-sample, point MLP, scatter, UNet, decoder, TSDF, frustum "
+                               "mask of the lattice (computed on the device per scene), post-mask.  NOT timed: the text tower (zero-shot weights of the "
+                               "16 labels are computed once per label set, like the reference's set_classes; synthetic unit-norm weights here - the BPE "
+                               "table is not on the GPU box) and the host->HBM upload of the frame (5 MB, 0.08 ms over PCIe Gen5)")
+        if world == 1 and not args.no_parity:
+            out["parity"] = parity_report(pipe, args.arch, args.precision)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, N_LABELS)
         print(json.dumps(out), flush=True)

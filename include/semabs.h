@@ -36,6 +36,8 @@ int semabs_device_info(char* name /*host*/, int name_len, int* cu_count /*host*/
  * xyz fp32 [H*W, 3] = float32(f64 math); mask uint8 [H*W] (NULL = skip) = inclusive AABB test of the fp32 point. */
 int semabs_pointcloud(const float* depth, int H, int W, const double* params, int has_pose, float* xyz,
                       unsigned char* mask, void* stream);
+/* same, returning the f64 points themselves (the reference's return dtype; point_cloud.py:51-66) */
+int semabs_pointcloud_f64(const float* depth, int H, int W, const double* params_dev, int has_pose, double* xyz64, void* stream);
 
 /* VirtualGrid.get_points_grid_idxs + flatten_idxs                    net.py:84-133
  * idx = clamp(trunc((p + off) * scale), 0, S-1) with two separately rounded fp32 ops (bit-exact integer output);

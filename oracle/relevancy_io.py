@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure, not product code) - CPU restatement of the relevancy storage format either side of the path:
 `generate_saliency_helper`'s post-processing (generate_relevancy.py:95-118) and the loader recipe (dataset.py:821-871, x 50 at :1053).
 The arithmetic is torch's own (`interpolate` nearest-exact / bilinear, mean, norm) - the same calls the reference makes.
-Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this.  Pinned by tests/golden/g14_relevancy_io.npz."""
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this.  Pinned by tests/golden/g19_relevancy_storage.npz (the reference's two functions executed from source)."""
 from __future__ import annotations
 
 import torch

@@ -22,6 +22,31 @@ def grid_points(scene_bounds, S):
     return (g * scales + lc).reshape(-1, 3).astype(np.float32)
 
 
+def sample_points(sampling_shape, scene_bounds):
+    """visualize.get_sample_points (:283-298): idx * ((uc - lc) / (shape - 1)) + lc in fp32, C order."""
+    lc = np.asarray(scene_bounds[0], np.float32)
+    uc = np.asarray(scene_bounds[1], np.float32)
+    scales = (uc - lc) / (np.asarray(sampling_shape, np.float32) - np.float32(1))
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in sampling_shape], indexing="ij"), axis=-1).astype(np.float32)
+    return (g * scales + lc).reshape(-1, 3).astype(np.float32)
+
+
+def ovssc_post_mask(logits: torch.Tensor, scene, scene_bounds, sampling_shape, cutoff=-3.0):
+    """The tail of visualize.process_batch_ovssc (:212-248): TSDF at the sampling resolution, arg-max over classes, "all below cutoff" /
+    out-of-frustum / tsdf > 0 masks -> fp32 {0, 1} volumes [C, *sampling_shape].  logits [C, prod(shape)].  Pinned by g18."""
+    H, W = scene["depth"].shape
+    lo, hi = np.asarray(scene_bounds[0], np.float64), np.asarray(scene_bounds[1], np.float64)
+    tv = og.TSDFVolume(np.stack([lo, hi], axis=1), (scene_bounds[1][0] - scene_bounds[0][0]) / sampling_shape[0])
+    tv.integrate(scene["rgb"], scene["depth"], scene["cam_intr"], scene["cam_pose"])
+    q = sample_points(sampling_shape, scene_bounds)
+    fr = og.check_pts_in_frustum(q.astype(np.float64), (H, W), scene["cam_pose"], scene["cam_intr"])
+    arg = logits.argmax(dim=0).numpy()
+    empty = (logits < cutoff).all(dim=0).numpy() | ~fr | (tv._tsdf_vol_cpu.reshape(-1) > 0)
+    C = logits.shape[0]
+    vols = np.stack([((arg == c) & ~empty) for c in range(C)]).astype(np.float32)
+    return vols.reshape(C, *sampling_shape)
+
+
 def run_scene(clip_sd, net_sd, scene, w_text, scene_bounds, S, num_input_pts, seed, cfg, images=None, subtract_mean=True,
               cutoff=-3.0, with_tsdf=True):
     """-> dict(relevancies [L,H,W] (x50, mean-subtracted), logits [L, S^3], labels [S^3], tsdf [S,S,S])."""

@@ -93,12 +93,17 @@ def decoder(sd, vol: torch.Tensor, query: torch.Tensor, scene_bounds, grid_shape
 
 
 def semabs3d_forward(sd, input_xyz_pts, input_feature_pts, output_xyz_pts, scene_bounds, grid_shape,
-                     num_levels: int = 6, groups: int = 8, concat_xyz: bool = True, taps: dict | None = None):
-    """input_xyz_pts [B, N, 3], input_feature_pts [B, P, N, F], output_xyz_pts [B, P, M, 3] -> [B, P, M]."""
+                     num_levels: int = 6, groups: int = 8, concat_xyz: bool = True, taps: dict | None = None, tsdf_vol=None):
+    """input_xyz_pts [B, N, 3], input_feature_pts [B, P, N, F], output_xyz_pts [B, P, M, 3] -> [B, P, M].
+    tsdf_vol [B, S, S, S] (network_inputs contains "tsdf", net.py:411-419): concatenated in front of the scattered point features - the
+    point MLP then has C - 1 outputs (net.py:365-367); repeated over the label volumes exactly like the reference's
+    `tsdf_vol.unsqueeze(1).repeat(num_patches, 1, 1, 1, 1)`."""
     B, P, N = input_feature_pts.shape[:3]
     xyz = input_xyz_pts.unsqueeze(1).repeat(1, P, 1, 1).view(B * P, N, 3)
     feat = point_mlp(sd, xyz, input_feature_pts.reshape(B * P, N, -1))
     vol = scatter_mean(xyz, feat, scene_bounds, grid_shape)
+    if tsdf_vol is not None:
+        vol = torch.cat((tsdf_vol.unsqueeze(1).repeat(P, 1, 1, 1, 1), vol), dim=1)
     if taps is not None:
         taps["scatter"] = vol
     vol = unet_forward(sd, vol, num_levels, groups, taps=taps)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "semabs_device_info": [C.c_char_p, I, C.POINTER(I), C.POINTER(C.c_longlong)],
     # geometry.hip
     "semabs_pointcloud": [P, I, I, P, I, P, P, P],
+    "semabs_pointcloud_f64": [P, I, I, P, I, P, P],
     "semabs_voxel_index": [P, L, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P],
     "semabs_tsdf_integrate": [P, P, I, I, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, P],
     "semabs_frustum_mask": [P, L, P, I, I, P, P],

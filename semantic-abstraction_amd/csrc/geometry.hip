@@ -15,7 +15,7 @@
 // inclusive AABB mask of the fp32 points against f64 bounds.
 // intr = {fx, fy, cx, cy}; pose = row-major 3x4 [R | t]; bounds = {lo[3], hi[3]} (may be null with mask).
 __global__ void k_pointcloud(const float* __restrict__ depth, int H, int W, const double* __restrict__ prm,
-                             int has_pose, float* __restrict__ xyz, unsigned char* __restrict__ mask) {
+                             int has_pose, float* __restrict__ xyz, unsigned char* __restrict__ mask, double* __restrict__ xyz64) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)H * W) return;
     const double fx = prm[0], fy = prm[1], cx = prm[2], cy = prm[3];
@@ -32,8 +32,9 @@ __global__ void k_pointcloud(const float* __restrict__ depth, int H, int W, cons
         double wz = fma(P[10], z, fma(P[9], y, P[8] * x)) + P[11];
         x = wx; y = wy; z = wz;
     }
+    if (xyz64) { xyz64[i * 3 + 0] = x; xyz64[i * 3 + 1] = y; xyz64[i * 3 + 2] = z; }     // the reference's own return type (point_cloud.py:51-66)
     float fx32 = (float)x, fy32 = (float)y, fz32 = (float)z;
-    xyz[i * 3 + 0] = fx32; xyz[i * 3 + 1] = fy32; xyz[i * 3 + 2] = fz32;
+    if (xyz) { xyz[i * 3 + 0] = fx32; xyz[i * 3 + 1] = fy32; xyz[i * 3 + 2] = fz32; }
     if (mask) {
         const double* B = prm + 16;
         bool m = (double)fx32 >= B[0] && (double)fx32 <= B[3] && (double)fy32 >= B[1] && (double)fy32 <= B[4] &&
@@ -47,7 +48,18 @@ extern "C" int semabs_pointcloud(const float* depth, int H, int W, const double*
     SEMABS_REQUIRE(depth && params_dev && xyz && H > 0 && W > 0, "semabs_pointcloud: bad args");
     long n = (long)H * W;
     hipLaunchKernelGGL(k_pointcloud, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, depth, H, W,
-                       params_dev, has_pose, xyz, mask);
+                       params_dev, has_pose, xyz, mask, (double*)nullptr);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// The same unprojection returning the f64 points themselves - `get_pointcloud`'s return type in the reference (its on-path caller casts to
+// fp32 at once, visualize.py:103-105, which is what semabs_pointcloud hands out; other callers get the full-precision values here).
+extern "C" int semabs_pointcloud_f64(const float* depth, int H, int W, const double* params_dev, int has_pose, double* xyz64, void* stream) {
+    SEMABS_REQUIRE(depth && params_dev && xyz64 && H > 0 && W > 0, "semabs_pointcloud_f64: bad args");
+    long n = (long)H * W;
+    hipLaunchKernelGGL(k_pointcloud, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, depth, H, W,
+                       params_dev, has_pose, (float*)nullptr, (unsigned char*)nullptr, xyz64);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -87,7 +87,12 @@ def allreduce_flat_gradients(flat: torch.Tensor, n_flags: int = 0) -> Tuple[floa
     tensor "used on any rank" or None when n_flags == 0).  World size 1 / no process group: nothing is sent."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world > 1:
-        dist.all_reduce(flat)
+        if flat.is_cuda and dist.get_backend() == "gloo":              # gloo (CPU / single-GPU tests): stage through the host; RCCL reduces in place
+            host = flat.detach().cpu()
+            dist.all_reduce(host)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat)
     flags = None
     if n_flags:
         flags = flat[flat.numel() - n_flags:].detach().cpu() > 0

@@ -58,9 +58,14 @@ class VirtualGrid:
         return flat.unsqueeze(-1) if keepdim else flat
 
 
-class SemAbs3D:
+class SemAbs3D(torch.nn.Module):
     """Drop-in (inference) for `net.SemAbs3D` (net.py:319-439): point MLP -> scatter-MEAN into the voxel grid ->
     ResidualUNet3D -> trilinear implicit decoder, all on HIP kernels, channels-last in between.
+
+    A real `torch.nn.Module`: parameters / the `steps` buffer live under the reference's state-dict keys, so the reference's caller
+    works unchanged - `net_class(**kwargs).to(device)`, `get_n_params`, `Lamb(net.parameters())`, `DistributedDataParallel(module=net)`,
+    `net.load_state_dict(ckpt["net"])`, `net.eval()` (utils.py:225-296).  `forward` is inference-only (no autograd graph; training runs
+    through `semabs_amd.train`).
 
     Quirks kept on purpose: the grid is built without a reduce method so points are reduced with MEAN although the
     constructor asserts "max" (net.py:339-344, 369, 185-199); the decoder divides by S (not S - 1) and feeds point-x
@@ -70,63 +75,84 @@ class SemAbs3D:
     def __init__(self, voxel_shape, scene_bounds, unet_num_channels, unet_f_maps, unet_num_groups, unet_num_levels,
                  network_inputs: List[str], use_pts_feat_extractor: bool, pts_feat_extractor_hidden_dim: int,
                  reduce_method: str, output_dim=1, device: str = "cuda", decoder_concat_xyz_pts: bool = False,
-                 precision: str = "fp16", **kwargs):
+                 precision: str = "exact", **kwargs):
+        super().__init__()
+        from .module import register_tree
         from .unet3d import ResidualUNet3D
+        from .weights import make_semabs3d_state_dict
         self.device = device
         self.vg = VirtualGrid(scene_bounds=np.array(scene_bounds), batch_size=kwargs.get("batch_size", 1),
                               grid_shape=tuple(voxel_shape), device=torch.device(device) if isinstance(device, str) else device)
-        self.steps = torch.zeros(1)
         self.network_inputs = list(network_inputs)
         self.use_pts_feat_extractor = use_pts_feat_extractor
         self.reduce_method = reduce_method
         self.pts_feature_dim = (("saliency" in self.network_inputs) + ("rgb" in self.network_inputs) * 3
                                 + ("patch_masks" in self.network_inputs))
-        if not (use_pts_feat_extractor and self.pts_feature_dim == 1 and "tsdf" not in self.network_inputs and output_dim == 1):
-            raise NotImplementedError("the HIP path covers the released OVSSC configuration: network_inputs=['saliency'], "
-                                      "use_pts_feat_extractor=True, output_dim=1")
+        self.with_tsdf = "tsdf" in self.network_inputs
+        if not (use_pts_feat_extractor and self.pts_feature_dim == 1 and output_dim == 1):
+            raise NotImplementedError("the HIP path covers network_inputs = ['saliency'] or ['saliency', 'tsdf'] with "
+                                      "use_pts_feat_extractor=True, output_dim=1 (the released OVSSC / VOOL configurations)")
         assert self.reduce_method == "max"          # asserted by the reference too (and then ignored)
         self.hidden = pts_feat_extractor_hidden_dim
         self.C = unet_num_channels
         self.concat_xyz = bool(decoder_concat_xyz_pts)
-        self.precision = precision
+        self.precision = precision                   # "exact" by default: the reference's fp32 results; "fp16" = opt-in fast mode
         self.vol_feature_extractor = ResidualUNet3D(in_channels=unet_num_channels, out_channels=unet_num_channels,
                                                     f_maps=unet_f_maps, num_groups=unet_num_groups,
                                                     num_levels=unet_num_levels, precision=precision)
-        self._sd = {}
-        self._w = None
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        init = make_semabs3d_state_dict(seed=seed, unet_num_channels=unet_num_channels, unet_f_maps=unet_f_maps, unet_num_groups=unet_num_groups,
+                                        unet_num_levels=unet_num_levels, pts_feat_extractor_hidden_dim=pts_feat_extractor_hidden_dim,
+                                        decoder_concat_xyz_pts=decoder_concat_xyz_pts)
+        if self.with_tsdf:                          # the point MLP leaves one UNet input channel to the TSDF volume (net.py:365-367)
+            init["pts_feat_extractor.4.weight"] = init["pts_feat_extractor.4.weight"][: unet_num_channels - 1].clone()
+            init["pts_feat_extractor.4.bias"] = init["pts_feat_extractor.4.bias"][: unet_num_channels - 1].clone()
+        register_tree(self, {k: v for k, v in init.items() if not k.startswith("vol_feature_extractor.")}, buffers=("steps",))
+        self._w = self._dec = self._final = None
+        self._sig = None
         self.features_cl = None
 
     # ---- weights -----------------------------------------------------------------------------------
-    def load_state_dict(self, sd, strict: bool = True):
-        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}     # DDP checkpoints
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        from .module import strip_module_prefix
+        return super().load_state_dict(strip_module_prefix(state_dict), strict=strict, **kw)
+
+    def _sync(self):
+        """(Re)derive the kernels' operand layouts when a parameter changed (see module.py)."""
         dev = _lib.require_gpu()
+        if any(p.device.type != "cuda" for p in self.parameters()):
+            self.to(dev)                                # there is no CPU path: a module left on the host is moved to the HIP device on first use
+        own = [t for n, t in list(self.named_parameters()) + list(self.named_buffers()) if not n.startswith("vol_feature_extractor.")]
+        sig = tuple((t.data_ptr(), t._version) for t in own)
+        if sig == self._sig:
+            return
+        sd = {k: v.detach() for k, v in self.state_dict().items() if not k.startswith("vol_feature_extractor.")}
         f = lambda k: sd[k].float().to(dev).contiguous()
         self._w = {k: f(f"pts_feat_extractor.{i}.{n}") for k, (i, n) in
                    dict(w1=(0, "weight"), b1=(0, "bias"), w2=(2, "weight"), b2=(2, "bias"), w3=(4, "weight"), b3=(4, "bias")).items()}
+        if self.with_tsdf:
+            # 15 output channels: run the 16-channel kernel with a zero row in front - channel 0 of the scattered volume then stays 0 and
+            # receives the TSDF (torch.cat((tsdf, features), dim=1), net.py:411-419)
+            self._w["w3"] = torch.cat([torch.zeros(1, self.hidden, device=dev), self._w["w3"]], dim=0).contiguous()
+            self._w["b3"] = torch.cat([torch.zeros(1, device=dev), self._w["b3"]], dim=0).contiguous()
         self._dec = {k: np.ascontiguousarray(sd[f"visual_sampler.mlp.{i}.{n}"].float().cpu().numpy().reshape(-1)) for k, (i, n) in
                      dict(w1=(0, "weight"), b1=(0, "bias"), w2=(2, "weight"), b2=(2, "bias")).items()}
-        self.vol_feature_extractor.load_state_dict(sd, strict=strict, prefix="vol_feature_extractor.")
-        self._final = (np.ascontiguousarray(sd["vol_feature_extractor.final_conv.weight"].float().cpu().numpy().reshape(-1)),
-                       np.ascontiguousarray(sd["vol_feature_extractor.final_conv.bias"].float().cpu().numpy().reshape(-1)))
-        if "steps" in sd:
-            self.steps = sd["steps"].clone()
-        self._sd = {k: v.detach().clone() for k, v in sd.items()}
-        return self
+        self._sig = sig
 
-    def state_dict(self):
-        return dict(self._sd)
-
-    def eval(self):
-        return self
-
-    def to(self, *a, **k):
-        return self
+    def _final_conv(self):
+        u = self.vol_feature_extractor
+        return (np.ascontiguousarray(u.final_conv.weight.detach().float().cpu().numpy().reshape(-1)),
+                np.ascontiguousarray(u.final_conv.bias.detach().float().cpu().numpy().reshape(-1)))
 
     # ---- stages ------------------------------------------------------------------------------------
-    def feature_volume(self, xyz: torch.Tensor, feat: torch.Tensor, taps: dict | None = None, skip_final: bool = False) -> torch.Tensor:
+    @torch.no_grad()
+    def feature_volume(self, xyz: torch.Tensor, feat: torch.Tensor, taps: dict | None = None, skip_final: bool = False,
+                       tsdf_vol: torch.Tensor | None = None) -> torch.Tensor:
         """xyz fp32 [N, 3], feat fp32 [P, N] (one scene, P label volumes) -> UNet features channels-last [P, S, S, S, C].
-        skip_final: stop in front of the UNet's final 1x1x1 convolution (see `decode(pre_final=True)`)."""
+        skip_final: stop in front of the UNet's final 1x1x1 convolution (see `decode(pre_final=True)`).
+        tsdf_vol fp32 [S, S, S] (required iff "tsdf" is a network input): becomes input channel 0 of every label volume (net.py:411-419)."""
         dev = _lib.require_gpu()
+        self._sync()
         P, N = int(feat.shape[0]), int(feat.shape[1])
         S0, S1, S2 = self.vg.grid_shape
         nvox = S0 * S1 * S2
@@ -138,11 +164,20 @@ class SemAbs3D:
                   _lib.ptr(w["w2"]), _lib.ptr(w["b2"]), _lib.ptr(w["w3"]), _lib.ptr(w["b3"]), _lib.ptr(pf), P, N, self.hidden, self.C, st)
         flat = self.vg.flat_idxs(xyz)
         unet = self.vol_feature_extractor
+        unet._sync()
         vol = torch.zeros(P, S0, S1, S2, self.C, dtype=unet.act_dtype, device=dev)
         head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
         nxt = torch.empty(N, dtype=torch.int32, device=dev)
         sums = None
-        if self.C == 16 and unet.in_channels == 16 and unet.enc[0][0].groups == 8:     # statistics for the first GroupNorm come out of the scatter
+        if self.with_tsdf:
+            if tsdf_vol is None:
+                raise ValueError("network_inputs contains 'tsdf': pass tsdf_vol")
+            _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
+                      unet.f32, st)
+            # channel 0 (kept zero by the padded point MLP) <- the TSDF: a strided copy, no arithmetic; GroupNorm statistics then come from the
+            # generic pass over the (now dense) volume, not from the occupied-voxel shortcut of the scatter kernel
+            vol[..., 0] = tsdf_vol.to(dev, unet.act_dtype).reshape(1, S0, S1, S2)
+        elif self.C == 16 and unet.in_channels == 16 and unet.enc[0][0].groups == 8:     # statistics for the first GroupNorm come out of the scatter
             sums = torch.zeros(P, 8, 2, dtype=torch.float64, device=dev)
             _lib.call("semabs_scatter_mean_stats", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
                       unet.f32, _lib.ptr(sums), st)
@@ -154,38 +189,43 @@ class SemAbs3D:
             taps["point_feat"] = pf
         return unet.forward_cl(vol, taps=taps, skip_final=skip_final, in_sums=sums)
 
+    @torch.no_grad()
     def decode(self, features_cl: torch.Tensor, query: torch.Tensor, shared: bool = False, lattice=None, pre_final: bool = False) -> torch.Tensor:
         """features [P, S, S, S, C]; query fp32 [P, M, 3] (or [M, 3] with shared=True) -> logits fp32 [P, M].
         lattice=(G0, G1, G2): the M queries are a dense C-order lattice (e.g. `VirtualGrid.get_grid_points`): same results, faster walk.
         pre_final: `features_cl` is `feature_volume(..., skip_final=True)`, i.e. the activation in front of the UNet's final 1x1x1
         convolution; that (linear) layer is applied to the sampled features inside the decoder kernel instead."""
         dev = _lib.require_gpu()
+        self._sync()
         P = int(features_cl.shape[0])
         M = int(query.shape[-2])
         out = torch.empty(P, M, dtype=torch.float32, device=dev)
         d = self._dec
+        final = self._final_conv() if pre_final else None
         fp = lambda a: a.ctypes.data
         query = query.contiguous()
         _lib.call("semabs_decoder", _lib.ptr(features_cl), _lib.ptr(query), _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales),
                   _lib.iarr(self.vg.grid_shape), fp(d["w1"]), fp(d["b1"]), fp(d["w2"]), fp(d["b2"]), int(self.concat_xyz), P, M,
                   0 if shared else M * 3, self.vol_feature_extractor.f32, _lib.ptr(out), None if lattice is None else _lib.iarr(lattice),
-                  fp(self._final[0]) if pre_final else None, fp(self._final[1]) if pre_final else None, _lib.stream())
+                  fp(final[0]) if pre_final else None, fp(final[1]) if pre_final else None, _lib.stream())
         return out
 
     # ---- reference surface ---------------------------------------------------------------------------
+    @torch.no_grad()
     def forward(self, input_xyz_pts, input_feature_pts, tsdf_vol, output_xyz_pts, **kwargs):
+        """input_xyz_pts [B, N, 3], input_feature_pts [B, P, N, 1], tsdf_vol [B, S, S, S] (used iff "tsdf" is a network input),
+        output_xyz_pts [B, P, M, 3] -> logits [B, P, M]   (net.py:383-439)."""
         dev = _lib.require_gpu()
         B, P, N = input_feature_pts.shape[:3]
         M = output_xyz_pts.shape[2]
         outs, feats = [], []
         for b in range(B):
-            f = self.feature_volume(input_xyz_pts[b].to(dev, torch.float32), input_feature_pts[b].to(dev, torch.float32).reshape(P, N))
+            f = self.feature_volume(input_xyz_pts[b].to(dev, torch.float32), input_feature_pts[b].to(dev, torch.float32).reshape(P, N),
+                                    tsdf_vol=tsdf_vol[b] if (self.with_tsdf and tsdf_vol is not None) else None)
             feats.append(f)
             outs.append(self.decode(f, output_xyz_pts[b].to(dev, torch.float32)))
         self.features_cl = torch.cat(feats, dim=0)
         return torch.stack(outs, dim=0).view(B, P, M)
-
-    __call__ = forward
 
     @property
     def visual_volumetric_features(self):
@@ -193,44 +233,57 @@ class SemAbs3D:
         return None if self.features_cl is None else self.features_cl.permute(0, 4, 1, 2, 3).float()
 
 
-class SemAbsVOOL:
+class SemAbsVOOL(torch.nn.Module):
     """Drop-in (inference) for `net.SemAbsVOOL` (net.py:469-579) with `pointing_method="cosine_sim"` (the default,
     utils.py:87-91): two SemAbs3D feature volumes (target / reference saliency), the 35 -> 32 -> 64 spatial sampler and the
-    cosine-similarity pointer against the relation embedding, fused in one HIP kernel (`semabs_vool_head`)."""
+    cosine-similarity pointer against the relation embedding, fused in one HIP kernel (`semabs_vool_head`).
+    A real nn.Module with the reference's keys: `completion_net.*`, `spatial_sampler.mlp.{0,2}.*`, `relation_embeddings.<name>`, `steps`."""
 
     RELATIONS = ["in", "behind", "in front of", "on the left of", "on the right of", "on", "[pad]"]
 
     def __init__(self, pointing_method: str, pointing_dim: int, device: str, decoder_concat_xyz_pts: bool, **kwargs):
+        super().__init__()
         if pointing_method != "cosine_sim" or pointing_dim != 64 or not decoder_concat_xyz_pts:
             raise NotImplementedError("the HIP VOOL head covers pointing_method='cosine_sim', pointing_dim=64, decoder_concat_xyz_pts=True")
+        from .module import register_tree
+        from .weights import make_semabsvool_state_dict
         self.device = device
-        self.steps = torch.zeros(1)
         self.completion_net = SemAbs3D(device=device, **kwargs)       # like the reference: built without the xyz concat
         self.pointing_temperature = 0.07
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        init = make_semabsvool_state_dict(seed=seed, pointing_dim=pointing_dim, unet_num_channels=kwargs["unet_num_channels"],
+                                          unet_f_maps=kwargs["unet_f_maps"], unet_num_groups=kwargs["unet_num_groups"],
+                                          unet_num_levels=kwargs["unet_num_levels"],
+                                          pts_feat_extractor_hidden_dim=kwargs["pts_feat_extractor_hidden_dim"])
+        register_tree(self, {k: v for k, v in init.items() if not k.startswith("completion_net.")}, buffers=("steps",))
         self._prm = None
         self._rel = {}
-        self._sd = {}
+        self._sig = None
 
-    def load_state_dict(self, sd, strict: bool = True):
-        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        from .module import strip_module_prefix
+        return super().load_state_dict(strip_module_prefix(state_dict), strict=strict, **kw)
+
+    def _sync(self):
         dev = _lib.require_gpu()
-        self.completion_net.load_state_dict({k[len("completion_net."):]: v for k, v in sd.items() if k.startswith("completion_net.")}, strict)
+        if any(p.device.type != "cuda" for p in self.parameters()):
+            self.to(dev)
+        own = [t for n, t in self.named_parameters() if not n.startswith("completion_net.")]
+        sig = tuple((t.data_ptr(), t._version) for t in own)
+        if sig == self._sig:
+            return
+        sd = {k: v.detach() for k, v in self.state_dict().items() if not k.startswith("completion_net.")}
         flat = [sd[f"spatial_sampler.mlp.{i}.{n}"].float().reshape(-1) for i, n in ((0, "weight"), (0, "bias"), (2, "weight"), (2, "bias"))]
         assert [t.numel() for t in flat] == [32 * 35, 32, 64 * 32, 64], "spatial sampler must be 35 -> 32 -> 64"
         self._prm = torch.cat(flat).to(dev).contiguous()
         self._rel = {k: sd["relation_embeddings." + k].float().to(dev) for k in self.RELATIONS}
-        self._sd = {k: v.detach().clone() for k, v in sd.items()}
-        return self
+        self._sig = sig
 
-    def state_dict(self):
-        return dict(self._sd)
-
-    def eval(self):
-        return self
-
+    @torch.no_grad()
     def forward(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts,
                 tsdf_vol=None, **kwargs):
         dev = _lib.require_gpu()
+        self._sync()
         net = self.completion_net
         batch_size, num_descs = np.array(spatial_relation_name).T.shape
         M = int(output_xyz_pts.shape[-2])
@@ -248,5 +301,3 @@ class SemAbsVOOL:
                       net.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
             outs.append(out)
         return torch.stack(outs, dim=0).view(batch_size, num_descs, M)
-
-    __call__ = forward

@@ -25,15 +25,30 @@ class Lamb(Optimizer):
         self._plan = None
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def load_state_dict(self, state_dict):
+        """`utils.py:289`'s resume path: the loaded moment tensors replace the ones the cached launch plan points at."""
+        super().load_state_dict(state_dict)
+        self._plan = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plan = None
+
     def _build_plan(self, ps, dev):
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        for p in ps:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p.data)
+                st["exp_avg_sq"] = torch.zeros_like(p.data)
+            for k in ("exp_avg", "exp_avg_sq"):                 # moments restored from a CPU checkpoint / another device / non-contiguous
+                m = st[k]
+                if m.device != p.device or m.dtype != torch.float32 or not m.is_contiguous():
+                    st[k] = m.to(p.device, torch.float32).contiguous()
+        # the plan holds raw device pointers: parameters, gradients AND both moment tensors are part of its identity
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel())
+                    for p in ps)
         if self._plan is None or self._plan["key"] != key:
-            for p in ps:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p.data)
-                    st["exp_avg_sq"] = torch.zeros_like(p.data)
             rows = []
             for t, p in enumerate(ps):
                 for off in range(0, p.numel(), _CHUNK):

@@ -1,7 +1,7 @@
 """Drop-in for the on-path functions of the reference's `point_cloud.py` (numpy in / numpy out), computed
 by HIP kernels (csrc/geometry.hip):
 
-  get_pointcloud        point_cloud.py:34-66   (f64 math on device; returned as f64 like the reference)
+  get_pointcloud        point_cloud.py:34-66   (f64 math on device, f64 results returned like the reference)
   filter_pts_bounds     point_cloud.py:24-31
   check_pts_in_frustum  point_cloud.py:88-110
 
@@ -42,12 +42,15 @@ def pointcloud_device(depth: torch.Tensor, cam_intr, cam_pose, bounds=None):
 
 
 def get_pointcloud(depth_img, color_img, cam_intr, cam_pose=None):
+    """-> (f64 [H*W, 3], colour points): the reference's return types (point_cloud.py:51-66); the f64 values are the kernel's own f64
+    results, not widened fp32."""
     dev = _lib.require_gpu()
     d = torch.from_numpy(np.ascontiguousarray(depth_img, dtype=np.float32)).to(dev)
-    xyz, _ = pointcloud_device(d, cam_intr, cam_pose)
-    # the reference returns f64; its only on-path consumer casts to f32 at once (visualize.py:103-105), which is
-    # what the kernel already did, so the f64 array below holds exactly those f32 values
-    cam_pts = xyz.cpu().numpy().astype(np.float64)
+    H, W = d.shape
+    xyz = torch.empty(H * W, 3, dtype=torch.float64, device=dev)
+    prm = _params(cam_intr, cam_pose, None, dev)
+    _lib.call("semabs_pointcloud_f64", _lib.ptr(d), H, W, _lib.ptr(prm), int(cam_pose is not None), _lib.ptr(xyz), _lib.stream())
+    cam_pts = xyz.cpu().numpy()
     color_pts = None if color_img is None else color_img.reshape(-1, 3)
     return cam_pts, color_pts
 
@@ -61,14 +64,20 @@ def filter_pts_bounds(xyz, bounds):
     return m
 
 
+def frustum_mask_device(pts64: torch.Tensor, h: int, w: int, cam_pose, cam_intr) -> torch.Tensor:
+    """pts64 f64 [M, 3] on the GPU -> uint8 [M] on the GPU (point_cloud.py:88-110); only the 16 pose / intrinsics doubles cross PCIe."""
+    dev = _lib.require_gpu()
+    T = np.linalg.inv(np.asarray(cam_pose, np.float64))
+    K = np.asarray(cam_intr, np.float64)
+    prm = torch.from_numpy(np.concatenate([T[:3, :4].reshape(-1), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]])).to(dev)
+    pts64 = pts64.contiguous()
+    mask = torch.empty(len(pts64), dtype=torch.uint8, device=dev)
+    _lib.call("semabs_frustum_mask", _lib.ptr(pts64), len(pts64), _lib.ptr(prm), int(h), int(w), _lib.ptr(mask), _lib.stream())
+    return mask
+
+
 def check_pts_in_frustum(xyz_pts, depth, cam_pose, cam_intr):
     dev = _lib.require_gpu()
     pts = torch.from_numpy(np.ascontiguousarray(xyz_pts, dtype=np.float64)).to(dev)
-    T = np.linalg.inv(np.asarray(cam_pose, np.float64))
-    K = np.asarray(cam_intr, np.float64)
-    prm = np.concatenate([T[:3, :4].reshape(-1), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]])
-    prm = torch.from_numpy(prm).to(dev)
     h, w = depth.shape
-    mask = torch.empty(len(pts), dtype=torch.uint8, device=dev)
-    _lib.call("semabs_frustum_mask", _lib.ptr(pts), len(pts), _lib.ptr(prm), h, w, _lib.ptr(mask), _lib.stream())
-    return mask.cpu().numpy().astype(bool)
+    return frustum_mask_device(pts, h, w, cam_pose, cam_intr).cpu().numpy().astype(bool)

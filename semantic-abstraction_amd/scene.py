@@ -26,7 +26,7 @@ from . import dist as sdist
 from .clip import ClipWrapper, plan_tiles, saliency_configs
 from .fusion import TSDFVolume
 from .net import SemAbs3D
-from .point_cloud import check_pts_in_frustum, pointcloud_device
+from .point_cloud import frustum_mask_device, pointcloud_device
 from .synth import SCENE_BOUNDS
 
 DEFAULT_NET_KWARGS = dict(voxel_shape=(128, 128, 128), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16,
@@ -37,7 +37,7 @@ DEFAULT_NET_KWARGS = dict(voxel_shape=(128, 128, 128), scene_bounds=SCENE_BOUNDS
 
 @dataclass
 class SceneResult:
-    relevancies: torch.Tensor          # fp32 [L, H, W]   (x 50, mean-subtracted when subtract_mean)
+    relevancies: torch.Tensor          # fp32 [L, H, W]   RAW get_clip_saliency maps (NOT x 50, NOT mean-subtracted: that is applied inside the point-feature gather)
     logits: torch.Tensor               # fp32 [L, S^3]    decoder outputs at the voxel centres
     labels: Optional[torch.Tensor]     # int32 [S^3]      argmax with the cutoff / frustum / tsdf mask, -1 = empty
     tsdf: Optional[torch.Tensor]       # fp32 [S, S, S]
@@ -63,7 +63,7 @@ class ScenePipeline:
         g = np.stack(np.meshgrid(np.arange(S0), np.arange(S1), np.arange(S2), indexing="ij"), axis=-1).astype(np.float32)
         self.grid_points_np = (g * scales + lc).reshape(-1, 3).astype(np.float32)
         self.grid_points = torch.from_numpy(self.grid_points_np).to(self.dev)
-        self._frustum_cache = {}
+        self._grid_points64 = None
 
     def upload(self, scene: dict) -> dict:
         """Host -> HBM once, outside the timed region."""
@@ -175,20 +175,24 @@ class ScenePipeline:
             rgb_dev = scene.get("rgb_dev")
             tv.integrate(rgb_dev if rgb_dev is not None else scene["rgb"], depth_dev, scene["cam_intr"], scene["cam_pose"])
             tsdf = tv._tsdf_vol
+            if tuple(int(d) for d in tv._vol_dim) != tuple(net.vg.grid_shape):
+                # ceil((hi - lo) / voxel_size) can come out as S + 1 for extents that are not exactly representable / not cubic; the label kernel
+                # indexes the TSDF with the logits' strides, so a mismatch must not pass silently (the reference fails on the shape mismatch)
+                raise RuntimeError(f"TSDF volume {tuple(tv._vol_dim)} does not match the voxel grid {tuple(net.vg.grid_shape)}")
             fr = self._frustum(scene, H, W)
             labels = torch.empty(logits.shape[1], dtype=torch.int32, device=dev)
             tsdf_flat = tsdf.reshape(-1)
             _lib.call("semabs_ovssc_labels", _lib.ptr(logits), _lib.ptr(fr), _lib.ptr(tsdf_flat), L, int(logits.shape[1]), float(self.cutoff),
                       _lib.ptr(labels), st)
-        # relevancies as prep_data returns them (x 50, mean-subtracted)
+        # `relevancies` = the raw relevancy maps; prep_data's x 50 / mean subtraction (visualize.py:100-112) lives in semabs_gather_point_features
         return SceneResult(relevancies=maps, logits=logits, labels=labels, tsdf=tsdf, n_in_bounds=n_in)
 
     def _frustum(self, scene, H, W):
-        key = (H, W, np.asarray(scene["cam_pose"]).tobytes(), np.asarray(scene["cam_intr"]).tobytes())
-        if key not in self._frustum_cache:
-            m = check_pts_in_frustum(self.grid_points_np.astype(np.float64), np.zeros((H, W), np.float32), scene["cam_pose"], scene["cam_intr"])
-            self._frustum_cache = {key: torch.from_numpy(m.astype(np.uint8)).to(self.dev)}
-        return self._frustum_cache[key]
+        """In-frustum mask of the voxel-centre lattice for THIS scene's pose, computed on the device inside the step (no host round trip, no
+        per-pose cache: every scene pays for it, like in the reference's process_batch_ovssc)."""
+        if self._grid_points64 is None:
+            self._grid_points64 = self.grid_points.double()          # the reference hands fp32 lattice points to an f64 routine (visualize.py:231-236)
+        return frustum_mask_device(self._grid_points64, H, W, scene["cam_pose"], scene["cam_intr"])
 
 
 def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 2448,

@@ -70,3 +70,18 @@ def synth_jitter(img: np.ndarray, k: int) -> np.ndarray:
     x = img.astype(np.float64) / 255.0
     x = np.clip(x, 0, 1) ** gamma * gain[None, None, :] + off / 255.0
     return np.clip(np.round(x * 255.0), 0, 255).astype(np.uint8)
+
+
+def synth_ovssc_logits(points, n_classes: int):
+    """Closed-form stand-in for the network inside `process_batch_ovssc` (parity fixture g18): fp32 multiply / add only (IEEE-exact, identical
+    on any host or device), values straddling the -3 cutoff with changing arg-max regions.  points torch fp32 [M, 3] -> [n_classes, M]."""
+    import torch
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    out = []
+    for c in range(n_classes):
+        a, b, d = 1.0 + 0.5 * c, 0.75 - 0.25 * c, 0.5 + 0.125 * c
+        q = x * a + y * b
+        q = q + z * d
+        q = q + (0.25 * c - 0.5)
+        out.append(q * q * (-2.0) + (0.5 - 0.375 * c) + x * (c - 1.5))
+    return torch.stack(out, dim=0)

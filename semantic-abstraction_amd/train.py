@@ -501,7 +501,24 @@ class VOOLTrainer:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         sd = {k: v.detach().clone() for k, v in self.params.items()}
         sd.update({k: v.clone() for k, v in self.extra.items()})
-        for k in sd:
-            if k.endswith("steps"):
-                sd[k] = sd[k] + self.steps
+        if "steps" in sd:                                    # only the top-level counter advances (utils.py:417 `net.steps += 1`); completion_net.steps stays
+            sd["steps"] = sd["steps"] + self.steps
         return sd
+
+    def checkpoint(self, epoch: int = 0) -> dict:
+        """The reference's checkpoint dict (utils.py:278-296): {"net": state_dict, "optimizer": Lamb.state_dict(), "epochs": int}."""
+        return {"net": self.state_dict(), "optimizer": self.opt.state_dict(), "epochs": int(epoch)}
+
+    def load_checkpoint(self, ckpt: dict) -> int:
+        """Restore parameters (in place: the kernels' launch plans keep pointing at the same tensors), the step counter and the optimizer
+        moments; returns the stored epoch.  Accepts DDP-saved nets ("module." prefix, utils.py:283-287)."""
+        net = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt["net"].items()}
+        with torch.no_grad():
+            for k, p in self.params.items():
+                p.copy_(net[k].to(p.device, p.dtype))
+        base = float(self.extra["steps"].item()) if "steps" in self.extra else 0.0
+        self.steps = int(round(float(net["steps"].item()) - base)) if "steps" in net else 0
+        if ckpt.get("optimizer") is not None:
+            self.opt.load_state_dict(ckpt["optimizer"])
+        self.unet.refresh()
+        return int(ckpt.get("epochs", 0))

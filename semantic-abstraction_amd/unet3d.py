@@ -39,7 +39,7 @@ class _Conv:
         w = weight.float().permute(0, 2, 3, 4, 1).reshape(cout, k * k * k * cin)
         kp = (w.shape[1] + 31) // 32 * 32
         if kp != w.shape[1]:
-            w = torch.cat([w, torch.zeros(cout, kp - w.shape[1])], dim=1)
+            w = torch.cat([w, torch.zeros(cout, kp - w.shape[1], device=w.device)], dim=1)
         self.w_hi, self.w_lo = _split16(w.contiguous(), dev)
         self.cin, self.cout, self.k = cin, cout, k
         self.gn_w = None if gn_w is None else gn_w.float().to(dev).contiguous()
@@ -74,23 +74,36 @@ class _ConvT:
         self.cin, self.cout = cin, cout
 
 
-class ResidualUNet3D:
+class ResidualUNet3D(torch.nn.Module):
+    """nn.Module surface of the reference (`parameters()`, `state_dict()` / `load_state_dict()`, `.to()`, `train()` / `eval()`); the forward pass
+    is inference-only (no autograd graph) and runs on the HIP kernels with operands derived from the parameters (see module.py)."""
+
     def __init__(self, in_channels, out_channels, f_maps=64, num_groups=8, num_levels=5, final_sigmoid=False,
-                 layer_order="gcr", is_segmentation=False, precision: str = "fp16", **kwargs):
+                 layer_order="gcr", is_segmentation=False, precision: str = "exact", **kwargs):
+        super().__init__()
         assert layer_order == "gcr" and not is_segmentation, "the path uses order 'gcr' without a final activation"
         assert precision in ("fp16", "exact")
         if isinstance(f_maps, int):
             f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
         self.f_maps = list(f_maps)
         self.in_channels, self.out_channels, self.num_groups = in_channels, out_channels, num_groups
+        # "exact" (fp32 activations, split-fp16 MFMA operands: the reference's fp32 results to ~1e-5) is the default of the reference-surface
+        # classes; "fp16" is the opt-in fast mode (activations rounded to fp16: 3.6e-3 on the voxel logits, measured)
         self.precision = precision
         self.f32 = int(precision == "exact")
         self.act_dtype = torch.float32 if self.f32 else torch.float16
-        self._sd: Dict[str, torch.Tensor] = {}
-        self.dev = None
+        from .module import register_tree
+        from .weights import make_unet_state_dict
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())            # follows torch's RNG like the reference's default init (seed_all)
+        register_tree(self, make_unet_state_dict(seed, in_channels, out_channels, self.f_maps[0], len(self.f_maps)))
         self.enc: List[List[_Conv]] = []
         self.dec: List = []
         self.final = None
+        self._sig = None
+
+    @property
+    def dev(self):
+        return _lib.require_gpu()
 
     # ---- weights -----------------------------------------------------------------------------------
     def expected_keys(self):
@@ -103,13 +116,25 @@ class ResidualUNet3D:
                 keys += [pre + "weight", pre + "bias"]
         return keys
 
-    def load_state_dict(self, sd, strict: bool = True, prefix: str = ""):
-        dev = self.dev = _lib.require_gpu()
-        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-        missing = [k for k in self.expected_keys() if k not in sd]
-        if missing and strict:
-            raise RuntimeError(f"Missing key(s) in state_dict: {missing[:5]}{' ...' if len(missing) > 5 else ''}")
-        self._sd = {k: sd[k].detach().clone() for k in self.expected_keys() if k in sd}
+    def load_state_dict(self, state_dict, strict: bool = True, prefix: str = "", **kw):
+        """nn.Module.load_state_dict (missing / unexpected keys raise under strict=True, are reported under strict=False) + an optional key
+        `prefix` to pick this module's entries out of an enclosing state dict."""
+        from .module import strip_module_prefix
+        sd = strip_module_prefix(state_dict)
+        if prefix:
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _sync(self):
+        """(Re)build the kernel operands when a parameter changed (module.signature)."""
+        from .module import signature
+        dev = _lib.require_gpu()
+        if any(p.device.type != "cuda" for p in self.parameters()):
+            self.to(dev)                                # there is no CPU path: a module left on the host is moved to the HIP device on first use
+        sig = signature(self)
+        if sig == self._sig:
+            return
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
         G = self.num_groups
 
         def block(pre):
@@ -121,13 +146,7 @@ class ResidualUNet3D:
         self.dec = [(_ConvT(sd[f"decoders.{i}.upsampling.upsample.weight"], sd[f"decoders.{i}.upsampling.upsample.bias"], dev),
                      block(f"decoders.{i}.basic_module.")) for i in range(L - 1)]
         self.final = _Conv(sd["final_conv.weight"], None, None, sd["final_conv.bias"], G, dev)
-        return self
-
-    def state_dict(self):
-        return dict(self._sd)
-
-    def eval(self):
-        return self
+        self._sig = sig
 
     # ---- kernels -----------------------------------------------------------------------------------
     def _gn(self, x, conv: _Conv, sums=None):
@@ -187,10 +206,11 @@ class ResidualUNet3D:
         return y
 
     # ---- forward -----------------------------------------------------------------------------------
+    @torch.no_grad()
     def forward_cl(self, x: torch.Tensor, taps: dict | None = None, skip_final: bool = False, in_sums=None) -> torch.Tensor:
         """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]  (skip_final: the input of `final_conv`;
         in_sums: GroupNorm statistics of x, fp64 [B, groups, 2], when its producer already has them)."""
-        assert self.final is not None, "load_state_dict first"
+        self._sync()
         assert x.dtype == self.act_dtype and x.is_contiguous()
         feats = []
         for i, convs in enumerate(self.enc):
@@ -215,5 +235,3 @@ class ResidualUNet3D:
         xc = x.to(dev).permute(0, 2, 3, 4, 1).contiguous().to(self.act_dtype)
         y = self.forward_cl(xc)
         return y.permute(0, 4, 1, 2, 3).contiguous().float()
-
-    __call__ = forward

@@ -114,6 +114,25 @@ def unet_layer_plan(in_channels: int, out_channels: int, f_maps: int, num_levels
     return plan
 
 
+def make_unet_state_dict(seed: int, in_channels: int, out_channels: int, f_maps: int, num_levels: int) -> dict:
+    """Default initialisation of a stand-alone `ResidualUNet3D` (torch-default-like scales; GroupNorm affine = (1, 0) like nn.GroupNorm)."""
+    rng = np.random.default_rng(seed)
+    u = lambda fan_in, *s: ((rng.random(s, dtype=np.float32) * 2 - 1) / np.sqrt(fan_in)).astype(np.float32)
+    sd = {}
+    for pre, kind, cin, cout in unet_layer_plan(in_channels, out_channels, f_maps, num_levels):
+        if kind in ("gcr", "gc"):
+            sd[pre + "groupnorm.weight"] = np.ones(cin, np.float32)
+            sd[pre + "groupnorm.bias"] = np.zeros(cin, np.float32)
+            sd[pre + "conv.weight"] = u(cin * 27, cout, cin, 3, 3, 3)
+        elif kind == "convT":
+            sd[pre + "weight"] = u(cout * 27, cin, cout, 3, 3, 3)
+            sd[pre + "bias"] = u(cout * 27, cout)
+        else:
+            sd[pre + "weight"] = u(cin, cout, cin, 1, 1, 1)
+            sd[pre + "bias"] = u(cin, cout)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
 def make_semabs3d_state_dict(seed: int = 0, unet_num_channels: int = 16, unet_f_maps: int = 16,
                              unet_num_groups: int = 8, unet_num_levels: int = 6,
                              pts_feat_extractor_hidden_dim: int = 128, pts_feature_dim: int = 1,

@@ -528,35 +528,6 @@ if __name__ == "__main__" and "g13" in sys.argv[1:]:
 
 
 # ---- appended: relevancy storage format (G14): the reference's own expressions at generate_relevancy.py:95-118 and dataset.py:821-871 -----
-def g14_relevancy_io():
-    """`generate_saliency_helper` is a ray remote writing HDF5 and the loader reads it back; neither can run here (ray / h5py / dataset files
-    absent), so the golden executes the reference's tensor expressions verbatim on seeded inputs (they are plain torch calls)."""
-    rng = np.random.default_rng(140)
-    res = {}
-    for tag, (L, H, W, h, w) in {"a": (5, 96, 96, 40, 40), "b": (3, 120, 90, 64, 48), "c": (4, 60, 60, 128, 128)}.items():
-        config_saliency = torch.from_numpy((rng.standard_normal((L, H, W)) * 0.01).astype(np.float32))
-        text_label_features = torch.from_numpy(rng.standard_normal((L, 512)).astype(np.float32))
-        storage_dims = np.array([h, w])
-        # generate_relevancy.py:95-118
-        cs = torch.nn.functional.interpolate(config_saliency[:, None, :, :], size=tuple(storage_dims), mode="nearest-exact")[:, 0]
-        cs = torch.cat([cs, cs.mean(dim=0, keepdim=True)], dim=0)
-        tf = torch.cat([text_label_features, text_label_features.mean(dim=0, keepdim=True)], dim=0)
-        tf /= tf.norm(dim=-1, keepdim=True)
-        # dataset.py:821-832, 866-871, 1053
-        saliency_indices = np.array(sorted(rng.choice(L, size=max(1, L - 1), replace=False)))
-        patch = cs[saliency_indices].float()
-        patch -= cs[L].float().squeeze()
-        patch = torch.nn.functional.interpolate(patch[:, None, :, :], size=(H, W), mode="bilinear", align_corners=False)[:, 0]
-        res.update({f"{tag}_maps": config_saliency.numpy(), f"{tag}_feats": text_label_features.numpy(), f"{tag}_dims": np.asarray([L, H, W, h, w]),
-                    f"{tag}_stored": cs.numpy(), f"{tag}_tf": tf.numpy(), f"{tag}_rows": saliency_indices.astype(np.int64),
-                    f"{tag}_loaded50": (patch * 50).numpy()})
-    save("g14_relevancy_io", **res)
-
-
-if __name__ == "__main__" and "g14" in sys.argv[1:]:
-    g14_relevancy_io()
-
-
 # ---- appended: evaluation metrics (G15): the reference's voxelize_points / prediction_analysis / iou run on seeded inputs ------------------
 def g15_metrics():
     """utils.py cannot be imported here (tensorboardX / transformers / dataset), so the three functions are compiled from its source,
@@ -640,3 +611,215 @@ def g16_headline(which=("aug0", "aug5")):
 
 if __name__ == "__main__" and any(a.startswith("g16") for a in sys.argv[1:]):
     g16_headline(tuple(a.split(":")[1] for a in sys.argv[1:] if a.startswith("g16:")) or ("aug0", "aug5"))
+
+
+# ---- appended (round 2): SemAbs3D with the TSDF network input, through the unmodified reference ------------------------------
+def g17_semabs3d_tsdf():
+    """net.SemAbs3D(network_inputs=["saliency", "tsdf"]).forward (net.py:346-357, 411-419) at 16^3, 3 UNet levels; the module's own
+    (torch-seeded) parameters are stored next to the output."""
+    net, _ = refimport.load_reference_net()
+    S, N, M, P = 16, 2000, 300, 2
+    torch.manual_seed(5)
+    m = net.SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+                     unet_num_levels=3, network_inputs=["saliency", "tsdf"], use_pts_feat_extractor=True,
+                     pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1, device="cpu", decoder_concat_xyz_pts=True,
+                     batch_size=1).eval()
+    rng = np.random.default_rng(1)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    xyz = (lo + (hi - lo) * rng.random((1, N, 3))).astype(np.float32)
+    feat = (rng.standard_normal((1, P, N, 1)) * 0.5).astype(np.float32)
+    q = (lo + (hi - lo) * rng.random((1, P, M, 3))).astype(np.float32)
+    tsdf = rng.uniform(-1, 1, (1, S, S, S)).astype(np.float32)
+    with torch.no_grad():
+        out = m(input_xyz_pts=torch.from_numpy(xyz), input_feature_pts=torch.from_numpy(feat), tsdf_vol=torch.from_numpy(tsdf),
+                output_xyz_pts=torch.from_numpy(q))
+    res = {"out": out.numpy(), "xyz": xyz, "feat": feat, "q": q, "tsdf": tsdf, "meta": np.asarray([S, N, M, P, 3], np.int32)}
+    for k, v in m.state_dict().items():
+        res["sd::" + k] = v.numpy()
+    save("g17_semabs3d_tsdf", **res)
+
+
+if __name__ == "__main__" and "g17" in sys.argv[1:]:
+    g17_semabs3d_tsdf()
+
+
+# ---- appended (round 2): f1 / f2 glue pinned by EXECUTING the reference's functions (compiled from its source here, outputs only) -------
+def _ref_functions(relpath, names, ns, in_class=None):
+    """Compile the named FunctionDefs of a reference file (decorators and annotations stripped) into namespace `ns`."""
+    import ast
+    tree = ast.parse(open(os.path.join(refimport.REF, relpath)).read())
+    body = tree.body
+    if in_class is not None:
+        body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == in_class][0].body
+    for name in names:
+        fn = [n for n in body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+        fn.decorator_list, fn.returns = [], None
+        for a in fn.args.args + fn.args.kwonlyargs:
+            a.annotation = None
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), f"{relpath}:{name}", "exec"), ns)
+    return ns
+
+
+from semabs_amd.synth import synth_ovssc_logits as ovssc_test_logits  # noqa: E402  (shared with tests/test_gpu_inference.py)
+
+
+def g18_process_batch_ovssc():
+    """visualize.process_batch_ovssc + get_sample_points (visualize.py:157-248, 283-298), EXECUTED: the functions are compiled from the
+    reference's source and run with the reference's own TSDFVolume / check_pts_in_frustum / filter_pts_bounds; only the network call is a
+    closed-form stand-in (`ovssc_test_logits`).  Pins sampling lattice, 2^k chunking incl. the ragged tail, TSDF at the sampling
+    resolution, arg-max / cutoff / frustum / tsdf > 0 post-mask and the return form."""
+    fusion, pc = refimport.load_reference_geometry()
+
+    class Progress:                                            # rich.progress.Progress stand-in
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def add_task(self, *a, **k):
+            return 0
+
+        def update(self, *a, **k):
+            pass
+
+    # API drift (numpy 2, NEP 50): `xyz[:, 0] >= bounds[0, 0]` with an fp32 array and an np.float64 SCALAR is evaluated in f64 here but in fp32
+    # under the reference's numpy 1.22 (value-based casting) - and fp32(-0.1) < -0.1, so the reference's own assertion (visualize.py:171)
+    # would fail on its own lattice.  Give the comparison numpy 1.22's type: bounds in the points' dtype.
+    fpb = lambda xyz, bounds: pc.filter_pts_bounds(xyz, np.asarray(bounds).astype(np.asarray(xyz).dtype))
+    ns = {"np": np, "torch": torch, "TSDFVolume": fusion.TSDFVolume, "check_pts_in_frustum": pc.check_pts_in_frustum,
+          "filter_pts_bounds": fpb, "Progress": Progress}
+    _ref_functions("visualize.py", ["get_sample_points", "process_batch_ovssc"], ns)
+    S, C = 40, 4
+    sc = synth_scene(96, 96, seed=21)
+    classes = [f"class{i}" for i in range(C)]
+
+    def net(output_xyz_pts, **kw):                              # [1, 1, m, 3] -> [1, 1, m] for the class whose features were passed
+        c = int(round(float(kw["input_feature_pts"].reshape(-1)[0])))
+        return ovssc_test_logits(output_xyz_pts.reshape(-1, 3).float(), C)[c][None, None]
+
+    n_in = 500
+    batch = {"ovssc_obj_classes": classes, "input_xyz_pts": torch.zeros(n_in, 3),
+             "input_feature_pts": torch.arange(C, dtype=torch.float32)[:, None].repeat(1, n_in),      # the stand-in reads the class id from here
+             "rgb": sc["rgb"], "depth": sc["depth"], "cam_intr": sc["cam_intr"], "cam_extr": sc["cam_pose"]}
+    # numba types the python-float voxel size as float64 (SURVEY.md 8c shim ii-b): the numpy-2 run must do the same
+    orig_init = fusion.TSDFVolume.__init__
+
+    def init64(self, vol_bnds, voxel_size):
+        orig_init(self, vol_bnds, np.float64(voxel_size))
+        self._voxel_size = np.float64(self._voxel_size)
+    fusion.TSDFVolume.__init__ = init64
+    orig_integrate = fusion.TSDFVolume.integrate
+    fusion.TSDFVolume.integrate = lambda self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.0: orig_integrate(
+        self, color_im, depth_im, cam_intr, cam_pose, np.float64(obs_weight))
+    fusion.TSDFVolume.get_volume = lambda self: (self._tsdf_vol_cpu, None)        # NEP-50 overflow in the colour unpacking (shim ii); [0] is what the path reads
+    try:
+        vols = ns["process_batch_ovssc"](net=net, batch=batch, scene_bounds=SCENE_BOUNDS, device="cpu", num_input_pts=64,
+                                         sampling_shape=(S, S, S), num_pts_per_pass=2 ** 14, cutoff=-3.0)
+        pts = ns["get_sample_points"](sampling_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, device="cpu")
+    finally:
+        fusion.TSDFVolume.__init__, fusion.TSDFVolume.integrate = orig_init, orig_integrate
+    assert list(vols.keys()) == classes and all(v.shape == (S, S, S) and v.dtype == np.float32 for v in vols.values())
+    stack = np.stack([vols[c] for c in classes])
+    assert set(np.unique(stack)) <= {0.0, 1.0}
+    save("g18_process_batch_ovssc", meta=np.asarray([S, C, 96, 21, 2 ** 14]), packed=np.packbits(stack.astype(bool).reshape(C, -1), axis=1),
+         counts=stack.reshape(C, -1).sum(1).astype(np.int64), points_sha=digest(pts.numpy()), points_sub=pts.numpy()[::997].copy())
+    print("    per-class voxel counts", stack.reshape(C, -1).sum(1))
+
+
+def g19_relevancy_storage():
+    """generate_relevancy.generate_saliency_helper (:93-145) and SceneCompletionDataset.get_scene_patches (dataset.py:687-871), EXECUTED from
+    the reference's source against in-memory stand-ins for ray / FileLock / h5py (containers only): what is written for a scene, and what the
+    loader hands back for it (row pick, mean subtraction, bilinear resize); x 50 of dataset.py:1053 applied last."""
+    rng = np.random.default_rng(190)
+    res = {}
+    for tag, (L, H, W, h, w) in {"a": (5, 96, 96, 40, 40), "b": (3, 120, 90, 64, 48), "c": (4, 60, 60, 128, 128)}.items():
+        maps = torch.from_numpy((rng.standard_normal((L, H, W)) * 0.01).astype(np.float32))
+        feats = torch.from_numpy(rng.standard_normal((L, 512)).astype(np.float32))
+        labels = [f"label{i}" for i in range(L)]
+        store = {"written": {}, "rows": None}
+
+        class Remote:
+            def __init__(self, fn):
+                self.remote = fn
+
+        class Wrapper:
+            get_clip_saliency = Remote(lambda **kw: (maps.clone(), feats.clone()))
+
+        class Ray:
+            @staticmethod
+            def get(x):
+                return x
+
+        class Lock:
+            def __init__(self, *a):
+                pass
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+        class Group(dict):
+            def create_group(self, name):
+                g = Group(); self[name] = g
+                return g
+
+        class DS:
+            shape = (0, h, w)
+
+        class File:
+            def __init__(self, *a, **k):
+                self.d = {"data": Group(), "saliencies": DS()}
+
+            def __enter__(self):
+                return self.d
+
+            def __exit__(self, *a):
+                return False
+
+        H5 = type("H5", (), {"File": File, "regionref_dtype": "regionref"})
+
+        def write_to_hdf5(group, key, value, dtype=None, replace=False):
+            store["written"][key] = value
+
+        def resize_and_add_data(dataset, data):
+            store["rows"] = data
+            return list(range(len(data)))
+
+        ns = {"np": np, "torch": torch, "ray": Ray, "FileLock": Lock, "h5py": H5, "write_to_hdf5": write_to_hdf5,
+              "resize_and_add_data": resize_and_add_data, "saliency_configs": {"ours": lambda img_dim: {}}, "imagenet_templates": []}
+        _ref_functions("generate_relevancy.py", ["generate_saliency_helper"], ns)
+        ns["generate_saliency_helper"](Wrapper(), {"rgb": np.zeros((H, W, 3), np.uint8)}, ["{}"], labels, "scene.hdf5", False)
+        stored = store["rows"]
+        tf = store["written"]["rgb|ours|saliency_text_label_features"]
+        names = store["written"]["rgb|ours|saliency_text_labels"]
+        # ---- loader -------------------------------------------------------------------------------------------------------------------
+        keep = sorted(rng.choice(L, size=max(1, L - 1), replace=False).tolist())
+        prefix = "data/saliencies/rgb|ours"
+
+        class Arr:
+            def __init__(self, shape):
+                self.shape = shape
+
+        sal = stored.numpy()
+        file = {"data/objid_to_class": np.array([f"{labels[i]}[{i}]" for i in keep]).astype("S"),
+                f"{prefix}|saliency_text_labels": names, "saliencies": sal, prefix: np.array([np.s_[i:i + 1] for i in range(len(sal))], dtype=object),
+                f"{prefix}|saliency_text_label_features": tf.numpy(), "rgb": Arr((1, H, W, 3))}
+        ns2 = {"np": np, "torch": torch, "synonyms": {}}
+        _ref_functions("dataset.py", ["deref_h5py"], ns2)
+        _ref_functions("dataset.py", ["get_scene_patches"], ns2, in_class="SceneCompletionDataset")
+        sp = ns2["get_scene_patches"](file, -1, "rgb", "ours", False, True)
+        assert list(sp["patch_labels"]) == [labels[i] for i in keep]
+        res.update({f"{tag}_maps": maps.numpy(), f"{tag}_feats": feats.numpy(), f"{tag}_dims": np.asarray([L, H, W, h, w]),
+                    f"{tag}_stored": stored.numpy(), f"{tag}_tf": tf.numpy(), f"{tag}_names": np.asarray(names).astype(str),
+                    f"{tag}_rows": np.asarray(keep, np.int64), f"{tag}_loaded50": (sp["patch_saliencies"] * 50).numpy(),
+                    f"{tag}_label_features": sp["patch_label_features"].numpy()})
+    save("g19_relevancy_storage", **res)
+
+
+if __name__ == "__main__" and "g18" in sys.argv[1:]:
+    g18_process_batch_ovssc()
+if __name__ == "__main__" and "g19" in sys.argv[1:]:
+    g19_relevancy_storage()

@@ -35,6 +35,12 @@ def test_pointcloud_and_voxel_index(golden, tag, hw, S):
     # numpy-facing drop-ins
     pts_np, _ = pc.get_pointcloud(sc["depth"], None, sc["cam_intr"], sc["cam_pose"])
     assert pts_np.dtype == np.float64 and np.array_equal(pts_np.astype(np.float32), ref)
+    # true f64 results (not widened fp32): against the reference's own f64 points - equal up to the last bit of the 3-term dot product
+    # (numpy's dgemm may fuse differently): |diff| <= 2 ulp of the largest coordinate
+    ref64 = g["48_pts64"] if tag == "48" else g["480_pts64_s"]
+    got64 = pts_np if tag == "48" else pts_np[g["480_si"]]
+    assert np.abs(got64 - ref64).max() <= 2 * np.spacing(np.abs(ref64).max())
+    assert np.abs(pts_np - pts_np.astype(np.float32)).max() > 1e-9          # genuinely carries more than fp32
     fr = pc.check_pts_in_frustum(ref[::3].astype(np.float64) * 1.01, sc["depth"], sc["cam_pose"], sc["cam_intr"])
     assert np.array_equal(sha(fr), g[f"{tag}_frustum_sha"])
 

@@ -1,0 +1,104 @@
+"""GPU: the reference-shaped inference entry points (`semabs_amd.inference`: get_sample_points / process_batch_ovssc / ovssc_post_mask, mirrors of
+visualize.py:157-248, 283-298).
+
+* post-mask + lattice + TSDF-at-sampling-resolution against g18 = the reference's own `process_batch_ovssc` EXECUTED (compiled from its source
+  in the build container with a closed-form stand-in for the network; tests/golden/gen_golden.py g18): volumes bit-identical;
+* the whole function with a real SemAbs3D: return form, chunked decoding == one-shot decoding (bit-exact), logits against the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import semabs_amd  # noqa: F401
+from semabs_amd.synth import SCENE_BOUNDS, synth_ovssc_logits, synth_scene
+from semabs_amd.weights import make_semabs3d_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(sc, classes, xyz=None, feat=None):
+    return {"ovssc_obj_classes": classes, "rgb": sc["rgb"], "depth": sc["depth"], "cam_intr": sc["cam_intr"], "cam_extr": sc["cam_pose"],
+            "input_xyz_pts": xyz, "input_feature_pts": feat}
+
+
+def test_post_mask_and_lattice_vs_executed_reference(golden):
+    from semabs_amd.inference import get_sample_points, ovssc_post_mask
+    g = golden("g18_process_batch_ovssc")
+    S, C, hw, seed, _ = (int(v) for v in g["meta"])
+    pts = get_sample_points((S, S, S), SCENE_BOUNDS)
+    host = pts.cpu().numpy()
+    assert np.array_equal(np.frombuffer(hashlib.sha256(host.tobytes()).digest(), np.uint8), g["points_sha"])
+    classes = [f"class{i}" for i in range(C)]
+    logits = synth_ovssc_logits(pts.cpu(), C).cuda()          # the stand-in evaluated on the host like in the golden run (exact either way)
+    vols, lab = ovssc_post_mask(logits, _batch(synth_scene(hw, hw, seed=seed), classes), SCENE_BOUNDS, (S, S, S), cutoff=-3.0)
+    ref = np.unpackbits(g["packed"], axis=1)[:, : S ** 3].reshape(C, S, S, S).astype(np.float32)
+    assert list(vols.keys()) == classes
+    got = np.stack([vols[c] for c in classes])
+    assert got.dtype == np.float32 and np.array_equal(got.reshape(C, -1).sum(1).astype(np.int64), g["counts"])
+    assert np.array_equal(got, ref)
+    assert int((lab >= 0).sum()) == int(g["counts"].sum())
+
+
+def test_process_batch_ovssc_form_chunking_and_logits():
+    from oracle import geometry as og
+    from oracle import semabs3d as os3
+    from semabs_amd.inference import process_batch_ovssc
+    from semabs_amd.net import SemAbs3D
+    Sv, Sq, C, npts = 32, 40, 3, 4000
+    net = SemAbs3D(voxel_shape=(Sv, Sv, Sv), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8, unet_num_levels=6,
+                   network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1,
+                   device="cuda", decoder_concat_xyz_pts=True, batch_size=1)
+    sd = make_semabs3d_state_dict(seed=3)
+    net.load_state_dict(sd)
+    sc = synth_scene(96, 96, seed=4)
+    pts = og.get_pointcloud(sc["depth"], sc["cam_intr"], sc["cam_pose"]).astype(np.float32)
+    inb = og.filter_pts_bounds(pts, np.asarray(SCENE_BOUNDS, np.float64))
+    xyz = torch.from_numpy(pts[inb])
+    rng = np.random.default_rng(0)
+    feat = torch.from_numpy((rng.standard_normal((C, len(xyz))) * 0.5).astype(np.float32))
+    classes = ["chair", "table", "lamp"]
+    batch = _batch(sc, classes, xyz, feat)
+    idx = np.random.default_rng(5).integers(0, len(xyz), size=npts)
+    v1, logit1, lab1 = process_batch_ovssc(net, batch, SCENE_BOUNDS, "cuda", npts, sampling_shape=(Sq, Sq, Sq), num_pts_per_pass=2 ** 13, indices=idx,
+                                           return_logits=True)
+    v2, logit2, lab2 = process_batch_ovssc(net, batch, SCENE_BOUNDS, "cuda", npts, sampling_shape=(Sq, Sq, Sq), num_pts_per_pass=2 ** 20, indices=idx,
+                                           return_logits=True)
+    assert list(v1.keys()) == classes and all(v.shape == (Sq, Sq, Sq) and v.dtype == np.float32 and set(np.unique(v)) <= {0.0, 1.0} for v in v1.values())
+    # the decoder is evaluated per query point: chunking cannot change a bit (GroupNorm statistics of the two feature-volume runs are
+    # accumulated with floating-point atomics, hence a last-bit tolerance on the logits and an exact match of nearly all labels)
+    assert float((logit1 - logit2).abs().max()) <= 2e-5 * float(logit2.abs().max())
+    assert float((lab1 != lab2).float().mean()) < 1e-3
+    assert np.stack(list(v1.values())).sum(0).max() <= 1.0                                  # classes are mutually exclusive
+    # logits against the oracle on the same sub-sample
+    from oracle import scene as osc
+    q = torch.from_numpy(osc.sample_points((Sq, Sq, Sq), SCENE_BOUNDS))
+    with torch.no_grad():
+        ref = os3.semabs3d_forward(sd, xyz[idx][None], feat[:, idx][None, :, :, None], q[None, None].repeat(1, C, 1, 1), SCENE_BOUNDS, (Sv, Sv, Sv))[0]
+    err = float((logit1.reshape(C, -1).cpu() - ref).abs().max())
+    print(f"process_batch_ovssc logits vs oracle: L-inf {err:.3e} (max|ref| {float(ref.abs().max()):.3f})")
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max()))
+    # and the volumes against the oracle's post-mask of the oracle's logits (ties at the cutoff aside)
+    ref_v = osc.ovssc_post_mask(ref, sc, SCENE_BOUNDS, (Sq, Sq, Sq))
+    assert float(np.abs(np.stack(list(v1.values())) - ref_v).mean()) < 1e-3
+
+
+def test_prep_data_batch_keys_and_features():
+    """prep_data's batch (visualize.py:61-154): keys, shapes, x 50 and mean subtraction, in-bounds selection - needs the BPE table for the
+    text tower, which only the build container has."""
+    from semabs_amd.clip import ClipWrapper
+    from semabs_amd.clip.tokenizer import find_vocab
+    if find_vocab() is None:
+        pytest.skip("CLIP BPE table not present on this box")
+    from semabs_amd.inference import prep_data
+    from semabs_amd.weights import make_clip_state_dict
+    ClipWrapper.engine = None
+    ClipWrapper("ViT-B/32", state_dict=make_clip_state_dict("ViT-B/32", 0), chunk_tiles=64, max_labels=8)
+    sc = synth_scene(96, 96, seed=2)
+    data = dict(rgb=sc["rgb"], depth=sc["depth"], cam_intr=sc["cam_intr"], cam_extr=sc["cam_pose"], ovssc_obj_classes=["chair", "table"],
+                descriptions=[("lamp", "on", "table")])
+    b = prep_data(data, SCENE_BOUNDS, subtract_mean=True, jittered_images=[sc["rgb"]] * 5)
+    n = len(b["input_xyz_pts"])
+    assert tuple(b["relevancies"].shape) == (3, 96, 96) and float(b["relevancies"].mean(dim=0).abs().max()) < 1e-6
+    assert tuple(b["input_feature_pts"].shape) == (2, n) and tuple(b["input_target_saliency_pts"].shape) == (1, n)
+    assert b["spatial_relation_name"] == ["on"] and b["descriptions"] == ["the lamp on the table"] and b["tsdf_vol"] is None

@@ -1,0 +1,91 @@
+"""Data-parallel VOOL training step (config 5; utils.get_net wraps the net in DistributedDataParallel, /root/reference/utils.py:255-258, and
+`loop` steps the optimizer on the averaged gradients, :404-417): two ranks with one scene each must take the SAME optimisation step as one
+rank with the batch of both scenes.  Two processes share the one GPU of the test box, so the group is gloo (RCCL admits one rank per device);
+the exchange is the trainer's single flat all-reduce (`dist.allreduce_flat_gradients`) either way."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import semabs_amd  # noqa: F401
+from semabs_amd.synth import SCENE_BOUNDS
+from semabs_amd.weights import make_semabsvool_state_dict
+
+pytestmark = pytest.mark.gpu
+S, N, M, D, L = 16, 1500, 700, 3, 4
+REL = [["on", "behind"], ["in", "[pad]"], ["on the left of", "on"]]          # D lists of B names; rank 1 never sees "in" / "on the left of"
+
+
+def _batch2():
+    rng = np.random.default_rng(21)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    return dict(input_xyz_pts=torch.from_numpy((lo + (hi - lo) * rng.random((2, N, 3))).astype(np.float32)),
+                input_target_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                input_reference_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                output_xyz_pts=torch.from_numpy((lo - 0.05 + (hi - lo + 0.1) * rng.random((2, D, M, 3))).astype(np.float32)),
+                output_label_pts=torch.from_numpy((rng.random((2, D, M)) < 0.25).astype(np.float32)),
+                spatial_relation_name=REL)
+
+
+def _item(batch, b):
+    out = {k: (v[b:b + 1] if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out["spatial_relation_name"] = [[names[b]] for names in batch["spatial_relation_name"]]
+    return out
+
+
+def _trainer():
+    from semabs_amd.train import VOOLTrainer
+    return VOOLTrainer(make_semabsvool_state_dict(seed=9, unet_num_levels=L), voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_levels=L)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr = _trainer()
+        out = tr.step(_item(_batch2(), rank))
+        torch.cuda.synchronize()
+        sd = tr.state_dict()
+        q.put((rank, float(out["loss"]), float(out["gradnorm"]), {k: v.cpu().numpy() for k, v in sd.items()},
+               {k: (tr.params[k].grad is not None) for k in tr.params if k.startswith("relation_embeddings.")}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_batch_of_two():
+    import torch.multiprocessing as mp
+    tr = _trainer()
+    before = {k: v.cpu().numpy().copy() for k, v in tr.state_dict().items()}
+    ref = tr.step(_batch2())
+    torch.cuda.synchronize()
+    ref_loss, ref_norm = float(ref["loss"]), float(ref["gradnorm"])
+    ref_sd = {k: v.cpu().numpy() for k, v in tr.state_dict().items()}
+    ref_used = {k: (tr.params[k].grad is not None) for k in tr.params if k.startswith("relation_embeddings.")}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=900) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    # the batch loss is the mean over both scenes' points; each rank reports the mean over its own scene
+    assert abs(0.5 * (got[0][1] + got[1][1]) - ref_loss) <= 1e-5 * ref_loss
+    for rank, loss, norm, sd, used in got:
+        # averaged per-rank gradients == gradient of the batch mean: same pre-clip norm, same LAMB step (fp32 atomics order aside)
+        assert abs(norm - ref_norm) <= 2e-4 * ref_norm, (rank, norm, ref_norm)
+        assert used == ref_used, (rank, used, ref_used)           # "used on ANY rank" (find_unused_parameters=True): rank 1 alone never sees "in"
+        worst = 0.0
+        for k, v in ref_sd.items():
+            step = np.abs(v - before[k]).max()
+            if step == 0:
+                assert np.array_equal(sd[k], v), k               # parameters without gradient stay put on every rank
+                continue
+            worst = max(worst, float(np.abs(sd[k] - v).max() / step))
+        print(f"rank {rank}: worst parameter deviation {worst:.3e} of that parameter's own step")
+        assert worst <= 2e-2, (rank, worst)                      # LAMB's first step is sign-like where |g| ~ eps: a few near-zero gradients flip
+    assert all(np.array_equal(got[0][3][k], got[1][3][k]) for k in ref_sd)      # both ranks hold identical parameters after the step

@@ -212,3 +212,33 @@ def test_unet128(golden):
         y = os3.unet_forward(sd, torch.from_numpy(x), 6).numpy()
     np.testing.assert_allclose(y.reshape(-1)[g["si"]], g["y_s"], rtol=1e-3, atol=1e-4)
     assert abs(np.abs(y.astype(np.float64)).sum() - g["y_abs"]) <= 1e-5 * g["y_abs"]
+
+
+def test_oracle_semabs3d_tsdf_input_vs_reference(golden):
+    """network_inputs = ["saliency", "tsdf"]: oracle vs the reference module's own output (g17, its torch-seeded parameters stored alongside)."""
+    import torch
+    from oracle import semabs3d as os3
+    g = golden("g17_semabs3d_tsdf")
+    S = int(g["meta"][0])
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    with torch.no_grad():
+        out = os3.semabs3d_forward(sd, torch.from_numpy(g["xyz"]), torch.from_numpy(g["feat"]), torch.from_numpy(g["q"]),
+                                   [[-1.0, -1.0, -0.1], [1.0, 1.0, 1.9]], (S, S, S), num_levels=int(g["meta"][4]), tsdf_vol=torch.from_numpy(g["tsdf"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-4, atol=2e-5)
+
+
+def test_oracle_ovssc_post_mask_vs_executed_reference(golden):
+    """f1 glue: the reference's process_batch_ovssc + get_sample_points executed from source (g18) vs oracle.scene.{sample_points, ovssc_post_mask}."""
+    import hashlib
+    import torch
+    from oracle import scene as osc
+    from semabs_amd.synth import SCENE_BOUNDS, synth_ovssc_logits, synth_scene
+    g = golden("g18_process_batch_ovssc")
+    S, C, hw, seed, _ = (int(v) for v in g["meta"])
+    pts = osc.sample_points((S, S, S), SCENE_BOUNDS)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pts.tobytes()).digest(), np.uint8), g["points_sha"])
+    assert np.array_equal(pts[::997], g["points_sub"])
+    vols = osc.ovssc_post_mask(synth_ovssc_logits(torch.from_numpy(pts), C), synth_scene(hw, hw, seed=seed), SCENE_BOUNDS, (S, S, S))
+    ref = np.unpackbits(g["packed"], axis=1)[:, : S ** 3].reshape(C, S, S, S).astype(np.float32)
+    assert np.array_equal(vols.reshape(C, -1).sum(1).astype(np.int64), g["counts"])
+    assert np.array_equal(vols, ref)

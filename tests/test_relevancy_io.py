@@ -1,4 +1,6 @@
-"""Relevancy storage format: oracle vs the golden of the reference's expressions (CPU), HIP kernels vs the oracle (GPU)."""
+"""Relevancy storage format.  Golden g19 = the reference's `generate_saliency_helper` and `get_scene_patches` EXECUTED (compiled
+from its source in the build container, containers stubbed; tests/golden/gen_golden.py g19): oracle vs golden on the CPU, HIP kernels vs golden
+on the GPU."""
 import numpy as np
 import pytest
 import torch
@@ -14,19 +16,21 @@ def _cases(g):
 
 
 def test_oracle_relevancy_io_matches_reference_expressions(golden):
-    g = golden("g14_relevancy_io")
+    g = golden("g19_relevancy_storage")
     for tag, L, H, W, h, w in _cases(g):
         stored, tf = orio.pack_relevancy(torch.from_numpy(g[f"{tag}_maps"]), torch.from_numpy(g[f"{tag}_feats"]), (h, w))
         assert np.array_equal(stored.numpy(), g[f"{tag}_stored"])
         assert np.array_equal(tf.numpy(), g[f"{tag}_tf"])
         loaded = orio.unpack_relevancy(stored, (H, W), rows=g[f"{tag}_rows"].tolist(), mean_index=L, scale=50.0)
         assert np.array_equal(loaded.numpy(), g[f"{tag}_loaded50"])
+        assert g[f"{tag}_names"].tolist() == [f"label{i}" for i in range(L)] + ["mean"]
+        assert np.array_equal(g[f"{tag}_label_features"], g[f"{tag}_tf"][g[f"{tag}_rows"]])          # the loader's feature rows
 
 
 @pytest.mark.gpu
 def test_hip_relevancy_io_vs_oracle(golden):
     from semabs_amd.relevancy_io import pack_relevancy, unpack_relevancy
-    g = golden("g14_relevancy_io")
+    g = golden("g19_relevancy_storage")
     for tag, L, H, W, h, w in _cases(g):
         maps, feats = torch.from_numpy(g[f"{tag}_maps"]), torch.from_numpy(g[f"{tag}_feats"])
         stored, tf = pack_relevancy(maps.cuda(), feats.cuda(), (h, w))

@@ -98,3 +98,44 @@ def test_gpu_lamb(golden):
         assert st["step"] == 3
     with pytest.raises(ValueError):
         Lamb(params, lr=-1.0)
+
+
+@pytest.mark.gpu
+def test_gpu_lamb_resume_from_state_dict(golden):
+    """The reference's resume flow (utils.py:289 `optimizer.load_state_dict(checkpoint["optimizer"])`) between steps: after one step the state
+    dict is saved (to the host, like torch.save / torch.load would), loaded into a FRESH optimizer over new parameter tensors AND back into
+    the running one (whose launch plan caches the old moment buffers' addresses); both must continue exactly like the uninterrupted run
+    (the golden's three steps).  Guards the cached-pointer bug: the loaded moments must be the ones the kernels read and write."""
+    import copy
+    from semabs_amd.optim import Lamb
+    g = golden("g12_vool_lamb")
+    ws, grads = _lamb_stream()
+
+    def set_grads(params, step):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(grads[step][i]).cuda()
+
+    params = [torch.nn.Parameter(torch.from_numpy(w).cuda()) for w in ws]
+    opt = Lamb(params, lr=1e-3, weight_decay=1e-5)
+    set_grads(params, 0)
+    opt.step()
+    ckpt = copy.deepcopy({"optimizer": opt.state_dict(), "w": [p.detach().cpu().clone() for p in params]})
+    ckpt["optimizer"]["state"] = {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in st.items()} for k, st in ckpt["optimizer"]["state"].items()}
+    # (a) a fresh optimizer over fresh tensors
+    params2 = [torch.nn.Parameter(w.clone().cuda()) for w in ckpt["w"]]
+    opt2 = Lamb(params2, lr=1e-3, weight_decay=1e-5)
+    opt2.load_state_dict(ckpt["optimizer"])
+    # (b) the running optimizer: poison its current moments first - if the stale plan were used, the poison would show up in the result
+    for p in params:
+        opt.state[p]["exp_avg"].fill_(123.0); opt.state[p]["exp_avg_sq"].fill_(456.0)
+    opt.load_state_dict(ckpt["optimizer"])
+    for o, ps in ((opt, params), (opt2, params2)):
+        for step in (1, 2):
+            set_grads(ps, step)
+            o.step()
+        for i, p in enumerate(ps):
+            st = o.state[p]
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"lamb_w{i}"], rtol=3e-6, atol=1e-7)
+            np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), g[f"lamb_m{i}"], rtol=3e-6, atol=2e-8)
+            np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), g[f"lamb_v{i}"], rtol=3e-6, atol=1e-10)
+            assert st["step"] == 3
