@@ -27,7 +27,7 @@ def _w(L, seed=0):
     return w / np.linalg.norm(w, axis=1, keepdims=True)
 
 
-def _check(maps, ref, tol=1e-2):
+def _check(maps, ref, tol=5.5e-3):          # relative L-infinity; 3 x the largest value measured on these small shapes
     err = np.abs(maps - ref).max()
     assert err <= tol * np.abs(ref).max() and err <= 1e-3, (err, np.abs(ref).max())
 

@@ -184,7 +184,8 @@ def _tiles(n, seed):
 @pytest.mark.parametrize("arch,tag", [("ViT-B/32", "b32"), ("ViT-B/16", "b16")])
 def test_vit_gradcam(golden, arch, tag):
     """HIP ViT + analytic rollout vs the reference's autograd result (golden) and vs the oracle.
-    Tolerance: 1% of max|rel| (fp16 GEMM operands over 12 blocks vs the fp32 CPU reference)."""
+    Tolerance: RELATIVE L-infinity (max|ours - ref| / max|ref|) <= 5.5e-3 = 3 x the largest measured value (fp16 GEMM operands over 12
+    blocks vs the fp32 CPU reference; measured on MI355X: B/32 1.65e-3 / 1.68e-3, B/16 7.5e-4 / 1.83e-3 for positive_attn_only True / False)."""
     CW, sd = _init_clip(arch)
     g = golden(f"g3g4_vit_{tag}")
     tiles = _tiles(3, 7)
@@ -193,8 +194,8 @@ def test_vit_gradcam(golden, arch, tag):
         rel, logits, feat = CW.engine.gradcam_tiles(tiles.cuda(), w_text, pos)
         ref = g[f"rel_pos{int(pos)}"]
         err = np.abs(rel.cpu().numpy() - ref).max()
-        assert err <= 1e-2 * np.abs(ref).max(), (err, np.abs(ref).max())
-        print(f"{arch} pos={pos}: rel Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e}")
+        print(f"{arch} pos={pos}: rel Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e} = {err / np.abs(ref).max():.2e} relative")
+        assert err <= 5.5e-3 * np.abs(ref).max(), (err, np.abs(ref).max())
     np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=0, atol=5e-3 * np.abs(g["feat"]).max())
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-3 * np.abs(g["logits"]).max() + 0.05)
     probs = CW.engine._workspace()["probs"][:3].cpu().numpy()
@@ -204,7 +205,7 @@ def test_vit_gradcam(golden, arch, tag):
     with torch.no_grad():
         ref_f, _ = orl.gradcam_tiles(make_clip_state_dict(arch, 0, text_tower=False), torch.flip(tiles, dims=[-1]),
                                      torch.from_numpy(g["w_text"]), True)
-    assert np.abs(rel_f.cpu().numpy() - ref_f.numpy()).max() <= 1e-2 * ref_f.abs().max().item()
+    assert np.abs(rel_f.cpu().numpy() - ref_f.numpy()).max() <= 5.5e-3 * ref_f.abs().max().item()
 
 
 def test_text_tower(golden):
@@ -231,7 +232,8 @@ def test_tokenizer_matches_reference_ids(golden):
                                              ("ViT-B/16", "b16", "two_scale64", 64)])
 def test_end_to_end_maps(golden, arch, tag, name, H):
     """uint8 image -> fp32 maps, whole HIP path, vs the reference's get_clip_saliency output (golden).
-    Tolerance: 1% of max|map| (L-inf); also reports the relative error for DESIGN.md."""
+    Tolerance: RELATIVE L-infinity <= 3.5e-3 = 3 x the largest measured value (1.15e-3 / 9.3e-4 / 1.03e-3 on MI355X); the headline shape has its
+    own test (test_gpu_headline.py)."""
     from semabs_amd.clip import saliency_configs
     CW, sd = _init_clip(arch)
     g = golden(f"g6_e2e_{tag}")
@@ -248,8 +250,8 @@ def test_end_to_end_maps(golden, arch, tag, name, H):
     ref = g[f"{name}_maps"]
     err = np.abs(maps.cpu().numpy() - ref).max()
     print(f"{arch}/{name}: map Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e} = {err / np.abs(ref).max():.2e}")
-    assert err <= 1e-2 * np.abs(ref).max()
-    assert err <= 1e-3                                                          # BASELINE: within 1e-3 of the reference
+    assert err <= 3.5e-3 * np.abs(ref).max()
+    assert err <= 1e-4                                                          # absolute: 3 x the measured 3.1e-5 (BASELINE's bar is 1e-3 absolute)
 
 
 class _FixtureTokenizer:
@@ -283,7 +285,7 @@ def test_public_get_clip_saliency_with_text_tower(golden):
     ref = g["chefer96_maps"]
     err = np.abs(maps.numpy() - ref).max()
     print(f"public API chefer96: map Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e}")
-    assert err <= 2e-2 * np.abs(ref).max() and err <= 1e-3
+    assert err <= 5.5e-3 * np.abs(ref).max() and err <= 1.5e-4          # 3 x measured (1.7e-3 relative / 4.6e-5 absolute; text tower included)
     # distractor labels subtract the mean distractor map (CLIP/clip/__init__.py:125-131)
     m2, _ = CW.get_clip_saliency(img=img, text_labels=labels[:2], prompts=[DEFAULT_PROMPT],
                                  **dict(saliency_configs["chefer_et_al"](96), distractor_labels={"lamp", "chair"}))

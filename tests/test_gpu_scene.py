@@ -31,7 +31,9 @@ def test_scene_end_to_end(precision):
     rel = res.relevancies.cpu().numpy() * 50
     rel = rel - rel.mean(axis=0, keepdims=True)
     r_ref = ref["relevancies"].numpy()
-    assert np.abs(rel - r_ref).max() <= 1e-2 * np.abs(r_ref).max()
+    e_rel = np.abs(rel - r_ref).max() / np.abs(r_ref).max()
+    print(f"scene relevancies (x 50, mean-subtracted): relative L-inf {e_rel:.2e}")
+    assert e_rel <= 1e-2                                 # mean subtraction shrinks the reference's range; measured 2.7e-3
     lg, lg_ref = res.logits.cpu().numpy(), ref["logits"].numpy()
     err = np.abs(lg - lg_ref).max()
     print(f"{precision}: logits Linf {err:.3e} (max|ref| {np.abs(lg_ref).max():.3f})")

@@ -197,6 +197,7 @@ def test_point_mlp():
     sd = make_semabs3d_state_dict(seed=3)
     ref = os3.point_mlp(sd, xyz[None].repeat(P, 1, 1), feat[..., None])
     pf = torch.empty(P, N, 16, dtype=torch.float32, device="cuda")
+    m._sync()                                        # derive the kernel operands from the module's parameters
     w = m._w
     xyz_d, feat_d = xyz.cuda(), feat.cuda()          # keep the device buffers alive across the launch
     _lib.call("semabs_point_mlp", _lib.ptr(xyz_d), _lib.ptr(feat_d), _lib.ptr(w["w1"]), _lib.ptr(w["b1"]), _lib.ptr(w["w2"]),

@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         sd = tr.state_dict()
         q.put((rank, float(out["loss"]), float(out["gradnorm"]), {k: v.cpu().numpy() for k, v in sd.items()},
-               {k: (tr.params[k].grad is not None) for k in tr.params if k.startswith("relation_embeddings.")}))
+               {k: (tr.params[k].grad is not None) for k in tr.params if k.startswith("relation_embeddings.")},
+               {k: v.cpu().numpy() for k, v in tr.grads.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -64,6 +65,7 @@ def test_two_rank_step_equals_single_rank_batch_of_two():
     ref_loss, ref_norm = float(ref["loss"]), float(ref["gradnorm"])
     ref_sd = {k: v.cpu().numpy() for k, v in tr.state_dict().items()}
     ref_used = {k: (tr.params[k].grad is not None) for k in tr.params if k.startswith("relation_embeddings.")}
+    ref_g = {k: v.cpu().numpy() for k, v in tr.grads.items()}                 # after the step: summed, averaged and clipped in place
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
@@ -75,17 +77,30 @@ def test_two_rank_step_equals_single_rank_batch_of_two():
         p.join(timeout=120)
     # the batch loss is the mean over both scenes' points; each rank reports the mean over its own scene
     assert abs(0.5 * (got[0][1] + got[1][1]) - ref_loss) <= 1e-5 * ref_loss
-    for rank, loss, norm, sd, used in got:
-        # averaged per-rank gradients == gradient of the batch mean: same pre-clip norm, same LAMB step (fp32 atomics order aside)
+    gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ref_g.values()))
+    for rank, loss, norm, sd, used, grads in got:
+        # averaged per-rank gradients == gradient of the batch mean: same pre-clip norm, same gradients tensor by tensor (fp32 atomics order and
+        # the per-launch dynamic gradient scale aside)
         assert abs(norm - ref_norm) <= 2e-4 * ref_norm, (rank, norm, ref_norm)
         assert used == ref_used, (rank, used, ref_used)           # "used on ANY rank" (find_unused_parameters=True): rank 1 alone never sees "in"
-        worst = 0.0
+        worst_g = 0.0
+        for k, g in ref_g.items():
+            n = float(np.linalg.norm(g.astype(np.float64)))
+            if n < 1e-5 * gnorm:
+                continue                                          # e.g. a bias in front of a GroupNorm: mathematically zero gradient, numerically noise
+            worst_g = max(worst_g, float(np.linalg.norm((grads[k] - g).astype(np.float64))) / n)
+        # parameters: LAMB's first step is sign-like (m / (sqrt(v) + eps)), so compare where the gradient is well above its tensor's noise floor
+        worst_p = 0.0
         for k, v in ref_sd.items():
-            step = np.abs(v - before[k]).max()
-            if step == 0:
-                assert np.array_equal(sd[k], v), k               # parameters without gradient stay put on every rank
+            if k not in ref_g:
+                assert np.array_equal(sd[k], v), k               # no gradient (visual_sampler, unused relation, counters): identical on every rank
                 continue
-            worst = max(worst, float(np.abs(sd[k] - v).max() / step))
-        print(f"rank {rank}: worst parameter deviation {worst:.3e} of that parameter's own step")
-        assert worst <= 2e-2, (rank, worst)                      # LAMB's first step is sign-like where |g| ~ eps: a few near-zero gradients flip
+            g = ref_g[k]
+            sel = np.abs(g) > 1e-2 * np.abs(g).max() if np.abs(g).max() > 0 else np.zeros_like(g, bool)
+            step = np.abs(v - before[k]).max()
+            if sel.any() and step > 0:
+                worst_p = max(worst_p, float(np.abs(sd[k] - v)[sel].max() / step))
+        print(f"rank {rank}: worst per-tensor gradient deviation {worst_g:.3e} (relative L2), worst parameter deviation {worst_p:.3e} of the tensor's own step")
+        assert worst_g <= 2e-3, (rank, worst_g)
+        assert worst_p <= 2e-2, (rank, worst_p)
     assert all(np.array_equal(got[0][3][k], got[1][3][k]) for k in ref_sd)      # both ranks hold identical parameters after the step
