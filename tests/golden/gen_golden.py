@@ -449,12 +449,13 @@ if __name__ == "__main__" and "g12" in sys.argv[1:]:
 
 
 # ---- appended: one VOOL training step on the reference (G13: loss, gradients, clipped LAMB update) ------------------
-def g13_vool_train():
+def g13_vool_train(S=32, N=3000, M=1500, D=3, name="g13_vool_train"):
+    """One VOOL optimisation step of the unmodified reference (SemAbsVOOL + BCE-with-logits + clip_grad_norm_ + arm.optim.lamb.Lamb).
+    g13: 32^3 (UNet level 5 = 1^3 voxels: GroupNorm singular there, gradients ill-conditioned); g20: 64^3, where that does not apply."""
     from semabs_amd.weights import make_semabsvool_state_dict
     net, _ = refimport.load_reference_net()
     sys.path.insert(0, refimport.REF)
     from arm.optim.lamb import Lamb
-    S, N, M, D = 32, 3000, 1500, 3
     m = net.SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cpu", decoder_concat_xyz_pts=True,
                        voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
                        unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128,
@@ -520,11 +521,13 @@ def g13_vool_train():
     res["bce_weight_balanced_sum"] = np.float64(w.double().sum().item())
     res["bce_weight_balanced_sub"] = w.numpy()[:, :, ::50].copy()
     res["loss_balanced"] = np.float64(torch.nn.functional.binary_cross_entropy_with_logits(out.detach(), lab, weight=w).item())
-    save("g13_vool_train", **res)
+    save(name, **res)
 
 
 if __name__ == "__main__" and "g13" in sys.argv[1:]:
     g13_vool_train()
+if __name__ == "__main__" and "g20" in sys.argv[1:]:
+    g13_vool_train(S=64, N=12000, M=4000, D=3, name="g20_vool_train64")
 
 
 # ---- appended: relevancy storage format (G14): the reference's own expressions at generate_relevancy.py:95-118 and dataset.py:821-871 -----

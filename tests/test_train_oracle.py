@@ -10,8 +10,12 @@ from oracle import train as ot
 from _train_inputs import vool_batch
 
 
-def test_oracle_train_step_matches_reference(golden):
-    g = golden("g13_vool_train")
+import pytest
+
+
+@pytest.mark.parametrize("name", ["g13_vool_train", "g20_vool_train64"])
+def test_oracle_train_step_matches_reference(golden, name):
+    g = golden(name)
     S, N, M, D, seed, wseed, _ = [int(v) for v in g["meta"]]
     batch = vool_batch(S, N, M, D, seed, g["label"])
     r = ot.vool_train_step(make_semabsvool_state_dict(seed=wseed), batch, SCENE_BOUNDS, (S, S, S))
