@@ -214,6 +214,8 @@ def _ln_vjp(x, w, gy, eps=1e-5):
 def gradcam_tiles(sd, tiles: torch.Tensor, w_text: torch.Tensor, positive_attn_only: bool,
                   heads: int = 12, layers: int = 12):
     """tiles fp32 [n, 3, 224, 224], w_text [E, L] -> (rel [L, n, g, g], logits [n, L])."""
+    if len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")]) > 12:
+        return gradcam_tiles_deep(sd, tiles, w_text, positive_attn_only)          # ViT-L/14: several blocks enter the rollout
     pre = f"visual.transformer.resblocks.{layers - 1}."
     feat, last = vit_forward(sd, tiles, heads, layers)
     n, E = feat.shape
@@ -248,6 +250,57 @@ def gradcam_tiles(sd, tiles: torch.Tensor, w_text: torch.Tensor, positive_attn_o
     cam = cam.mean(dim=2)                                                      # [L, n, T]
     g = int(round(math.sqrt(cam.shape[-1] - 1)))
     return cam[:, :, 1:].reshape(L, n, g, g), logits
+
+
+def gradcam_tiles_deep(sd, tiles: torch.Tensor, w_text: torch.Tensor, positive_attn_only: bool, num_layers: int = 10):
+    """Multi-layer rollout for towers deeper than ViT-B (ViT-L/14: 24 blocks, heads = width / 64) - ClipGradcam.interpret restated with
+    torch autograd like the reference itself (clip_gradcam.py:70-132): per label, the gradient of sum_n logit[n, l] wrt the attention
+    probabilities of every block i > num_layers; cam = mean_h clamp(grad * probs); R <- R + cam R; returns R[:, :, 0, 1:].
+    tiles [n, 3, 224, 224], w_text [E, L] -> (rel [L, n, g, g], logits [n, L])."""
+    D = sd["visual.conv1.weight"].shape[0]
+    heads = D // 64
+    layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    with torch.enable_grad():
+        x = vit_embed(sd, tiles)
+        probs = []
+        for i in range(layers):
+            want = {}
+            pre = f"visual.transformer.resblocks.{i}."
+            if i <= num_layers:
+                x = _block(sd, pre, x, heads)
+                continue
+            # same block, with the softmax output exposed as a leaf-like node of the graph
+            n, T, _ = x.shape
+            dh = D // heads
+            h = _ln(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"])
+            q, k, v = F.linear(h, sd[pre + "attn.in_proj_weight"], sd[pre + "attn.in_proj_bias"]).chunk(3, dim=-1)
+            q = (q * (float(dh) ** -0.5)).view(n, T, heads, dh).transpose(1, 2)
+            k = k.view(n, T, heads, dh).transpose(1, 2)
+            v = v.view(n, T, heads, dh).transpose(1, 2)
+            p = F.softmax(q @ k.transpose(-1, -2), dim=-1)
+            if not p.requires_grad:
+                p.requires_grad_(True)
+            probs.append(p)
+            o = (p @ v).transpose(1, 2).reshape(n, T, D)
+            x1 = x + F.linear(o, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"])
+            h2 = _ln(x1, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"])
+            fc = F.linear(h2, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"])
+            x = x1 + F.linear(fc * torch.sigmoid(1.702 * fc), sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
+        feat = _ln(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]
+        fh = feat / feat.norm(dim=-1, keepdim=True)
+        logits = 100.0 * fh @ w_text
+        n, L, T = logits.shape[0], logits.shape[1], probs[0].shape[-1]
+        R = torch.eye(T)[None, None].repeat(L, n, 1, 1)
+        one_hot = logits.sum(dim=0)
+        for p in probs:
+            grad = torch.stack([torch.autograd.grad(one_hot[l], [p], retain_graph=True)[0].detach() for l in range(L)])      # [L, n, H, T, T]
+            cam = grad * p.detach()[None]
+            if positive_attn_only:
+                cam = cam.clamp(min=0)
+            cam = cam.mean(dim=2)
+            R = R + torch.matmul(cam, R)
+    g = int(round(math.sqrt(T - 1)))
+    return R[:, :, 0, 1:].reshape(L, n, g, g), logits.detach()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .vit import TextEncoder, VisionRollout
+from .vit import TextEncoder, VisionRollout, make_vision_engine
 
 KMAX = 24
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -126,7 +126,7 @@ class ClipWrapper:
             state_dict = ClipWrapper._load_checkpoint(clip_model_type)
         ClipWrapper.device = dev
         ClipWrapper.clip_model_type = clip_model_type
-        ClipWrapper.engine = VisionRollout(state_dict, chunk_tiles=chunk_tiles, max_labels=max_labels)
+        ClipWrapper.engine = make_vision_engine(state_dict, chunk_tiles=chunk_tiles, max_labels=max_labels)
         ClipWrapper.text = TextEncoder(state_dict) if "token_embedding.weight" in state_dict else None
         ClipWrapper._coeffs = _ResizeCoeffs(dev)
         # ToTensor (/255) then Normalize, all fp32 like torchvision, then rounded once to the GEMM operand type
@@ -140,9 +140,9 @@ class ClipWrapper:
     def _load_checkpoint(clip_model_type):
         if ClipWrapper.state_dict_provider is not None:
             return ClipWrapper.state_dict_provider(clip_model_type)
-        fname = {"ViT-B/32": "ViT-B-32.pt", "ViT-B/16": "ViT-B-16.pt"}.get(clip_model_type)
+        fname = {"ViT-B/32": "ViT-B-32.pt", "ViT-B/16": "ViT-B-16.pt", "ViT-L/14": "ViT-L-14.pt"}.get(clip_model_type)
         if fname is None:
-            raise RuntimeError(f"Model {clip_model_type} not found; available models = ['ViT-B/32', 'ViT-B/16']")
+            raise RuntimeError(f"Model {clip_model_type} not found; available models = ['ViT-B/32', 'ViT-B/16', 'ViT-L/14']")
         path = clip_model_type if os.path.isfile(clip_model_type) else os.path.expanduser(f"~/.cache/clip/{fname}")
         if not os.path.isfile(path):
             raise RuntimeError(f"CLIP checkpoint {path} not found (no network here): put the OpenAI checkpoint there or "

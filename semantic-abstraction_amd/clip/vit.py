@@ -117,7 +117,7 @@ def _interp_pos_emb(pe: torch.Tensor, T: int) -> torch.Tensor:
 
 
 class _BlockWeights:
-    def __init__(self, sd, pre, D, heads, dev, last=False):
+    def __init__(self, sd, pre, D, heads, dev, last=False, bwd=False):
         dh = D // heads
         w_in = sd[pre + "attn.in_proj_weight"].float().clone()
         b_in = sd[pre + "attn.in_proj_bias"].float().clone()
@@ -133,10 +133,23 @@ class _BlockWeights:
         self.ln2_w, self.ln2_b = f(sd[pre + "ln_2.weight"]), f(sd[pre + "ln_2.bias"])
         self.w_fc, self.b_fc = h(sd[pre + "mlp.c_fc.weight"]), f(sd[pre + "mlp.c_fc.bias"])
         self.w_pr, self.b_pr = h(sd[pre + "mlp.c_proj.weight"]), f(sd[pre + "mlp.c_proj.bias"])
-        if last:  # transposed copies: B operands ([N, K]) of the VJP GEMMs
+        if last or bwd:  # transposed copies: B operands ([N, K]) of the VJP GEMMs
             self.w_o_t = h(sd[pre + "attn.out_proj.weight"].float().t())
             self.w_fc_t = h(sd[pre + "mlp.c_fc.weight"].float().t())
             self.w_pr_t = h(sd[pre + "mlp.c_proj.weight"].float().t())
+        if bwd:          # d(ln_1 out) = dqkv . W_in (q rows carry the folded 1 / sqrt(dh), like the forward)
+            self.w_in_t = h(w_in.t())
+
+
+def make_vision_engine(state_dict, chunk_tiles: int = 2448, max_labels: int = 16):
+    """ViT-B (12 blocks: only the last one enters the rollout -> closed form) or a deeper tower (ViT-L/14: 13 blocks -> `VisionRolloutDeep`)."""
+    layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    if layers <= ROLLOUT_SKIP + 2:
+        return VisionRollout(state_dict, chunk_tiles=chunk_tiles, max_labels=max_labels)
+    return VisionRolloutDeep(state_dict, chunk_tiles=min(chunk_tiles, 16), max_labels=max_labels)
+
+
+ROLLOUT_SKIP = 10      # ClipGradcam(num_layers=10): blocks with index <= 10 do not enter the rollout (clip_gradcam.py:37, 85-87)
 
 
 class VisionRollout:
@@ -322,11 +335,180 @@ class VisionRollout:
         return rel, logits, feat
 
 
+class VisionRolloutDeep:
+    """Deep CLIP image tower (ViT-L/14: width 1024, 24 blocks, 16 heads, patch 14 -> 257 tokens) with the TRUE multi-layer rollout of
+    `ClipGradcam.interpret` (clip_gradcam.py:70-132): every block i > 10 contributes cam_i = mean_h clamp(grad_i * probs_i), which needs the
+    gradient of each label's logit wrt that block's attention probabilities for ALL query rows, i.e. a backward pass through blocks 23 ... 12.
+
+    No autograd: the forward keeps, for the 13 contributing blocks, the residual stream before / between the two sub-layers, the QKV
+    projections and the MLP pre-activations; the backward carries one residual gradient per (label, tile) sequence - L * n sequences batched
+    as GEMM rows - down the blocks with the LayerNorm / QuickGELU VJP kernels of the ViT-B path, fp16-MFMA GEMMs against transposed weights
+    and the attention-backward kernels of csrc/vitl.hip, which also accumulate the rollout update r <- r + r cam_i of the row vector that is
+    all the result needs (R[0, 1:]).  The per-sequence gradient is renormalised by a power of two at every block (the chain is linear, cam is
+    positively homogeneous) so the fp16 GEMM operands stay in range; the factor is divided back out inside the rollout update.
+    Same engine interface as `VisionRollout` (embed / trunk / head / rollout / gradcam_tiles)."""
+
+    def __init__(self, state_dict, chunk_tiles: int = 16, max_labels: int = 16):
+        dev = self.dev = _lib.require_gpu()
+        sd = state_dict
+        w = sd["visual.conv1.weight"]
+        self.D, self.p = int(w.shape[0]), int(w.shape[-1])
+        self.g = 224 // self.p
+        self.T = self.g * self.g + 1
+        self.H = self.D // 64
+        self.layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        self.first_roll = ROLLOUT_SKIP + 1
+        assert self.layers > self.first_roll + 1 and self.T <= 288
+        self.E = int(sd["visual.proj"].shape[1])
+        h = lambda t: t.to(dev, torch.float16).contiguous()
+        f = lambda t: t.to(dev, torch.float32).contiguous()
+        self.Kp = 3 * self.p * self.p
+        self.Kpad = (self.Kp + 63) // 64 * 64                                # GEMM K granularity: 588 -> 640 zero-padded columns
+        wp = torch.zeros(self.D, self.Kpad)
+        wp[:, : self.Kp] = w.float().reshape(self.D, -1)
+        self.w_patch = h(wp)
+        pe = sd["visual.positional_embedding"].float()
+        self.pos = f(_interp_pos_emb(pe, self.T) if self.T != 50 else pe)
+        self.cls = f(sd["visual.class_embedding"])
+        self.ln_pre = (f(sd["visual.ln_pre.weight"]), f(sd["visual.ln_pre.bias"]))
+        self.ln_post = (f(sd["visual.ln_post.weight"]), f(sd["visual.ln_post.bias"]))
+        self.proj = h(sd["visual.proj"])
+        self.proj_t = h(sd["visual.proj"].float().t())
+        self.blocks = [_BlockWeights(sd, f"visual.transformer.resblocks.{i}.", self.D, self.H, dev, bwd=(i >= self.first_roll))
+                       for i in range(self.layers)]
+        self.chunk = int(chunk_tiles)
+        self.max_labels = int(max_labels)
+        self._wss, self._cap = {}, {}
+        self.slot = 0
+
+    def _reserve(self, n: int):
+        if self._cap.get(self.slot, 0) < n:
+            self._cap[self.slot] = int(n)
+            self._wss.pop(self.slot, None)
+
+    def _workspace(self):
+        if self.slot not in self._wss:
+            n, T, D, Lm, E, H = self._cap.get(self.slot) or self.chunk, self.T, self.D, self.max_labels, self.E, self.H
+            dev = self.dev
+            e16 = lambda *s: torch.empty(*s, dtype=torch.float16, device=dev)
+            e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            R = Lm * n
+            saved = {b: dict(x_in=e32(n * T, D), x_mid=e32(n * T, D), qkv=e16(n * T, 3 * D), fc=e32(n * T, 4 * D))
+                     for b in range(self.first_roll, self.layers)}
+            self._wss[self.slot] = dict(
+                x=e32(n * T, D), h=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D), saved=saved,
+                xcls=e32(n, D), yc=e16(n, D), feat=e32(n, E), logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dxc=e32(R, D),
+                g32=e32(R * T, D), g16=e16(R * T, D), dact=e32(R * T, 4 * D), dfc=e16(R * T, 4 * D), dh=e32(R * T, D), gmid32=e32(R * T, D),
+                gmid16=e16(R * T, D), dO=e16(R * T, D), dqkv=e16(R * T, 3 * D), stats=e32(R * H * T, 4), rvec=e32(R, T), cacc=e32(R, T),
+                gscale=e32(R))
+        return self._wss[self.slot]
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def embed(self, patches: torch.Tensor, n: int):
+        assert n <= self.chunk
+        self._reserve(n)
+        ws = self._workspace()
+        T, D, G = self.T, self.D, self.g * self.g
+        x = ws["x"]
+        if self.Kpad != self.Kp:                                             # zero-padded copy (data movement only): rows become 16-byte aligned
+            pp = torch.zeros(n * G, self.Kpad, dtype=torch.float16, device=self.dev)
+            pp[:, : self.Kp] = patches[: n * G]
+            patches = pp
+        gemm(patches, self.w_patch, x, None, n * G, D, self.Kpad, self.Kpad, self.Kpad, D, EPI_ROWMAP, addend=self.pos, rowmap=(G, T, 1))
+        _lib.call("semabs_embed_finish", _lib.ptr(x), _lib.ptr(self.cls), _lib.ptr(self.pos), n, T, D, _lib.stream())
+        layernorm(x, *self.ln_pre, x, n * T, D, out_f32=True)
+
+    def trunk(self, n: int):
+        ws = self._workspace()
+        T, D, H = self.T, self.D, self.H
+        M = n * T
+        x, h, att, hid = ws["x"], ws["h"], ws["att"], ws["hid"]
+        st = _lib.stream()
+        for i, b in enumerate(self.blocks):
+            sv = ws["saved"].get(i)
+            qkv = ws["qkv"] if sv is None else sv["qkv"]
+            if sv is not None:
+                sv["x_in"][:M].copy_(x[:M])
+            layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
+            gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16)
+            _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, 0, st)
+            gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32)
+            if sv is not None:
+                sv["x_mid"][:M].copy_(x[:M])
+            layernorm(x, b.ln2_w, b.ln2_b, h, M, D)
+            if sv is None:
+                gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
+            else:                                                            # keep the pre-activation: the QuickGELU VJP needs it
+                gemm(h, b.w_fc, sv["fc"], b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_F32)
+                _lib.call("semabs_quickgelu", _lib.ptr(sv["fc"]), _lib.ptr(hid), M * 4 * D, st)
+            gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
+
+    def head(self, n: int):
+        ws = self._workspace()
+        T, D, E = self.T, self.D, self.E
+        _lib.call("semabs_rows_gather", _lib.ptr(ws["x"]), _lib.ptr(ws["xcls"]), n, D, T * D, 0, _lib.stream())
+        layernorm(ws["xcls"], *self.ln_post, ws["yc"], n, D)
+        gemm(ws["yc"], self.proj_t, ws["feat"], None, n, E, D, D, D, E, EPI_F32)
+
+    # ---- backward + rollout ------------------------------------------------------------------------
+    def rollout(self, n: int, w_text: torch.Tensor, positive_attn_only: bool, rel_out: torch.Tensor, tile0: int):
+        ws = self._workspace()
+        T, D, H, E = self.T, self.D, self.H, self.E
+        L = int(w_text.shape[0])
+        assert L <= self.max_labels
+        R = L * n
+        M = R * T
+        st = _lib.stream()
+        _lib.call("semabs_logit_grad", _lib.ptr(ws["feat"]), _lib.ptr(w_text), n, L, E, _lib.ptr(ws["logits"]), _lib.ptr(ws["dfeat"]),
+                  _lib.ptr(ws["scale"]), st)
+        gemm(ws["dfeat"], self.proj, ws["dy"], None, R, D, E, E, E, D, EPI_F32)
+        _lib.call("semabs_ln_bwd", _lib.ptr(ws["xcls"]), _lib.ptr(self.ln_post[0]), _lib.ptr(ws["dy"]), None, _lib.ptr(ws["dxc"]), None,
+                  R, D, n, D, 1e-5, st)
+        g32, g16, gscale, rvec, cacc = ws["g32"], ws["g16"], ws["gscale"], ws["rvec"], ws["cacc"]
+        g32[:M].zero_()
+        g32[:M].view(R, T, D)[:, 0, :] = ws["dxc"][:R]                       # only the class token of the last block reaches the feature
+        gscale[:R].copy_(ws["scale"][:R])
+        _lib.call("semabs_seq_rescale", _lib.ptr(g32), _lib.ptr(g16), _lib.ptr(gscale), R, T * D, st)
+        rvec[:R].zero_()
+        rvec[:R, 0] = 1.0                                                    # row 0 of R = I
+        cacc[:R].zero_()
+        NT = n * T
+        for i in range(self.layers - 1, self.first_roll - 1, -1):
+            b, sv = self.blocks[i], ws["saved"][i]
+            # MLP sub-layer: g_mid = g_out + LN2^T( W_fc^T( gelu'(fc) * (W_pr^T g_out) ) )
+            gemm(g16, b.w_pr_t, ws["dact"], None, M, 4 * D, D, D, D, 4 * D, EPI_F32)
+            _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(sv["fc"]), _lib.ptr(ws["dfc"]), M, 4 * D, NT, st)
+            gemm(ws["dfc"], b.w_fc_t, ws["dh"], None, M, D, 4 * D, 4 * D, 4 * D, D, EPI_F32)
+            _lib.call("semabs_ln_bwd", _lib.ptr(sv["x_mid"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh"]), _lib.ptr(g32), _lib.ptr(ws["gmid32"]),
+                      _lib.ptr(ws["gmid16"]), M, D, NT, D, 1e-5, st)
+            # attention sub-layer: dO = g_mid W_o, then (dQ | dK | dV) and this block's rollout update
+            gemm(ws["gmid16"], b.w_o_t, ws["dO"], None, M, D, D, D, D, D, EPI_F16)
+            last = i == self.first_roll
+            _lib.call("semabs_attention_bwd", _lib.ptr(sv["qkv"]), _lib.ptr(ws["dO"]), _lib.ptr(rvec), _lib.ptr(gscale), _lib.ptr(cacc),
+                      _lib.ptr(ws["stats"]), None if last else _lib.ptr(ws["dqkv"]), n, L, T, H, 64, int(positive_attn_only), st)
+            _lib.call("semabs_rollout_step", _lib.ptr(rvec), _lib.ptr(cacc), R * T, st)
+            if not last:
+                gemm(ws["dqkv"], b.w_in_t, ws["dh"], None, M, D, 3 * D, 3 * D, 3 * D, D, EPI_F32)
+                _lib.call("semabs_ln_bwd", _lib.ptr(sv["x_in"]), _lib.ptr(b.ln1_w), _lib.ptr(ws["dh"]), _lib.ptr(ws["gmid32"]), _lib.ptr(g32),
+                          _lib.ptr(g16), M, D, NT, D, 1e-5, st)
+                _lib.call("semabs_seq_rescale", _lib.ptr(g32), _lib.ptr(g16), _lib.ptr(gscale), R, T * D, st)
+        rel_out[:L, tile0:tile0 + n] = rvec[:R].view(L, n, T)[:, :, 1:].reshape(L, n, self.g, self.g)
+
+    def gradcam_patches(self, patches, n, w_text, positive_attn_only, rel_out, tile0):
+        assert n <= self.chunk
+        self.embed(patches, n)
+        self.trunk(n)
+        self.head(n)
+        self.rollout(n, w_text, positive_attn_only, rel_out, tile0)
+
+    gradcam_tiles = VisionRollout.gradcam_tiles
+
+
 class TextEncoder:
     """CLIP text tower on the same kernels (model_explainability.py:469-482) -> zero-shot weights
     (clip_gradcam.py:12-27: per-template L2 normalise, mean over templates, not re-normalised)."""
 
-    def __init__(self, state_dict, heads: int = 8):
+    def __init__(self, state_dict, heads: int | None = None):
         dev = self.dev = _lib.require_gpu()
         sd = state_dict
         f = lambda t: t.to(dev, torch.float32).contiguous()
@@ -334,7 +516,7 @@ class TextEncoder:
         self.pos = f(sd["positional_embedding"])
         self.D = int(self.emb.shape[1])
         self.ctx = int(self.pos.shape[0])
-        self.H = heads
+        self.H = int(heads) if heads else self.D // 64              # transformer_heads = transformer_width // 64 (model_explainability.py:593)
         self.layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.")})
         self.blocks = [_BlockWeights(sd, f"transformer.resblocks.{i}.", self.D, heads, dev) for i in range(self.layers)]
         self.ln_final = (f(sd["ln_final.weight"]), f(sd["ln_final.bias"]))

@@ -304,7 +304,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved
     if (n_seq == 0) return SEMABS_OK;
     SEMABS_REQUIRE(qkv && out && n_seq > 0 && T > 0 && H > 0, "semabs_attention: bad args");
     SEMABS_REQUIRE(head_dim == 64, "semabs_attention: head_dim must be 64");
-    SEMABS_REQUIRE(T <= 224 && ld % 8 == 0, "semabs_attention: T must be <= 224");
+    SEMABS_REQUIRE(T <= 288 && ld % 8 == 0, "semabs_attention: T must be <= 288");
     const int D = H * 64;
     const int nkb = (T + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
@@ -323,7 +323,9 @@ extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved
         case 4: ATT_CASE(4) break;
         case 5: ATT_CASE(5) break;
         case 6: ATT_CASE(6) break;
-        default: ATT_CASE(7) break;
+        case 7: ATT_CASE(7) break;
+        case 8: ATT_CASE(8) break;
+        default: ATT_CASE(9) break;                          // T = 257: ViT-L/14
     }
 #undef ATT_CASE
 #undef ATT_LAUNCH

@@ -22,6 +22,8 @@ CLIP_ARCHS = {
     # name: (patch, vision_width, vision_layers, vision_heads, embed_dim, text_width, text_heads, text_layers)
     "ViT-B/32": dict(patch=32, width=768, layers=12, heads=12, embed=512, twidth=512, theads=8, tlayers=12),
     "ViT-B/16": dict(patch=16, width=768, layers=12, heads=12, embed=512, twidth=512, theads=8, tlayers=12),
+    # clip_gradcam.py:51-56 also lists ViT-L/14: 24 blocks of which 13 (i > 10) enter the rollout
+    "ViT-L/14": dict(patch=14, width=1024, layers=24, heads=16, embed=768, twidth=768, theads=12, tlayers=12),
 }
 CONTEXT_LENGTH = 77
 VOCAB_SIZE = 49408

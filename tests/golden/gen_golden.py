@@ -826,3 +826,34 @@ if __name__ == "__main__" and "g18" in sys.argv[1:]:
     g18_process_batch_ovssc()
 if __name__ == "__main__" and "g19" in sys.argv[1:]:
     g19_relevancy_storage()
+
+
+# ---- appended (round 2): f4 - ViT-L/14, the true 13-layer rollout, through the unmodified reference ------------------------------
+def g21_vit_l14():
+    """ClipGradcam.forward / interpret of the reference (clip_gradcam.py:58-132) for "ViT-L/14" (24 blocks, blocks 11..23 enter the rollout,
+    16 heads, 257 tokens) on 2 tiles x 3 labels, positive_attn_only True / False, seeded random-init weights of that architecture."""
+    rc = refimport.load_reference_clip("ViT-L/14", seed=0)
+    gc = rc.ClipWrapper.clip_gradcam
+    assert gc.num_res_attn_blocks == 16 and len(list(gc.model.visual.transformer.resblocks.children())) == 24
+    labels = ["chair", "table", "lamp"]
+    gc.templates = [DEFAULT_PROMPT]
+    gc.set_classes(labels)
+    w_text = torch.cat([gc.class_to_language_feature[c] for c in labels], dim=1)
+    tiles = _tiles_from_seed(rc, 2, seed=7)
+    out = {"w_text": w_text.numpy(), "tiles_sum": np.float64(tiles.double().sum().item())}
+    with torch.no_grad():
+        out["feat"] = gc.model.encode_image(tiles).numpy()
+    for pos in (True, False):
+        gc.positive_attn_only = pos
+        t = time.time()
+        rel = gc(x=tiles, o=labels)
+        print(f"    ViT-L/14 interpret pos={pos}: {time.time() - t:.1f}s  max|rel| {rel.abs().max():.4g}", flush=True)
+        out[f"rel_pos{int(pos)}"] = rel.detach().numpy()
+    feats = gc.model.encode_image(tiles)
+    feats = feats / feats.norm(dim=-1, keepdim=True)
+    out["logits"] = (100.0 * feats @ w_text).detach().numpy()
+    save("g21_vit_l14", **out)
+
+
+if __name__ == "__main__" and "g21" in sys.argv[1:]:
+    g21_vit_l14()
