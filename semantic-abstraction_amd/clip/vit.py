@@ -518,7 +518,7 @@ class TextEncoder:
         self.ctx = int(self.pos.shape[0])
         self.H = int(heads) if heads else self.D // 64              # transformer_heads = transformer_width // 64 (model_explainability.py:593)
         self.layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.")})
-        self.blocks = [_BlockWeights(sd, f"transformer.resblocks.{i}.", self.D, heads, dev) for i in range(self.layers)]
+        self.blocks = [_BlockWeights(sd, f"transformer.resblocks.{i}.", self.D, self.H, dev) for i in range(self.layers)]
         self.ln_final = (f(sd["ln_final.weight"]), f(sd["ln_final.bias"]))
         self.proj_t = sd["text_projection"].float().t().to(dev, torch.float16).contiguous()     # [E, D]
         self.E = int(self.proj_t.shape[0])

@@ -248,22 +248,25 @@ struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
-static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0;
+static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0, g_prefetch = 1;
 static unsigned long long* g_trace = nullptr;
 extern "C" int semabs_gemm_tune(int key, long long value) {
     switch (key) {
         case 0: g_force_cfg = (int)value; break;     // alternative ring-kernel tile configurations (see launch())
         case 1: g_group_m = value < 1 ? 1 : (int)value; break;
         case 2: g_ablate = (int)value; break;
+        case 3: g_prefetch = (int)value; break;       // 1 = fragment reads in the MFMA shadow (production), 0 = read block before the barrier
         case 4: g_trace = (unsigned long long*)value; break;
         default: return SEMABS_EINVAL;
     }
     return SEMABS_OK;
 }
 #define GEMM_GROUP_M g_group_m
+#define GEMM_PREFETCH g_prefetch
 #define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).trace = g_trace; } while (0)
 #else
 #define GEMM_GROUP_M 8
+#define GEMM_PREFETCH 1
 #define GEMM_TUNE_ARGS(g) do { } while (0)
 #endif
 
@@ -330,7 +333,7 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 
-template <int EPI>
+template <int EPI, bool PF>
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
@@ -403,6 +406,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     }
     f32x4 acc[2][4][2][2];                                  // [A half][row tile][B half][col tile]
     f16x8 fa[4][2], fb[2][2][2];                            // fa[row tile][kk] (A0 then A1 reuse it); fb[B half][col tile][kk]
+    // PF (fragment prefetch in the shadow of the MFMAs): the LDS reads of the NEXT phase are issued inside the current phase's MFMA block -
+    // A1 then needs its own registers (it is read while A0 is multiplied) and B0 of the next K tile a second set (read during the last
+    // phase, which still multiplies this tile's B0)
+    f16x8 fa1[PF ? 4 : 1][2], fb0n[PF ? 2 : 1][2];
 
     auto read_a = [&](int h, int par) {
         const char* base = smem + par * BUFSZ + (h ? OFF_A1 : OFF_A0);
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>();                       \
         __builtin_amdgcn_sched_barrier(0);                                       \
         __builtin_amdgcn_s_barrier();                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0); the builtin (not inline asm) so that the compiler's own counter model sees it */ \
         __builtin_amdgcn_sched_barrier(0);                                       \
     } while (0)
 #define GEMM8_END()                                                              \
@@ -591,6 +598,48 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         }
     };
 
+    auto read_a1 = [&](int par) {                            // PF: A1 -> its own registers
+        const char* base = smem + par * BUFSZ + OFF_A1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa1[PF ? i : 0][kk] = *reinterpret_cast<const f16x8*>(base + i * 2048 + offA[kk]);
+    };
+    auto read_b0n = [&](int par) {                           // PF: B0 of the next K tile -> the spare set
+        const char* base = smem + par * BUFSZ + OFF_B0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb0n[PF ? j : 0][kk] = *reinterpret_cast<const f16x8*>(base + offB[j][kk]);
+    };
+    auto mma_a1 = [&](int hb) {                              // PF: quadrants (A1, *) from fa1
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[hb][j][kk], fa1[PF ? i : 0][kk], acc[1][i][hb][j], 0, 0, 0);
+    };
+    auto mma_a0 = [&](int hb) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[hb][j][kk], fa[i][kk], acc[0][i][hb][j], 0, 0, 0);
+    };
+    // one DS read slotted after every MFMA for the first `nread` MFMAs of a 16-MFMA block, the rest of the MFMAs back to back
+#define GEMM8_INTERLEAVE(nread)                                                  \
+    do {                                                                         \
+        _Pragma("unroll") for (int q_ = 0; q_ < (nread); ++q_) {                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+        }                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - (nread), 0);            \
+    } while (0)
+
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
     long m0; int n0;
     tile_of(blockIdx.x, m0, n0);
@@ -608,9 +657,63 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     if (g.trace) t_start = __builtin_amdgcn_s_memrealtime();
 #endif
     prologue();
-    wait_vmcnt<8>();                                        // A0(0), B0(0) have landed (this wave's share)
+    if constexpr (PF) stage_b(1, 1);                        // the prefetching loop stages one phase earlier (below)
+    wait_vmcnt<8>();                                        // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();              // skew the second wave row by one barrier
+    if constexpr (PF) {
+        // Fragment reads one phase ahead, inside the MFMA blocks (see the register comment above).  What is read where, K tile t:
+        //   phase 0 (A0, B0): B1(t)      phase 1 (A0, B1): A1(t)      phase 2 (A1, B1): A0(t + 1)      phase 3 (A1, B0): B0(t + 1) -> spare set
+        // Reading a half-tile one phase earlier means the OTHER wave row (one barrier behind) must have retired its DMA share of it one
+        // phase earlier too, so the staging schedule moves one phase earlier as well (the slots are free by then - their last reads also
+        // moved up).  Global phase numbers P = 4 t + phase; reads at P need stages at <= P - 5 (vmcnt(8) leaves the 4 newest stage calls in
+        // flight, and the reader's barrier pairs with the other row's previous phase):
+        //   stages:  A1(t + 1) at 4t      A0(t + 2) at 4t + 1      B0(t + 2) at 4t + 2      B1(t + 2) at 4t + 3
+        //   reads :  B1(t) at 4t [staged 4t - 5]   A1(t) at 4t + 1 [4t - 4]   A0(t + 1) at 4t + 2 [4t - 3]   B0(t + 1) at 4t + 3 [4t - 2]
+        // and every slot is re-staged >= 2 phases after its last read (A1: read 4t - 3, staged 4t; A0: 4t - 2 / 4t + 1; B0: 4t - 1 / 4t + 2;
+        // B1: 4t / 4t + 3).  The prologue therefore also stages B1(1) (seven half-tiles, the first three retired by vmcnt(8)).
+        read_b(0, 0); read_a(0, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int t = 0; t < nk; ++t) {
+            const int par = t & 1;
+            const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+            if (s1) stage_a(1, t + 1);
+            GEMM8_SYNC(s1);
+            __builtin_amdgcn_s_setprio(1);
+            read_b(1, par); mma_a0(0);
+            GEMM8_INTERLEAVE(4);
+            __builtin_amdgcn_s_setprio(0);
+            GEMM8_END();
+            if (s2) stage_a(0, t + 2);
+            GEMM8_SYNC(s2);
+            __builtin_amdgcn_s_setprio(1);
+            read_a1(par); mma_a0(1);
+            GEMM8_INTERLEAVE(8);
+            __builtin_amdgcn_s_setprio(0);
+            GEMM8_END();
+            if (s2) stage_b(0, t + 2);
+            GEMM8_SYNC(s2);
+            __builtin_amdgcn_s_setprio(1);
+            read_a(0, par ^ 1);                      // (last K tile: reads a stale slot, never used - keeps the block branch-free)
+            mma_a1(1);
+            GEMM8_INTERLEAVE(8);
+            __builtin_amdgcn_s_setprio(0);
+            GEMM8_END();
+            if (s2) stage_b(1, t + 2);
+            GEMM8_SYNC(s2);
+            __builtin_amdgcn_s_setprio(1);
+            read_b0n(par ^ 1);
+            mma_a1(0);
+            GEMM8_INTERLEAVE(4);
+            __builtin_amdgcn_s_setprio(0);
+            GEMM8_END();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb[0][j][kk] = fb0n[PF ? j : 0][kk];
+        }
+    } else
     for (int t = 0; t < nk; ++t) {
         const int par = t & 1;
         const bool s1 = t + 1 < nk && !GEMM_ABL(1), s2 = t + 2 < nk && !GEMM_ABL(1);
@@ -662,13 +765,18 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #endif
 #undef GEMM8_SYNC
 #undef GEMM8_END
+#undef GEMM8_INTERLEAVE
 }
 
 template <int EPI>
 static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     constexpr int LDS = 2 * 4 * 16384;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
     g.n_tiles_n = g.N / 256;
     const long mt = (g.M + 255) / 256;
     g.n_tiles_m = (int)mt;
@@ -676,7 +784,8 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     GEMM_TUNE_ARGS(g);
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
-    gemm_dispatch(k_gemm8<EPI>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
+    if (GEMM_PREFETCH) gemm_dispatch(k_gemm8<EPI, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
+    else gemm_dispatch(k_gemm8<EPI, false>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -55,7 +55,10 @@ what = sys.argv[1:] or ["base", "ablate", "trace"]
 log = {}
 if "base" in what:
     for rep in range(2):
-        log[f"base_{rep}"] = line(f"baseline (rep {rep})")
+        for pf in (1, 0):
+            tune(3, pf)
+            log[f"base_pf{pf}_{rep}"] = line(f"fragment prefetch {pf} (rep {rep})")
+    tune(3, 1)
 if "ablate" in what:
     for ab, label in [(8, "no epilogue"), (1, "no in-loop DMA"), (2, "no in-loop ds_read"), (3, "MFMA + barriers"), (11, "MFMA + barriers, no epilogue"), (9, "no DMA, no epilogue"), (10, "no ds_read, no epilogue")]:
         tune(2, ab)
