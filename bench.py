@@ -70,12 +70,13 @@ def cpu_baseline(arch, n_labels, tiles_sample=64):
     from semabs_amd.weights import make_clip_state_dict, make_semabs3d_state_dict
     sd = make_clip_state_dict(arch, 0, text_tower=False)
     # thread count: all logical CPUs is NOT the fastest setting for torch-CPU at these sizes (256 threads on the 2 x 64-core host ran the ViT
-    # 15 x slower than 64) - calibrate on a 4-tile forward and keep the fastest of {all, 1/2, 1/4, 1/8 of the logical CPUs, >= 8}
+    # 15 x slower than 64) - calibrate on one batch of 16 tiles (the oracle runs batches of 32) and keep the fastest of {1/2 (= the physical
+    # cores), 1/4, 1/8, 1/16 of the logical CPUs, >= 8}
     ncpu = os.cpu_count() or 1
-    cal_tiles = torch.zeros(4, 3, 224, 224)
+    cal_tiles = torch.zeros(16, 3, 224, 224)
     cal_w = torch.zeros(512, n_labels)
     best = (None, float("inf"))
-    for t in sorted({max(8, ncpu // d) for d in (1, 2, 4, 8)} | {min(ncpu, 8)}):
+    for t in sorted({max(8, ncpu // d) for d in (2, 4, 8, 16)} | {min(ncpu, 8)}):
         if t > ncpu:
             continue
         torch.set_num_threads(t)

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     // between the read / DMA-issue block and the MFMA block of a phase
 #define GEMM8_SYNC(staged)                                                       \
     do {                                                                         \
-        if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>();                       \
+        if (!GEMM_ABL(4)) { if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>(); } /* tuning: bit 2 = no DMA waits (wrong results) */ \
         __builtin_amdgcn_sched_barrier(0);                                       \
         __builtin_amdgcn_s_barrier();                                            \
         __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0); the builtin (not inline asm) so that the compiler's own counter model sees it */ \
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         for (int t = 0; t < nk; ++t) {
             const int par = t & 1;
-            const bool s1 = t + 1 < nk, s2 = t + 2 < nk;
+            const bool s1 = t + 1 < nk && !GEMM_ABL(1), s2 = t + 2 < nk && !GEMM_ABL(1);
             if (s1) stage_a(1, t + 1);
             GEMM8_SYNC(s1);
             __builtin_amdgcn_s_setprio(1);

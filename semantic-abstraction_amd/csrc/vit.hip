@@ -175,23 +175,43 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
     const int seq = blockIdx.x / H, h = blockIdx.x % H;
     const f16* base = qkv + (long)seq * T * ld + h * 64;
 
-    for (int c = tid; c < TP * 8; c += NTHR) {
-        int row = c >> 3, kc = c & 7;
-        f16x8 kv, vv;
-        if (row < T) {
-            kv = *reinterpret_cast<const f16x8*>(base + (long)row * ld + D + kc * 8);
-            vv = *reinterpret_cast<const f16x8*>(base + (long)row * ld + 2 * D + kc * 8);
+    // Staging: ALL of a thread's K / V rows are requested before the first LDS store (the loop used to alternate load - store, i.e. one
+    // ~1-2 us HBM round trip per iteration, 4-7 of them in a row: SQ_WAIT_ANY was 48 % of the wave cycles), and the query fragments of the
+    // wave's first block are requested before the barrier as well.
+    constexpr int NIT_ST = (TP * 8 + NTHR - 1) / NTHR;
+    f16x8 kvs[NIT_ST], vvs[NIT_ST];
+#pragma unroll
+    for (int it = 0; it < NIT_ST; ++it) {
+        const int c = tid + it * NTHR;
+        const int row = c >> 3, kc = c & 7;
+        if (c < TP * 8 && row < T) {
+            kvs[it] = *reinterpret_cast<const f16x8*>(base + (long)row * ld + D + kc * 8);
+            vvs[it] = *reinterpret_cast<const f16x8*>(base + (long)row * ld + 2 * D + kc * 8);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = (f16)0.f; vv[e] = (f16)0.f; }
+            for (int e = 0; e < 8; ++e) { kvs[it][e] = (f16)0.f; vvs[it][e] = (f16)0.f; }
         }
-        *reinterpret_cast<f16x8*>(sK + kswz(row, kc)) = kv;
+    }
+    const int ql = lane & 31, hi = lane >> 5;
+    f16x8 fq0[4];
+    {
+        const int q = wid * 32 + ql;
+        const int qc = q < T ? q : T - 1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sV[(kc * 8 + e) * VS + row] = vv[e];
+        for (int ks = 0; ks < 4; ++ks) fq0[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT_ST; ++it) {
+        const int c = tid + it * NTHR;
+        const int row = c >> 3, kc = c & 7;
+        if (c < TP * 8) {
+            *reinterpret_cast<f16x8*>(sK + kswz(row, kc)) = kvs[it];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sV[(kc * 8 + e) * VS + row] = vvs[it][e];
+        }
     }
     __syncthreads();
 
-    const int ql = lane & 31, hi = lane >> 5;
     int koff[4];                                   // swizzled K-row offsets: row-block independent
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) koff[ks] = kswz(ql, ks * 2 + hi);
@@ -200,8 +220,13 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         const int q = qb * 32 + ql;
         const int qc = q < T ? q : T - 1;
         f16x8 fq[4];
+        if (qb == wid) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+            for (int ks = 0; ks < 4; ++ks) fq[ks] = fq0[ks];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+        }
         // One score block (4 MFMAs) at a time instead of keeping all NKB blocks in registers (112 VGPRs at T = 197): exponentiate, feed the
         // un-normalised probabilities straight into P.V; O is scaled by 1 / sum at the end.  ~100 VGPRs -> two workgroups per CU.
         auto scores = [&](int kb, f32x16& sc, float init) {      // init = -(reference maximum): the MFMA accumulator does the subtraction
