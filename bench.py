@@ -297,7 +297,7 @@ def main():
         # HBM bytes per GEMM launch: PMC counters cannot be read from inside the process that is being timed (rocprofv3 owns them and
         # serialises the kernels), so this figure is IMPORTED from the committed counter run of this same command and labelled as such
         traffic, traffic_src = None, None
-        for name in ("r02_gemm_pmc.json", "gemm_pmc.json"):
+        for name in ("r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:

@@ -53,6 +53,30 @@ def line(label):
 
 what = sys.argv[1:] or ["base", "ablate", "trace"]
 log = {}
+if "table" in what:
+    # per-shape table of the production configuration + the vendor library's PLAIN fp16 GEMM (torch.matmul -> hipBLASLt, no bias / GELU /
+    # residual) as calibration of what a large fp16 GEMM reaches on this box at these shapes
+    tab = {}
+    for name, n, k, epi in SHAPES:
+        ms, tf = time_shape(n, k, epi)
+        A, B, _, _ = operands(n, k, epi)
+        Bt = B.t().contiguous()
+        for _ in range(2):
+            torch.matmul(A, Bt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(6):
+            torch.matmul(A, Bt)
+        e1.record(); torch.cuda.synchronize()
+        vms = e0.elapsed_time(e1) / 6
+        bytes_alg = M * k * 2 + n * k * 2 + M * n * (2 if epi in (0, 1) else (8 if epi == 2 else 4))
+        tab[name] = dict(M=M, N=n, K=k, epilogue=epi, us=round(ms * 1e3, 1), tflops=round(tf, 1), vendor_plain_us=round(vms * 1e3, 1),
+                         vendor_plain_tflops=round(2.0 * M * n * k / vms / 1e9, 1), algorithmic_bytes=bytes_alg,
+                         hbm_floor_us=round(bytes_alg / 8e6, 1), mfma_floor_us=round(2.0 * M * n * k / 2.5e9, 1))
+        print(name, tab[name], flush=True)
+        del Bt
+    json.dump(tab, open(os.path.join(OUT, "shapes.json"), "w"), indent=1)
+    what = [w for w in what if w != "table"]
 if "base" in what:
     for rep in range(2):
         for pf in (1, 0):
