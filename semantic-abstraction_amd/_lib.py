@@ -110,7 +110,7 @@ SIGNATURES = {
 }
 
 
-TUNING_SIGNATURES = {"semabs_gemm_tune": [I, C.c_longlong], "semabs_conv_tune": [I]}
+TUNING_SIGNATURES = {"semabs_gemm_tune": [I, C.c_longlong], "semabs_conv_tune": [I, C.c_longlong]}
 
 
 def lib():

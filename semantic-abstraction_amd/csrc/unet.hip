@@ -453,7 +453,8 @@ struct ConvArgs {
                                 // bias / residual / ReLU are then applied by k_conv_finish
     signed char td0[28], td1[28], td2[28];   // tap offsets: input coordinate = m + td  (conv pad-1: -1..1; convT: 0/+1)
     double* stats;              // optional (k_conv16_lds): fp64 [B, 8, 2] sum / sum of squares of the OUTPUT per GroupNorm group, accumulated
-    int ablate;                 // tuning only (k_conv16_lds, tools/conv16_ablate.py): 1 producers only, 2 consumers only, 4 consumers without epilogue
+    int ablate;                 // tuning only (k_conv16_lds): 1 producers only, 2 consumers only, 4 consumers without epilogue
+    long long* trace;           // tuning only (k_conv_brick, tools/conv_probe.py): [workgroup][8] s_memtime stamps of wave 0
 };
 
 template <bool F32>
@@ -950,8 +951,15 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
 // the generic gather kernel even where a brick kernel exists - the per-call cross-check used by tests/ (no process-global switch).
 #define SEMABS_CONV_GENERIC 256
 #ifdef SEMABS_TUNING
-static int g_conv16_ablate = 0;      // tools/conv16_ablate.py, tuning build only (libsemabs_hip_tune.so)
-extern "C" int semabs_conv_tune(int ablate) { g_conv16_ablate = ablate & 7; return SEMABS_OK; }
+static int g_conv16_ablate = 0;      // tuning build only (libsemabs_hip_tune.so)
+static long long* g_conv_trace = nullptr;
+static int g_brick_persist = 0;      // k_conv_brick: persistent-workgroup variant (measured slower, kept in the tuning build for A/B)
+extern "C" int semabs_conv_tune(int key, long long value) {
+    if (key == 0) g_conv16_ablate = (int)value & 7;
+    else if (key == 1) g_conv_trace = reinterpret_cast<long long*>(value);
+    else if (key == 2) g_brick_persist = (int)value;
+    return SEMABS_OK;
+}
 #endif
 
 static int semabs_num_cus() {
@@ -994,11 +1002,17 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
 // fragment read cover all 64 banks) and runs the 27 taps of that channel chunk out of LDS.  A wave keeps 4 rows x NB x 16 output
 // channels in registers; the weights (too many for registers) stream from L2 once per k-step and wave.
 // -------------------------------------------------------------------------------------------------
-template <bool F32, int CW, int NB, bool ONE>             // CW = channels staged at a time (16: Cin == 16, else 32); ONE: Cin == CW
-__global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
+template <bool F32, int CW, int NB, bool ONE, bool PERSIST>   // CW = channels staged at a time (16 or 32); ONE: Cin == CW (compile-time offsets)
+__global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
     constexpr int T0 = 4, H0 = T0 + 2, HALO = H0 * C16_H1 * C16_H2, NTHR = 512;
     constexpr int CPV = CW / 8;                             // 16-byte chunks per staged voxel
     constexpr int NSTEPS = CW == 32 ? 27 : 14;
+    // Round 2: PERSISTENT workgroups (one or two per CU, tiles t = blockIdx.x, + gridDim.x, ...) and a software pipeline over the staging
+    // units (tile, channel chunk): the halo of unit u + 1 is requested into registers before (NB <= 2) or right after (NB = 4: registers)
+    // the k-loop of unit u, so its HBM / L2 round trip runs under the MFMAs and the epilogue.  With one workgroup per tile, 7.7 us per
+    // tile (of 25) passed between the last store of one workgroup and the first load of the next on the same CU, and staging + epilogue
+    // added another 40 % with the matrix pipe idle (tools/conv_probe.py).
+    constexpr bool EARLY = false;                           // (true: requested before the k-loop - 72 more live registers: every variant spilled)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout: one plane per 8-channel chunk, [CPV][PLANE] 16-byte half-voxels, plane size a multiple of 256 B.  A ds_read_b128 is served
     // in lane groups such as {0-3, 12-15, 20-27} = voxels 0-3 / 12-15 of chunk kg and voxels 4-11 of chunk kg ^ 1: with the planes a
@@ -1010,41 +1024,46 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vl = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.y;
-    const int cout0 = blockIdx.z * (NB * 16);
-    const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1;
-    int t = blockIdx.x;
-    const int t2 = t % n2; t /= n2;
-    const int t1 = t % n1; const int t0 = t / n1;
-    const int z0 = t0 * T0, y0 = t1 * C16_T1, x0 = t2 * C16_T2;
+    const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1, n0 = a.I0 / T0;
+    const int per_vol = n0 * n1 * n2;
     const bool has_gn = a.gn_scale != nullptr;
-
-    f32x4 acc[4][NB];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Cin = ONE ? CW : a.Cin;                       // compile-time when there is a single chunk: immediate weight offsets
+    const int nchunks = ONE ? 1 : Cin / CW;
+#ifdef SEMABS_TUNING
+    long long* trc = a.trace ? a.trace + (long)blockIdx.x * 8 : nullptr;      // stamps of the LAST tile this workgroup processed
+#define BRICK_STAMP(i) do { if (trc && tid == 0) trc[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BRICK_STAMP(i) do { } while (0)
+#endif
+    // tile index -> (output-channel slice, volume, brick); the slice is slowest so that concurrently running workgroups share their weights in L2
+    auto decode = [&](int t, int& b, int& cout0, int& z0, int& y0, int& x0) {
+        int br = t % per_vol; t /= per_vol;
+        b = t % a.B; cout0 = (t / a.B) * (NB * 16);
+        const int t2 = br % n2; br /= n2;
+        const int t1 = br % n1; const int t0 = br / n1;
+        z0 = t0 * T0; y0 = t1 * C16_T1; x0 = t2 * C16_T2;
+    };
     int rbase[4];                                           // halo voxel index of the centre tap of this lane's voxel in each row
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = wid * 4 + r;                        // 0..31 = z * 8 + y
         rbase[r] = (((row >> 3) + 1) * C16_H1 + ((row & 7) + 1)) * C16_H2 + (vl + 1);
     }
-    const int Cin = ONE ? CW : a.Cin;                       // compile-time when there is a single chunk: immediate weight offsets
-    const int nchunks = ONE ? 1 : Cin / CW;
-    for (int cc = 0; cc < nchunks; ++cc) {
-        if (cc) __syncthreads();                            // every wave is done reading the previous channel chunk
-        // ---- halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
-        // Eight consecutive lanes = eight consecutive halo voxels of ONE chunk, the next eight lanes the next chunk of the same voxels: a wave's
-        // loads still cover whole voxels, each 8-lane ds_write_b128 group writes 128 contiguous bytes of one plane.  A thread keeps its chunk
-        // for all of its tasks (one GroupNorm scale / shift fetch); all of its halo loads are in flight together; out-of-volume taps read a
-        // clamped address and are zeroed afterwards (no divergent branches around the loads).
-        constexpr int VPI = NTHR / CPV;                     // halo voxels staged per iteration
-        constexpr int NIT = (HALO + VPI - 1) / VPI;
-        const int c = (tid >> 3) % CPV;
-        const int vsub = (tid & 7) + ((tid / (8 * CPV)) << 3);
+    // ---- staging: halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
+    // Chunk fastest over the lanes: a quad of lanes reads ONE 128-byte line (4 x 32 B of a voxel, or 2 voxels x 2 x 32 B for Cin = 16).  A
+    // thread keeps its chunk for all of its tasks (one GroupNorm scale / shift fetch per unit); all of its halo loads are in flight
+    // together; out-of-volume taps read a clamped address and are zeroed afterwards (no divergent branches around the loads).
+    constexpr int VPI = NTHR / CPV;                         // halo voxels staged per iteration
+    constexpr int NIT = (HALO + VPI - 1) / VPI;
+    const int c = tid % CPV;
+    const int vsub = tid / CPV;
+    float raw[NIT][8];
+    float gs[8], gh[8];
+    unsigned inb = 0;                                       // bit it: task it lies inside the volume
+    auto issue = [&](int tile, int cc) {
+        int b, cout0, z0, y0, x0;
+        decode(tile, b, cout0, z0, y0, x0);
         const int ch = cc * CW + c * 8;
-        float gs[8], gh[8];
         if (has_gn) {
             const float4* ps = reinterpret_cast<const float4*>(a.gn_scale + (long)b * Cin + ch);
             const float4* pt = reinterpret_cast<const float4*>(a.gn_shift + (long)b * Cin + ch);
@@ -1055,24 +1074,26 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { gs[j] = 1.f; gh[j] = 0.f; }
         }
-        float raw[NIT][8];
-        bool inb[NIT];
+        inb = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int v = min(vsub + it * VPI, HALO - 1);
             const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            inb[it] = gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
+            if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) inb |= 1u << it;
             const int cz = min(max(gz, 0), a.I0 - 1), cy = min(max(gy, 0), a.I1 - 1), cx = min(max(gx, 0), a.I2 - 1);
             load8<F32>(a.x, ((((long)b * a.I0 + cz) * a.I1 + cy) * a.I2 + cx) * Cin + ch, raw[it]);
         }
+    };
+    auto commit = [&]() {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int v = vsub + it * VPI;
+            const bool in = (inb >> it) & 1u;
             f16x8 h, l;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float val = inb[it] ? raw[it][j] * gs[j] + gh[j] : 0.f;     // zero padding AFTER the normalisation
+                const float val = in ? raw[it][j] * gs[j] + gh[j] : 0.f;          // zero padding AFTER the normalisation
                 h[j] = (f16)val; if (F32) l[j] = (f16)(val - (float)h[j]);
             }
             if (v < HALO) {
@@ -1081,14 +1102,35 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
                 if (F32) *reinterpret_cast<f16x8*>(s_lo + off) = l;
             }
         }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    BRICK_STAMP(6);
+    issue(tile, 0);
+    for (;;) {
+    int b, cout0, z0, y0, x0;
+    decode(tile, b, cout0, z0, y0, x0);
+    BRICK_STAMP(0);
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();                                    // every wave is done reading the previous LDS image
+        commit();
+        BRICK_STAMP(2);
         __syncthreads();
+        BRICK_STAMP(3);
+        int ntile = tile, ncc = cc + 1;
+        if (ncc == nchunks) { ntile = PERSIST ? tile + (int)gridDim.x : total; ncc = 0; }
+        if (EARLY && ntile < total) issue(ntile, ncc);
         // ---- 27 taps of this channel chunk; wave = 4 rows (16 voxels along x each) x NB x 16 output channels ----
-        // (fully unrolled with immediate offsets when Cin is a compile-time constant; a rolled loop for the multi-chunk variant, whose
-        //  unrolled form makes the scheduler hoist dozens of run-time-addressed weight loads and spill)
-    constexpr int KUNROLL = ONE ? NSTEPS : 1;
-#pragma unroll KUNROLL
-        for (int ks = 0; ks < NSTEPS; ++ks) {
-            int voff, chunk; long kofs;                     // kofs: k index of this lane's 8 weights = tap * Cin + channel
+        // The weights of k-step ks + 1 are requested BEFORE the MFMAs of k-step ks, and all eight activation fragments of a step are
+        // requested up front so that the LDS latency is paid once per step.  Fully unrolled with immediate offsets when Cin is a compile-time
+        // constant; a rolled loop for the multi-chunk variant.
+        auto step_geom = [&](int ks, int& voff, int& chunk, long& kofs) {     // kofs: k index of this lane's 8 weights = tap * Cin + channel
             if (CW == 32) {
                 chunk = kg; voff = ((ks / 9) - 1) * C16_H1 * C16_H2 + (((ks / 3) % 3) - 1) * C16_H2 + ((ks % 3) - 1);
                 kofs = (long)ks * Cin + cc * 32 + kg * 8;
@@ -1097,63 +1139,198 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a) {
                 const int offa = ((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1);
                 const int offb = ((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1);
                 voff = (kg >> 1) ? offb : offa; chunk = kg & 1;
-                kofs = ks * 32 + kg * 8;
+                // k index = tap * Cin + channel; tap 27 (second tap of the last step) does not exist: with Cin == 16 the padded weight row holds
+                // zeros there, otherwise its lanes read tap 26's weights again and load_w zeroes them
+                const int tap = ONE ? 2 * ks + (kg >> 1) : min(2 * ks + (kg >> 1), 26);
+                kofs = (long)tap * Cin + cc * 16 + (kg & 1) * 8;
             }
-            f16x8 wh[NB], wl[NB];
+        };
+        auto load_w = [&](int ks, f16x8* wh, f16x8* wl) {
+            int voff, chunk; long kofs;
+            step_geom(ks, voff, chunk, kofs);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const long widx = (long)(cout0 + nb * 16 + vl) * a.Kp + kofs;
                 wh[nb] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
                 if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+                if (CW == 16 && !ONE) {
+                    const bool dead = ks == NSTEPS - 1 && (kg >> 1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { wh[nb][e] = dead ? (f16)0.f : wh[nb][e]; if (F32) wl[nb][e] = dead ? (f16)0.f : wl[nb][e]; }
+                }
             }
+        };
+        auto step = [&](int ks, const f16x8* wh, const f16x8* wl, f16x8* whn, f16x8* wln) {
+            int voff, chunk; long kofs;
+            step_geom(ks, voff, chunk, kofs);
+            f16x8 xh[4], xl[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = chunk * PLANE + (rbase[r] + voff) * 8;
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(s_hi + off);
+                xh[r] = *reinterpret_cast<const f16x8*>(s_hi + off);
+                if (F32) xl[r] = *reinterpret_cast<const f16x8*>(s_lo + off);
+            }
+            if (ks + 1 < NSTEPS) load_w(ks + 1, whn, wln);
+            __builtin_amdgcn_sched_barrier(0);                 // requests first, then the MFMAs
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh, acc[r][nb], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh[r], acc[r][nb], 0, 0, 0);
                 if (F32) {
-                    const f16x8 xl = *reinterpret_cast<const f16x8*>(s_lo + off);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh, acc[r][nb], 0, 0, 0);
-                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl, acc[r][nb], 0, 0, 0);
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh[r], acc[r][nb], 0, 0, 0);
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl[r], acc[r][nb], 0, 0, 0);
                     }
                 }
             }
-        }
-    }
-    // acc[r][nb][e] = out[voxel x0 + vl of row r][cout = cout0 + nb * 16 + 4 * kg + e]
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (NB <= 2) {
+            f16x8 wa_h[NB], wa_l[NB], wb_h[NB], wb_l[NB];      // two weight fragment sets, alternating by k-step parity
+            load_w(0, wa_h, wa_l);
+            if (ONE && !PERSIST) {                          // (full unroll: in the persistent kernel its hoisted invariants spill)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = wid * 4 + r;
-        const long ovox = (((long)b * a.I0 + (z0 + (row >> 3))) * a.I1 + (y0 + (row & 7))) * a.I2 + (x0 + vl);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int co = cout0 + nb * 16 + 4 * kg;
-            const long oidx = ovox * a.Cout + co;
-            float o[4] = {acc[r][nb][0], acc[r][nb][1], acc[r][nb][2], acc[r][nb][3]};
-            if (a.bias) { const float4 bv = *reinterpret_cast<const float4*>(a.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
-            if (a.resid) {
-                if (F32) { const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx); o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
-                else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oidx); o[0] += (float)q[0]; o[1] += (float)q[1]; o[2] += (float)q[2]; o[3] += (float)q[3]; }
+                for (int ks = 0; ks < NSTEPS; ks += 2) {
+                    step(ks, wa_h, wa_l, wb_h, wb_l);
+                    if (ks + 1 < NSTEPS) step(ks + 1, wb_h, wb_l, wa_h, wa_l);
+                }
+            } else {
+                // rolled two steps at a time (the unrolled form of the multi-chunk variant makes the scheduler hoist dozens of run-time-addressed
+                // weight loads and spill); NSTEPS is odd for CW == 32 -> one tail step
+#pragma unroll 1
+                for (int ks = 0; ks + 1 < NSTEPS; ks += 2) {
+                    step(ks, wa_h, wa_l, wb_h, wb_l);
+                    step(ks + 1, wb_h, wb_l, wa_h, wa_l);
+                }
+                if (NSTEPS & 1) step(NSTEPS - 1, wa_h, wa_l, wb_h, wb_l);
             }
-            if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
-            if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
-            else { f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h; }
+        } else {
+            // four output-channel blocks: a second weight set would not fit the registers.  The blocks are walked one after the other and a
+            // block's fragments are re-requested IN PLACE for the next k-step as soon as its twelve MFMAs are issued: every request has the
+            // other three blocks' MFMAs (3/4 of a step) to arrive.
+            f16x8 wh[NB], wl[NB];
+            load_w(0, wh, wl);
+            constexpr int KU = (ONE && !PERSIST) ? NSTEPS : 1;
+#pragma unroll KU
+            for (int ks = 0; ks < NSTEPS; ++ks) {
+                int voff, chunk; long kofs, kofs_n;
+                step_geom(ks, voff, chunk, kofs);
+                { int v2, c2; step_geom(ks + 1 < NSTEPS ? ks + 1 : ks, v2, c2, kofs_n); }
+                f16x8 xh[4], xl[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int off = chunk * PLANE + (rbase[r] + voff) * 8;
+                    xh[r] = *reinterpret_cast<const f16x8*>(s_hi + off);
+                    if (F32) xl[r] = *reinterpret_cast<const f16x8*>(s_lo + off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh[r], acc[r][nb], 0, 0, 0);
+                    if (F32) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh[r], acc[r][nb], 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl[r], acc[r][nb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {                                           // (the last step re-requests its own fragments: no branch in the loop)
+                        const long widx = (long)(cout0 + nb * 16 + vl) * a.Kp + kofs_n;
+                        wh[nb] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+                        if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (!EARLY && ntile < total) issue(ntile, ncc);
+    }
+    BRICK_STAMP(4);
+    // acc[r][nb][e] = out[voxel x0 + vl of row r][cout = cout0 + nb * 16 + 4 * kg + e]: lane = kg * 16 + voxel, i.e. consecutive lanes are
+    // consecutive VOXELS, Cout * 4 bytes apart - a store in that layout touches four different lines per lane quad.  The accumulators are
+    // therefore transposed across lanes first (ds_bpermute: register exchange through the LDS crossbar, no memory): lane' = voxel * 4 + kg,
+    // so that a quad of lanes owns 64 contiguous bytes of one voxel; bias, residual and ReLU are applied in that layout.
+    {
+        const int v2 = lane >> 2, k2 = lane & 3;
+        const int src = (k2 * 16 + v2) << 2;                 // byte address of the source lane for ds_bpermute
+        // (the lanes' values are passed as scalars through __float_as_int: `__builtin_bit_cast(int, acc[r][nb][e])` on the vector element made
+        //  clang 19 / ROCm 7.2 emit ONE ds_bpermute per accumulator and copy its result to all four elements)
+        long obase[4];                                       // element index of (voxel, cout0 + 4 * k2); output block nb is 16 channels further
+        float q[4][NB][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wid * 4 + r;
+            const long ovox = (((long)b * a.I0 + (z0 + (row >> 3))) * a.I1 + (y0 + (row & 7))) * a.I2 + (x0 + v2);
+            obase[r] = ovox * a.Cout + (cout0 + 4 * k2);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const long oi = obase[r] + nb * 16;
+                if (a.resid) {                               // every residual row is requested before the first store (one round trip, not 4 x NB)
+                    if (F32) { const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oi); q[r][nb][0] = t.x; q[r][nb][1] = t.y; q[r][nb][2] = t.z; q[r][nb][3] = t.w; }
+                    else { const f16x4 t = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.resid) + oi); q[r][nb][0] = (float)t[0]; q[r][nb][1] = (float)t[1]; q[r][nb][2] = (float)t[2]; q[r][nb][3] = (float)t[3]; }
+                } else {
+                    q[r][nb][0] = q[r][nb][1] = q[r][nb][2] = q[r][nb][3] = 0.f;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = cout0 + nb * 16 + 4 * k2;
+                const long oi = obase[r] + nb * 16;
+                const float a0 = acc[r][nb][0], a1 = acc[r][nb][1], a2 = acc[r][nb][2], a3 = acc[r][nb][3];
+                float o[4];
+                o[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a0))) + q[r][nb][0];
+                o[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a1))) + q[r][nb][1];
+                o[2] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a2))) + q[r][nb][2];
+                o[3] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a3))) + q[r][nb][3];
+                if (a.bias) { const float4 bv = *reinterpret_cast<const float4*>(a.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
+                if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+                if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oi) = make_float4(o[0], o[1], o[2], o[3]);
+                else { f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oi) = h; }
+            }
         }
     }
+    BRICK_STAMP(5);
+    if (!PERSIST) break;
+    tile += gridDim.x;
+    if (tile >= total) break;
+    }
+    BRICK_STAMP(7);
 }
 
-template <bool F32, int CW, int NB, bool ONE>
-static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
+template <bool F32, int CW, int NB, bool ONE, bool PERSIST>
+static int conv_brick_launch_p(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)((6 * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * (CW / 8) * 2 * (F32 ? 2 : 1);      // CW / 8 planes (256-B padded), hi (+ lo), fp16
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    dim3 grid((a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2), a.B, a.Cout / (NB * 16));
-    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE>), grid, dim3(512), lds, s, a);
+    static int per_cu = 0;                                  // co-resident workgroups per CU (LDS and registers), queried once
+    if (!per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE, PERSIST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_brick<F32, CW, NB, ONE, PERSIST>, 512, lds) != hipSuccess || n < 1) n = 1;
+        per_cu = n;
+    }
+    const long total = (long)(a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2) * a.B * (a.Cout / (NB * 16));
+    SEMABS_REQUIRE(total < (1L << 30), "conv brick: too many tiles");
+    long nwg = total;
+    if (PERSIST) { nwg = (long)semabs_num_cus() * per_cu; if (nwg > total) nwg = total; }   // as many workgroups as fit the chip at once
+    ConvArgs at = a;
+#ifdef SEMABS_TUNING
+    at.trace = g_conv_trace;
+#endif
+    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE, PERSIST>), dim3((unsigned)nwg), dim3(512), lds, s, at, (int)total);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
+}
+template <bool F32, int CW, int NB, bool ONE>
+static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
+#ifdef SEMABS_TUNING
+    if (g_brick_persist) return conv_brick_launch_p<F32, CW, NB, ONE, true>(a, s);
+#endif
+    return conv_brick_launch_p<F32, CW, NB, ONE, false>(a, s);
 }
 static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
     const long bricks = (long)a.B * (a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
@@ -1162,6 +1339,9 @@ static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
         if (nb4) return f32 ? conv_brick_launch_t<true, 16, 4, true>(a, s) : conv_brick_launch_t<false, 16, 4, true>(a, s);
         return f32 ? conv_brick_launch_t<true, 16, 2, true>(a, s) : conv_brick_launch_t<false, 16, 2, true>(a, s);
     }
+    // (Tried in round 2: 16-channel chunks for Cin >= 32 - half the LDS, two workgroups per CU so that one stages / stores while the other is in
+    //  its k-loop.  Slower, 1 198 vs 1 027 us at 64^3 x 32 ch: two co-resident workgroups doing identical work fall into lockstep, both stage
+    //  and both multiply at the same time - the same behaviour that led to the producer / consumer split of k_conv16_lds.)
     if (a.Cin == 32) {
         if (nb4) return f32 ? conv_brick_launch_t<true, 32, 4, true>(a, s) : conv_brick_launch_t<false, 32, 4, true>(a, s);
         return f32 ? conv_brick_launch_t<true, 32, 2, true>(a, s) : conv_brick_launch_t<false, 32, 2, true>(a, s);

@@ -78,6 +78,34 @@ def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid):
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
+@pytest.mark.parametrize("cin,cout,dims,B,resid", [(16, 32, (4, 8, 16), 2, False), (32, 32, (8, 16, 32), 3, True), (64, 64, (4, 16, 16), 2, True),
+                                                   (32, 64, (8, 16, 32), 64, True), (64, 64, (8, 16, 32), 64, False), (16, 64, (8, 16, 32), 64, True),
+                                                   (128, 128, (4, 8, 16), 1, True)])
+def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid):
+    """k_conv_brick (64^3 .. 16^3 levels: LDS halo bricks of 4 x 8 x 16, weights software-pipelined, lane-transposed epilogue) vs torch fp32 and
+    vs the generic gather kernel; the B = 64 cases have enough bricks for the four-output-block (in-place weight re-request) variants."""
+    from semabs_amd.unet3d import _Conv
+    rng = np.random.default_rng(cin * 7 + cout + B)
+    x = torch.from_numpy(rng.standard_normal((B, cin, *dims)).astype(np.float32)) * 1.5 + 0.3
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+    gw = torch.from_numpy((1 + 0.2 * rng.standard_normal(cin)).astype(np.float32))
+    gb = torch.from_numpy((0.2 * rng.standard_normal(cin)).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((B, cout, *dims)).astype(np.float32))
+    u = _unet(precision)
+    conv = _Conv(w, gw, gb, None, 8, u.dev)
+    xd, rd = _cl(x).cuda().to(u.act_dtype), _cl(res).cuda().to(u.act_dtype)
+    ref = F.conv3d(F.group_norm(xd.float().cpu().permute(0, 4, 1, 2, 3), 8, gw, gb, 1e-5), w, None, padding=1)
+    if resid:
+        ref = ref + rd.float().cpu().permute(0, 4, 1, 2, 3)
+    ref = F.relu(ref)
+    y_brick = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
+    y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
+    scale = max(1.0, ref.abs().max().item())
+    assert (y_brick - ref).abs().max().item() <= tol * scale, (y_brick - ref).abs().max().item()
+    assert (y_brick - y_gen).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale
+
+
+@pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 16, 6, 2), (64, 32, 4, 1), (512, 256, 2, 2), (128, 64, 3, 1)])
 def test_convtranspose3d_skip(precision, tol, cin, cout, S, B):
     from semabs_amd.unet3d import _ConvT
