@@ -127,8 +127,10 @@ int semabs_add_layernorm(float* x, const void* delta, const float* gamma, const 
                          void* stream);
 /* class token rows: x[n, 0, :] = class_embedding + pos[0, :]          model_explainability.py:329-343 */
 int semabs_embed_finish(float* x, const float* cls, const float* pos, int n, int T, int D, void* stream);
-/* fused multi-head attention, head_dim 64, T <= 288                  auxiliary.py:260-340 (q pre-scaled) */
-int semabs_attention(const void* qkv, void* out, const void* reserved, int n_seq, int T, int H, int head_dim, int ld,
+/* fused multi-head attention, head_dim 64, T <= 288                  auxiliary.py:260-340 (q pre-scaled)
+ * row_stats (optional, NULL = none) fp32 [n_seq, H, T, 2]: every query's softmax normalisation (reference maximum, 1 / sum), i.e.
+ * attn_probs[q, k] = exp(S[q, k] - row_stats[.., 0]) * row_stats[.., 1] - kept for semabs_attention_bwd */
+int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim, int ld,
                      int causal, void* stream);
 /* last block, CLS query only; keeps the softmax row (the hooked attn_probs, auxiliary.py:330-335).  q fp32 [n, D], k fp32 [n, T, D] (the
  * scores stay fp32), v fp16 [n, T, D] (it only enters averaged: o, and the rollout's V . u dots) */
@@ -144,13 +146,14 @@ int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W
 int semabs_rollout(const float* probs, const void* v /* fp16 [n, T, D] */, const float* u, const float* scale, float* rel, int n, int T, int H,
                    int L, int positive_only, long n_total, long tile0, void* stream);
 /* ---- multi-layer rollout for deep towers (csrc/vitl.hip; ViT-L/14: clip_gradcam.py:51-56, 85-126) -------------------------------------
- * Attention backward of one block for R = L * n sequences ordered (label, tile) + that block's rollout update.
- * qkv fp16 [n, T, 3 D] of the block (q pre-scaled | k | v), dO fp16 [R, T, D] = gradient wrt the attention output (before out_proj),
+ * Attention backward of one block for R = L * n sequences ordered (label, tile) + that block's rollout update (two MFMA kernels).
+ * qkv fp16 [n, T, 3 D] of the block (q pre-scaled | k | v), att fp16 [n, T, D] = its attention output and fwd_stats fp32 [n, H, T, 2] =
+ * semabs_attention's row_stats of the forward pass, dO fp16 [R, T, D] = gradient wrt the attention output (before out_proj),
  * rvec fp32 [R, T] = rollout row before this block, gscale fp32 [R] (true gradient = stored * gscale),
  * c fp32 [R, T] += (1 / H) sum_q rvec[q] act(P dP gscale)  (act = clamp(min 0) iff positive_only), stats fp32 [R, H, T, 4] scratch,
- * dqkv fp16 [R, T, 3 D] <- (dQ | dK | dV), or NULL for the rollout update only.  head_dim 64, T <= 320. */
-int semabs_attention_bwd(const void* qkv, const void* dO, const float* rvec, const float* gscale, float* c, float* stats, void* dqkv,
-                         int n, int L, int T, int H, int head_dim, int positive_only, void* stream);
+ * dqkv fp16 [R, T, 3 D] <- (dQ | dK | dV), or NULL for the rollout update only.  head_dim 64, T <= 288. */
+int semabs_attention_bwd(const void* qkv, const void* att, const float* fwd_stats, const void* dO, const float* rvec, const float* gscale,
+                         float* c, float* stats, void* dqkv, int n, int L, int T, int H, int head_dim, int positive_only, void* stream);
 /* per sequence r: g32[r, :len] *= 2^k (max |g| -> [0.5, 1)), g16 = fp16(g32) (optional), gscale[r] /= 2^k */
 int semabs_seq_rescale(float* g32, void* g16, float* gscale, long R, long len, void* stream);
 /* one rollout layer: r += c, c = 0                                                    clip_gradcam.py:121-124 (row 0 of R only) */

@@ -60,7 +60,7 @@ SIGNATURES = {
     "semabs_rollout": [P, P, P, P, P, I, I, I, I, I, L, L, P],
     "semabs_gather_text": [P, P, P, P, I, I, I, P],
     # vitl.hip (multi-layer rollout: attention backward)
-    "semabs_attention_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "semabs_attention_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "semabs_seq_rescale": [P, P, P, L, L, P],
     "semabs_rollout_step": [P, P, L, P],
     "semabs_text_finish": [P, P, I, I, I, P],

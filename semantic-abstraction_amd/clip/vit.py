@@ -393,7 +393,8 @@ class VisionRolloutDeep:
             e16 = lambda *s: torch.empty(*s, dtype=torch.float16, device=dev)
             e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             R = Lm * n
-            saved = {b: dict(x_in=e32(n * T, D), x_mid=e32(n * T, D), qkv=e16(n * T, 3 * D), fc=e32(n * T, 4 * D))
+            saved = {b: dict(x_in=e32(n * T, D), x_mid=e32(n * T, D), qkv=e16(n * T, 3 * D), fc=e32(n * T, 4 * D), att=e16(n * T, D),
+                             fstats=e32(n * H * T, 2))                       # attention output + softmax row statistics: the backward rebuilds P from them
                      for b in range(self.first_roll, self.layers)}
             self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D), saved=saved,
@@ -427,11 +428,12 @@ class VisionRolloutDeep:
         for i, b in enumerate(self.blocks):
             sv = ws["saved"].get(i)
             qkv = ws["qkv"] if sv is None else sv["qkv"]
+            att = ws["att"] if sv is None else sv["att"]
             if sv is not None:
                 sv["x_in"][:M].copy_(x[:M])
             layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
             gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16)
-            _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, 0, st)
+            _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None if sv is None else _lib.ptr(sv["fstats"]), n, T, H, 64, 3 * D, 0, st)
             gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32)
             if sv is not None:
                 sv["x_mid"][:M].copy_(x[:M])
@@ -484,8 +486,9 @@ class VisionRolloutDeep:
             # attention sub-layer: dO = g_mid W_o, then (dQ | dK | dV) and this block's rollout update
             gemm(ws["gmid16"], b.w_o_t, ws["dO"], None, M, D, D, D, D, D, EPI_F16)
             last = i == self.first_roll
-            _lib.call("semabs_attention_bwd", _lib.ptr(sv["qkv"]), _lib.ptr(ws["dO"]), _lib.ptr(rvec), _lib.ptr(gscale), _lib.ptr(cacc),
-                      _lib.ptr(ws["stats"]), None if last else _lib.ptr(ws["dqkv"]), n, L, T, H, 64, int(positive_attn_only), st)
+            _lib.call("semabs_attention_bwd", _lib.ptr(sv["qkv"]), _lib.ptr(sv["att"]), _lib.ptr(sv["fstats"]), _lib.ptr(ws["dO"]), _lib.ptr(rvec),
+                      _lib.ptr(gscale), _lib.ptr(cacc), _lib.ptr(ws["stats"]), None if last else _lib.ptr(ws["dqkv"]), n, L, T, H, 64,
+                      int(positive_attn_only), st)
             _lib.call("semabs_rollout_step", _lib.ptr(rvec), _lib.ptr(cacc), R * T, st)
             if not last:
                 gemm(ws["dqkv"], b.w_in_t, ws["dh"], None, M, D, 3 * D, 3 * D, 3 * D, D, EPI_F32)

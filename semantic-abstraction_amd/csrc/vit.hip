@@ -162,8 +162,8 @@ extern "C" int semabs_embed_finish(float* x, const float* cls, const float* pos,
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int NKB, bool CAUSAL>   // number of 32-key blocks: TP = 32 * NKB
-__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int H,
-                                                   int ld, int D) {
+__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out,
+                                                   float* __restrict__ stats, int T, int H, int ld, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = 32 * NKB;
     constexpr int VS = TP + 4;                    // V^T row stride (elements): keeps ds_read_b64 8-byte aligned
@@ -302,6 +302,12 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
+        // optional: the softmax normalisation of every query, P[q, k] = exp(S[q, k] - stats[.., 0]) * stats[.., 1] - what the attention backward
+        // of the multi-layer rollout (vitl.hip) needs to rebuild P without a statistics pass of its own
+        if (stats && q < T && hi == 0) {
+            float* st = stats + (((long)seq * H + h) * T + q) * 2;
+            st[0] = mref; st[1] = inv;
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -323,9 +329,9 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 }
 
 // qkv fp16 [n_seq, T, ld] with q | k | v at column offsets 0, D, 2D (q already scaled); out fp16 [n_seq, T, D]
-extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved, int n_seq, int T, int H, int head_dim,
+// row_stats (optional, may be NULL) fp32 [n_seq, H, T, 2] = (reference maximum, 1 / sum) of every query's softmax
+extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim,
                                 int ld, int causal, void* stream) {
-    (void)reserved;
     if (n_seq == 0) return SEMABS_OK;
     SEMABS_REQUIRE(qkv && out && n_seq > 0 && T > 0 && H > 0, "semabs_attention: bad args");
     SEMABS_REQUIRE(head_dim == 64, "semabs_attention: head_dim must be 64");
@@ -339,7 +345,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, const void* reserved
         size_t lds = (size_t)(32 * N) * 128 + 64 * (32 * N + 4) * 2;                                                 \
         static bool set = false;                                                                                     \
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
-        hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, T, H, ld, D); \
+        hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
     }
 #define ATT_CASE(N) { if (causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }
     switch (nkb) {

@@ -6,207 +6,336 @@
 // and returns R[:, :, 0, 1:].  Only row 0 of the final R is used and R_final = (I + cam_23) ... (I + cam_11), so a ROW VECTOR is enough:
 //     r <- e_0;   for i = 23 ... 11:   r <- r + r cam_i.
 // grad_i[h, q, k] = dO_i[q, h, :] . V_i[k, h, :] with dO_i the gradient wrt the attention output of block i (before out_proj), so no T x T
-// matrix is ever materialised: one pass over (query, key) pairs per (label, tile, head) recomputes P from Q, K, forms dP = dO V^T on the
-// fly and accumulates both the rollout update  c[k] += r[q] act(P dP) / H  and the attention backward (dQ, dK, dV) that carries the
-// gradient down to the previous block.  ViT-B never gets here: only its last block enters the rollout (closed form in vit.hip).
+// matrix is ever materialised: P is rebuilt from Q, K and the forward's row statistics, dP = dO V^T is formed on the fly, and both the
+// rollout update  c[k] += r[q] act(P dP) / H  and the attention backward (dQ, dK, dV) that carries the gradient down to the previous
+// block are accumulated block by block.  ViT-B never gets here: only its last block enters the rollout (closed form in vit.hip).
 //
-// Kernels (fp32 accumulate, fp16 operands = what the forward stored; one workgroup per (sequence, head), T <= 320, head_dim 64):
-//   k_attn_bwd_q   thread = query: row max / sum (online softmax), delta = sum_k P dP, rollout update, dQ
-//   k_attn_bwd_kv  thread = key:   dK = dS^T Q, dV = P^T dO   (reads the row statistics k_attn_bwd_q left behind)
-//   k_seq_rescale  per sequence power-of-two renormalisation of the residual gradient (the chain is linear and cam is positively
-//                  homogeneous in it, so the factor is divided out of the rollout update) - keeps the fp16 GEMM operands in range
-//   k_rollout_step r += c, c = 0
-// These first versions run on the vector ALU (v_dot2c_f32_f16 for the 64-long dots); an MFMA formulation is the obvious next step.
+// Round 2: both kernels run on the matrix pipe (v_mfma_f32_32x32x16_f16, one workgroup per (sequence, head), one wave per 32-row block,
+// T <= 288, head_dim 64).  An MFMA result D = A B has its ROWS in registers and its COLUMNS in lanes, and can be fed back only as a B
+// operand, i.e. contracted over its rows.  Hence two orientations:
+//   k_attn_bwd_dq   wave = query block.  S^T = K Q^T, dP^T = V dO^T (rows = keys, lanes = queries: the per-query softmax statistics and
+//                   delta = dO . O are one value per lane), dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T (contracts over keys).
+//   k_attn_bwd_dkv  wave = key block.   S = Q K^T, dP = dO V^T (rows = queries, lanes = keys), the rollout update is an in-lane sum over
+//                   the rows, dV^T += dO^T P and dK^T += Q^T dS (contract over queries).
+// delta_q = sum_k P dP = dO_q . O_q needs the attention OUTPUT of the forward pass, and P = exp(S - m) * inv its row statistics
+// (semabs_attention's row_stats); dS goes through fp16 as an MFMA operand scaled by 2^4 (fp32 accumulators, un-scaled at the store).
+// The first, vector-ALU versions of these kernels (v_dot2, thread = row) took 78 % of the ViT-L/14 step.
 #include "semabs_common.h"
 
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int kswz_l(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+#define DS_SCALE 16.f
 
-__device__ __forceinline__ float dot64(const f16x8 (&a)[8], const f16x8* __restrict__ b) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const f16x8 y = b[c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_fdot2(f16x2v{a[c][2 * e], a[c][2 * e + 1]}, f16x2v{y[2 * e], y[2 * e + 1]}, s, false);
-    }
-    return s;
-}
-
-// qkv fp16 [n, T, 3D] (q pre-scaled | k | v) of the block; dO fp16 [R, T, D] with R = L * n sequences ordered (label, tile);
-// rvec fp32 [R, T] (the rollout row BEFORE this block), gscale fp32 [R] (true gradient = stored gradient * gscale);
-// c fp32 [R, T] += (1 / H) sum_q rvec[q] act(P[q, k] dP[q, k] gscale)          (atomic over heads);
-// stats fp32 [R, H, T, 4] = (row max, 1 / row sum, delta, -) for k_attn_bwd_kv;  dqkv fp16 [R, T, 3D]: the dQ third (null: rollout only).
-__global__ __launch_bounds__(320) void k_attn_bwd_q(const f16* __restrict__ qkv, const f16* __restrict__ dO, const float* __restrict__ rvec,
-                                                    const float* __restrict__ gscale, float* __restrict__ c, float* __restrict__ stats,
-                                                    f16* __restrict__ dqkv, int n, int T, int H, int positive_only) {
+// qkv fp16 [n, T, 3D] (q pre-scaled | k | v) of the block; att fp16 [n, T, D] its attention output; fstats fp32 [n, H, T, 2] the forward's
+// (reference maximum, 1 / sum); dO fp16 [R, T, D] with R = L * n sequences ordered (label, tile); rvec fp32 [R, T] (the rollout row
+// BEFORE this block).  Writes stats fp32 [R, H, T, 4] = (maximum, 1 / sum, delta, rvec) for k_attn_bwd_dkv and, when GRAD, the dQ third of
+// dqkv fp16 [R, T, 3D].
+template <int NKB, bool GRAD>
+__global__ __launch_bounds__(64 * NKB) void k_attn_bwd_dq(const f16* __restrict__ qkv, const f16* __restrict__ att, const float* __restrict__ fstats,
+                                                          const f16* __restrict__ dO, const float* __restrict__ rvec, float* __restrict__ stats,
+                                                          f16* __restrict__ dqkv, int n, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* sK = reinterpret_cast<f16*>(smem);                 // [T][64]
-    f16* sV = sK + (size_t)T * 64;                          // [T][64]
-    float* sC = reinterpret_cast<float*>(sV + (size_t)T * 64);   // [T]
-    const int D = H * 64;
+    constexpr int TP = 32 * NKB, VS = TP + 4, NTHR = 64 * NKB;
+    char* sK = smem;                                        // [TP][64] fp16, 16-byte chunks swizzled
+    char* sV = smem + TP * 128;
+    f16* sKT = reinterpret_cast<f16*>(smem + TP * 256);     // [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int D = H * 64, ld = 3 * D;
     const int r = blockIdx.x / H, h = blockIdx.x % H;
     const int tile = r % n;
-    const f16* base = qkv + (size_t)tile * T * 3 * D + h * 64;
-    for (int i = threadIdx.x; i < T * 8; i += blockDim.x) {
-        const int row = i >> 3, ch = i & 7;
-        *reinterpret_cast<f16x8*>(sK + row * 64 + ch * 8) = *reinterpret_cast<const f16x8*>(base + (size_t)row * 3 * D + D + ch * 8);
-        *reinterpret_cast<f16x8*>(sV + row * 64 + ch * 8) = *reinterpret_cast<const f16x8*>(base + (size_t)row * 3 * D + 2 * D + ch * 8);
-    }
-    for (int i = threadIdx.x; i < T; i += blockDim.x) sC[i] = 0.f;
-    __syncthreads();
-    const int q = threadIdx.x;
+    const f16* base = qkv + (size_t)tile * T * ld + h * 64;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int q = wid * 32 + ql;
     const bool live = q < T;
     const int qc = live ? q : T - 1;
-    f16x8 fq[8], fo[8];
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-        fq[ch] = *reinterpret_cast<const f16x8*>(base + (size_t)qc * 3 * D + ch * 8);
-        fo[ch] = *reinterpret_cast<const f16x8*>(dO + ((size_t)r * T + qc) * D + h * 64 + ch * 8);
-    }
-    // pass A: row max and sum (online)
-    float m = -INFINITY, sum = 0.f;
-    for (int k = 0; k < T; ++k) {
-        const float s = dot64(fq, reinterpret_cast<const f16x8*>(sK + k * 64));
-        const float mn = fmaxf(m, s);
-        sum = sum * __expf(m - mn) + __expf(s - mn);
-        m = mn;
-    }
-    const float inv = 1.f / sum;
-    // pass B: delta and the rollout update
-    const float rq = live ? rvec[(size_t)r * T + q] : 0.f;
-    const float gs = gscale[r] / (float)H;
+    f16x8 fq[4], fo[4];
     float delta = 0.f;
-    for (int k = 0; k < T; ++k) {
-        const float s = dot64(fq, reinterpret_cast<const f16x8*>(sK + k * 64));
-        const float p = __expf(s - m) * inv;
-        const float dp = dot64(fo, reinterpret_cast<const f16x8*>(sV + k * 64));
-        const float pd = p * dp;
-        delta += pd;
-        float t = pd * gs;
-        if (positive_only) t = fmaxf(t, 0.f);
-        t = wave_sum(rq * t);                               // dead lanes carry rq = 0
-        if ((threadIdx.x & 63) == 0) atomicAdd(&sC[k], t);
+    {
+        const f16* ob = dO + ((size_t)r * T + qc) * D + h * 64;
+        const f16* ab = att + ((size_t)tile * T + qc) * D + h * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            fq[ks] = *reinterpret_cast<const f16x8*>(base + (size_t)qc * ld + (ks * 2 + hi) * 8);
+            fo[ks] = *reinterpret_cast<const f16x8*>(ob + (ks * 2 + hi) * 8);
+            const f16x8 fa = *reinterpret_cast<const f16x8*>(ab + (ks * 2 + hi) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta = fmaf((float)fo[ks][e], (float)fa[e], delta);
+        }
     }
-    if (live) {
-        float* st = stats + (((size_t)r * H + h) * T + q) * 4;
-        st[0] = m; st[1] = inv; st[2] = delta;
-    }
-    // pass C: dQ = dS K with dS = P (dP - delta)
-    if (dqkv) {
-        float dq[64];
+    delta += __shfl_xor(delta, 32, 64);
+    const float* fs = fstats + (((size_t)tile * H + h) * T + qc) * 2;
+    const float mref = fs[0];
+    const float inv = live ? fs[1] : 0.f;
+    if (live && hi == 0) *reinterpret_cast<float4*>(stats + (((size_t)r * H + h) * T + q) * 4) = make_float4(mref, inv, delta, rvec[(size_t)r * T + q]);
+    if (!GRAD) return;
+    constexpr int NIT = (TP * 8 + NTHR - 1) / NTHR;
+    {
+        f16x8 kvs[NIT], vvs[NIT];
 #pragma unroll
-        for (int d = 0; d < 64; ++d) dq[d] = 0.f;
-        for (int k = 0; k < T; ++k) {
-            const f16x8* kr = reinterpret_cast<const f16x8*>(sK + k * 64);
-            const float s = dot64(fq, kr);
-            const float p = __expf(s - m) * inv;
-            const float dp = dot64(fo, reinterpret_cast<const f16x8*>(sV + k * 64));
-            const float ds = p * (dp - delta);
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * NTHR, row = c >> 3, kc = c & 7;
+            if (c < TP * 8 && row < T) {
+                kvs[it] = *reinterpret_cast<const f16x8*>(base + (size_t)row * ld + D + kc * 8);
+                vvs[it] = *reinterpret_cast<const f16x8*>(base + (size_t)row * ld + 2 * D + kc * 8);
+            } else {
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                const f16x8 kv = kr[ch];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dq[ch * 8 + e] = fmaf(ds, (float)kv[e], dq[ch * 8 + e]);
+                for (int e = 0; e < 8; ++e) { kvs[it][e] = (f16)0.f; vvs[it][e] = (f16)0.f; }
             }
         }
-        if (live) {
-            f16* o = dqkv + ((size_t)r * T + q) * 3 * D + h * 64;
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                f16x8 hv;
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + it * NTHR, row = c >> 3, kc = c & 7;
+            if (c < TP * 8) {
+                *reinterpret_cast<f16x8*>(sK + kswz_l(row, kc)) = kvs[it];
+                *reinterpret_cast<f16x8*>(sV + kswz_l(row, kc)) = vvs[it];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (f16)dq[ch * 8 + e];
-                *reinterpret_cast<f16x8*>(o + ch * 8) = hv;
+                for (int e = 0; e < 8; ++e) sKT[(kc * 8 + e) * VS + row] = kvs[it][e];
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < T; i += blockDim.x) atomicAdd(&c[(size_t)r * T + i], sC[i]);
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = kswz_l(ql, ks * 2 + hi);
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sc[e] = -mref; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + kb * 4096 + koff[ks]);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fq[ks], sc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 fv = *reinterpret_cast<const f16x8*>(sV + kb * 4096 + koff[ks]);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv, fo[ks], dp, 0, 0, 0);
+        }
+        // sc[e] = S[key, q] - m_q, dp[e] = dP[key, q] with key = kb*32 + (e&3) + 8*(e>>2) + 4*hi
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            const float p = key < T ? __builtin_amdgcn_exp2f(sc[e] * 1.44269504088896340736f) * inv : 0.f;
+            sc[e] = p * (dp[e] - delta) * DS_SCALE;                              // dS^T (scaled)
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f16x8 pk;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pk[jj] = (f16)sc[hf * 8 + jj];
+            const int kbase = kb * 32 + hf * 16 + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const f16* kr = sKT + (db * 32 + ql) * VS + kbase;
+                const f16x4 v0 = *reinterpret_cast<const f16x4*>(kr);
+                const f16x4 v1 = *reinterpret_cast<const f16x4*>(kr + 8);
+                f16x8 fa;
+                fa[0] = v0[0]; fa[1] = v0[1]; fa[2] = v0[2]; fa[3] = v0[3];
+                fa[4] = v1[0]; fa[5] = v1[1]; fa[6] = v1[2]; fa[7] = v1[3];
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, pk, o[db], 0, 0, 0);
+            }
+        }
+    }
+    // o[db][e] = dQ^T[d = db*32 + (e&3) + 8*(e>>2) + 4*hi][q] * DS_SCALE
+    if (live) {
+        f16* orow = dqkv + ((size_t)r * T + q) * ld + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f16x4 hv;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) hv[jj] = (f16)(o[db][rq * 4 + jj] * (1.f / DS_SCALE));
+                *reinterpret_cast<f16x4*>(orow + db * 32 + rq * 8 + 4 * hi) = hv;
+            }
+    }
 }
 
-// dK[k] = sum_q dS[q, k] Q[q],  dV[k] = sum_q P[q, k] dO[q]   -> the K and V thirds of dqkv
-__global__ __launch_bounds__(320) void k_attn_bwd_kv(const f16* __restrict__ qkv, const f16* __restrict__ dO, const float* __restrict__ stats,
-                                                     f16* __restrict__ dqkv, int n, int T, int H) {
+// stats fp32 [R, H, T, 4] from k_attn_bwd_dq; gscale fp32 [R] (true gradient = stored gradient * gscale);
+// c fp32 [R, T] += (1 / H) sum_q rvec[q] act(P[q, k] dP[q, k] gscale)   (atomic over heads); GRAD: the dK and dV thirds of dqkv.
+template <int NKB, bool GRAD>
+__global__ __launch_bounds__(64 * NKB) void k_attn_bwd_dkv(const f16* __restrict__ qkv, const f16* __restrict__ dO, const float* __restrict__ stats,
+                                                           const float* __restrict__ gscale, float* __restrict__ c, f16* __restrict__ dqkv,
+                                                           int n, int T, int H, int positive_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* sQ = reinterpret_cast<f16*>(smem);                 // [T][64]
-    f16* sO = sQ + (size_t)T * 64;                          // [T][64]  (dO)
-    float* sS = reinterpret_cast<float*>(sO + (size_t)T * 64);   // [T][4]
-    const int D = H * 64;
+    constexpr int TP = 32 * NKB, VS = TP + 4, NTHR = 64 * NKB;
+    char* sQ = smem;                                        // [TP][64] fp16 swizzled
+    char* sO = smem + TP * 128;                             // dO, same layout
+    float* sS = reinterpret_cast<float*>(smem + TP * 256);  // [TP][4]
+    f16* sQT = reinterpret_cast<f16*>(smem + TP * 256 + TP * 16);   // [64][VS]   (GRAD only)
+    f16* sOT = sQT + 64 * VS;                               // [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int D = H * 64, ld = 3 * D;
     const int r = blockIdx.x / H, h = blockIdx.x % H;
     const int tile = r % n;
-    const f16* base = qkv + (size_t)tile * T * 3 * D + h * 64;
-    for (int i = threadIdx.x; i < T * 8; i += blockDim.x) {
-        const int row = i >> 3, ch = i & 7;
-        *reinterpret_cast<f16x8*>(sQ + row * 64 + ch * 8) = *reinterpret_cast<const f16x8*>(base + (size_t)row * 3 * D + ch * 8);
-        *reinterpret_cast<f16x8*>(sO + row * 64 + ch * 8) = *reinterpret_cast<const f16x8*>(dO + ((size_t)r * T + row) * D + h * 64 + ch * 8);
+    const f16* base = qkv + (size_t)tile * T * ld + h * 64;
+    const f16* obase = dO + (size_t)r * T * D + h * 64;
+    constexpr int NIT = (TP * 8 + NTHR - 1) / NTHR;
+    {
+        f16x8 qs[NIT], os[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cidx = tid + it * NTHR, row = cidx >> 3, kc = cidx & 7;
+            if (cidx < TP * 8 && row < T) {
+                qs[it] = *reinterpret_cast<const f16x8*>(base + (size_t)row * ld + kc * 8);
+                os[it] = *reinterpret_cast<const f16x8*>(obase + (size_t)row * D + kc * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { qs[it][e] = (f16)0.f; os[it][e] = (f16)0.f; }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int cidx = tid + it * NTHR, row = cidx >> 3, kc = cidx & 7;
+            if (cidx < TP * 8) {
+                *reinterpret_cast<f16x8*>(sQ + kswz_l(row, kc)) = qs[it];
+                *reinterpret_cast<f16x8*>(sO + kswz_l(row, kc)) = os[it];
+                if (GRAD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sQT[(kc * 8 + e) * VS + row] = qs[it][e]; sOT[(kc * 8 + e) * VS + row] = os[it][e]; }
+                }
+            }
+        }
+        for (int i = tid; i < TP; i += NTHR)                 // dead query rows: 1 / sum = 0 -> P = 0
+            *reinterpret_cast<float4*>(sS + i * 4) = i < T ? *reinterpret_cast<const float4*>(stats + (((size_t)r * H + h) * T + i) * 4)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = threadIdx.x; i < T; i += blockDim.x)
-        *reinterpret_cast<float4*>(sS + i * 4) = *reinterpret_cast<const float4*>(stats + (((size_t)r * H + h) * T + i) * 4);
     __syncthreads();
-    const int k = threadIdx.x;
-    const bool live = k < T;
-    const int kc = live ? k : T - 1;
-    f16x8 fk[8], fv[8];
+    const int ql = lane & 31, hi = lane >> 5;
+    const int k = wid * 32 + ql;
+    const bool livek = k < T;
+    const int kc2 = livek ? k : T - 1;
+    f16x8 fk[4], fv[4];
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-        fk[ch] = *reinterpret_cast<const f16x8*>(base + (size_t)kc * 3 * D + D + ch * 8);
-        fv[ch] = *reinterpret_cast<const f16x8*>(base + (size_t)kc * 3 * D + 2 * D + ch * 8);
+    for (int ks = 0; ks < 4; ++ks) {
+        fk[ks] = *reinterpret_cast<const f16x8*>(base + (size_t)kc2 * ld + D + (ks * 2 + hi) * 8);
+        fv[ks] = *reinterpret_cast<const f16x8*>(base + (size_t)kc2 * ld + 2 * D + (ks * 2 + hi) * 8);
     }
-    float dk[64], dv[64];
+    int koff[4];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    for (int q = 0; q < T; ++q) {
-        const f16x8* qr = reinterpret_cast<const f16x8*>(sQ + q * 64);
-        const f16x8* orow = reinterpret_cast<const f16x8*>(sO + q * 64);
-        const float4 st = *reinterpret_cast<const float4*>(sS + q * 4);
-        const float s = dot64(fk, qr);
-        const float p = __expf(s - st.x) * st.y;
-        const float dp = dot64(fv, orow);
-        const float ds = p * (dp - st.z);
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = kswz_l(ql, ks * 2 + hi);
+    f32x16 ok[2], ov[2];
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            const f16x8 qv = qr[ch], ov = orow[ch];
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                dk[ch * 8 + e] = fmaf(ds, (float)qv[e], dk[ch * 8 + e]);
-                dv[ch * 8 + e] = fmaf(p, (float)ov[e], dv[ch * 8 + e]);
+        for (int e = 0; e < 16; ++e) { ok[db][e] = 0.f; ov[db][e] = 0.f; }
+    float csum = 0.f;
+#pragma unroll 1
+    for (int qb = 0; qb < NKB; ++qb) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qq = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            sc[e] = -sS[qq * 4];                                              // accumulator starts at - m_q: the subtraction is free
+            dp[e] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 fa = *reinterpret_cast<const f16x8*>(sQ + qb * 4096 + koff[ks]);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fk[ks], sc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 fa = *reinterpret_cast<const f16x8*>(sO + qb * 4096 + koff[ks]);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fv[ks], dp, 0, 0, 0);
+        }
+        // sc[e] = S[qq, k] - m_qq, dp[e] = dP[qq, k]; afterwards sc = P, dp = dS * DS_SCALE
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qq = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            const float4 st = *reinterpret_cast<const float4*>(sS + qq * 4);  // (m, 1 / sum, delta, r_q)
+            const float p = livek ? __builtin_amdgcn_exp2f(sc[e] * 1.44269504088896340736f) * st.y : 0.f;
+            const float t = p * dp[e];
+            csum = fmaf(st.w, positive_only ? fmaxf(t, 0.f) : t, csum);
+            sc[e] = p;
+            dp[e] = p * (dp[e] - st.z) * DS_SCALE;
+        }
+        if (GRAD) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f16x8 pp, dd;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) { pp[jj] = (f16)sc[hf * 8 + jj]; dd[jj] = (f16)dp[hf * 8 + jj]; }
+                const int qbase = qb * 32 + hf * 16 + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const f16* orow = sOT + (db * 32 + ql) * VS + qbase;
+                    const f16* qrow = sQT + (db * 32 + ql) * VS + qbase;
+                    const f16x4 a0 = *reinterpret_cast<const f16x4*>(orow), a1 = *reinterpret_cast<const f16x4*>(orow + 8);
+                    const f16x4 b0 = *reinterpret_cast<const f16x4*>(qrow), b1 = *reinterpret_cast<const f16x4*>(qrow + 8);
+                    f16x8 fa, fb;
+                    fa[0] = a0[0]; fa[1] = a0[1]; fa[2] = a0[2]; fa[3] = a0[3]; fa[4] = a1[0]; fa[5] = a1[1]; fa[6] = a1[2]; fa[7] = a1[3];
+                    fb[0] = b0[0]; fb[1] = b0[1]; fb[2] = b0[2]; fb[3] = b0[3]; fb[4] = b1[0]; fb[5] = b1[1]; fb[6] = b1[2]; fb[7] = b1[3];
+                    ov[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, pp, ov[db], 0, 0, 0);        // dV^T += dO^T P
+                    ok[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, dd, ok[db], 0, 0, 0);        // dK^T += Q^T dS
+                }
             }
         }
     }
-    if (live) {
-        f16* o = dqkv + ((size_t)r * T + k) * 3 * D + h * 64;
+    csum += __shfl_xor(csum, 32, 64);
+    if (livek && hi == 0) atomicAdd(&c[(size_t)r * T + k], csum * (gscale[r] / (float)H));
+    if (GRAD && livek) {
+        f16* orow = dqkv + ((size_t)r * T + k) * ld + h * 64;
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            f16x8 hk, hv;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { hk[e] = (f16)dk[ch * 8 + e]; hv[e] = (f16)dv[ch * 8 + e]; }
-            *reinterpret_cast<f16x8*>(o + D + ch * 8) = hk;
-            *reinterpret_cast<f16x8*>(o + 2 * D + ch * 8) = hv;
-        }
+            for (int rq = 0; rq < 4; ++rq) {
+                f16x4 hk, hv;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { hk[jj] = (f16)(ok[db][rq * 4 + jj] * (1.f / DS_SCALE)); hv[jj] = (f16)ov[db][rq * 4 + jj]; }
+                *reinterpret_cast<f16x4*>(orow + D + db * 32 + rq * 8 + 4 * hi) = hk;
+                *reinterpret_cast<f16x4*>(orow + 2 * D + db * 32 + rq * 8 + 4 * hi) = hv;
+            }
     }
 }
 
 // Attention backward of one block for R = L * n sequences (+ the rollout update of that block).  dqkv NULL: rollout update only (the
 // last block that enters the rollout needs no gradient below it).  stats: scratch fp32 [R, H, T, 4].
-extern "C" int semabs_attention_bwd(const void* qkv, const void* dO, const float* rvec, const float* gscale, float* c, float* stats, void* dqkv,
-                                    int n, int L, int T, int H, int head_dim, int positive_only, void* stream) {
+extern "C" int semabs_attention_bwd(const void* qkv, const void* att, const float* fwd_stats, const void* dO, const float* rvec, const float* gscale,
+                                    float* c, float* stats, void* dqkv, int n, int L, int T, int H, int head_dim, int positive_only, void* stream) {
     if (n == 0 || L == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(qkv && dO && rvec && gscale && c && stats && n > 0 && L > 0 && H > 0, "semabs_attention_bwd: bad args");
-    SEMABS_REQUIRE(head_dim == 64 && T > 0 && T <= 320, "semabs_attention_bwd: head_dim must be 64 and T <= 320");
+    SEMABS_REQUIRE(qkv && att && fwd_stats && dO && rvec && gscale && c && stats && n > 0 && L > 0 && H > 0, "semabs_attention_bwd: bad args");
+    SEMABS_REQUIRE(head_dim == 64 && T > 0 && T <= 288, "semabs_attention_bwd: head_dim must be 64 and T <= 288");
     const long R = (long)L * n;
     SEMABS_REQUIRE(R * H < (1L << 31), "semabs_attention_bwd: too many sequences");
-    const size_t lds = (size_t)T * 64 * 2 * 2 + (size_t)T * 4 * 4;
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_q), hipFuncAttributeMaxDynamicSharedMemorySize, 320 * 64 * 4 + 320 * 16);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_kv), hipFuncAttributeMaxDynamicSharedMemorySize, 320 * 64 * 4 + 320 * 16);
-        set = true;
-    }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_attn_bwd_q, dim3((unsigned)(R * H)), dim3(320), lds, s, (const f16*)qkv, (const f16*)dO, rvec, gscale, c, stats, (f16*)dqkv,
-                       n, T, H, positive_only);
-    if (dqkv)
-        hipLaunchKernelGGL(k_attn_bwd_kv, dim3((unsigned)(R * H)), dim3(320), lds, s, (const f16*)qkv, (const f16*)dO, stats, (f16*)dqkv, n, T, H);
+    const dim3 grid((unsigned)(R * H));
+    const int nkb = (T + 31) / 32;
+#define BWD_LAUNCH(N)                                                                                                               \
+    {                                                                                                                                \
+        constexpr int TPc = 32 * N, VSc = TPc + 4;                                                                                   \
+        const size_t lq = (size_t)TPc * 256 + 64 * VSc * 2, lkv = (size_t)TPc * 256 + TPc * 16 + 2 * 64 * VSc * 2, lr = (size_t)TPc * 256 + TPc * 16; \
+        static bool set = false;                                                                                                     \
+        if (!set) {                                                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_dq<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_dkv<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lkv); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_dkv<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr); \
+            set = true;                                                                                                              \
+        }                                                                                                                            \
+        if (dqkv) {                                                                                                                  \
+            hipLaunchKernelGGL((k_attn_bwd_dq<N, true>), grid, dim3(64 * N), lq, s, (const f16*)qkv, (const f16*)att, fwd_stats, (const f16*)dO, rvec, stats, (f16*)dqkv, n, T, H); \
+            hipLaunchKernelGGL((k_attn_bwd_dkv<N, true>), grid, dim3(64 * N), lkv, s, (const f16*)qkv, (const f16*)dO, stats, gscale, c, (f16*)dqkv, n, T, H, positive_only);     \
+        } else {                                                                                                                     \
+            hipLaunchKernelGGL((k_attn_bwd_dq<N, false>), grid, dim3(64 * N), 0, s, (const f16*)qkv, (const f16*)att, fwd_stats, (const f16*)dO, rvec, stats, (f16*)nullptr, n, T, H); \
+            hipLaunchKernelGGL((k_attn_bwd_dkv<N, false>), grid, dim3(64 * N), lr, s, (const f16*)qkv, (const f16*)dO, stats, gscale, c, (f16*)nullptr, n, T, H, positive_only);   \
+        }                                                                                                                            \
+    }
+    switch (nkb) {
+        case 1: case 2: BWD_LAUNCH(2) break;
+        case 3: BWD_LAUNCH(3) break;
+        case 4: BWD_LAUNCH(4) break;
+        case 5: BWD_LAUNCH(5) break;
+        case 6: BWD_LAUNCH(6) break;
+        case 7: BWD_LAUNCH(7) break;
+        case 8: BWD_LAUNCH(8) break;
+        default: BWD_LAUNCH(9) break;                        // T = 257: ViT-L/14
+    }
+#undef BWD_LAUNCH
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

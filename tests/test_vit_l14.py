@@ -71,3 +71,60 @@ def test_hip_vit_l14_end_to_end_maps_vs_oracle():
     err = float(np.abs(maps - ref).max())
     print(f"ViT-L/14 end-to-end maps: L-inf {err:.3e} / max|ref| {np.abs(ref).max():.3e} = {err / np.abs(ref).max():.2e} relative")
     assert err <= 2e-3 * np.abs(ref).max()                       # 3 x the measured 6.2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,H,n,L,positive", [(257, 2, 2, 2, True), (257, 1, 1, 3, False), (70, 2, 3, 1, True), (197, 3, 1, 2, True)])
+def test_attention_backward_kernels_vs_fp64(T, H, n, L, positive):
+    """semabs_attention (forward, with row statistics) + semabs_attention_bwd (MFMA kernels of csrc/vitl.hip) against the fp64 formulas on the
+    same fp16 inputs: dQ, dK, dV of softmax attention and the rollout update c[k] = (1 / H) sum_h sum_q r[q] act(P dP gscale)."""
+    import torch
+    from semabs_amd import _lib
+    dev = _lib.require_gpu()
+    g = torch.Generator().manual_seed(T * 7 + H)
+    D, R = H * 64, L * n
+    qkv = (torch.randn(n, T, 3 * D, generator=g) * 0.6).half()
+    qkv[..., :D] *= 0.35                                                   # q is pre-scaled in the real path
+    dO = (torch.randn(R, T, D, generator=g) * 0.3).half()
+    rvec = torch.rand(R, T, generator=g)
+    gscale = torch.rand(R, generator=g) + 0.5
+    qkv_d, dO_d = qkv.to(dev), dO.to(dev)
+    att = torch.empty(n * T, D, dtype=torch.float16, device=dev)
+    fst = torch.zeros(n * H * T, 2, device=dev)
+    st = _lib.stream()
+    _lib.call("semabs_attention", _lib.ptr(qkv_d), _lib.ptr(att), _lib.ptr(fst), n, T, H, 64, 3 * D, 0, st)
+    c = torch.zeros(R, T, device=dev)
+    stats = torch.zeros(R * H * T, 4, device=dev)
+    dqkv = torch.zeros(R, T, 3 * D, dtype=torch.float16, device=dev)
+    rvec_d, gs_d = rvec.to(dev), gscale.to(dev)
+    _lib.call("semabs_attention_bwd", _lib.ptr(qkv_d), _lib.ptr(att), _lib.ptr(fst), _lib.ptr(dO_d), _lib.ptr(rvec_d), _lib.ptr(gs_d), _lib.ptr(c),
+              _lib.ptr(stats), _lib.ptr(dqkv), n, L, T, H, 64, int(positive), st)
+    c2 = torch.zeros(R, T, device=dev)
+    _lib.call("semabs_attention_bwd", _lib.ptr(qkv_d), _lib.ptr(att), _lib.ptr(fst), _lib.ptr(dO_d), _lib.ptr(rvec_d), _lib.ptr(gs_d), _lib.ptr(c2),
+              _lib.ptr(stats), None, n, L, T, H, 64, int(positive), st)
+    torch.cuda.synchronize()
+    q64 = qkv.double().view(n, T, 3, H, 64)
+    ref_c = torch.zeros(R, T, dtype=torch.float64)
+    ref = torch.zeros(R, T, 3, H, 64, dtype=torch.float64)
+    for r in range(R):
+        t = r % n
+        for h in range(H):
+            Q, K, V = q64[t, :, 0, h], q64[t, :, 1, h], q64[t, :, 2, h]
+            P = torch.softmax(Q @ K.T, dim=-1)
+            dOh = dO[r].double().view(T, H, 64)[:, h]
+            dP = dOh @ V.T
+            cam = P * dP * gscale[r].double()
+            if positive:
+                cam = cam.clamp(min=0)
+            ref_c[r] += (rvec[r].double()[:, None] * cam).sum(0) / H
+            dS = P * (dP - (P * dP).sum(-1, keepdim=True))
+            ref[r, :, 0, h], ref[r, :, 1, h], ref[r, :, 2, h] = dS @ K, dS.T @ Q, P.T @ dOh
+    got = dqkv.cpu().double().view(R, T, 3, H, 64)
+    for j, name in enumerate(("dQ", "dK", "dV")):
+        err = (got[:, :, j] - ref[:, :, j]).abs().max().item()
+        scale = ref[:, :, j].abs().max().item()
+        assert err <= 4e-3 * scale, (name, err, scale)                     # fp16 outputs and fp16 P / dS operands (measured ~1e-3)
+    for cc in (c, c2):
+        err = (cc.cpu().double() - ref_c).abs().max().item()
+        assert err <= 2e-3 * ref_c.abs().max().item(), (err, ref_c.abs().max().item())
+    assert torch.equal(c.cpu(), c2.cpu()) or (c - c2).abs().max().item() <= 1e-6 * c.abs().max().item()
