@@ -606,63 +606,81 @@ extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, lo
 // =================================================================================================
 // Rollout (closed form of clip_gradcam.py:90-131 for the only contributing block):
 //   rel[l, i, j-1] = scale[l, i] / H * sum_h clampmin0?(A[i, h, j] * (V[i, j, h, :] . u[l, i, h, :])),  j = 1..T-1
-// One workgroup per (tile i, group of 4 labels); that group's u rows staged in LDS; thread = token j.
 //   probs fp32 [n, H, T]; v fp16 [n, T, D] (the last block's V); u fp32 [L, n, D]; out fp32 [L, n_total, T-1]
 //   written at tile offset `tile0` (so chunks of tiles fill one [L, N, g, g] array).
+// Round 2: the V . u dots are a [labels x 64] x [64 x tokens] product per (tile, head) and run on v_mfma_f32_16x16x32_f16: A = u rows of a
+// group of 16 labels (fp32 split into fp16 hi + lo: two MFMAs, products exact to 2^-22), B = V rows of 16 tokens, so a lane owns one token
+// and four labels, V is read ONCE per group of 16 labels (the thread-per-token VALU kernel it replaces re-read it per group of 4: 3.2 GB
+// for a 0.74 GB tensor, 0.81 ms per scene) and the stores of a label are 64 contiguous bytes per 16 lanes.  One workgroup (4 waves) per
+// (tile, label group); a wave takes every fourth block of 16 tokens and keeps its (at most five) accumulators across the heads, so that u
+// is fetched once per head.
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_rollout(const float* __restrict__ probs, const f16* __restrict__ vmat,
                                                  const float* __restrict__ u, const float* __restrict__ scale,
                                                  float* __restrict__ rel, int n, int T, int H, int L, int positive_only,
                                                  long n_total, long tile0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* su = reinterpret_cast<float*>(smem);            // [4][D]: this workgroup's group of 4 labels
+    constexpr int MB = 5;                                   // token blocks per wave: 4 waves x 5 x 16 = 320 >= T
     const int D = H * 64;
     const int i = blockIdx.x;
-    const int l0 = blockIdx.y * 4;                         // (tile, label group) per workgroup: n tiles alone would not even fill the CUs
-    const int nl = (L - l0 < 4) ? L - l0 : 4;
-    for (int c = threadIdx.x; c < nl * D; c += blockDim.x) su[c] = u[((long)(l0 + c / D) * n + i) * D + (c % D)];
-    for (int c = nl * D + threadIdx.x; c < 4 * D; c += blockDim.x) su[c] = 0.f;
-    __syncthreads();
-    for (int j = 1 + threadIdx.x; j < T; j += blockDim.x) {
-        const f16* vrow = vmat + ((long)i * T + j) * D;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int h = 0; h < H; ++h) {
-            float dot[4] = {0.f, 0.f, 0.f, 0.f};
-            const f16x8* v8 = reinterpret_cast<const f16x8*>(vrow + h * 64);
+    const int l0 = blockIdx.y * 16;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int vl = lane & 15, kg = lane >> 4;
+    const int la = min(l0 + vl, L - 1);                     // this lane's label row of the A operand
+    const float* urow = u + ((long)la * n + i) * D + kg * 8;
+    int jc[MB];
+    f32x4 acc[MB];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const f16x8 vh = v8[d];
-                float vv[8];
+    for (int m = 0; m < MB; ++m) {
+        jc[m] = min((wid + 4 * m) * 16 + vl, T - 1);
+        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int h = 0; h < H; ++h) {
+        f16x8 ah[2], al[2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] = (float)vh[e];
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4 x0 = *reinterpret_cast<const float4*>(urow + h * 64 + ks * 32);
+            const float4 x1 = *reinterpret_cast<const float4*>(urow + h * 64 + ks * 32 + 4);
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 u0 = *reinterpret_cast<const float4*>(su + k * D + h * 64 + d * 8);
-                    const float4 u1 = *reinterpret_cast<const float4*>(su + k * D + h * 64 + d * 8 + 4);
-                    dot[k] += vv[0] * u0.x + vv[1] * u0.y + vv[2] * u0.z + vv[3] * u0.w;
-                    dot[k] += vv[4] * u1.x + vv[5] * u1.y + vv[6] * u1.z + vv[7] * u1.w;
-                }
-            }
-            const float a = probs[((long)i * H + h) * T + j];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float c = a * dot[k];
-                acc[k] += positive_only ? fmaxf(c, 0.f) : c;
-            }
+            for (int e = 0; e < 8; ++e) { ah[ks][e] = (f16)xs[e]; al[ks][e] = (f16)(xs[e] - (float)ah[ks][e]); }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < nl)
-                rel[((long)(l0 + k) * n_total + tile0 + i) * (T - 1) + (j - 1)] = acc[k] / H * scale[(long)(l0 + k) * n + i];
+        for (int m = 0; m < MB; ++m) {
+            if ((wid + 4 * m) * 16 >= T) continue;          // wave-uniform
+            const f16* vrow = vmat + ((long)i * T + jc[m]) * D + h * 64 + kg * 8;
+            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 b = *reinterpret_cast<const f16x8*>(vrow + ks * 32);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], b, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], b, d, 0, 0, 0);
+            }
+            const float a = probs[((long)i * H + h) * T + jc[m]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = a * d[e];
+                acc[m][e] += positive_only ? fmaxf(c, 0.f) : c;
+            }
+        }
+    }
+    // acc[m][e] = sum over heads for (label l0 + 4 kg + e, token (wid + 4 m) * 16 + vl)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int j = (wid + 4 * m) * 16 + vl;
+        if (j < 1 || j >= T) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int l = l0 + 4 * kg + e;
+            if (l < L) rel[((long)l * n_total + tile0 + i) * (T - 1) + (j - 1)] = acc[m][e] / H * scale[(long)l * n + i];
+        }
     }
 }
 extern "C" int semabs_rollout(const float* probs, const void* v, const float* u, const float* scale, float* rel, int n,
                               int T, int H, int L, int positive_only, long n_total, long tile0, void* stream) {
     if (n == 0 || L == 0) return SEMABS_OK;
     SEMABS_REQUIRE(probs && v && u && scale && rel && n > 0 && T > 1 && H > 0, "semabs_rollout: bad args");
-    size_t lds = (size_t)4 * H * 64 * 4;
-    SEMABS_REQUIRE(lds <= 64 * 1024, "semabs_rollout: H * 64 * 16 bytes must fit the default LDS allocation");
-    hipLaunchKernelGGL(k_rollout, dim3(n, (L + 3) / 4), dim3(256), lds, (hipStream_t)stream, probs, (const f16*)v, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
+    SEMABS_REQUIRE(T <= 320, "semabs_rollout: T must be <= 320");
+    hipLaunchKernelGGL(k_rollout, dim3(n, (L + 15) / 16), dim3(256), 0, (hipStream_t)stream, probs, (const f16*)v, u, scale, rel, n, T, H, L, positive_only, n_total, tile0);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
