@@ -184,7 +184,10 @@ int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta
                        int G, long nvox, float eps, void* stream);
 /* [GroupNorm ->] Conv3d k in {1, 3} pad k/2 [+ bias] [+ residual] [-> ReLU], channels-last   unet3d.py:16-17, 98-128, 247-259, 579
  * act_f32 (here and in the ConvTranspose3d entry points) is a flag word: bit 0 = fp32 activations ("exact" mode), bit 8 = run the generic
- * gather kernel even where an LDS-brick kernel exists (per-call cross-check for tests; results agree to rounding). */
+ * gather kernel even where an LDS-brick kernel exists (per-call cross-check for tests; results agree to rounding), bit 9 = the w_hi / w_lo
+ * buffers carry, behind the [Cout, Kp] matrix (behind all eight class matrices for the transposed convolution, each packed on its own), a
+ * fragment-packed copy [Kp / 32][Cout / 16][64 lanes = kg * 16 + row][8] fp16 with k = 32 * k-step + 8 * kg + e, which the kernels then read
+ * instead (one MFMA A operand = 1 KB of contiguous memory; same values, same results). */
 int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                   const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                   int act_f32, void* stream);

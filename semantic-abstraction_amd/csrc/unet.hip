@@ -455,6 +455,7 @@ struct ConvArgs {
     double* stats;              // optional (k_conv16_lds): fp64 [B, 8, 2] sum / sum of squares of the OUTPUT per GroupNorm group, accumulated
     int ablate;                 // tuning only (k_conv16_lds): 1 producers only, 2 consumers only, 4 consumers without epilogue
     long long* trace;           // tuning only (k_conv_brick, tools/conv_probe.py): [workgroup][8] s_memtime stamps of wave 0
+    const f16* wp_hi; const f16* wp_lo;   // optional (k_conv_brick): fragment-packed copy of the weights, see SEMABS_CONV_PACKED
 };
 
 template <bool F32>
@@ -541,9 +542,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
             if (LDSW && ni != 0) continue;                  // this wave's own tile only (tile wid), kept in slot 0
-            const long widx = (long)(n0 + (LDSW ? wid : ni) * 16 + vl) * a.Kp + ks * 32 + kg * 8;
-            R.wh[ni] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
-            if (F32) R.wl[ni] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+            const int cb = (n0 >> 4) + (LDSW ? wid : ni);
+            const long widx = a.wp_hi ? ((long)(ks * (a.Cout >> 4) + cb) * 64 + lane) * 8 : (long)(cb * 16 + vl) * a.Kp + ks * 32 + kg * 8;
+            R.wh[ni] = *reinterpret_cast<const f16x8*>((a.wp_hi ? a.wp_hi : a.w_hi) + widx);
+            if (F32) R.wl[ni] = *reinterpret_cast<const f16x8*>((a.wp_hi ? a.wp_lo : a.w_lo) + widx);
         }
     };
     auto park = [&](int ks, Raw& R) {                       // LDSW: this wave's tile of k-step ks -> LDS, then the workgroup barrier
@@ -961,6 +963,13 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
 // `act_f32` of the convolution entry points is a flag word: bit 0 = fp32 activations ("exact" mode), bit 8 (SEMABS_CONV_GENERIC) = run
 // the generic gather kernel even where a brick kernel exists - the per-call cross-check used by tests/ (no process-global switch).
 #define SEMABS_CONV_GENERIC 256
+// bit 9 (SEMABS_CONV_PACKED): the w_hi / w_lo buffers carry, right after the [Cout, Kp] matrix (after all eight class matrices for the transposed
+// convolution, each packed on its own), a FRAGMENT-PACKED copy: [k-step = Kp / 32][Cout / 16][lane = kg * 16 + row][8] fp16 with
+// k = 32 * k-step + 8 * kg + e, so that the A operand of one MFMA (16 output channels x 32 k) is 1 KB of contiguous memory read with
+// lane-linear 16-byte pieces.  From the row-major matrix the same fragment is 16 rows x 64 bytes, Kp * 2 bytes apart, and a 128-byte line is
+// half used whenever consecutive k-steps of a kernel are not adjacent in k (k_conv_brick walks (channel chunk, tap)): the rolled k-loops
+// of the 32^3 / 16^3 levels ran at 0.43 of the MFMA rate on it, at the MFMA rate on the packed copy.
+#define SEMABS_CONV_PACKED 512
 #ifdef SEMABS_TUNING
 static int g_conv16_ablate = 0;      // tuning build only (libsemabs_hip_tune.so)
 static long long* g_conv_trace = nullptr;
@@ -1156,14 +1165,22 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
                 kofs = (long)tap * Cin + cc * 16 + (kg & 1) * 8;
             }
         };
+        const bool packed = a.wp_hi != nullptr;
+        const int ncb = a.Cout >> 4;                        // output-channel blocks of 16 in the packed layout
+        auto w_index = [&](int ks, int nb, long kofs) -> long {          // element index of this lane's 8 weights of (k-step ks, block nb)
+            return packed ? ((long)((CW == 32 ? ks * (Cin >> 5) + cc : ks) * ncb + (cout0 >> 4) + nb) * 64 + lane) * 8
+                          : (long)(cout0 + nb * 16 + vl) * a.Kp + kofs;
+        };
+        const f16* const wbase_h = packed ? a.wp_hi : a.w_hi;
+        const f16* const wbase_l = packed ? a.wp_lo : a.w_lo;
         auto load_w = [&](int ks, f16x8* wh, f16x8* wl) {
             int voff, chunk; long kofs;
             step_geom(ks, voff, chunk, kofs);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const long widx = (long)(cout0 + nb * 16 + vl) * a.Kp + kofs;
-                wh[nb] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
-                if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
+                const long widx = w_index(ks, nb, kofs);
+                wh[nb] = *reinterpret_cast<const f16x8*>(wbase_h + widx);
+                if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(wbase_l + widx);
                 if (CW == 16 && !ONE) {
                     const bool dead = ks == NSTEPS - 1 && (kg >> 1);
 #pragma unroll
@@ -1171,32 +1188,63 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
                 }
             }
         };
-        auto step = [&](int ks, const f16x8* wh, const f16x8* wl, f16x8* whn, f16x8* wln) {
+        // Activation fragments are loop-carried: xh / xl hold the fragments of the CURRENT k-step on entry, and each of them is re-requested
+        // in place for the next k-step right behind its last MFMA (in the last output-channel block), so that neither the LDS round trip nor the
+        // address arithmetic of the rolled loops stands between two MFMA blocks (they did: the rolled k-loop ran at 0.7 / 0.43 of the MFMA
+        // rate with two / four output blocks).
+        f16x8 xh[4], xl[4];
+        auto read_x = [&](int ks) {
             int voff, chunk; long kofs;
             step_geom(ks, voff, chunk, kofs);
-            f16x8 xh[4], xl[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int off = chunk * PLANE + (rbase[r] + voff) * 8;
                 xh[r] = *reinterpret_cast<const f16x8*>(s_hi + off);
                 if (F32) xl[r] = *reinterpret_cast<const f16x8*>(s_lo + off);
             }
-            if (ks + 1 < NSTEPS) load_w(ks + 1, whn, wln);
-            __builtin_amdgcn_sched_barrier(0);                 // requests first, then the MFMAs
+        };
+        // one k-step.  whn / wln != nullptr: the next step's weights go to a second register set, requested before the MFMAs (NB <= 2);
+        // nullptr: every block's weights are re-requested in place behind its own MFMAs (NB = 4)
+        auto step = [&](int ks, f16x8* wh, f16x8* wl, f16x8* whn, f16x8* wln) {
+            const int ksn = ks + 1 < NSTEPS ? ks + 1 : ks;      // (the last step re-requests its own operands: no branch in the loop)
+            int voffn, chunkn; long kofsn;
+            step_geom(ksn, voffn, chunkn, kofsn);
+            int offn[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 4; ++r) offn[r] = chunkn * PLANE + (rbase[r] + voffn) * 8;
+            if (whn) load_w(ksn, whn, wln);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh[r], acc[r][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) {
+                const bool lastb = nb == NB - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh[r], acc[r][nb], 0, 0, 0);
+                    if (!F32 && lastb) { xh[r] = *reinterpret_cast<const f16x8*>(s_hi + offn[r]); __builtin_amdgcn_sched_barrier(0); }
+                }
                 if (F32) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
+                    for (int r = 0; r < 4; ++r) {
                         acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh[r], acc[r][nb], 0, 0, 0);
-                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl[r], acc[r][nb], 0, 0, 0);
+                        if (lastb) { xh[r] = *reinterpret_cast<const f16x8*>(s_hi + offn[r]); __builtin_amdgcn_sched_barrier(0); }
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl[r], acc[r][nb], 0, 0, 0);
+                        if (lastb) { xl[r] = *reinterpret_cast<const f16x8*>(s_lo + offn[r]); __builtin_amdgcn_sched_barrier(0); }
+                    }
+                }
+                if (!whn) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const long widx = w_index(ksn, nb, kofsn);
+                    wh[nb] = *reinterpret_cast<const f16x8*>(wbase_h + widx);
+                    if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(wbase_l + widx);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
+        read_x(0);
         if constexpr (NB <= 2) {
             f16x8 wa_h[NB], wa_l[NB], wb_h[NB], wb_l[NB];      // two weight fragment sets, alternating by k-step parity
             load_w(0, wa_h, wa_l);
@@ -1224,37 +1272,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
             load_w(0, wh, wl);
             constexpr int KU = (ONE && !PERSIST) ? NSTEPS : 1;
 #pragma unroll KU
-            for (int ks = 0; ks < NSTEPS; ++ks) {
-                int voff, chunk; long kofs, kofs_n;
-                step_geom(ks, voff, chunk, kofs);
-                { int v2, c2; step_geom(ks + 1 < NSTEPS ? ks + 1 : ks, v2, c2, kofs_n); }
-                f16x8 xh[4], xl[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int off = chunk * PLANE + (rbase[r] + voff) * 8;
-                    xh[r] = *reinterpret_cast<const f16x8*>(s_hi + off);
-                    if (F32) xl[r] = *reinterpret_cast<const f16x8*>(s_lo + off);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh[r], acc[r][nb], 0, 0, 0);
-                    if (F32) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh[r], acc[r][nb], 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl[r], acc[r][nb], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    {                                           // (the last step re-requests its own fragments: no branch in the loop)
-                        const long widx = (long)(cout0 + nb * 16 + vl) * a.Kp + kofs_n;
-                        wh[nb] = *reinterpret_cast<const f16x8*>(a.w_hi + widx);
-                        if (F32) wl[nb] = *reinterpret_cast<const f16x8*>(a.w_lo + widx);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            for (int ks = 0; ks < NSTEPS; ++ks) step(ks, wh, wl, nullptr, nullptr);
         }
         if (!EARLY && ntile < total) issue(ntile, ncc);
     }
@@ -1449,7 +1467,11 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
     a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.ntaps = ksize * ksize * ksize;
     a.Kp = ((a.ntaps * Cin + 31) / 32) * 32;
-    a.stats = nullptr; a.ablate = 0;
+    a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr;
+    if (act_flags & SEMABS_CONV_PACKED) {
+        a.wp_hi = a.w_hi + (long)Cout * a.Kp;
+        if (w_lo) a.wp_lo = a.w_lo + (long)Cout * a.Kp;
+    }
     int t = 0;
     for (int kd = 0; kd < ksize; ++kd)
         for (int kh = 0; kh < ksize; ++kh)
@@ -1487,15 +1509,18 @@ extern "C" int semabs_conv3d_gather(const void* x, const void* w_hi, const void*
                                     int B, int I0, int I1, int I2, int M0, int M1, int M2, int in_stride, int Cin, int Cout, int ntaps,
                                     const signed char* taps, int act_f32, void* stream) {
     if (B == 0) return SEMABS_OK;
+    const int act_flags = act_f32;
+    act_f32 = act_flags & 1;
     int rc = conv_common_checks(x, w_hi, w_lo, y, Cin, Cout, act_f32);
     if (rc) return rc;
     SEMABS_REQUIRE(taps && ntaps >= 1 && ntaps <= 28 && in_stride >= 1, "semabs_conv3d_gather: bad taps / stride");
     ConvArgs a;
     SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gather: in_scale and in_shift go together");
     a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
-    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.ablate = 0; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
+    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
     a.M0 = M0; a.M1 = M1; a.M2 = M2; a.os = 1; a.is = in_stride; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
     a.ntaps = ntaps; a.Kp = ((ntaps * Cin + 31) / 32) * 32;
+    if (act_flags & SEMABS_CONV_PACKED) { a.wp_hi = a.w_hi + (long)Cout * a.Kp; if (a.w_lo) a.wp_lo = a.w_lo + (long)Cout * a.Kp; }
     for (int t = 0; t < ntaps; ++t) { a.td0[t] = taps[t * 3]; a.td1[t] = taps[t * 3 + 1]; a.td2[t] = taps[t * 3 + 2]; }
     return conv_launch(a, act_f32, (hipStream_t)stream);
 }
@@ -1512,6 +1537,7 @@ struct ConvTArgs {
     long class_off[8];
     int B, D0, D1, D2, Cin, Cout;
     double* stats;              // optional: fp64 [B, 8, 2] GroupNorm statistics (8 groups) of the output (after bias and skip), accumulated
+    long packed_off;            // > 0: element offset of the fragment-packed copies of the class matrices (SEMABS_CONV_PACKED), same class offsets
 };
 template <bool F32, int P0>                              // P0 = output parity along axis 0: two launches of four classes each (acc registers)
 __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
@@ -1579,8 +1605,8 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
             const int cls = P0 * 4 + c4, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
             const int ntaps = (p0 + 1) * (p1 + 1) * (p2 + 1);
             const long kp = (long)ntaps * a.Cin;                                // row stride of this class's weight matrix
-            const f16* wh_c = a.w_hi + a.class_off[cls];
-            const f16* wl_c = F32 ? a.w_lo + a.class_off[cls] : nullptr;
+            const f16* wh_c = a.w_hi + a.packed_off + a.class_off[cls];
+            const f16* wl_c = F32 ? a.w_lo + a.packed_off + a.class_off[cls] : nullptr;
             int tt = 0;
 #pragma unroll
             for (int q0 = 0; q0 <= p0; ++q0)
@@ -1590,7 +1616,8 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
                     for (int q2 = 0; q2 <= p2; ++q2, ++tt) {
                         const int d0 = p0 ? (q0 == 0 ? 1 : 0) : 0, d1 = p1 ? (q1 == 0 ? 1 : 0) : 0, d2 = p2 ? (q2 == 0 ? 1 : 0) : 0;
                         const int voff = (d0 * H1 + d1) * H2 + d2;
-                        const long widx = (long)(cout0 + vl) * kp + (long)tt * a.Cin + cc * 32 + kg * 8;
+                        const long widx = a.packed_off ? ((long)((tt * (a.Cin >> 5) + cc) * (a.Cout >> 4) + (cout0 >> 4)) * 64 + lane) * 8
+                                                       : (long)(cout0 + vl) * kp + (long)tt * a.Cin + cc * 32 + kg * 8;
                         const f16x8 wh = *reinterpret_cast<const f16x8*>(wh_c + widx);
                         f16x8 wl;
                         if (F32) wl = *reinterpret_cast<const f16x8*>(wl_c + widx);
@@ -1717,6 +1744,7 @@ static int convT_impl(const void* x, const void* w_hi, const void* w_lo, const l
         ta.x = x; ta.y = y; ta.w_hi = (const f16*)w_hi; ta.w_lo = (const f16*)w_lo; ta.bias = bias; ta.skip = skip;
         for (int c = 0; c < 8; ++c) ta.class_off[c] = class_off[c];
         ta.B = B; ta.D0 = D0; ta.D1 = D1; ta.D2 = D2; ta.Cin = Cin; ta.Cout = Cout;
+        ta.packed_off = (act_flags & SEMABS_CONV_PACKED) ? 27L * Cin * Cout : 0;
         const bool fused = out_sums && out_groups == 8 && Cout % 16 == 0;
         ta.stats = fused ? out_sums : nullptr;
         rc = act_f32 ? convT_brick_launch<true>(ta, (hipStream_t)stream) : convT_brick_launch<false>(ta, (hipStream_t)stream);
@@ -1727,7 +1755,8 @@ static int convT_impl(const void* x, const void* w_hi, const void* w_lo, const l
         const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
         ConvArgs a;
         a.x = x; a.y = y; a.w_hi = (const f16*)w_hi + class_off[cls]; a.w_lo = w_lo ? (const f16*)w_lo + class_off[cls] : nullptr;
-        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip; a.stats = nullptr; a.ablate = 0;
+        a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip; a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr;
+        if (act_flags & SEMABS_CONV_PACKED) { a.wp_hi = a.w_hi + 27L * Cin * Cout; if (a.w_lo) a.wp_lo = a.w_lo + 27L * Cin * Cout; }
         a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = 2 * D0; a.O1 = 2 * D1; a.O2 = 2 * D2;
         a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.is = 1; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
         int t = 0;

@@ -39,6 +39,17 @@ def _split16(w: torch.Tensor):
     return hi.contiguous(), lo.contiguous()
 
 
+def _split16p(w: torch.Tensor):
+    """fp16 hi / lo split of a [rows, Kp] weight matrix with its fragment-packed copy appended (unet3d._pack_fragments, flag bit 9 of the
+    convolution entry points' flag word) -> (hi, lo, flag)."""
+    from .unet3d import _pack_fragments
+    if w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
+        hi, lo = _split16(torch.cat([w.reshape(-1), _pack_fragments(w)]))
+        return hi, lo, 512
+    hi, lo = _split16(w)
+    return hi, lo, 0
+
+
 def _pad32(w: torch.Tensor) -> torch.Tensor:
     kp = (w.shape[1] + 31) // 32 * 32
     if kp == w.shape[1]:
@@ -78,10 +89,11 @@ class UNetTrainer:
                 fwd = _pad32(w.permute(0, 2, 3, 4, 1).reshape(cout, -1))
                 bwd = _pad32(w.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(cin, -1))
                 self.mats[pre] = dict(kind="conv", cin=cin, cout=cout, k=k, groups=self.G if cin >= self.G else 1,
-                                      fwd=_split16(fwd), bwd=_split16(bwd))
+                                      fwd=_split16p(fwd), bwd=_split16p(bwd))
             elif kind == "convT":
                 w = self.p[key + "weight"]                                             # [cin, cout, 3, 3, 3]
-                mats, offs, off = [], [], 0
+                from .unet3d import _pack_fragments
+                mats, packs, offs, off = [], [], [], 0
                 for cls in range(8):
                     pp = (cls >> 2, (cls >> 1) & 1, cls & 1)
                     cols = []
@@ -91,14 +103,14 @@ class UNetTrainer:
                                 kk = [1 if q == 0 else (0 if t == 0 else 2) for q, t in zip(pp, (t0, t1, t2))]
                                 cols.append(w[:, :, kk[0], kk[1], kk[2]].t())
                     m = torch.cat(cols, dim=1).contiguous()
-                    mats.append(m.reshape(-1)); offs.append(off); off += m.numel()
+                    mats.append(m.reshape(-1)); packs.append(_pack_fragments(m)); offs.append(off); off += m.numel()
                 bwd = _pad32(w.permute(0, 2, 3, 4, 1).reshape(cin, -1))               # [cin, (k, cout)]
-                self.mats[pre] = dict(kind="convT", cin=cin, cout=cout, fwd=_split16(torch.cat(mats)), class_off=(C.c_long * 8)(*offs),
-                                      bwd=_split16(bwd))
+                self.mats[pre] = dict(kind="convT", cin=cin, cout=cout, fwd=_split16(torch.cat(mats + packs)) + (512,),
+                                      class_off=(C.c_long * 8)(*offs), bwd=_split16p(bwd))
             else:                                                                      # final 1x1x1 conv with bias
                 w = self.p[key + "weight"]
-                self.mats[pre] = dict(kind="final", cin=cin, cout=cout, k=1, fwd=_split16(_pad32(w.reshape(cout, cin))),
-                                      bwd=_split16(_pad32(w.reshape(cout, cin).t().contiguous())))
+                self.mats[pre] = dict(kind="final", cin=cin, cout=cout, k=1, fwd=_split16p(_pad32(w.reshape(cout, cin))),
+                                      bwd=_split16p(_pad32(w.reshape(cout, cin).t().contiguous())))
 
     # ---- forward -----------------------------------------------------------------------------------------------------------------
     def _conv_fwd(self, x, pre, relu, resid=None) -> _Rec:
@@ -119,7 +131,7 @@ class UNetTrainer:
         _lib.call("semabs_gn_meanrstd", _lib.ptr(sums), _lib.ptr(r.mean), _lib.ptr(r.rstd), B, G, nvox * (Cc // G), 1e-5, st)
         r.y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
         _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(r.y), _lib.ptr(r.scale), _lib.ptr(r.shift),
-                  None, _lib.ptr(resid), B, D0, D1, D2, m["cin"], m["cout"], 3, int(relu), 1, st)
+                  None, _lib.ptr(resid), B, D0, D1, D2, m["cin"], m["cout"], 3, int(relu), 1 | m["fwd"][2], st)
         return r
 
     def _block_fwd(self, x, pre, tape):
@@ -151,14 +163,14 @@ class UNetTrainer:
             B, D0, D1, D2, _ = x.shape
             y = torch.empty_like(skip)
             _lib.call("semabs_convtranspose3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), m["class_off"], _lib.ptr(y),
-                      _lib.ptr(self.p[self.prefix + pre + "bias"]), _lib.ptr(skip), B, D0, D1, D2, m["cin"], m["cout"], 1, st)
+                      _lib.ptr(self.p[self.prefix + pre + "bias"]), _lib.ptr(skip), B, D0, D1, D2, m["cin"], m["cout"], 1 | m["fwd"][2], st)
             tape.append(("up", pre, x, L - 2 - i))
             x = self._block_fwd(y, f"decoders.{i}.basic_module.", tape)
         m = self.mats["final_conv."]
         B, D0, D1, D2, _ = x.shape
         y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
         _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(y), None, None,
-                  _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1, st)
+                  _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1 | m["fwd"][2], st)
         tape.append(("final", x))
         return y, tape
 
@@ -216,7 +228,7 @@ class UNetTrainer:
                       cout, cin, 27, TAPS_CONV3, 1, st)
         dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
         _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
-                  B, D0, D1, D2, cout, cin, 3, 0, 1, st)
+                  B, D0, D1, D2, cout, cin, 3, 0, 1 | m["bwd"][2], st)
         red = torch.zeros(B, cin, 2, dtype=torch.float64, device=self.dev)
         _lib.call("semabs_chan_reduce", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(red), B, nvox, cin, G, st)
         coef = torch.empty(B, cin, 3, dtype=torch.float32, device=self.dev)
@@ -250,7 +262,7 @@ class UNetTrainer:
         dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
         sc, sh, s2 = self._scale(g, B, cout)
         _lib.call("semabs_conv3d_gather", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh),
-                  B, 2 * D0, 2 * D1, 2 * D2, D0, D1, D2, 2, cout, cin, 27, TAPS_CONV3, 1, st)
+                  B, 2 * D0, 2 * D1, 2 * D2, D0, D1, D2, 2, cout, cin, 27, TAPS_CONV3, 1 | m["bwd"][2], st)
         return self._unscale(dx, s2)
 
     def backward(self, tape, dy: torch.Tensor) -> torch.Tensor:
@@ -275,7 +287,7 @@ class UNetTrainer:
                 dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
                 sc, sh, s2 = self._scale(g, B, cout)
                 _lib.call("semabs_conv3d", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh), None, None,
-                          B, D0, D1, D2, cout, cin, 1, 0, 1, st)
+                          B, D0, D1, D2, cout, cin, 1, 0, 1 | m["bwd"][2], st)
                 g = self._unscale(dx, s2)
             elif kind == "block":
                 g = self._block_bwd(item[1:], g)
@@ -351,14 +363,14 @@ class VOOLTrainer:
         gradient (arbitrarily small): scaled by a power of two on the way in and back on the way out."""
         R, Ci = x.shape
         Co = w.shape[0]
-        hi, lo = _split16(_pad32(w.contiguous()))
+        hi, lo, pk = _split16p(_pad32(w.contiguous()))
         y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
         u = self.unet
         sc = sh = s2 = None
         if grad_in:
             sc, sh, s2 = u._scale(x, 1, Ci)
         _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(b), None,
-                  1, 1, 1, R, Ci, Co, 1, 2 if act else 0, 1, _lib.stream())
+                  1, 1, 1, R, Ci, Co, 1, 2 if act else 0, 1 | pk, _lib.stream())
         return u._unscale(y, s2) if grad_in else y
 
     def _wgrad_linear(self, dOut, x, grad_w, cols=None):

@@ -25,6 +25,15 @@ def number_of_features_per_level(init_channel_number, num_levels):
     return [init_channel_number * 2 ** k for k in range(num_levels)]
 
 
+def _pack_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Kp] (Kp % 32 == 0, Cout % 16 == 0) -> [Kp / 32][Cout / 16][lane = kg * 16 + row][8] flattened, k = 32 * k-step + 8 * kg + e:
+    the order in which a wave's 64 lanes hold the A operand of v_mfma_f32_16x16x32_f16 (csrc/unet.hip, SEMABS_CONV_PACKED)."""
+    cout, kp = int(w.shape[0]), int(w.shape[1])
+    assert cout % 16 == 0 and kp % 32 == 0
+    # w[cb * 16 + vl, ks * 32 + kg * 8 + e] -> [ks, cb, kg, vl, e]
+    return w.reshape(cout // 16, 16, kp // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
+
+
 def _split16(w: torch.Tensor, dev):
     hi = w.to(torch.float16)
     lo = (w - hi.float()).to(torch.float16)
@@ -40,7 +49,14 @@ class _Conv:
         kp = (w.shape[1] + 31) // 32 * 32
         if kp != w.shape[1]:
             w = torch.cat([w, torch.zeros(cout, kp - w.shape[1], device=w.device)], dim=1)
-        self.w_hi, self.w_lo = _split16(w.contiguous(), dev)
+        # Fragment-packed copy appended behind the [Cout, Kp] matrix (flag bit 9 of the convolution entry points' flag word,
+        # SEMABS_CONV_PACKED): one MFMA A operand = 1 KB of contiguous memory (see _pack_fragments)
+        self.packed = 0
+        flat = w.contiguous().reshape(-1)
+        if cout % 16 == 0:
+            flat = torch.cat([flat, _pack_fragments(w)])
+            self.packed = 512
+        self.w_hi, self.w_lo = _split16(flat, dev)
         self.cin, self.cout, self.k = cin, cout, k
         self.gn_w = None if gn_w is None else gn_w.float().to(dev).contiguous()
         self.gn_b = None if gn_b is None else gn_b.float().to(dev).contiguous()
@@ -54,7 +70,7 @@ class _ConvT:
     def __init__(self, weight: torch.Tensor, bias, dev):
         cin, cout = int(weight.shape[0]), int(weight.shape[1])
         w = weight.float()
-        mats, offs, off = [], [], 0
+        mats, packs, offs, off = [], [], [], 0
         for cls in range(8):
             p = (cls >> 2, (cls >> 1) & 1, cls & 1)
             cols = []
@@ -65,9 +81,11 @@ class _ConvT:
                         cols.append(w[:, :, k[0], k[1], k[2]].t())          # [Cout, Cin]
             m = torch.cat(cols, dim=1).contiguous()                            # [Cout, ntaps * Cin]
             mats.append(m.reshape(-1))
+            packs.append(_pack_fragments(m) if cout % 16 == 0 and cin % 32 == 0 else None)
             offs.append(off)
             off += m.numel()
-        flat = torch.cat(mats)
+        self.packed = 512 if all(p is not None for p in packs) else 0       # fragment-packed copies of the class matrices behind the plain ones
+        flat = torch.cat(mats + (packs if self.packed else []))
         self.w_hi, self.w_lo = _split16(flat, dev)
         self.class_off = (C.c_long * 8)(*offs)
         self.bias = bias.float().to(dev).contiguous()
@@ -170,7 +188,7 @@ class ResidualUNet3D(torch.nn.Module):
         y = torch.empty(B, D0, D1, D2, conv.cout, dtype=self.act_dtype, device=self.dev)
         scale, shift = self._gn(x, conv, in_sums) if gn else (None, None)
         args = (_lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
-                _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32 | (256 if generic else 0))
+                _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32 | (256 if generic else 0) | conv.packed)
         if out_groups:
             sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
             _lib.call("semabs_conv3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
@@ -197,7 +215,7 @@ class ResidualUNet3D(torch.nn.Module):
         assert tuple(skip.shape) == (B, 2 * D0, 2 * D1, 2 * D2, ct.cout)
         y = torch.empty_like(skip)
         args = (_lib.ptr(x), _lib.ptr(ct.w_hi), _lib.ptr(ct.w_lo), ct.class_off, _lib.ptr(y),
-                _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32 | (256 if generic else 0))
+                _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32 | (256 if generic else 0) | ct.packed)
         if out_groups:
             sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
             _lib.call("semabs_convtranspose3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
