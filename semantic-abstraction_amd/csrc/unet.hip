@@ -1022,9 +1022,13 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
 // fragment read cover all 64 banks) and runs the 27 taps of that channel chunk out of LDS.  A wave keeps 4 rows x NB x 16 output
 // channels in registers; the weights (too many for registers) stream from L2 once per k-step and wave.
 // -------------------------------------------------------------------------------------------------
-template <bool F32, int CW, int NB, bool ONE, bool PERSIST>   // CW = channels staged at a time (16 or 32); ONE: Cin == CW (compile-time offsets)
+// TX = tile extent along the innermost axis: 16 (one fragment = 16 consecutive voxels of a row, a wave owns 4 rows) or 8 (volumes 8 wide, the
+// 8^3 level: one fragment = two y-rows x 8 voxels, a wave owns 2 fragments; round 2 - that level used to run on the gather kernel at 0.11 of
+// its bound).
+template <bool F32, int CW, int NB, bool ONE, bool PERSIST, int TX = 16>   // CW = channels staged at a time (16 or 32); ONE: Cin == CW (compile-time offsets)
 __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
-    constexpr int T0 = 4, H0 = T0 + 2, HALO = H0 * C16_H1 * C16_H2, NTHR = 512;
+    constexpr int T0 = 4, H0 = T0 + 2, HX = TX + 2, HALO = H0 * C16_H1 * HX, NTHR = 512;
+    constexpr int R = TX / 4;                               // fragments (16 voxels each) per wave: the tile has 2 * TX of them
     constexpr int CPV = CW / 8;                             // 16-byte chunks per staged voxel
     constexpr int NSTEPS = CW == 32 ? 27 : 14;
     // Round 2: PERSISTENT workgroups (one or two per CU, tiles t = blockIdx.x, + gridDim.x, ...) and a software pipeline over the staging
@@ -1044,7 +1048,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int vl = lane & 15, kg = lane >> 4;
-    const int n2 = a.I2 / C16_T2, n1 = a.I1 / C16_T1, n0 = a.I0 / T0;
+    const int n2 = a.I2 / TX, n1 = a.I1 / C16_T1, n0 = a.I0 / T0;
     const int per_vol = n0 * n1 * n2;
     const bool has_gn = a.gn_scale != nullptr;
     const int Cin = ONE ? CW : a.Cin;                       // compile-time when there is a single chunk: immediate weight offsets
@@ -1061,13 +1065,17 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         b = t % a.B; cout0 = (t / a.B) * (NB * 16);
         const int t2 = br % n2; br /= n2;
         const int t1 = br % n1; const int t0 = br / n1;
-        z0 = t0 * T0; y0 = t1 * C16_T1; x0 = t2 * C16_T2;
+        z0 = t0 * T0; y0 = t1 * C16_T1; x0 = t2 * TX;
     };
-    int rbase[4];                                           // halo voxel index of the centre tap of this lane's voxel in each row
+    // fragment f = wid * R + r of the tile -> voxel of lane-slot v (0..15): TX = 16: (z, y, x) = (f >> 3, f & 7, v); TX = 8: (f >> 2, 2 (f & 3) + (v >> 3), v & 7)
+    auto frag_z = [&](int f) { return TX == 16 ? f >> 3 : f >> 2; };
+    auto frag_y = [&](int f, int v) { return TX == 16 ? (f & 7) : 2 * (f & 3) + (v >> 3); };
+    auto frag_x = [&](int v) { return TX == 16 ? v : (v & 7); };
+    int rbase[R];                                           // halo voxel index of the centre tap of this lane's voxel in each fragment
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = wid * 4 + r;                        // 0..31 = z * 8 + y
-        rbase[r] = (((row >> 3) + 1) * C16_H1 + ((row & 7) + 1)) * C16_H2 + (vl + 1);
+    for (int r = 0; r < R; ++r) {
+        const int f = wid * R + r;
+        rbase[r] = ((frag_z(f) + 1) * C16_H1 + (frag_y(f, vl) + 1)) * HX + (frag_x(vl) + 1);
     }
     // ---- staging: halo of channels [cc * CW, +CW) -> GroupNorm affine -> fp16 hi/lo -> LDS; task = (halo voxel, 8-channel chunk) ----
     // Chunk fastest over the lanes: a quad of lanes reads ONE 128-byte line (4 x 32 B of a voxel, or 2 voxels x 2 x 32 B for Cin = 16).  A
@@ -1098,7 +1106,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int v = min(vsub + it * VPI, HALO - 1);
-            const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
+            const int hx = v % HX, hy = (v / HX) % C16_H1, hz = v / (HX * C16_H1);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             if (gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2) inb |= 1u << it;
             const int cz = min(max(gz, 0), a.I0 - 1), cy = min(max(gy, 0), a.I1 - 1), cx = min(max(gx, 0), a.I2 - 1);
@@ -1132,9 +1140,9 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
     int b, cout0, z0, y0, x0;
     decode(tile, b, cout0, z0, y0, x0);
     BRICK_STAMP(0);
-    f32x4 acc[4][NB];
+    f32x4 acc[R][NB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[r][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -1152,12 +1160,12 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         // constant; a rolled loop for the multi-chunk variant.
         auto step_geom = [&](int ks, int& voff, int& chunk, long& kofs) {     // kofs: k index of this lane's 8 weights = tap * Cin + channel
             if (CW == 32) {
-                chunk = kg; voff = ((ks / 9) - 1) * C16_H1 * C16_H2 + (((ks / 3) % 3) - 1) * C16_H2 + ((ks % 3) - 1);
+                chunk = kg; voff = ((ks / 9) - 1) * C16_H1 * HX + (((ks / 3) % 3) - 1) * HX + ((ks % 3) - 1);
                 kofs = (long)ks * Cin + cc * 32 + kg * 8;
             } else {
                 const int ta = 2 * ks, tb = (2 * ks + 1 < 27) ? 2 * ks + 1 : 26;  // tap 27 has zero weights: reuse tap 26's address
-                const int offa = ((ta / 9) - 1) * C16_H1 * C16_H2 + (((ta / 3) % 3) - 1) * C16_H2 + ((ta % 3) - 1);
-                const int offb = ((tb / 9) - 1) * C16_H1 * C16_H2 + (((tb / 3) % 3) - 1) * C16_H2 + ((tb % 3) - 1);
+                const int offa = ((ta / 9) - 1) * C16_H1 * HX + (((ta / 3) % 3) - 1) * HX + ((ta % 3) - 1);
+                const int offb = ((tb / 9) - 1) * C16_H1 * HX + (((tb / 3) % 3) - 1) * HX + ((tb % 3) - 1);
                 voff = (kg >> 1) ? offb : offa; chunk = kg & 1;
                 // k index = tap * Cin + channel; tap 27 (second tap of the last step) does not exist: with Cin == 16 the padded weight row holds
                 // zeros there, otherwise its lanes read tap 26's weights again and load_w zeroes them
@@ -1192,12 +1200,12 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         // in place for the next k-step right behind its last MFMA (in the last output-channel block), so that neither the LDS round trip nor the
         // address arithmetic of the rolled loops stands between two MFMA blocks (they did: the rolled k-loop ran at 0.7 / 0.43 of the MFMA
         // rate with two / four output blocks).
-        f16x8 xh[4], xl[4];
+        f16x8 xh[R], xl[R];
         auto read_x = [&](int ks) {
             int voff, chunk; long kofs;
             step_geom(ks, voff, chunk, kofs);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < R; ++r) {
                 const int off = chunk * PLANE + (rbase[r] + voff) * 8;
                 xh[r] = *reinterpret_cast<const f16x8*>(s_hi + off);
                 if (F32) xl[r] = *reinterpret_cast<const f16x8*>(s_lo + off);
@@ -1209,27 +1217,27 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
             const int ksn = ks + 1 < NSTEPS ? ks + 1 : ks;      // (the last step re-requests its own operands: no branch in the loop)
             int voffn, chunkn; long kofsn;
             step_geom(ksn, voffn, chunkn, kofsn);
-            int offn[4];
+            int offn[R];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) offn[r] = chunkn * PLANE + (rbase[r] + voffn) * 8;
+            for (int r = 0; r < R; ++r) offn[r] = chunkn * PLANE + (rbase[r] + voffn) * 8;
             if (whn) load_w(ksn, whn, wln);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const bool lastb = nb == NB - 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < R; ++r) {
                     acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xh[r], acc[r][nb], 0, 0, 0);
                     if (!F32 && lastb) { xh[r] = *reinterpret_cast<const f16x8*>(s_hi + offn[r]); __builtin_amdgcn_sched_barrier(0); }
                 }
                 if (F32) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < R; ++r) {
                         acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nb], xh[r], acc[r][nb], 0, 0, 0);
                         if (lastb) { xh[r] = *reinterpret_cast<const f16x8*>(s_hi + offn[r]); __builtin_amdgcn_sched_barrier(0); }
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < R; ++r) {
                         acc[r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nb], xl[r], acc[r][nb], 0, 0, 0);
                         if (lastb) { xl[r] = *reinterpret_cast<const f16x8*>(s_lo + offn[r]); __builtin_amdgcn_sched_barrier(0); }
                     }
@@ -1286,12 +1294,12 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         const int src = (k2 * 16 + v2) << 2;                 // byte address of the source lane for ds_bpermute
         // (the lanes' values are passed as scalars through __float_as_int: `__builtin_bit_cast(int, acc[r][nb][e])` on the vector element made
         //  clang 19 / ROCm 7.2 emit ONE ds_bpermute per accumulator and copy its result to all four elements)
-        long obase[4];                                       // element index of (voxel, cout0 + 4 * k2); output block nb is 16 channels further
-        float q[4][NB][4];
+        long obase[R];                                       // element index of (voxel, cout0 + 4 * k2); output block nb is 16 channels further
+        float q[R][NB][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = wid * 4 + r;
-            const long ovox = (((long)b * a.I0 + (z0 + (row >> 3))) * a.I1 + (y0 + (row & 7))) * a.I2 + (x0 + v2);
+        for (int r = 0; r < R; ++r) {
+            const int f = wid * R + r;
+            const long ovox = (((long)b * a.I0 + (z0 + frag_z(f))) * a.I1 + (y0 + frag_y(f, v2))) * a.I2 + (x0 + frag_x(v2));
             obase[r] = ovox * a.Cout + (cout0 + 4 * k2);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -1306,7 +1314,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = cout0 + nb * 16 + 4 * k2;
@@ -1332,17 +1340,17 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
     BRICK_STAMP(7);
 }
 
-template <bool F32, int CW, int NB, bool ONE, bool PERSIST>
+template <bool F32, int CW, int NB, bool ONE, bool PERSIST, int TX = 16>
 static int conv_brick_launch_p(const ConvArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)((6 * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * (CW / 8) * 2 * (F32 ? 2 : 1);      // CW / 8 planes (256-B padded), hi (+ lo), fp16
+    const size_t lds = (size_t)((6 * C16_H1 * (TX + 2) * 8 + 127) / 128 * 128) * (CW / 8) * 2 * (F32 ? 2 : 1);      // CW / 8 planes (256-B padded), hi (+ lo), fp16
     static int per_cu = 0;                                  // co-resident workgroups per CU (LDS and registers), queried once
     if (!per_cu) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE, PERSIST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE, PERSIST, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_brick<F32, CW, NB, ONE, PERSIST>, 512, lds) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_brick<F32, CW, NB, ONE, PERSIST, TX>, 512, lds) != hipSuccess || n < 1) n = 1;
         per_cu = n;
     }
-    const long total = (long)(a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2) * a.B * (a.Cout / (NB * 16));
+    const long total = (long)(a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / TX) * a.B * (a.Cout / (NB * 16));
     SEMABS_REQUIRE(total < (1L << 30), "conv brick: too many tiles");
     long nwg = total;
     if (PERSIST) { nwg = (long)semabs_num_cus() * per_cu; if (nwg > total) nwg = total; }   // as many workgroups as fit the chip at once
@@ -1350,7 +1358,7 @@ static int conv_brick_launch_p(const ConvArgs& a, hipStream_t s) {
 #ifdef SEMABS_TUNING
     at.trace = g_conv_trace;
 #endif
-    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE, PERSIST>), dim3((unsigned)nwg), dim3(512), lds, s, at, (int)total);
+    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE, PERSIST, TX>), dim3((unsigned)nwg), dim3(512), lds, s, at, (int)total);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -1362,6 +1370,9 @@ static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
     return conv_brick_launch_p<F32, CW, NB, ONE, false>(a, s);
 }
 static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
+    if (a.I2 % C16_T2 != 0) {                               // 8 wide (the 8^3 level; Cin >= 32 there): 4 x 8 x 8 tiles, two output blocks
+        return f32 ? conv_brick_launch_p<true, 32, 2, false, false, 8>(a, s) : conv_brick_launch_p<false, 32, 2, false, false, 8>(a, s);
+    }
     const long bricks = (long)a.B * (a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
     const bool nb4 = a.Cout % 64 == 0 && bricks * (a.Cout / 64) >= 512;      // wider Cout slices only while the grid still fills the chip
     if (a.Cin == 16) {
@@ -1482,7 +1493,8 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
     if (bricks && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31)) {
         if (out_sums && out_groups == 8) { a.stats = out_sums; fused = true; }
         rc = conv16_lds_launch(a, act_f32, (hipStream_t)stream);
-    } else if (bricks && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0) {
+    } else if (bricks && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 &&
+               (D2 % C16_T2 == 0 || (D2 % 8 == 0 && Cin % 32 == 0))) {
         rc = conv_brick_launch(a, act_f32, (hipStream_t)stream);
     } else {
         rc = conv_launch(a, act_f32, (hipStream_t)stream);
