@@ -680,7 +680,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             if (s1) stage_a(1, t + 1);
             GEMM8_SYNC(s1);
             __builtin_amdgcn_s_setprio(1);
-            read_b(1, par); mma_a0(0);
+            if (!GEMM_ABL(16)) read_b(1, par);          // tuning bit 4: no B staging, no B fragment reads (wrong results: what would B from registers buy?)
+            mma_a0(0);
             GEMM8_INTERLEAVE(4);
             __builtin_amdgcn_s_setprio(0);
             GEMM8_END();
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             GEMM8_INTERLEAVE(8);
             __builtin_amdgcn_s_setprio(0);
             GEMM8_END();
-            if (s2) stage_b(0, t + 2);
+            if (s2 && !GEMM_ABL(16)) stage_b(0, t + 2);
             GEMM8_SYNC(s2);
             __builtin_amdgcn_s_setprio(1);
             read_a(0, par ^ 1);                      // (last K tile: reads a stale slot, never used - keeps the block branch-free)
@@ -699,10 +700,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             GEMM8_INTERLEAVE(8);
             __builtin_amdgcn_s_setprio(0);
             GEMM8_END();
-            if (s2) stage_b(1, t + 2);
+            if (s2 && !GEMM_ABL(16)) stage_b(1, t + 2);
             GEMM8_SYNC(s2);
             __builtin_amdgcn_s_setprio(1);
-            read_b0n(par ^ 1);
+            if (!GEMM_ABL(16)) read_b0n(par ^ 1);
             mma_a1(0);
             GEMM8_INTERLEAVE(4);
             __builtin_amdgcn_s_setprio(0);

@@ -84,7 +84,7 @@ if "base" in what:
             log[f"base_pf{pf}_{rep}"] = line(f"fragment prefetch {pf} (rep {rep})")
     tune(3, 1)
 if "ablate" in what:
-    for ab, label in [(8, "no epilogue"), (4, "no DMA waits"), (12, "no DMA waits, no epilogue"), (9, "no DMA, no epilogue")]:
+    for ab, label in [(8, "no epilogue"), (16, "no B staging / B reads"), (24, "no B staging / reads, no epilogue"), (9, "no DMA, no epilogue")]:
         tune(2, ab)
         log[f"ablate{ab}"] = line(label)
     tune(2, 0)
