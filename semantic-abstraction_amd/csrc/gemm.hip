@@ -248,14 +248,15 @@ struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
-static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0, g_prefetch = 1;
+static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0, g_prefetch = 1, g_persist = 0;
 static unsigned long long* g_trace = nullptr;
 extern "C" int semabs_gemm_tune(int key, long long value) {
     switch (key) {
         case 0: g_force_cfg = (int)value; break;     // alternative ring-kernel tile configurations (see launch())
         case 1: g_group_m = value < 1 ? 1 : (int)value; break;
         case 2: g_ablate = (int)value; break;
-        case 3: g_prefetch = (int)value; break;       // 1 = fragment reads in the MFMA shadow (production), 0 = read block before the barrier
+        case 3: g_prefetch = (int)value; break;
+        case 5: g_persist = (int)value; break;        // 1 = persistent workgroups (one per CU)       // 1 = fragment reads in the MFMA shadow (production), 0 = read block before the barrier
         case 4: g_trace = (unsigned long long*)value; break;
         default: return SEMABS_EINVAL;
     }
@@ -333,7 +334,7 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 
-template <int EPI, bool PF>
+template <int EPI, bool PF, bool PERS = false>      // PERS: persistent workgroups, tiles vb = blockIdx.x, + gridDim.x, ... (see the end of the kernel)
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
@@ -641,8 +642,9 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     } while (0)
 
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
+    for (int vb = blockIdx.x; vb < g.n_blocks; vb += PERS ? (int)gridDim.x : g.n_blocks) {
     long m0; int n0;
-    tile_of(blockIdx.x, m0, n0);
+    tile_of(vb, m0, n0);
     set_tile(m0, n0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -759,11 +761,20 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* tr = g.trace + (size_t)blockIdx.x * 4;
+            unsigned long long* tr = g.trace + (size_t)vb * 4;
             tr[0] = t_start; tr[1] = t_main; tr[2] = t_end; tr[3] = ((unsigned long long)xcc << 32) | hw;
         }
     }
 #endif
+    if (PERS) {
+        // Persistent workgroups (one per CU): the next tile's first half-tiles are requested while this tile's stores drain - a workgroup is
+        // not retired before its stores complete, and the next one cannot start before it is (the operand buffers take 128 of the 160 KB):
+        // 0.9 - 5 us per tile (tools/gemm_probe.py trace).  Every wave is done with its epilogue slice of LDS before the DMA overwrites it;
+        // no ordinary load is outstanding at this point (the residual rows were consumed before their stores).
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    }
+    }
 #undef GEMM8_SYNC
 #undef GEMM8_END
 #undef GEMM8_INTERLEAVE
@@ -785,6 +796,16 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     GEMM_TUNE_ARGS(g);
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
+#ifdef SEMABS_TUNING
+    if (g_persist) {
+        static bool pset = false;
+        if (!pset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); pset = true; }
+        int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+        gemm_dispatch(k_gemm8<EPI, true, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS, s, g, o);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
+#endif
     if (GEMM_PREFETCH) gemm_dispatch(k_gemm8<EPI, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     else gemm_dispatch(k_gemm8<EPI, false>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     SEMABS_CHECK_LAUNCH();

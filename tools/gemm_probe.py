@@ -83,6 +83,12 @@ if "base" in what:
             tune(3, pf)
             log[f"base_pf{pf}_{rep}"] = line(f"fragment prefetch {pf} (rep {rep})")
     tune(3, 1)
+if "persist" in what:
+    for rep in range(2):
+        for ps in (0, 1):
+            tune(5, ps)
+            log[f"persist{ps}_{rep}"] = line(f"persistent {ps} (rep {rep})")
+    tune(5, 0)
 if "ablate" in what:
     for ab, label in [(8, "no epilogue"), (16, "no B staging / B reads"), (24, "no B staging / reads, no epilogue"), (9, "no DMA, no epilogue")]:
         tune(2, ab)
