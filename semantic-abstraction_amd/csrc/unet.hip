@@ -1296,6 +1296,9 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         //  clang 19 / ROCm 7.2 emit ONE ds_bpermute per accumulator and copy its result to all four elements)
         long obase[R];                                       // element index of (voxel, cout0 + 4 * k2); output block nb is 16 channels further
         float q[R][NB][4];
+        float st_s[NB], st_q[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { st_s[nb] = 0.f; st_q[nb] = 0.f; }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int f = wid * R + r;
@@ -1328,8 +1331,38 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
                 if (a.bias) { const float4 bv = *reinterpret_cast<const float4*>(a.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
                 if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
                 if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oi) = make_float4(o[0], o[1], o[2], o[3]);
-                else { f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oi) = h; }
+                else {
+                    f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oi) = h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (float)h[e];          // statistics of the values as stored
+                }
+                st_s[nb] += (o[0] + o[1]) + (o[2] + o[3]);
+                st_q[nb] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
             }
+        }
+        // Fused GroupNorm statistics of the output (8 groups; a lane's four channels always lie in one group): fp32 per lane over its
+        // R fragments -> reduction over the 16 voxel lanes -> LDS float atomics per group of this NB x 16-channel slice -> one fp64
+        // atomic per (group, moment) per workgroup.  Saves the statistics pass over y that the next layer's GroupNorm needs.
+        if (a.stats) {
+            const int cg = a.Cout >> 3;                     // channels per group (>= 4)
+            float* s_stat = reinterpret_cast<float*>(smem); // [local group][2]; the operand planes are dead after the barrier
+            __syncthreads();                                // every wave is done with the k-loop's LDS reads
+            if (tid < 16) s_stat[tid] = 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float vs = st_s[nb], vq = st_q[nb];
+#pragma unroll
+                for (int m = 4; m < 64; m <<= 1) { vs += __shfl_xor(vs, m, 64); vq += __shfl_xor(vq, m, 64); }
+                if (v2 == 0) {
+                    const int gl = (nb * 16 + 4 * k2) / cg;                  // group index local to this slice
+                    atomicAdd(&s_stat[gl * 2], vs); atomicAdd(&s_stat[gl * 2 + 1], vq);
+                }
+            }
+            __syncthreads();
+            const int ngl = (NB * 16 >= cg) ? NB * 16 / cg : 1;
+            if (tid < ngl * 2) atomicAdd(a.stats + ((long)b * 8 + cout0 / cg + (tid >> 1)) * 2 + (tid & 1), (double)s_stat[tid]);
+            if (PERSIST) __syncthreads();
         }
     }
     BRICK_STAMP(5);
@@ -1495,6 +1528,7 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
         rc = conv16_lds_launch(a, act_f32, (hipStream_t)stream);
     } else if (bricks && ksize == 3 && Cout % 32 == 0 && (Cin == 16 || Cin % 32 == 0) && relu != 2 && D0 % 4 == 0 && D1 % C16_T1 == 0 &&
                (D2 % C16_T2 == 0 || (D2 % 8 == 0 && Cin % 32 == 0))) {
+        if (out_sums && out_groups == 8) { a.stats = out_sums; fused = true; }     // (a lane's four output channels lie in one of the 8 groups: Cout >= 32)
         rc = conv_brick_launch(a, act_f32, (hipStream_t)stream);
     } else {
         rc = conv_launch(a, act_f32, (hipStream_t)stream);

@@ -312,10 +312,11 @@ def test_decoder_folded_final_conv_matches_materialised():
 
 
 @pytest.mark.parametrize("precision", ["exact", "fp16"])
-@pytest.mark.parametrize("cin,cout,dims,B", [(16, 16, (16, 24, 32), 3), (16, 16, (8, 8, 16), 1), (16, 32, (8, 8, 16), 2), (32, 64, (3, 5, 6), 2)])
+@pytest.mark.parametrize("cin,cout,dims,B", [(16, 16, (16, 24, 32), 3), (16, 16, (8, 8, 16), 1), (16, 32, (8, 8, 16), 2), (32, 64, (3, 5, 6), 2),
+                                            (32, 32, (8, 16, 32), 2), (64, 64, (8, 16, 32), 64), (128, 256, (4, 8, 8), 2), (256, 512, (4, 8, 8), 1)])
 def test_conv3d_output_statistics(precision, cin, cout, dims, B):
     """semabs_conv3d_stats: the GroupNorm statistics of the output handed to the next layer - fused into the level-0 kernel's epilogue
-    (Cin = Cout = 16 on 8 x 8 x 16 bricks), a statistics pass elsewhere - equal the sums of the stored output, and the output itself
+    (Cin = Cout = 16 on 8 x 8 x 16 bricks) and the brick kernel's (4 x 8 x 16 / 4 x 8 x 8 tiles), a statistics pass elsewhere - equal the sums of the stored output, and the output itself
     is the plain semabs_conv3d result."""
     from semabs_amd.unet3d import _Conv
     rng = np.random.default_rng(cin * 7 + cout)
