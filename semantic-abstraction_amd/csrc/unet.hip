@@ -1894,7 +1894,37 @@ struct DecArgs {
 // (1 MB apart at 128^3, every lane its own cache lines: 2.4 ms per scene).  Here a workgroup takes a 32 x 2 x 4 tile of the lattice with the
 // lane index along query axis 0 - reads are contiguous along the volume's innermost axis - and transposes its 256 results through LDS so
 // the output still goes out in query order (16-byte pieces).  Same arithmetic per query, same output layout.
-template <typename T, bool LATTICE>
+// sampled features f[16] (+ normalised query qn) -> [optional folded final 1x1x1 convolution] -> Linear(19 | 16, 16) LeakyReLU Linear(16, 1)
+// (CXYZ = concat_xyz as a template parameter: with a run-time row length the compiler copied the 2.4 KB argument struct to scratch and indexed
+//  it there - every weight of every query came out of scratch memory instead of the scalar cache)
+template <bool CXYZ>
+__device__ __forceinline__ float decoder_mlp(const DecArgs& a, float (&f)[16], const float (&qn)[3]) {
+    if (a.has_final) {                                      // f <- W_final . f + b_final  (the corner weights of the in-range corners sum to 1)
+        float g[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float t = a.fb[j];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t += a.fw[j * 16 + c] * f[c];
+            g[j] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = g[j];
+    }
+    float o = a.b2;
+    constexpr int din = CXYZ ? 19 : 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float h = a.b1[j];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h += a.w1[j * din + c] * f[c];
+        if (CXYZ) h += a.w1[j * 19 + 16] * qn[0] + a.w1[j * 19 + 17] * qn[1] + a.w1[j * 19 + 18] * qn[2];
+        h = h > 0.f ? h : 0.01f * h;
+        o += a.w2[j] * h;
+    }
+    return o;
+}
+template <typename T, bool LATTICE, bool CXYZ>
 __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, const float* __restrict__ query, DecArgs a, int P, long M,
                                                  long q_stride_p, float* __restrict__ out, int G0, int G1, int G2) {
     __shared__ float s_out[LATTICE ? 256 : 1];
@@ -1948,29 +1978,7 @@ __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, cons
 #pragma unroll
         for (int c = 0; c < 8; ++c) f[8 + c] += v[c] * w;
     }
-    if (a.has_final) {                                      // f <- W_final . f + b_final  (the corner weights of the in-range corners sum to 1)
-        float g[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float t = a.fb[j];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t += a.fw[j * 16 + c] * f[c];
-            g[j] = t;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) f[j] = g[j];
-    }
-    float o = a.b2;
-    const int din = a.concat_xyz ? 19 : 16;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float h = a.b1[j];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) h += a.w1[j * din + c] * f[c];
-        if (a.concat_xyz) h += a.w1[j * 19 + 16] * qn[0] + a.w1[j * 19 + 17] * qn[1] + a.w1[j * 19 + 18] * qn[2];
-        h = h > 0.f ? h : 0.01f * h;
-        o += a.w2[j] * h;
-    }
+    const float o = decoder_mlp<CXYZ>(a, f, qn);
     if (LATTICE) {
         s_out[(threadIdx.x & 63) * 4 + (threadIdx.x >> 6)] = o;                 // [(i0, i1) pair][i2]
         __syncthreads();
@@ -2010,15 +2018,27 @@ extern "C" int semabs_decoder(const void* vol, const float* query, const float* 
     }
     const bool lattice = qgrid3 && (long)qgrid3[0] * qgrid3[1] * qgrid3[2] == M && qgrid3[0] % 32 == 0 && qgrid3[1] % 2 == 0 && qgrid3[2] % 4 == 0 &&
                          (long)P * (M / 256) < (1L << 31);
+#define DEC_LAUNCH(KERN, GRID)                                                                                                        \
+    do {                                                                                                                              \
+        if (vol_f32) { if (concat_xyz) hipLaunchKernelGGL((KERN(float, true)), GRID, block, 0, (hipStream_t)stream, (const float*)vol, query, a, P, M, q_stride_p, out, g0, g1, g2); \
+                       else hipLaunchKernelGGL((KERN(float, false)), GRID, block, 0, (hipStream_t)stream, (const float*)vol, query, a, P, M, q_stride_p, out, g0, g1, g2); }         \
+        else { if (concat_xyz) hipLaunchKernelGGL((KERN(f16, true)), GRID, block, 0, (hipStream_t)stream, (const f16*)vol, query, a, P, M, q_stride_p, out, g0, g1, g2);             \
+               else hipLaunchKernelGGL((KERN(f16, false)), GRID, block, 0, (hipStream_t)stream, (const f16*)vol, query, a, P, M, q_stride_p, out, g0, g1, g2); }                     \
+    } while (0)
+#define DEC_K_LAT(T, C) k_decoder<T, true, C>
+#define DEC_K_ANY(T, C) k_decoder<T, false, C>
+    const dim3 block(256);
+    const int g0 = qgrid3 ? qgrid3[0] : 0, g1 = qgrid3 ? qgrid3[1] : 0, g2 = qgrid3 ? qgrid3[2] : 0;
     if (lattice) {
-        dim3 grid((unsigned)(P * (M / 256))), block(256);
-        if (vol_f32) hipLaunchKernelGGL((k_decoder<float, true>), grid, block, 0, (hipStream_t)stream, (const float*)vol, query, a, P, M, q_stride_p, out, qgrid3[0], qgrid3[1], qgrid3[2]);
-        else hipLaunchKernelGGL((k_decoder<f16, true>), grid, block, 0, (hipStream_t)stream, (const f16*)vol, query, a, P, M, q_stride_p, out, qgrid3[0], qgrid3[1], qgrid3[2]);
+        const dim3 grid((unsigned)(P * (M / 256)));
+        DEC_LAUNCH(DEC_K_LAT, grid);
     } else {
-        dim3 grid(semabs_cdiv((long)P * M, 256)), block(256);
-        if (vol_f32) hipLaunchKernelGGL((k_decoder<float, false>), grid, block, 0, (hipStream_t)stream, (const float*)vol, query, a, P, M, q_stride_p, out, 0, 0, 0);
-        else hipLaunchKernelGGL((k_decoder<f16, false>), grid, block, 0, (hipStream_t)stream, (const f16*)vol, query, a, P, M, q_stride_p, out, 0, 0, 0);
+        const dim3 grid(semabs_cdiv((long)P * M, 256));
+        DEC_LAUNCH(DEC_K_ANY, grid);
     }
+#undef DEC_LAUNCH
+#undef DEC_K_LAT
+#undef DEC_K_ANY
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
