@@ -327,11 +327,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p, long 
     const int n = bytes > 0x7fffffffL ? 0x7fffffff : (bytes < 0 ? 0 : (int)bytes);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
 }
+// AUX = cache policy bits of the access (bit 1 = nt, "non-temporal": streaming).  The fp32 epilogues (residual read-modify-write, fp32 outputs)
+// use nt for their loads and stores - the tile is touched once and should not push operand tiles out of L2: out-proj 666 -> 696, c_proj
+// 1 028 -> 1 044, K|V 829 -> 846 TFLOP/s - while the fp16 outputs, which the next kernel reads, are slower with it (QKV -4 %, c_fc -5 %).
+template <int AUX>
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
 }
+template <int AUX>
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
 template <int EPI, bool PF, bool PERS = false>      // PERS: persistent workgroups, tiles vb = blockIdx.x, + gridDim.x, ... (see the end of the kernel)
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
     constexpr bool OUT16 = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
     constexpr int ES = OUT16 ? 2 : 4;                       // bytes per output element
+    constexpr int EAUX = OUT16 ? 0 : 2;                     // epilogue cache policy: nt for the fp32 tiles (see buf_store4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                         const float4 a = *reinterpret_cast<const float4*>(g.addend + (long)(g.g_off + within) * g.N + (n0 + hb * 128 + wc * 32 + cchunk * 4));
                         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
                     }
-                    buf_store4(rC, (unsigned)(orow - orow0) * ldcb + (unsigned)(cchunk * 16), (unsigned)(hb * 128 * ES), v);
+                    buf_store4<EAUX>(rC, (unsigned)(orow - orow0) * ldcb + (unsigned)(cchunk * 16), (unsigned)(hb * 128 * ES), v);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                 f32x4 res[2][NIT];
                 auto issue = [&](int pass) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) res[pass & 1][it] = buf_load4(rC, voff, soff_of(pass, it));
+                    for (int it = 0; it < NIT; ++it) res[pass & 1][it] = buf_load4<EAUX>(rC, voff, soff_of(pass, it));
                 };
                 issue(0);
 #pragma unroll
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     for (int it = 0; it < NIT; ++it) {
                         const f32x4 v = lds_read(pass, it);
                         const f32x4 o = res[pass & 1][it];
-                        buf_store4(rC, voff, soff_of(pass, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
+                        buf_store4<EAUX>(rC, voff, soff_of(pass, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                 for (int pass = 0; pass < 4; ++pass) {
                     lds_write(pass);
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) buf_store4(rC, voff, soff_of(pass, it), lds_read(pass, it));
+                    for (int it = 0; it < NIT; ++it) buf_store4<EAUX>(rC, voff, soff_of(pass, it), lds_read(pass, it));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
