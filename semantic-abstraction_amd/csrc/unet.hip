@@ -1710,7 +1710,7 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
             const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
             const long oidx = ovox * a.Cout + cout0 + 4 * kg;
             if (a.skip) {
-                if (F32) { const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.skip) + oidx); sk[r][c4][0] = q.x; sk[r][c4][1] = q.y; sk[r][c4][2] = q.z; sk[r][c4][3] = q.w; }
+                if (F32) { const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.skip) + oidx)); sk[r][c4][0] = q[0]; sk[r][c4][1] = q[1]; sk[r][c4][2] = q[2]; sk[r][c4][3] = q[3]; }
                 else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); sk[r][c4][0] = (float)q[0]; sk[r][c4][1] = (float)q[1]; sk[r][c4][2] = (float)q[2]; sk[r][c4][3] = (float)q[3]; }
             } else {
                 sk[r][c4][0] = sk[r][c4][1] = sk[r][c4][2] = sk[r][c4][3] = 0.f;
@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
             const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
             const long oidx = ovox * a.Cout + cout0 + 4 * kg;
             float o[4] = {acc[r][c4][0] + bv.x + sk[r][c4][0], acc[r][c4][1] + bv.y + sk[r][c4][1], acc[r][c4][2] + bv.z + sk[r][c4][2], acc[r][c4][3] + bv.w + sk[r][c4][3]};
-            if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oidx) = make_float4(o[0], o[1], o[2], o[3]);
+            if (F32) __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + oidx));
             else {
                 f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
 #pragma unroll
