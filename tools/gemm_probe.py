@@ -57,6 +57,9 @@ if "table" in what:
     # per-shape table of the production configuration + the vendor library's PLAIN fp16 GEMM (torch.matmul -> hipBLASLt, no bias / GELU /
     # residual) as calibration of what a large fp16 GEMM reaches on this box at these shapes
     tab = {}
+    for _ in range(2):                                   # clocks up before the first measured shape
+        for name, n, k, epi in SHAPES:
+            time_shape(n, k, epi, reps=3)
     for name, n, k, epi in SHAPES:
         ms, tf = time_shape(n, k, epi)
         A, B, _, _ = operands(n, k, epi)
