@@ -106,6 +106,38 @@ def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid):
     assert (y_brick - y_gen).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale
 
 
+@pytest.mark.parametrize("precision", ["exact", "fp16"])
+@pytest.mark.parametrize("cin,cout,dims", [(32, 32, (8, 16, 32)), (64, 64, (4, 8, 8)), (16, 32, (4, 8, 16)), (128, 64, (3, 5, 6)), (16, 16, (8, 8, 16))])
+def test_packed_weights_equal_rowmajor(precision, cin, cout, dims):
+    """SEMABS_CONV_PACKED (flag bit 9: the kernels read the fragment-packed copy behind the [Cout, Kp] matrix) only changes WHERE a weight fragment
+    comes from: brick, level-0 and gather kernels give bit-identical outputs with and without it, and so does the transposed convolution."""
+    from semabs_amd.unet3d import _Conv, _ConvT
+    rng = np.random.default_rng(cin + 3 * cout)
+    u = _unet(precision)
+    x = _cl(torch.from_numpy(rng.standard_normal((2, cin, *dims)).astype(np.float32))).cuda().to(u.act_dtype)
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32))
+    conv = _Conv(w, torch.ones(cin), torch.zeros(cin), None, 8, u.dev)
+    assert conv.packed == 512
+    # (no GroupNorm in front: its statistics are reduced with floating-point atomics, so two calls may differ by an ulp of the affine)
+    y1 = u._conv(x, conv, relu=True, gn=False)
+    y1g = u._conv(x, conv, relu=True, gn=False, generic=True)
+    conv.packed = 0
+    y0 = u._conv(x, conv, relu=True, gn=False)
+    y0g = u._conv(x, conv, relu=True, gn=False, generic=True)
+    scale = float(y0.float().abs().max())
+    # (bit-equal where the kernel is deterministic; the gather kernel's split-K partial sums are added with fp32 atomics)
+    assert float((y1.float() - y0.float()).abs().max()) <= 2e-6 * scale and float((y1g.float() - y0g.float()).abs().max()) <= 2e-6 * scale
+    if cin % 32 == 0 and cout % 16 == 0:
+        wt = torch.from_numpy((rng.standard_normal((cin, cout, 3, 3, 3)) / np.sqrt(27 * cin / 8)).astype(np.float32))
+        ct = _ConvT(wt, torch.zeros(cout), u.dev)
+        skip = torch.zeros(2, 2 * dims[0], 2 * dims[1], 2 * dims[2], cout, device="cuda", dtype=u.act_dtype)
+        z1 = u._up(x, skip, ct)
+        assert ct.packed == 512
+        ct.packed = 0
+        z0 = u._up(x, skip, ct)
+        assert float((z1.float() - z0.float()).abs().max()) <= 2e-6 * max(1.0, float(z0.float().abs().max()))
+
+
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 16, 6, 2), (64, 32, 4, 1), (512, 256, 2, 2), (128, 64, 3, 1)])
 def test_convtranspose3d_skip(precision, tol, cin, cout, S, B):
