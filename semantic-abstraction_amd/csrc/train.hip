@@ -162,6 +162,11 @@ extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scal
 // Per-(batch, channel) reductions over voxels: Sa = sum dY, Sb = sum dY * xhat (xhat = (X - mean_g) * rstd_g), fp64 atomics.
 // Used for bias gradients (X = null) and GroupNorm backward.
 // =================================================================================================
+// 16-byte load with the streaming ("non-temporal") cache policy: the element-wise passes of the backward read their 1-2 GB operands once
+__device__ __forceinline__ float4 ld_nt4(const float* p) {
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
 __global__ __launch_bounds__(256) void k_chan_reduce(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, double* __restrict__ out, long nvox, int C, int G) {
     const int b = blockIdx.y;
@@ -182,10 +187,10 @@ __global__ __launch_bounds__(256) void k_chan_reduce(const float* __restrict__ d
         float sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
         const float* dyb = dY + (long)b * nvox * C; const float* xb = X ? X + (long)b * nvox * C : nullptr;
         for (long i = start; i < chunks; i += stride) {
-            const float4 d = *reinterpret_cast<const float4*>(dyb + i * 4);
+            const float4 d = ld_nt4(dyb + i * 4);
             sa[0] += d.x; sa[1] += d.y; sa[2] += d.z; sa[3] += d.w;
             if (xb) {
-                const float4 x = *reinterpret_cast<const float4*>(xb + i * 4);
+                const float4 x = ld_nt4(xb + i * 4);
                 sb[0] += d.x * ((x.x - mu[0]) * rs[0]); sb[1] += d.y * ((x.y - mu[1]) * rs[1]);
                 sb[2] += d.z * ((x.z - mu[2]) * rs[2]); sb[3] += d.w * ((x.w - mu[3]) * rs[3]);
             }
@@ -265,8 +270,8 @@ __global__ void k_gn_bwd_apply(const float* __restrict__ dXn, const float* __res
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < tot) {
         const int c0 = (int)(i % (C / 4)) * 4; const int b = (int)(i / (nvox * (C / 4)));
-        const float4 d = *reinterpret_cast<const float4*>(dXn + i * 4);
-        const float4 x = *reinterpret_cast<const float4*>(X + i * 4);
+        const float4 d = ld_nt4(dXn + i * 4);
+        const float4 x = ld_nt4(X + i * 4);
         const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -275,10 +280,10 @@ __global__ void k_gn_bwd_apply(const float* __restrict__ dXn, const float* __res
             const float* k = coef + ((long)b * C + c) * 3;
             o[j] = k[0] * dv[j] - k[1] - xh * k[2];
         }
-        if (add1) { const float4 a = *reinterpret_cast<const float4*>(add1 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
-        if (add2) { const float4 a = *reinterpret_cast<const float4*>(add2 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+        if (add1) { const float4 a = ld_nt4(add1 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
+        if (add2) { const float4 a = ld_nt4(add2 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
         if (mask_y) {                                          // X is the post-ReLU output of the previous layer only when the caller says so
-            const float4 y = *reinterpret_cast<const float4*>(mask_y + i * 4);
+            const float4 y = ld_nt4(mask_y + i * 4);
             o[0] = y.x > 0.f ? o[0] : 0.f; o[1] = y.y > 0.f ? o[1] : 0.f; o[2] = y.z > 0.f ? o[2] : 0.f; o[3] = y.w > 0.f ? o[3] : 0.f;
         }
         *reinterpret_cast<float4*>(dX + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -310,10 +315,10 @@ __global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, 
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
-        const float4 d = *reinterpret_cast<const float4*>(dY + i * 4);
+        const float4 d = ld_nt4(dY + i * 4);
         if (mode == 3) { const float k = Y[0]; o = make_float4(d.x * k, d.y * k, d.z * k, d.w * k); }
         else {
-            const float4 y = *reinterpret_cast<const float4*>(Y + i * 4);
+            const float4 y = ld_nt4(Y + i * 4);
             if (mode == 2) { o.x = d.x + y.x; o.y = d.y + y.y; o.z = d.z + y.z; o.w = d.w + y.w; }
             else {
                 const float s = mode == 0 ? 0.f : slope;
