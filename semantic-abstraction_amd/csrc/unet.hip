@@ -690,8 +690,6 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 template <bool F32, int C16_T0>      // brick depth 8 (fp16: 2 x 57.6 KB LDS) or 4 (exact: 2 x 69 KB): one 8-wave workgroup per CU, two halo buffers
 __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2;
-    constexpr int NPROD = 256;                                      // producer threads (waves 4-7)
-    constexpr int NIT = (C16_HALO + NPROD - 1) / NPROD;
     // One plane = the 16-byte half-voxels (channels 0-7 or 8-15) of the whole halo.  Its size is rounded up to a multiple of 256 B: a
     // ds_read_b128 is served in lane groups such as {0-3, 12-15, 20-27}, i.e. voxels 0-3 / 12-15 of plane 0 together with voxels 4-11 of
     // plane 1 - the group covers all 64 banks exactly once only if the plane offset is = 0 mod 256 B (unpadded it is 128 mod 256: 2-way
