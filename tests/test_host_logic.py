@@ -122,3 +122,20 @@ def test_sharding_collectives_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def test_pack_fragments_layout():
+    """unet3d._pack_fragments: [Cout, Kp] -> [Kp / 32][Cout / 16][lane = kg * 16 + row][8] with k = 32 * k-step + 8 * kg + e - the order in which
+    a wave holds the A operand of v_mfma_f32_16x16x32_f16 (SEMABS_CONV_PACKED, include/semabs.h)."""
+    import torch
+    from semabs_amd.unet3d import _pack_fragments
+    cout, kp = 48, 96
+    w = torch.arange(cout * kp, dtype=torch.float32).view(cout, kp)
+    p = _pack_fragments(w).view(kp // 32, cout // 16, 64, 8)
+    for ks in range(kp // 32):
+        for cb in range(cout // 16):
+            for lane in (0, 5, 16, 37, 63):
+                row, kg = lane & 15, lane >> 4
+                for e in (0, 3, 7):
+                    assert p[ks, cb, lane, e] == w[cb * 16 + row, ks * 32 + kg * 8 + e]
+    assert p.numel() == w.numel()
