@@ -285,6 +285,25 @@ __global__ void k_scatter_mean(const long long* __restrict__ flat, const float* 
         }
     }
     const float denom = (float)total;
+    if (C == 16 && total <= SCATTER_MAXLIST) {      // the released configuration: whole 64-byte point rows, same per-channel summation order
+        float sv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sv[c] = 0.f;
+        for (int i = 0; i < cnt; ++i) {
+            const float4* fp = reinterpret_cast<const float4*>(feat + ((long)b * N + ids[i]) * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float4 t = fp[k]; sv[4 * k] += t.x; sv[4 * k + 1] += t.y; sv[4 * k + 2] += t.z; sv[4 * k + 3] += t.w; }
+        }
+        TOut ov[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            ov[c] = (TOut)(sv[c] / denom);
+            if (stats) { const float of = (float)ov[c]; gs[c >> 1] += of; gq[c >> 1] += of * of; }
+        }
+        TOut* vp = vol + ((long)b * nvox + v) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) vp[c] = ov[c];
+    } else
     for (int c = 0; c < C; ++c) {
         float s = 0.f;
         if (total <= SCATTER_MAXLIST) {
