@@ -250,7 +250,8 @@ def test_vool_train_step_vs_reference_golden_64(golden):
     e_total = abs(total - float(g["total_norm"])) / float(g["total_norm"])
     print(f"64^3 train step vs reference: loss rel {e_loss:.2e}, logits L-inf {e_logit:.2e}, worst per-tensor grad-norm rel {worst_norm:.2e}, "
           f"worst sampled-gradient rel L2 {worst_l2:.2e} ({worst_key}), total norm rel {e_total:.2e}")
-    # measured: loss 1.6e-7, logits 7.5e-5, grad norms 9.2e-3, sampled gradients 2.4e-2 (a 32-element GroupNorm bias), total norm 3.0e-5
+    # measured over repeated runs (the reductions use floating-point atomics): loss 1.4-1.6e-7, logits 6.9-8.0e-5, grad norms 1.1-1.3e-2,
+    # sampled gradients 2.0-2.6e-2 (small GroupNorm / bias tensors), total norm 3.9e-5 .. 1.3e-4
     assert e_loss <= 1e-6 and e_logit <= 2.5e-4
     # (total norm: 3e-5 .. 1.3e-4 depending on the summation order inside the level-0 convolution - which ReLU ties flip - asserted at 3 x)
     assert worst_norm <= 2.8e-2 and worst_l2 <= 7.2e-2 and e_total <= 4e-4
