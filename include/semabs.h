@@ -57,6 +57,11 @@ int semabs_tsdf_integrate(const unsigned char* color, const float* depth, int H,
  * pts f64 [M, 3]; params f64 [16] = {inv(pose) 3x4, fx, fy, cx, cy}; mask uint8 [M]. */
 int semabs_frustum_mask(const double* pts, long M, const double* params, int H, int W, unsigned char* mask, void* stream);
 
+/* in-bounds compaction + seeded sub-sample on the device (visualize.py:103-108 boolean indexing, :193 np.random.choice with replacement):
+ * pix[0..n_in) = ascending i with mask[i] != 0; sel[j] = pix[mulhi64(splitmix64(seed * 0x9E3779B97F4A7C15 + j), n_in)]; n_in int64 [1] device */
+int semabs_compact_subsample(const unsigned char* mask, long n, unsigned long long seed, long num, long long* pix, long long* n_in,
+                             long long* sel, void* stream);
+
 /* relevancy -> per-point features                                    visualize.py:93-122 (x50, -mean over labels, gather)
  * rel fp32 [L, HW]; sel int64 [n] pixel ids; xyz fp32 [HW, 3]; feat fp32 [L, n]; xyz_out fp32 [n, 3] (optional). */
 int semabs_gather_point_features(const float* rel, const long long* sel, const float* xyz, int L, long HW, long n,
@@ -298,6 +303,11 @@ int semabs_vool_sample_bwd(const float* df, const float* query, const float* off
  *                                                                                                        net.py:566-579, train_vool.py:171-178 */
 int semabs_cos_bce(const float* o, const float* rel, const float* label, const float* weight, int P, long M, float temperature, long n_total,
                    float* logits, float* dO, float* drel, double* loss, void* stream);
+
+/* the pointer head with the loss left to the caller (autograd boundary of SemAbsVOOL: `loss.backward()` of utils.py:404-417):
+ * dlogits == NULL: logits = cos(o, rel) / T only; dlogits = d loss / d logits [P*M]: dO, drel (accumulated) = d loss / d o, d rel   net.py:566-579 */
+int semabs_cos_head(const float* o, const float* rel, const float* dlogits, int P, long M, float temperature, float* logits, float* dO,
+                    float* drel, void* stream);
 
 /* clip_grad_norm_ over the LAMB chunk table: g *= extra_scale, then g *= min(1, max_norm / (norm + 1e-6)); sq fp64 [1] = sum g^2   utils.py:415 */
 int semabs_clip_grad_norm(const long long* chunks, int n_chunks, const long long* ptrs, int n_tensors, float max_norm, float extra_scale,

@@ -47,6 +47,22 @@ def ovssc_post_mask(logits: torch.Tensor, scene, scene_bounds, sampling_shape, c
     return vols.reshape(C, *sampling_shape)
 
 
+def subsample_indices(seed: int, n_in: int, num: int) -> np.ndarray:
+    """The seeded draw with replacement standing in for visualize.py:193 `np.random.choice(len(pts), size=num_input_pts)` (unseeded in the
+    reference): index j = mulhi64(splitmix64(seed * 0x9E3779B97F4A7C15 + j), n_in), a counter-based generator the device evaluates without
+    knowing n_in on the host (csrc/geometry.hip k_subsample)."""
+    M = (1 << 64) - 1
+    out = np.empty(num, np.int64)
+    base = (int(seed) * 0x9E3779B97F4A7C15) & M
+    for j in range(num):
+        x = (base + j + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        x ^= x >> 31
+        out[j] = (x * int(n_in)) >> 64
+    return out
+
+
 def run_scene(clip_sd, net_sd, scene, w_text, scene_bounds, S, num_input_pts, seed, cfg, images=None, subtract_mean=True,
               cutoff=-3.0, with_tsdf=True):
     """-> dict(relevancies [L,H,W] (x50, mean-subtracted), logits [L, S^3], labels [S^3], tsdf [S,S,S])."""
@@ -60,8 +76,7 @@ def run_scene(clip_sd, net_sd, scene, w_text, scene_bounds, S, num_input_pts, se
     if subtract_mean:
         rel = rel - rel.mean(dim=0, keepdim=True)
     pix = np.nonzero(mask)[0]
-    choice = np.random.default_rng(seed).integers(0, len(pix), size=num_input_pts)
-    sel = pix[choice]
+    sel = pix[subsample_indices(seed, len(pix), num_input_pts)]
     feat = rel.reshape(rel.shape[0], -1)[:, sel]                                           # [L, n]
     xyz = torch.from_numpy(pts[sel])[None]
     q = torch.from_numpy(grid_points(scene_bounds, S))

@@ -35,6 +35,7 @@ SIGNATURES = {
     "semabs_voxel_index": [P, L, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P],
     "semabs_tsdf_integrate": [P, P, I, I, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), P, P, P, P, P],
     "semabs_frustum_mask": [P, L, P, I, I, P, P],
+    "semabs_compact_subsample": [P, L, C.c_ulonglong, L, P, P, P, P],
     "semabs_gather_point_features": [P, P, P, I, L, L, F, I, P, P, P],
     "semabs_ovssc_labels": [P, P, P, I, L, F, P, P],
     # tiles.hip
@@ -95,6 +96,7 @@ SIGNATURES = {
     "semabs_vool_sample": [P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P],
     "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P, P, P],
     "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P],
+    "semabs_cos_head": [P, P, P, I, L, F, P, P, P, P],
     "semabs_clip_grad_norm": [P, I, P, I, F, F, P, P],
     # relio.hip
     "semabs_relevancy_pack": [P, P, I, I, I, I, I, P],

@@ -1,5 +1,8 @@
-"""Drop-in for the relevancy surface of the reference's `CLIP.clip` package: `ClipWrapper`, `saliency_configs`,
-`imagenet_templates` is not needed on the path (imagenet_prompt_ensemble is False in both configs).
+"""Drop-in for the relevancy surface of the reference's `CLIP.clip` package: `ClipWrapper`, `saliency_configs`, `imagenet_templates`
+(`from CLIP.clip import ClipWrapper, saliency_configs, imagenet_templates`, generate_relevancy.py:10).  `imagenet_prompt_ensemble` is a flag
+for the CALLER (generate_relevancy.py:70-80 passes `imagenet_templates` as `prompts` when a config sets it; both shipped configs leave it
+False); `get_clip_saliency` itself takes any template list: the zero-shot weight of a label is the mean over the templates' normalised
+text features (clip_gradcam.py:12-27).
 
     ClipWrapper.get_clip_saliency(img, text_labels, prompts, **saliency_configs["ours"](h))
         -> (fp32 [L, H, W] on CPU, text features [L, 512] on CPU)            CLIP/clip/__init__.py:103-133
@@ -18,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .templates import imagenet_templates
 from .vit import TextEncoder, VisionRollout, make_vision_engine
 
 KMAX = 24
@@ -337,4 +341,4 @@ class ClipWrapper:
         return out
 
 
-__all__ = ["ClipWrapper", "saliency_configs", "plan_tiles"]
+__all__ = ["ClipWrapper", "saliency_configs", "imagenet_templates", "plan_tiles"]

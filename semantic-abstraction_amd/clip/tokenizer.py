@@ -3,8 +3,7 @@
 
 The merge table (`bpe_simple_vocab_16e6.txt.gz`, 1.3 MB, OpenAI CLIP) is third-party DATA that this repo does not
 carry; it is looked up at run time (first hit wins):
-    $SEMABS_BPE_VOCAB, <package>/assets/bpe_simple_vocab_16e6.txt.gz, ~/.cache/clip/bpe_simple_vocab_16e6.txt.gz,
-    a sibling checkout of the reference (CLIP/clip/bpe_simple_vocab_16e6.txt.gz).
+    $SEMABS_BPE_VOCAB, <package>/assets/bpe_simple_vocab_16e6.txt.gz, ~/.cache/clip/bpe_simple_vocab_16e6.txt.gz.
 Callers that already hold token ids (int64 [B, 77]) can pass them straight to `ClipWrapper.set_classes_tokens`.
 """
 from __future__ import annotations
@@ -23,12 +22,11 @@ _CANDIDATES = (
     os.environ.get("SEMABS_BPE_VOCAB", ""),
     os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets", "bpe_simple_vocab_16e6.txt.gz"),
     os.path.expanduser("~/.cache/clip/bpe_simple_vocab_16e6.txt.gz"),
-    "/root/reference/CLIP/clip/bpe_simple_vocab_16e6.txt.gz",
 )
 
 
 def find_vocab() -> str | None:
-    for c in _CANDIDATES:
+    for c in (os.environ.get("SEMABS_BPE_VOCAB", ""),) + _CANDIDATES[1:]:
         if c and os.path.isfile(c):
             return c
     return None

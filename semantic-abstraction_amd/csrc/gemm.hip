@@ -28,6 +28,7 @@ struct GemmArgs {
     long M; int N, K; long lda; int ldb; long ldc;
     int g_in, g_out, g_off;     // EPI_ROWMAP_ADD_F32: out row = (m / g_in) * g_out + g_off + m % g_in
     int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
+    int sc_w;                   // column panels per super-column of the raster (see tile_of in k_gemm8); 0 = all of them
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
@@ -248,25 +249,28 @@ struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
-static int g_group_m = 8, g_ablate = 0, g_force_cfg = 0, g_prefetch = 1, g_persist = 0;
+static int g_group_m = 0, g_ablate = 0, g_force_cfg = 0, g_prefetch = 1, g_persist = 0, g_sc_w = 0;
 static unsigned long long* g_trace = nullptr;
 extern "C" int semabs_gemm_tune(int key, long long value) {
     switch (key) {
         case 0: g_force_cfg = (int)value; break;     // alternative ring-kernel tile configurations (see launch())
-        case 1: g_group_m = value < 1 ? 1 : (int)value; break;
+        case 1: g_group_m = value < 0 ? 0 : (int)value; break;     // 0 = the per-shape heuristic of gemm8_group_m()
         case 2: g_ablate = (int)value; break;
         case 3: g_prefetch = (int)value; break;
         case 5: g_persist = (int)value; break;        // 1 = persistent workgroups (one per CU)       // 1 = fragment reads in the MFMA shadow (production), 0 = read block before the barrier
         case 4: g_trace = (unsigned long long*)value; break;
+        case 6: g_sc_w = (int)value; break;           // column panels per super-column (0 = one super-column)
         default: return SEMABS_EINVAL;
     }
     return SEMABS_OK;
 }
 #define GEMM_GROUP_M g_group_m
+#define GEMM_SC_W g_sc_w
 #define GEMM_PREFETCH g_prefetch
 #define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).trace = g_trace; } while (0)
 #else
-#define GEMM_GROUP_M 8
+#define GEMM_GROUP_M 0
+#define GEMM_SC_W 0
 #define GEMM_PREFETCH 1
 #define GEMM_TUNE_ARGS(g) do { } while (0)
 #endif
@@ -288,7 +292,7 @@ static int launch_cfg(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     g.n_tiles_n = g.N / BN;
     long mt = (g.M + BM - 1) / BM;
     g.n_tiles_m = (int)mt;
-    g.group_m = GEMM_GROUP_M;
+    g.group_m = GEMM_GROUP_M > 0 ? GEMM_GROUP_M : 8;
     GEMM_TUNE_ARGS(g);
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
@@ -359,11 +363,20 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             const int nb = g.n_blocks, q = nb >> 3, r = nb & 7, xcd = vb & 7, k = vb >> 3;
             b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
         }
-        const int per_group = g.group_m * g.n_tiles_n, gid = b / per_group, first_m = gid * g.group_m;
+        // super-columns: the column panels are walked sc_w at a time over ALL row panels, so that the sc_w weight panels of a super-column
+        // (sc_w x 256 x K fp16) stay in the XCD's 4 MiB L2 for its whole pass while the activation panels stream through once per pass
+        const int scw = g.sc_w > 0 && g.sc_w < g.n_tiles_n ? g.sc_w : g.n_tiles_n;
+        const int per_super = g.n_tiles_m * scw;
+        int sc = b / per_super;
+        const int nsc = (g.n_tiles_n + scw - 1) / scw;
+        if (sc > nsc - 1) sc = nsc - 1;                     // only the last super-column can be narrower
+        const int rb = b - sc * per_super;
+        const int width = g.n_tiles_n - sc * scw < scw ? g.n_tiles_n - sc * scw : scw;
+        const int per_group = g.group_m * width, gid = rb / per_group, first_m = gid * g.group_m;
         const int gsz = (g.n_tiles_m - first_m < g.group_m) ? g.n_tiles_m - first_m : g.group_m;
-        const int r = b - gid * per_group;
+        const int r = rb - gid * per_group;
         m0 = (long)(first_m + r % gsz) * 256;
-        n0 = (r / gsz) * 256;
+        n0 = (sc * scw + r / gsz) * 256;
     };
 
     // ---- DMA sources: thread -> (row = j * 64 + tid / 8, 16-byte chunk position tid % 8) of every half-tile, j = 0, 1 ----
@@ -786,6 +799,15 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #undef GEMM8_INTERLEAVE
 }
 
+// Raster group size (row panels walked fastest) by the number of 256-wide column panels.  An XCD runs 32 tiles at a time = group_m row
+// panels x 32 / group_m column panels, and an operand panel is only re-used out of its 4 MiB L2 while the panels of the resident tiles
+// fit next to the C tiles streaming through (tools/gemm_raster.py + tools/pmc_seq.py, M = 482 256; FETCH x 2 + WRITE over the algorithmic
+// bytes / TFLOP/s):  N = 768 (out-proj, K = 768): group 8 1.19 / 677, 2 1.02 / 714;  N = 768 (c_proj, K = 3072): 8 1.55 / 1030, 2 1.40 / 1048;
+// N = 2304 (QKV): 8 2.31 / 981, 4 1.76 / 998, 1 2.52 / 976;  N = 3072 (c_fc): 8 1.77 / 918, 4 1.86 / 909, 1 2.68 / 884.  With three column
+// panels all of W stays resident and A is read once; with 9 - 12 the 3.5 - 4.7 MB of W cannot, and A is re-read ~2.5 x whatever the raster
+// (super-columns that keep a W slice resident re-read A once per slice instead: QKV 1.61 - 1.68 at -3 .. -5 % TFLOP/s, not taken).
+static inline int gemm8_group_m(int n_tiles_n) { return n_tiles_n <= 3 ? 2 : (n_tiles_n <= 9 ? 4 : 8); }
+
 template <int EPI>
 static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     constexpr int LDS = 2 * 4 * 16384;
@@ -798,7 +820,8 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     g.n_tiles_n = g.N / 256;
     const long mt = (g.M + 255) / 256;
     g.n_tiles_m = (int)mt;
-    g.group_m = GEMM_GROUP_M;
+    g.group_m = GEMM_GROUP_M > 0 ? GEMM_GROUP_M : gemm8_group_m(g.n_tiles_n);
+    g.sc_w = GEMM_SC_W;
     GEMM_TUNE_ARGS(g);
     if (mt * g.n_tiles_n >= (1L << 30)) { semabs_set_error("semabs_gemm_f16: grid too large"); return SEMABS_EINVAL; }
     g.n_blocks = (int)(mt * g.n_tiles_n);
@@ -857,7 +880,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         SEMABS_REQUIRE(rowmap3 && rowmap3[0] > 0, "semabs_gemm_f16: epi 4 needs rowmap");
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
-    g.n_tiles_n = 0; g.n_blocks = 0;
+    g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0;
     GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {

@@ -199,6 +199,56 @@ extern "C" int semabs_frustum_mask(const double* pts, long M, const double* para
 }
 
 // ------------------------------------------------------------------------------------------------
+// In-bounds compaction + seeded sub-sample, entirely on the device (visualize.py:103-108 `input_xyz_pts[in_bounds_mask]` and :193
+// `np.random.choice(len(pts), size=num_input_pts)`): no host round trip for the point count.
+//   pix[0 .. n_in) = ascending indices i with mask[i] != 0   (what torch.nonzero / boolean indexing produce)
+//   sel[j] = pix[ mulhi64( splitmix64(seed * 0x9E3779B97F4A7C15 + j), n_in ) ]        a uniform draw with replacement, counter-based:
+//            reproducible from (seed, j, n_in) alone - oracle/scene.py:subsample_indices restates it
+// One 1024-thread workgroup scans the mask (H * W = 230 400 at the BASELINE shape: a few microseconds), a second launch draws.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(1024) void k_compact(const unsigned char* __restrict__ mask, long n, long long* __restrict__ pix, long long* __restrict__ n_out) {
+    __shared__ int wsum[16];
+    __shared__ int total_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long per = (n + 1023) / 1024;
+    const long lo = (long)tid * per, hi = lo + per < n ? lo + per : n;
+    int cnt = 0;
+    for (long i = lo; i < hi; ++i) cnt += mask[i] != 0;
+    int incl = cnt;                                          // inclusive scan across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < 16; ++i) { const int v = wsum[i]; wsum[i] = run; run += v; } total_s = run; }
+    __syncthreads();
+    long pos = wsum[w] + incl - cnt;
+    for (long i = lo; i < hi; ++i) if (mask[i] != 0) pix[pos++] = i;
+    if (tid == 0) *n_out = total_s;
+}
+__global__ void k_subsample(const long long* __restrict__ pix, const long long* __restrict__ n_in, unsigned long long seed, long num, long long* __restrict__ sel) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num) return;
+    const unsigned long long n = (unsigned long long)*n_in;
+    const unsigned long long r = splitmix64(seed * 0x9E3779B97F4A7C15ull + (unsigned long long)j);
+    sel[j] = n ? pix[__umul64hi(r, n)] : 0;
+}
+// mask uint8 [n]; pix int64 [n] scratch (first *n_in entries valid afterwards); n_in int64 [1] on the device; sel int64 [num]
+extern "C" int semabs_compact_subsample(const unsigned char* mask, long n, unsigned long long seed, long num, long long* pix, long long* n_in,
+                                        long long* sel, void* stream) {
+    SEMABS_REQUIRE(mask && pix && n_in && n > 0 && (num == 0 || sel), "semabs_compact_subsample: bad args");
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n, pix, n_in);
+    if (num > 0) hipLaunchKernelGGL(k_subsample, dim3(semabs_cdiv(num, 256)), dim3(256), 0, (hipStream_t)stream, pix, n_in, seed, num, sel);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Point features for SemAbs3D from the relevancy maps (visualize.py:93-122 + dataset.py:1049-1056 recipe):
 //   r = rel * 50;  r -= mean over labels (if subtract_mean);  feat[l, j] = r[l, sel[j]];  xyz_out[j] = xyz[sel[j]]
 // rel fp32 [L, HW], sel int64 [n] (pixel indices of the sub-sampled in-bounds points), xyz fp32 [HW, 3]

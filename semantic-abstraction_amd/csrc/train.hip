@@ -607,6 +607,48 @@ extern "C" int semabs_cos_bce(const float* o, const float* rel, const float* lab
     return SEMABS_OK;
 }
 
+// The same pointer head with the loss left to the CALLER (the reference's own loop: `loss = BCE(net(**batch), label); loss.backward()`,
+// train_vool.py:171-178, utils.py:404-417 - semabs_amd.net.SemAbsVOOL under autograd): dz == NULL -> logits only (forward);
+// dz = d loss / d logits [P*M] -> dO = d loss / d o and drel (accumulated) = d loss / d rel.
+__global__ __launch_bounds__(256) void k_cos_head(const float* __restrict__ o, const float* __restrict__ rel, const float* __restrict__ dz_in, int P, long M,
+                                                  float inv_temp, float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel) {
+    __shared__ float s_drel[64];
+    if (threadIdx.x < 64) s_drel[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.y;
+    const float rv = rel[d * 64 + lane];
+    const float nr = fmaxf(sqrtf(wave_sum(rv * rv)), 1e-8f);
+    const float rh = rv / nr;
+    float acc_drel = 0.f;
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
+        const long pt = (long)d * M + m;
+        const float ov = o[pt * 64 + lane];
+        const float no = fmaxf(sqrtf(wave_sum(ov * ov)), 1e-8f);
+        const float oh = ov / no;
+        const float cs = wave_sum(oh * rh);
+        if (logits && lane == 0) logits[pt] = cs * inv_temp;
+        if (dz_in) {
+            const float dc = dz_in[pt] * inv_temp;
+            dO[pt * 64 + lane] = (rh - oh * cs) / no * dc;
+            acc_drel += (oh - rh * cs) / nr * dc;
+        }
+    }
+    if (!dz_in) return;
+    atomicAdd(&s_drel[lane], acc_drel);
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&drel[d * 64 + threadIdx.x], s_drel[threadIdx.x]);
+}
+extern "C" int semabs_cos_head(const float* o, const float* rel, const float* dlogits, int P, long M, float temperature, float* logits, float* dO,
+                               float* drel, void* stream) {
+    if (P == 0 || M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(o && rel && temperature > 0.f && (dlogits ? (dO && drel) : (logits != nullptr)), "semabs_cos_head: bad args");
+    int bx = semabs_cdiv(M, 4 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_cos_head, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, dlogits, P, M, 1.0f / temperature, logits, dO, drel);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // =================================================================================================
 // Dynamic per-tensor gradient scale for the split-fp16 data-gradient convolutions: the MFMA operands are fp16 hi + lo pairs, which
 // keep ~22 bits only for magnitudes inside fp16's normal range, while gradients are routinely 1e-6 and smaller.  s = 2^k puts the

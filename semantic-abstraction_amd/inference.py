@@ -33,39 +33,52 @@ def get_sample_points(sampling_shape: Tuple[int, int, int], scene_bounds, device
     return torch.from_numpy((idx * scales + lc).reshape(-1, 3).astype(np.float32)).to(dev)
 
 
-def prep_data(data, scene_bounds, subtract_mean: bool, prompts: Sequence[str] = ("a photograph of a {} in a home.",),
-              jittered_images=None) -> Dict[str, Any]:
-    """visualize.prep_data without the plotting / dump side effects.  `data`: the scene dict (or a path to its pickle) with rgb uint8
+def prep_data(data_pickle_path, scene_bounds, subtract_mean: bool, dump_path: Optional[str] = None,
+              prompts: Sequence[str] = ("a photograph of a {} in a home.",), jittered_images=None) -> Dict[str, Any]:
+    """visualize.prep_data (visualize.py:61-154), same leading arguments; the relevancy plot it dumps under `dump_path` is visualisation and
+    not produced here (`dump_path` is accepted and ignored).  `data_pickle_path`: the scene pickle (or the already loaded dict) with rgb uint8
     [H, W, 3], depth fp32 [H, W], cam_intr, cam_extr, descriptions [(target, relation, reference)], ovssc_obj_classes.
-    Returns the reference's batch dict (same keys; tensors on the host like the reference's)."""
-    if isinstance(data, str):
-        data = pickle.load(open(data, "rb"))
+    Returns the reference's batch dict (same keys; tensors on the host like the reference's).  Row order of `relevancies`: the reference
+    takes `list(set(...))` of the label strings (hash order, differs from process to process); here first-seen order - the per-class /
+    per-description stacks, which is what the networks read, do not depend on it."""
+    scene_id = "scene"
+    data = data_pickle_path
+    if isinstance(data_pickle_path, str):
+        scene_id = data_pickle_path.split("/")[-1].split(".pkl")[0]
+        data = pickle.load(open(data_pickle_path, "rb"))
     rgb, depth = data["rgb"], data["depth"]
-    assert rgb.dtype == np.uint8 and depth.dtype == np.float32
+    assert rgb.dtype == np.uint8
+    assert depth.dtype == np.float32
     cam_intr, cam_extr = data["cam_intr"], data["cam_extr"]
-    descriptions = data.get("descriptions", [])
+    if "img_shape" in data:
+        # visualize.py:80-82 resizes rgb and depth with cv2.resize (fixed-point bilinear for uint8); OpenCV is not in this image, so its
+        # rounding cannot be pinned - refuse instead of silently running at the native resolution
+        raise NotImplementedError("scene pickles with 'img_shape' (cv2.resize of rgb / depth, visualize.py:80-82) are not supported: resize "
+                                  "the frame before handing it over")
+    descriptions = data["descriptions"]
     target_obj_classes = [d[0] for d in descriptions]
     spatial_relation_names = [d[1] for d in descriptions]
     reference_obj_classes = [d[2] for d in descriptions]
-    ovssc_obj_classes = list(data["ovssc_obj_classes"])
+    ovssc_obj_classes = data["ovssc_obj_classes"]
     relevancy_keys = list(dict.fromkeys(list(ovssc_obj_classes) + target_obj_classes + reference_obj_classes))    # set union, order fixed
     h = rgb.shape[0]
     cfg = saliency_configs["ours"](h)
     if jittered_images is not None:
         cfg = dict(cfg, jittered_images=jittered_images)
     relevancies = ClipWrapper.get_clip_saliency(img=rgb, text_labels=np.array(relevancy_keys), prompts=list(prompts), **cfg)[0] * 50
+    assert len(relevancy_keys) == len(relevancies)
     input_xyz_pts = torch.from_numpy(get_pointcloud(depth, None, cam_intr, cam_extr)[0].astype(np.float32))
-    in_bounds_mask = torch.from_numpy(filter_pts_bounds(input_xyz_pts, np.array(scene_bounds)))
+    in_bounds_mask = torch.from_numpy(filter_pts_bounds(input_xyz_pts, np.array(scene_bounds))).bool()
     input_xyz_pts = input_xyz_pts[in_bounds_mask]
     if subtract_mean:
         relevancies -= relevancies.mean(dim=0, keepdim=True)
-    pick = lambda classes: torch.stack([relevancies[relevancy_keys.index(c)].view(-1)[in_bounds_mask] for c in classes]) if classes else None
+    pick = lambda classes: torch.stack([relevancies[relevancy_keys.index(c)].view(-1)[in_bounds_mask] for c in classes])
     return {"input_xyz_pts": input_xyz_pts, "input_rgb_pts": rgb.reshape(-1, 3)[in_bounds_mask.numpy()], "relevancies": relevancies,
             "input_feature_pts": pick(ovssc_obj_classes), "ovssc_obj_classes": ovssc_obj_classes, "rgb": rgb, "depth": depth,
-            "cam_intr": cam_intr, "cam_extr": cam_extr, "scene_id": data.get("scene_id", "scene"),
+            "cam_intr": cam_intr, "cam_extr": cam_extr, "scene_id": data.get("scene_id", scene_id) if isinstance(data, dict) else scene_id,
             "input_target_saliency_pts": pick(target_obj_classes), "input_reference_saliency_pts": pick(reference_obj_classes),
             "spatial_relation_name": spatial_relation_names, "tsdf_vol": None,
-            "descriptions": [f"the {d[0]} {d[1]} the {d[2]}" for d in descriptions]}
+            "descriptions": [f"the {d[0]} {d[1]} the {d[2]}" for d in data["descriptions"]]}
 
 
 @torch.no_grad()

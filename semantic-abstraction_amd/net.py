@@ -150,7 +150,8 @@ class SemAbs3D(torch.nn.Module):
                        tsdf_vol: torch.Tensor | None = None) -> torch.Tensor:
         """xyz fp32 [N, 3], feat fp32 [P, N] (one scene, P label volumes) -> UNet features channels-last [P, S, S, S, C].
         skip_final: stop in front of the UNet's final 1x1x1 convolution (see `decode(pre_final=True)`).
-        tsdf_vol fp32 [S, S, S] (required iff "tsdf" is a network input): becomes input channel 0 of every label volume (net.py:411-419)."""
+        tsdf_vol fp32 [S, S, S] or [P, S, S, S] (required iff "tsdf" is a network input): becomes input channel 0 of every (of its) label
+        volume (net.py:411-419)."""
         dev = _lib.require_gpu()
         self._sync()
         P, N = int(feat.shape[0]), int(feat.shape[1])
@@ -176,7 +177,7 @@ class SemAbs3D(torch.nn.Module):
                       unet.f32, st)
             # channel 0 (kept zero by the padded point MLP) <- the TSDF: a strided copy, no arithmetic; GroupNorm statistics then come from the
             # generic pass over the (now dense) volume, not from the occupied-voxel shortcut of the scatter kernel
-            vol[..., 0] = tsdf_vol.to(dev, unet.act_dtype).reshape(1, S0, S1, S2)
+            vol[..., 0] = tsdf_vol.to(dev, unet.act_dtype).reshape(-1, S0, S1, S2)       # [S, S, S] for every volume, or one per volume [P, S, S, S]
         elif self.C == 16 and unet.in_channels == 16 and unet.enc[0][0].groups == 8:     # statistics for the first GroupNorm come out of the scatter
             sums = torch.zeros(P, 8, 2, dtype=torch.float64, device=dev)
             _lib.call("semabs_scatter_mean_stats", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
@@ -220,8 +221,12 @@ class SemAbs3D(torch.nn.Module):
         M = output_xyz_pts.shape[2]
         outs, feats = [], []
         for b in range(B):
-            f = self.feature_volume(input_xyz_pts[b].to(dev, torch.float32), input_feature_pts[b].to(dev, torch.float32).reshape(P, N),
-                                    tsdf_vol=tsdf_vol[b] if (self.with_tsdf and tsdf_vol is not None) else None)
+            tv = None
+            if self.with_tsdf and tsdf_vol is not None:
+                # the reference pairs volume i = b * P + p of the b-major feature stack with `tsdf_vol.unsqueeze(1).repeat(P, 1, 1, 1, 1)[i]`,
+                # i.e. tsdf_vol[i % B] (net.py:411-419) - for B > 1 and P > 1 not the volume's own scene; kept as it is
+                tv = torch.stack([tsdf_vol[(b * P + p_) % B] for p_ in range(P)], dim=0)
+            f = self.feature_volume(input_xyz_pts[b].to(dev, torch.float32), input_feature_pts[b].to(dev, torch.float32).reshape(P, N), tsdf_vol=tv)
             feats.append(f)
             outs.append(self.decode(f, output_xyz_pts[b].to(dev, torch.float32)))
         self.features_cl = torch.cat(feats, dim=0)
@@ -279,9 +284,46 @@ class SemAbsVOOL(torch.nn.Module):
         self._rel = {k: sd["relation_embeddings." + k].float().to(dev) for k in self.RELATIONS}
         self._sig = sig
 
-    @torch.no_grad()
     def forward(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts,
                 tsdf_vol=None, **kwargs):
+        """-> logits [B, D, M] (net.py:506-579).  Under `torch.no_grad()` / `eval`-style use: the fused inference kernels.  With grad mode on and
+        trainable parameters the result carries a `grad_fn`: `loss.backward()` on anything computed from it runs the hand-written backward
+        pass of `semabs_amd.train` and leaves the gradients in `p.grad` of this module's parameters - what `utils.loop` needs
+        (utils.py:404-417: `loss.backward(); clip_grad_norm_(net.parameters(), ...); optimizer.step()`), and what DistributedDataParallel's
+        gradient hooks listen to."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(dict(output_xyz_pts=output_xyz_pts, spatial_relation_name=spatial_relation_name, input_xyz_pts=input_xyz_pts,
+                                            input_target_saliency_pts=input_target_saliency_pts,
+                                            input_reference_saliency_pts=input_reference_saliency_pts))
+        return self._forward_infer(output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts)
+
+    def _engine(self):
+        """The training engine bound to THIS module's parameters (built on first use; follows `.to()` / `load_state_dict` through the
+        parameters' storage)."""
+        _lib.require_gpu()
+        if any(p.device.type != "cuda" for p in self.parameters()):
+            self.to(_lib.require_gpu())
+        key = tuple(p.data_ptr() for p in self.parameters())
+        if getattr(self, "_train_engine", None) is None or self._train_key != key:
+            from .train import VOOLTrainer
+            net = self.completion_net
+            u = net.vol_feature_extractor
+            self.__dict__["_train_engine"] = VOOLTrainer(None, voxel_shape=net.vg.grid_shape, scene_bounds=[net.vg.lower_corner, net.vg.upper_corner],
+                                                         unet_num_channels=net.C, unet_f_maps=u.f_maps, unet_num_groups=u.num_groups,
+                                                         unet_num_levels=len(u.f_maps), pts_feat_extractor_hidden_dim=net.hidden,
+                                                         pointing_temperature=self.pointing_temperature, module=self)
+            self.__dict__["_train_key"] = key
+        return self._train_engine
+
+    def _forward_train(self, batch: dict):
+        eng = self._engine()
+        names = np.array(batch["spatial_relation_name"]).T
+        used = sorted(set(names.reshape(-1).tolist()), key=self.RELATIONS.index)
+        pnames = [k for k in eng.graph_params(used) if eng.params[k].requires_grad]
+        return _VOOLFunction.apply(eng, batch, pnames, *[eng.params[k] for k in pnames])
+
+    @torch.no_grad()
+    def _forward_infer(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts):
         dev = _lib.require_gpu()
         self._sync()
         net = self.completion_net
@@ -301,3 +343,24 @@ class SemAbsVOOL(torch.nn.Module):
                       net.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
             outs.append(out)
         return torch.stack(outs, dim=0).view(batch_size, num_descs, M)
+
+
+class _VOOLFunction(torch.autograd.Function):
+    """Autograd node of `SemAbsVOOL.forward`: forward = the HIP forward with a tape, backward = the hand-written backward pass against it
+    (`VOOLTrainer.forward_tape` / `backward_tape`).  Its differentiable inputs are exactly the parameters the reference's autograd graph of
+    this batch would contain (not `visual_sampler.*`, not relation embeddings no description names), so unused ones keep `grad = None` and
+    DistributedDataParallel(find_unused_parameters=True) sees the same used / unused split as with the reference (utils.py:255-258)."""
+
+    @staticmethod
+    def forward(ctx, eng, batch, pnames, *params):
+        logits, tape = eng.forward_tape(batch)
+        ctx.eng, ctx.tape, ctx.pnames = eng, tape, pnames
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.tape is None:
+            raise RuntimeError("SemAbsVOOL: the backward tape is single-use (backward through the same forward twice is not supported)")
+        grads = ctx.eng.backward_tape(ctx.tape, dlogits)
+        ctx.tape = None
+        return (None, None, None) + tuple(grads[k] for k in ctx.pnames)

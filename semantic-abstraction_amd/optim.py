@@ -81,6 +81,9 @@ class Lamb(Optimizer):
             _lib.call("semabs_lamb_step", _lib.ptr(plan["chunks"]), plan["n_chunks"], _lib.ptr(plan["ptrs"]), len(ps), float(group["lr"]),
                       float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), int(self.adam), _lib.ptr(plan["norms"]),
                       _lib.ptr(plan["stats"]), _lib.stream())
+            # The kernels wrote through raw device pointers: tell torch the parameters changed, so that everything keyed on a tensor's
+            # version counter - the derived kernel operands of the nn.Modules (module.signature), autograd's saved-tensor checks - sees the step
+            torch._C._increment_version(ps)
             stats = plan["stats"]
             for t, p in enumerate(ps):
                 st = self.state[p]

@@ -8,7 +8,7 @@ Stage map (reference file:line -> kernel file):
   ClipWrapper.get_clip_saliency * 50                visualize.py:93-101     tiles.hip, gemm.hip, vit.hip
   get_pointcloud -> float32, filter_pts_bounds      visualize.py:103-108    geometry.hip
   relevancies -= mean over labels; per-class points visualize.py:109-122    geometry.hip (gather_point_features)
-  np.random.choice(80 000 of N)                     visualize.py:193        host RNG (seeded), indices only
+  in-bounds compaction + np.random.choice(80 000)   visualize.py:103-108,193  geometry.hip (compact_subsample: counter-based seeded draw)
   SemAbs3D.forward                                  net.py:383-439          unet.hip
   TSDFVolume.integrate                              visualize.py:217-227    geometry.hip
   argmax / cutoff / frustum / tsdf mask             visualize.py:228-247    geometry.hip (ovssc_labels)
@@ -41,7 +41,16 @@ class SceneResult:
     logits: torch.Tensor               # fp32 [L, S^3]    decoder outputs at the voxel centres
     labels: Optional[torch.Tensor]     # int32 [S^3]      argmax with the cutoff / frustum / tsdf mask, -1 = empty
     tsdf: Optional[torch.Tensor]       # fp32 [S, S, S]
-    n_in_bounds: int
+    n_in: torch.Tensor                 # int64 [1] on the device: points of the depth image inside scene_bounds
+
+    @property
+    def n_in_bounds(self) -> int:
+        """Host value (synchronises).  Zero in-bounds points is an error in the reference (np.random.choice on an empty population,
+        visualize.py:193); the device path cannot raise at launch time, so it is raised here, on first read."""
+        n = int(self.n_in.item())
+        if n == 0:
+            raise RuntimeError("no point of the depth image falls inside scene_bounds")
+        return n
 
 
 class ScenePipeline:
@@ -95,22 +104,20 @@ class ScenePipeline:
         cfg = saliency_configs[self.config](H)
         cur = torch.cuda.current_stream()
         gs, vs = geo_stream or cur, vit_stream or cur
-        # ---- geometry first: its compaction (nonzero) is the one host synchronisation of the scene, and here the GPU queue is still
-        # empty; placed after the relevancy stage (the reference's order) the host would sit behind 120 ms of queued ViT work and the GPU
-        # would then idle while the UNet launches are issued ---------------------------------------------------------------------------
+        # ---- geometry first (cheap; its results are needed by the voxel stage only) -------------------------------------------------------
         with torch.cuda.stream(gs):
             depth_dev = scene.get("depth_dev")
             if depth_dev is None:
                 depth_dev = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(dev)
             bounds = np.array([net.vg.lower_corner, net.vg.upper_corner], np.float64)
             xyz, mask = pointcloud_device(depth_dev, scene["cam_intr"], scene["cam_pose"], bounds)
-            pix = torch.nonzero(mask, as_tuple=False).view(-1)                                # in-bounds pixel ids (compaction)
-            n_in = int(pix.numel())
-            if n_in == 0:
-                raise RuntimeError("no point of the depth image falls inside scene_bounds")
-            rng = np.random.default_rng(seed)
-            choice = torch.from_numpy(rng.integers(0, n_in, size=self.num_input_pts)).to(dev)  # np.random.choice with replacement
-            sel = pix.index_select(0, choice).contiguous()
+            # in-bounds compaction + the seeded draw of num_input_pts points with replacement, on the device: the host never learns the point
+            # count, so a scene has NO host synchronisation (several ranks sharing one host each used to block on torch.nonzero per scene)
+            pix = torch.empty(H * W, dtype=torch.int64, device=dev)
+            n_in = torch.empty(1, dtype=torch.int64, device=dev)
+            sel = torch.empty(self.num_input_pts, dtype=torch.int64, device=dev)
+            _lib.call("semabs_compact_subsample", _lib.ptr(mask), H * W, int(seed) & 0xFFFFFFFFFFFFFFFF, self.num_input_pts, _lib.ptr(pix),
+                      _lib.ptr(n_in), _lib.ptr(sel), _lib.stream())
             geo_done = torch.cuda.Event()
             geo_done.record(gs)
         # ---- relevancy --------------------------------------------------------------------------------
@@ -185,7 +192,7 @@ class ScenePipeline:
             _lib.call("semabs_ovssc_labels", _lib.ptr(logits), _lib.ptr(fr), _lib.ptr(tsdf_flat), L, int(logits.shape[1]), float(self.cutoff),
                       _lib.ptr(labels), st)
         # `relevancies` = the raw relevancy maps; prep_data's x 50 / mean subtraction (visualize.py:100-112) lives in semabs_gather_point_features
-        return SceneResult(relevancies=maps, logits=logits, labels=labels, tsdf=tsdf, n_in_bounds=n_in)
+        return SceneResult(relevancies=maps, logits=logits, labels=labels, tsdf=tsdf, n_in=n_in)
 
     def _frustum(self, scene, H, W):
         """In-frustum mask of the voxel-centre lattice for THIS scene's pose, computed on the device inside the step (no host round trip, no

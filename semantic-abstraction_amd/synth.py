@@ -85,3 +85,19 @@ def synth_ovssc_logits(points, n_classes: int):
         q = q + (0.25 * c - 0.5)
         out.append(q * q * (-2.0) + (0.5 - 0.375 * c) + x * (c - 1.5))
     return torch.stack(out, dim=0)
+
+
+def synth_relevancy(img: np.ndarray, labels) -> np.ndarray:
+    """Closed-form stand-in for `ClipWrapper.get_clip_saliency(...)[0]` (parity fixture g25: `prep_data` executed from the reference's source):
+    one fp32 map [H, W] per label STRING, a pure function of the label's bytes and the image - so that the reference's data plumbing around
+    the CLIP call (key set, x 50, mean subtraction, in-bounds selection, stacking) can be compared bit for bit.  -> fp32 [L, H, W]."""
+    import zlib
+    H, W = img.shape[:2]
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    out = []
+    for lab in labels:
+        h = zlib.crc32(str(lab).encode())
+        a, b, c = np.float32((h & 0xff) / 256.0), np.float32(((h >> 8) & 0xff) / 256.0), int((h >> 16) & 3) % 3
+        m = img[..., c].astype(np.float32) * np.float32(1.0 / 255.0) * a + (yy * np.float32(1.0 / 64.0) - xx * np.float32(1.0 / 128.0)) * b
+        out.append((m * np.float32(0.004)).astype(np.float32))
+    return np.stack(out, axis=0)

@@ -317,38 +317,56 @@ class VOOLTrainer:
     spatial_relation_name (D lists of B names).
     """
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], voxel_shape, scene_bounds, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+    def __init__(self, state_dict: Optional[Dict[str, torch.Tensor]], voxel_shape, scene_bounds, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
                  unet_num_levels=6, pts_feat_extractor_hidden_dim=128, pointing_dim=64, lr=1e-3, weight_decay=1e-5, grad_max_norm=2.0,
-                 balance_positive_negative=False, pointing_temperature=0.07):
+                 balance_positive_negative=False, pointing_temperature=0.07, module: Optional[torch.nn.Module] = None):
+        """state_dict: the reference's `SemAbsVOOL.state_dict()` (fp32 master copies are made), or `module=` an nn.Module with the reference's
+        parameter tree (`semabs_amd.net.SemAbsVOOL`): then the module's OWN nn.Parameters are the master weights - nothing is copied, the
+        caller's optimiser updates them - and gradients are handed to autograd (`forward_tape` / `backward_tape`, used by `SemAbsVOOL.forward`)."""
         dev = self.dev = _lib.require_gpu()
         assert pointing_dim == 64 and unet_num_channels == 16, "the VOOL head kernels cover pointing_dim=64 over 16-channel volumes"
-        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         self.vg = VirtualGrid(scene_bounds=np.array(scene_bounds), batch_size=1, grid_shape=tuple(voxel_shape))
         self.C, self.H, self.E = unet_num_channels, pts_feat_extractor_hidden_dim, pointing_dim
         self.grad_max_norm, self.balance, self.temperature = float(grad_max_norm), bool(balance_positive_negative), float(pointing_temperature)
-        self.extra = {k: v.clone() for k, v in sd.items() if not torch.is_floating_point(v) or k.endswith("steps")}
-        names = [k for k in sd if k not in self.extra]
-        self.params: Dict[str, torch.nn.Parameter] = {k: torch.nn.Parameter(sd[k].detach().float().to(dev).contiguous(), requires_grad=False)
-                                                      for k in names}
+        self.module = module
+        if module is not None:
+            assert state_dict is None
+            self.extra = {k: v for k, v in module.named_buffers()}
+            self.params = dict(module.named_parameters())
+            names = list(self.params)
+            for k, p_ in self.params.items():
+                assert p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous(), f"{k}: parameters must be fp32 on the HIP device"
+        else:
+            sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+            self.extra = {k: v.clone() for k, v in sd.items() if not torch.is_floating_point(v) or k.endswith("steps")}
+            names = [k for k in sd if k not in self.extra]
+            self.params = {k: torch.nn.Parameter(sd[k].detach().float().to(dev).contiguous(), requires_grad=False) for k in names}
         # parameters the VOOL graph never touches get no gradient, like p.grad = None in the reference (completion_net.visual_sampler.*)
+        self.names = names
         self.trainable = [k for k in names if ".visual_sampler." not in k]
-        total = sum(self.params[k].numel() for k in self.trainable)
-        # one flat buffer: every gradient + one "used in this step" flag per relation embedding (they ride in the same all-reduce)
-        self.flat_grad = torch.zeros(total + len(RELATIONS), dtype=torch.float32, device=dev)
-        self.rel_flags = self.flat_grad[total:]
+        self.total = sum(self.params[k].numel() for k in self.trainable)
         self.grads: Dict[str, torch.Tensor] = {}
-        off = 0
-        for k in self.trainable:
-            n = self.params[k].numel()
-            self.grads[k] = self.flat_grad[off: off + n].view_as(self.params[k])
-            self.params[k].grad = self.grads[k]
-            off += n
         self.unet = UNetTrainer(self.params, self.grads, "completion_net.vol_feature_extractor.", unet_num_channels, unet_num_channels,
                                 unet_f_maps, unet_num_groups, unet_num_levels)
-        self.opt = Lamb([self.params[k] for k in self.trainable], lr=lr, weight_decay=weight_decay)
+        self._bind_grads(torch.zeros(self.total + len(RELATIONS), dtype=torch.float32, device=dev), attach=module is None)
+        # Like the reference (`Lamb(net.parameters())`, utils.py:264-266) the optimiser spans EVERY parameter in state-dict order - the ones the
+        # VOOL graph never reaches keep grad = None and are skipped by step() - so `optimizer.state_dict()` is interchangeable with the reference's
+        self.opt = Lamb([self.params[k] for k in names], lr=lr, weight_decay=weight_decay) if module is None else None
         self.steps = 0
         self._sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.last = {}
+
+    def _bind_grads(self, flat: torch.Tensor, attach: bool):
+        """One flat buffer: every gradient + one "used in this step" flag per relation embedding (they ride in the same all-reduce)."""
+        self.flat_grad = flat
+        self.rel_flags = flat[self.total:]
+        off = 0
+        for k in self.trainable:
+            n = self.params[k].numel()
+            self.grads[k] = flat[off: off + n].view_as(self.params[k])
+            if attach:
+                self.params[k].grad = self.grads[k]
+            off += n
 
     # ---- helpers -----------------------------------------------------------------------------------------------------------------
     def _linear(self, x, w, b, act):
@@ -394,10 +412,11 @@ class VOOLTrainer:
         w = torch.where(pos, 1.0 / (pp + 1e-10), 1.0 / ((1 - pp) + 1e-10))
         return (w * (label.numel() / w.sum())).contiguous()
 
-    # ---- forward + backward of one scene --------------------------------------------------------------------------------------------
-    def _scene(self, xyz, sal_t, sal_r, query, label, weight, rel_names, n_total, loss_acc, logits_out):
+    # ---- forward / backward of one scene -------------------------------------------------------------------------------------------
+    def _scene_fwd(self, xyz, sal_t, sal_r, query, rel_names) -> dict:
+        """Forward up to the pointer head's input `o` [D*M, 64]; returns the tape the backward walks."""
         dev, st, u = self.dev, _lib.stream(), self.unet
-        p, g = self.params, self.grads
+        p = self.params
         D, N = sal_t.shape
         M = query.shape[1]
         P = 2 * D
@@ -425,17 +444,25 @@ class VOOLTrainer:
         w1p[:, :35] = p[ss + "0.weight"]
         h = self._linear(f, w1p, p[ss + "0.bias"], 1)
         o = self._linear_mfma(h, p[ss + "2.weight"], p[ss + "2.bias"], 0)
-        rel = torch.stack([p["relation_embeddings." + n] for n in rel_names], dim=0).contiguous()
-        dO = torch.empty_like(o)
-        drel = torch.zeros(D, self.E, dtype=torch.float32, device=dev)
-        _lib.call("semabs_cos_bce", _lib.ptr(o), _lib.ptr(rel), _lib.ptr(label), _lib.ptr(weight), D, M, self.temperature, n_total,
-                  _lib.ptr(logits_out), _lib.ptr(dO), _lib.ptr(drel), _lib.ptr(loss_acc), st)
-        # ---- backward ----
-        for d, n in enumerate(rel_names):
+        rel = torch.stack([p["relation_embeddings." + n].detach() for n in rel_names], dim=0).contiguous()
+        return dict(D=D, N=N, M=M, P=P, x4=x4, h1=h1, h2=h2, flat=flat, tape=tape, query=query, f=f, w1p=w1p, h=h, o=o, rel=rel,
+                    rel_names=list(rel_names))
+
+    def _scene_bwd(self, c: dict, dO: torch.Tensor, drel: torch.Tensor):
+        """dO = d loss / d o [D*M, 64], drel = d loss / d (relation embedding rows) [D, 64]: accumulates every parameter gradient."""
+        dev, st, u = self.dev, _lib.stream(), self.unet
+        p, g = self.params, self.grads
+        D, N, M, P = c["D"], c["N"], c["M"], c["P"]
+        S0, S1, S2 = self.vg.grid_shape
+        nvox = S0 * S1 * S2
+        cn, ss = "completion_net.pts_feat_extractor.", "spatial_sampler.mlp."
+        off3, sc3, shp = _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales), _lib.iarr(self.vg.grid_shape)
+        h, f, w1p, query, flat, h1, h2, x4 = c["h"], c["f"], c["w1p"], c["query"], c["flat"], c["h1"], c["h2"], c["x4"]
+        for d, n in enumerate(c["rel_names"]):
             g["relation_embeddings." + n].add_(drel[d])
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
         u._colsum(dO, g[ss + "2.bias"])
-        dh = u._ew(self._linear_mfma(dO, p[ss + "2.weight"].t().contiguous(), None, 0, grad_in=True), h, 1)
+        dh = u._ew(self._linear_mfma(dO, p[ss + "2.weight"].detach().t().contiguous(), None, 0, grad_in=True), h, 1)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
@@ -444,34 +471,84 @@ class VOOLTrainer:
         cell_next = torch.empty(D * M, dtype=torch.int32, device=dev)
         _lib.call("semabs_vool_sample_bwd", _lib.ptr(df), _lib.ptr(query), off3, sc3, shp, D, M, _lib.ptr(cell_head), _lib.ptr(cell_next),
                   _lib.ptr(dvol[:D]), _lib.ptr(dvol[D:]), st)
-        dscat = u.backward(tape, dvol)
+        dscat = u.backward(c["tape"], dvol)
         count = torch.zeros(nvox, dtype=torch.int32, device=dev)
         dpf = torch.empty(P * N, self.C, dtype=torch.float32, device=dev)
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
-        dh2 = u._ew(self._linear_mfma(dpf, p[cn + "4.weight"].t().contiguous(), None, 0, grad_in=True), h2, 1)
+        dh2 = u._ew(self._linear_mfma(dpf, p[cn + "4.weight"].detach().t().contiguous(), None, 0, grad_in=True), h2, 1)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
-        dh1 = u._ew(self._linear_mfma(dh2, p[cn + "2.weight"].t().contiguous(), None, 0, grad_in=True), h1, 1)
+        dh1 = u._ew(self._linear_mfma(dh2, p[cn + "2.weight"].detach().t().contiguous(), None, 0, grad_in=True), h1, 1)
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
+
+    def _scene(self, xyz, sal_t, sal_r, query, label, weight, rel_names, n_total, loss_acc, logits_out):
+        """Fused form (VOOLTrainer.step): the BCE-with-logits loss and its gradient come out of the pointer-head kernel."""
+        c = self._scene_fwd(xyz, sal_t, sal_r, query, rel_names)
+        dO = torch.empty_like(c["o"])
+        drel = torch.zeros(c["D"], self.E, dtype=torch.float32, device=self.dev)
+        _lib.call("semabs_cos_bce", _lib.ptr(c["o"]), _lib.ptr(c["rel"]), _lib.ptr(label), _lib.ptr(weight), c["D"], c["M"], self.temperature, n_total,
+                  _lib.ptr(logits_out), _lib.ptr(dO), _lib.ptr(drel), _lib.ptr(loss_acc), _lib.stream())
+        self._scene_bwd(c, dO, drel)
+
+    # ---- autograd boundary (SemAbsVOOL.forward under grad mode) ---------------------------------------------------------------------
+    def _unpack(self, batch: dict):
+        dev = self.dev
+        xyz = batch["input_xyz_pts"].to(dev, torch.float32)
+        B, N = xyz.shape[:2]
+        st_ = batch["input_target_saliency_pts"].to(dev, torch.float32).reshape(B, -1, N)
+        sr_ = batch["input_reference_saliency_pts"].to(dev, torch.float32).reshape(B, -1, N)
+        D = st_.shape[1]
+        q = batch["output_xyz_pts"].to(dev, torch.float32).reshape(B, D, -1, 3)
+        names = np.array(batch["spatial_relation_name"]).T.reshape(B, D)                 # [B, D] like net.py:527
+        return xyz, st_, sr_, q, names, B, N, D, int(q.shape[2])
+
+    @torch.no_grad()
+    def forward_tape(self, batch: dict):
+        """-> (logits [B, D, M], ctx).  No loss: the caller computes it from the logits (the reference's `get_losses`, train_vool.py:118-178)."""
+        self.unet.refresh()
+        xyz, st_, sr_, q, names, B, N, D, M = self._unpack(batch)
+        logits = torch.empty(B, D, M, dtype=torch.float32, device=self.dev)
+        scenes = []
+        for b in range(B):
+            c = self._scene_fwd(xyz[b].contiguous(), st_[b].contiguous(), sr_[b].contiguous(), q[b].contiguous(), list(names[b]))
+            _lib.call("semabs_cos_head", _lib.ptr(c["o"]), _lib.ptr(c["rel"]), None, D, M, self.temperature, _lib.ptr(logits[b]), None, None, _lib.stream())
+            scenes.append(c)
+        return logits, dict(scenes=scenes, used=sorted(set(names.reshape(-1).tolist()), key=RELATIONS.index))
+
+    @torch.no_grad()
+    def backward_tape(self, ctx: dict, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """dlogits = d loss / d logits [B, D, M] -> {parameter name: gradient} for every parameter the graph reached (views of ONE fresh flat
+        buffer; autograd accumulates them into `.grad`, where DistributedDataParallel's hooks pick them up)."""
+        self._bind_grads(torch.zeros(self.total + len(RELATIONS), dtype=torch.float32, device=self.dev), attach=False)
+        dl = dlogits.to(self.dev, torch.float32).contiguous()
+        for b, c in enumerate(ctx["scenes"]):
+            dO = torch.empty_like(c["o"])
+            drel = torch.zeros(c["D"], self.E, dtype=torch.float32, device=self.dev)
+            _lib.call("semabs_cos_head", _lib.ptr(c["o"]), _lib.ptr(c["rel"]), _lib.ptr(dl[b]), c["D"], c["M"], self.temperature, None, _lib.ptr(dO),
+                      _lib.ptr(drel), _lib.stream())
+            self._scene_bwd(c, dO, drel)
+            c.clear()                                                        # the tape is single-use (retain_graph is not supported)
+        return {k: self.grads[k] for k in self.graph_params(ctx["used"])}
+
+    def graph_params(self, used_relations) -> List[str]:
+        """Names of the parameters an autograd graph of this forward contains: everything but `visual_sampler.*` and the relation embeddings
+        no description of the batch names (they end the step with grad = None in the reference too)."""
+        used = set(used_relations)
+        return [k for k in self.trainable if not k.startswith("relation_embeddings.") or k[len("relation_embeddings."):] in used]
 
     # ---- public ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_backward(self, batch: dict) -> dict:
         """Zero the gradients, run forward + loss + backward over the batch; returns {"loss": device scalar, "logits": [B, D, M]}."""
         dev = self.dev
+        assert self.module is None, "module-bound engines hand their gradients to autograd (SemAbsVOOL.forward under grad mode)"
         self.flat_grad.zero_()
         self.unet.refresh()
-        xyz = batch["input_xyz_pts"].to(dev, torch.float32)
-        B, N = xyz.shape[:2]
-        st_ = batch["input_target_saliency_pts"].to(dev, torch.float32).reshape(B, -1, N)
-        sr_ = batch["input_reference_saliency_pts"].to(dev, torch.float32).reshape(B, -1, N)
-        q = batch["output_xyz_pts"].to(dev, torch.float32)
+        xyz, st_, sr_, q, names, B, N, D, M = self._unpack(batch)
         label = batch["output_label_pts"].to(dev, torch.float32).contiguous()
-        D, M = label.shape[1:]
-        names = np.array(batch["spatial_relation_name"]).T.reshape(B, D)                 # [B, D] like net.py:527
         weight = self.bce_weight(label)
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
         logits = torch.empty(B, D, M, dtype=torch.float32, device=dev)

@@ -4,7 +4,7 @@ import torch
 
 from semabs_amd.synth import SCENE_BOUNDS
 
-REL_NAMES = [["behind"], ["on"], ["behind"]]
+REL_NAMES = [["behind"], ["on"], ["behind"], ["in"]]          # gen_golden.py: g13 / g20 use the first three, g22 (4 descriptions) all four
 
 
 def vool_batch(S, N, M, D, seed, label):
@@ -17,4 +17,4 @@ def vool_batch(S, N, M, D, seed, label):
     q = (lo - 0.05 + (hi - lo + 0.1) * rng.random((1, P, M, 3))).astype(np.float32)
     return dict(input_xyz_pts=torch.from_numpy(xyz), input_target_saliency_pts=torch.from_numpy(feat[:, :D]),
                 input_reference_saliency_pts=torch.from_numpy(feat[:, D:]), output_xyz_pts=torch.from_numpy(q[:, :D]),
-                output_label_pts=torch.from_numpy(np.asarray(label, np.float32)), spatial_relation_name=[list(r) for r in REL_NAMES])
+                output_label_pts=torch.from_numpy(np.asarray(label, np.float32)), spatial_relation_name=[list(r) for r in REL_NAMES[:D]])

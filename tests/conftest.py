@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CLIP BPE merge table is third-party data the repo does not carry.  In the build container the tokenizer tests borrow the copy that
+# sits next to the reference checkout (test infrastructure only: the product looks at $SEMABS_BPE_VOCAB / its assets dir / ~/.cache/clip);
+# on the GPU box the path does not exist and those tests use the committed token-id fixtures instead.
+_BPE = "/root/reference/CLIP/clip/bpe_simple_vocab_16e6.txt.gz"
+if "SEMABS_BPE_VOCAB" not in os.environ and os.path.isfile(_BPE):
+    os.environ["SEMABS_BPE_VOCAB"] = _BPE
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -857,3 +857,221 @@ def g21_vit_l14():
 
 if __name__ == "__main__" and "g21" in sys.argv[1:]:
     g21_vit_l14()
+
+
+# ---- appended (round 3): config 5 at its stated size (g22: 128^3, 4 descriptions, 80 000 / 400 000 points) and the reference's OWN gradient
+# ---- spread under a 1e-6 relative weight perturbation (g22, and g20s for the 64^3 golden) ---------------------------------------------------
+REL4 = [["behind"], ["on"], ["behind"], ["in"]]
+
+
+def _vool_reference_step(S, N, M, D, rel_names, perturb_seed=None, eps=1e-6, step=True):
+    """The unmodified reference: SemAbsVOOL forward -> BCE-with-logits -> backward -> clip_grad_norm_ -> arm.optim.lamb.Lamb.step (train_vool.py:118-178,
+    utils.py:404-417).  perturb_seed: every parameter is first multiplied by (1 + eps * N(0, 1)) element-wise - the fp32-rounding-level perturbation
+    whose effect on the reference's own gradients is the yardstick for the HIP path's deviation."""
+    from semabs_amd.weights import make_semabsvool_state_dict
+    net, _ = refimport.load_reference_net()
+    if refimport.REF not in sys.path:
+        sys.path.insert(0, refimport.REF)
+    from arm.optim.lamb import Lamb
+    m = net.SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cpu", decoder_concat_xyz_pts=True,
+                       voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
+                       unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128,
+                       reduce_method="max", batch_size=1)
+    sd = make_semabsvool_state_dict(seed=3)
+    if perturb_seed is not None:
+        gen = torch.Generator().manual_seed(perturb_seed)
+        sd = {k: (v * (1 + eps * torch.randn(v.shape, generator=gen)) if torch.is_floating_point(v) and "steps" not in k else v) for k, v in sd.items()}
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    xyz, feat, q = _semabs_inputs(S, N, M, 2 * D, seed=13)
+    label = (np.random.default_rng(131).random((1, D, M)) < 0.3).astype(np.float32)
+    params = [(k, p) for k, p in m.named_parameters()]
+    opt = Lamb([p for _, p in params], lr=1e-3, weight_decay=1e-5)
+    before = {k: p.detach().clone() for k, p in params}
+    t = time.time()
+    out = m(output_xyz_pts=torch.from_numpy(q[:, :D]), spatial_relation_name=rel_names, input_xyz_pts=torch.from_numpy(xyz),
+            input_target_saliency_pts=torch.from_numpy(feat[:, :D]), input_reference_saliency_pts=torch.from_numpy(feat[:, D:]), tsdf_vol=None)
+    lab = torch.from_numpy(label)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, lab, weight=torch.ones_like(lab))
+    opt.zero_grad()
+    loss.backward()
+    print(f"    reference fwd + bwd at {S}^3, {D} descriptions: {time.time() - t:.1f}s", flush=True)
+    r = dict(label=label, loss=float(loss.item()), logits=out.detach().numpy().copy(), names=[k for k, _ in params],
+             grads={k: (None if p.grad is None else p.grad.detach().numpy().copy()) for k, p in params})
+    if step:
+        r["total_norm"] = float(torch.nn.utils.clip_grad_norm_([p for _, p in params], 2.0))
+        opt.step()
+        r["new"] = {k: p.detach().numpy().copy() for k, p in params}
+        r["before"] = {k: v.numpy() for k, v in before.items()}
+    return r
+
+
+def _spread(a, b):
+    """Deviation of run b from run a in the statistics the GPU tests assert: per-tensor gradient norm (relative), relative L2 of each gradient
+    tensor, total norm, loss, logits."""
+    gtot = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in a["grads"].values() if g is not None)))
+    names, norm_rel, l2_rel = [], [], []
+    for k in a["names"]:
+        ga, gb = a["grads"][k], b["grads"][k]
+        if ga is None:
+            continue
+        na = float(np.linalg.norm(ga.astype(np.float64)))
+        names.append(k)
+        norm_rel.append(abs(float(np.linalg.norm(gb.astype(np.float64))) - na) / max(na, 1e-300))
+        l2_rel.append(float(np.linalg.norm((gb - ga).astype(np.float64))) / max(na, 1e-300))
+    return dict(spread_names=np.asarray(names), spread_norm_rel=np.asarray(norm_rel), spread_l2_rel=np.asarray(l2_rel), spread_gtot=np.float64(gtot),
+                spread_loss_rel=np.float64(abs(b["loss"] - a["loss"]) / a["loss"]), spread_logits_linf=np.float64(np.abs(b["logits"] - a["logits"]).max()),
+                spread_total_rel=np.float64(abs(b.get("total_norm", 0.0) - a.get("total_norm", 0.0)) / max(a.get("total_norm", 1.0), 1e-300)))
+
+
+def g22_vool_train128(S=128, N=80000, M=400000, D=4, name="g22_vool_train128", perturbations=(1,)):
+    a = _vool_reference_step(S, N, M, D, REL4[:D] if D <= 4 else None)
+    res = {"meta": np.asarray([S, N, M, D, 13, 3, 131], np.int32), "label_packed": np.packbits(a["label"].astype(np.uint8).reshape(-1)),
+           "loss": np.float64(a["loss"]), "total_norm": np.float64(a["total_norm"]), "names": np.asarray(a["names"]),
+           "rel_names": np.asarray([r[0] for r in REL4[:D]])}
+    li = sample_idx(a["logits"].size, 16384)
+    res["logit_idx"], res["logits_s"] = li, a["logits"].reshape(-1)[li]
+    res["logits_sum"], res["logits_abs"] = np.float64(a["logits"].astype(np.float64).sum()), np.float64(np.abs(a["logits"].astype(np.float64)).sum())
+    gnorm, has, dnorm = [], [], []
+    for k in a["names"]:
+        g = a["grads"][k]
+        has.append(g is not None)
+        gnorm.append(0.0 if g is None else float(np.linalg.norm(g.astype(np.float64))))
+        dnorm.append(float(np.linalg.norm((a["new"][k] - a["before"][k]).astype(np.float64))))
+        if g is not None:
+            if g.size <= 4096:
+                res["grad/" + k] = g
+            else:
+                si = sample_idx(g.size, 2048)
+                res["gradidx/" + k], res["grads/" + k] = si, g.reshape(-1)[si]
+    res["grad_norm"], res["has_grad"], res["delta_norm"] = np.asarray(gnorm, np.float64), np.asarray(has), np.asarray(dnorm, np.float64)
+    sp = None
+    for ps in perturbations:
+        b = _vool_reference_step(S, N, M, D, REL4[:D], perturb_seed=ps)
+        s = _spread(a, b)
+        if sp is None:
+            sp = s
+        else:                                                   # worst over the perturbations, element-wise
+            for k in ("spread_norm_rel", "spread_l2_rel"):
+                sp[k] = np.maximum(sp[k], s[k])
+            for k in ("spread_loss_rel", "spread_logits_linf", "spread_total_rel"):
+                sp[k] = max(sp[k], s[k])
+        del b
+    res.update(sp)
+    print(f"    {name}: loss {a['loss']:.6f}, total norm {a['total_norm']:.4e}; reference self-spread under 1e-6 perturbation: "
+          f"grad-norm rel max {sp['spread_norm_rel'].max():.3e} median {np.median(sp['spread_norm_rel']):.3e}, "
+          f"grad L2 rel max {sp['spread_l2_rel'].max():.3e} median {np.median(sp['spread_l2_rel']):.3e}, total {float(sp['spread_total_rel']):.3e}", flush=True)
+    save(name, **res)
+
+
+def g20s_spread64():
+    """The 64^3 golden's companion: the reference's own gradient spread at g20's configuration (3 descriptions, 12 000 / 4 000 points)."""
+    a = _vool_reference_step(64, 12000, 4000, 3, REL4[:3])
+    g = np.load(os.path.join(HERE, "g20_vool_train64.npz"))
+    assert abs(a["loss"] - float(g["loss"])) <= 1e-9 and np.array_equal(a["logits"], g["logits"]), "base run must reproduce g20"
+    sp = None
+    for ps in (1, 2, 3):
+        s = _spread(a, _vool_reference_step(64, 12000, 4000, 3, REL4[:3], perturb_seed=ps))
+        if sp is None:
+            sp = s
+        else:
+            for k in ("spread_norm_rel", "spread_l2_rel"):
+                sp[k] = np.maximum(sp[k], s[k])
+            for k in ("spread_loss_rel", "spread_logits_linf", "spread_total_rel"):
+                sp[k] = max(sp[k], s[k])
+    print(f"    g20s: grad-norm rel max {sp['spread_norm_rel'].max():.3e} median {np.median(sp['spread_norm_rel']):.3e}, grad L2 rel max "
+          f"{sp['spread_l2_rel'].max():.3e} median {np.median(sp['spread_l2_rel']):.3e}, total {float(sp['spread_total_rel']):.3e}", flush=True)
+    save("g20s_vool_train64_spread", **sp)
+
+
+if __name__ == "__main__" and "g20s" in sys.argv[1:]:
+    g20s_spread64()
+if __name__ == "__main__" and "g22" in sys.argv[1:]:
+    g22_vool_train128()
+
+
+# ---- appended (round 3): imagenet prompt ensemble (g24) and prep_data executed from the reference's source (g25) ------------------------------
+def g24_prompt_ensemble():
+    """`imagenet_prompt_ensemble=True` as generate_relevancy.py:70-80 does it: `prompts=imagenet_templates` (80 templates) into the unmodified
+    `ClipWrapper.get_clip_saliency`; 2 labels, ViT-B/32, chefer_et_al at 96^2.  Also pins the template table itself (digest + count) and the
+    reference tokenizer's ids for the 160 strings (the BPE table is not on the GPU box)."""
+    rc = refimport.load_reference_clip("ViT-B/32", seed=0)
+    import CLIP.clip.clip_explainability as rexp
+    W = rc.ClipWrapper
+    tpl = list(rc.imagenet_templates)
+    labels = ["chair", "table"]
+    texts = [t.format(c) for c in labels for t in tpl]
+    img = synth_rgb(96, 96, seed=42)
+    cfg = dict(rc.saliency_configs["chefer_et_al"](96), imagenet_prompt_ensemble=True)
+    t = time.time()
+    maps, feats = W.get_clip_saliency(img=img, text_labels=labels, prompts=tpl, **cfg)
+    print(f"    prompt ensemble, 2 labels x {len(tpl)} templates: {time.time() - t:.1f}s  max|map| {maps.abs().max():.4g}")
+    save("g24_prompt_ensemble", maps=maps.numpy(), text=feats.numpy(), tokens=rexp.tokenize(texts).numpy().astype(np.int32),
+         templates_sha=np.frombuffer(hashlib.sha256("\n".join(tpl).encode()).digest(), dtype=np.uint8), n_templates=np.int32(len(tpl)),
+         labels=np.asarray(labels))
+
+
+def g25_prep_data():
+    """visualize.prep_data (visualize.py:61-154) EXECUTED from the reference's source with the reference's own get_pointcloud / filter_pts_bounds;
+    the CLIP call is a closed-form stand-in (`semabs_amd.synth.synth_relevancy`: a map per label string) shared with the GPU test, plotting /
+    directory creation are no-ops.  Pins: relevancy key set, x 50, mean subtraction, in-bounds point selection and its order, the per-class /
+    per-description feature stacks, the returned key set and the description strings."""
+    import pickle
+    import tempfile
+    from semabs_amd.synth import synth_relevancy
+    fusion, pc = refimport.load_reference_geometry()
+    calls = []
+
+    class ClipWrapper:                                          # stand-in: records what prep_data asks for
+        @classmethod
+        def get_clip_saliency(cls, img, text_labels, prompts, **kwargs):
+            calls.append(dict(labels=[str(t) for t in text_labels], prompts=list(prompts), kwargs=dict(kwargs), shape=tuple(img.shape)))
+            return torch.from_numpy(synth_relevancy(img, [str(t) for t in text_labels])), None
+
+    class _Path:
+        def __init__(self, p):
+            pass
+
+        def mkdir(self, **k):
+            pass
+
+    fpb = lambda xyz, bounds: pc.filter_pts_bounds(xyz, np.asarray(bounds).astype(np.float32))      # numpy-1.22 typing of the comparison (see g18)
+    import CLIP.clip as rc
+    ns = {"np": np, "torch": torch, "pickle": pickle, "os": os, "Path": _Path, "ClipWrapper": ClipWrapper, "saliency_configs": rc.saliency_configs,
+          "get_pointcloud": pc.get_pointcloud, "filter_pts_bounds": fpb, "visualize_relevancies": lambda **k: None}
+    _ref_functions("visualize.py", ["prep_data"], ns)
+    sc = synth_scene(96, 96, seed=5)
+    data = dict(rgb=sc["rgb"], depth=sc["depth"], cam_intr=sc["cam_intr"], cam_extr=sc["cam_pose"],
+                ovssc_obj_classes=["chair", "table", "lamp"], descriptions=[("lamp", "on", "table"), ("cushion", "behind", "chair")])
+    out = {"meta": np.asarray([96, 5], np.int32)}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "scene_0007.pkl")
+        pickle.dump(data, open(path, "wb"))
+        for sub in (True, False):
+            b = ns["prep_data"](data_pickle_path=path, scene_bounds=SCENE_BOUNDS, subtract_mean=sub, dump_path=d)
+            tag = f"sub{int(sub)}"
+            keys = calls[-1]["labels"]
+            out[f"{tag}_keys"] = np.asarray(keys)
+            out[f"{tag}_relevancies"] = b["relevancies"].numpy()
+            out[f"{tag}_xyz_sha"] = digest(b["input_xyz_pts"].numpy())
+            out[f"{tag}_xyz_sub"] = b["input_xyz_pts"].numpy()[::97].copy()
+            out[f"{tag}_n"] = np.int64(len(b["input_xyz_pts"]))
+            out[f"{tag}_rgb_sha"] = digest(b["input_rgb_pts"])
+            for k in ("input_feature_pts", "input_target_saliency_pts", "input_reference_saliency_pts"):
+                out[f"{tag}_{k}"] = b[k].numpy()
+            out[f"{tag}_batch_keys"] = np.asarray(sorted(b.keys()))
+            out[f"{tag}_descriptions"] = np.asarray(b["descriptions"])
+            out[f"{tag}_relations"] = np.asarray(b["spatial_relation_name"])
+            out[f"{tag}_scene_id"] = np.asarray(b["scene_id"])
+            assert b["tsdf_vol"] is None and b["ovssc_obj_classes"] == data["ovssc_obj_classes"]
+    c = calls[-1]
+    out["call_prompts"] = np.asarray(c["prompts"])
+    out["call_kwargs"] = np.asarray(sorted(c["kwargs"].keys()))
+    assert c["kwargs"]["augmentations"] == 5 and c["kwargs"]["horizontal_flipping"] and c["shape"] == (96, 96, 3)
+    save("g25_prep_data", **out)
+
+
+if __name__ == "__main__" and "g24" in sys.argv[1:]:
+    g24_prompt_ensemble()
+if __name__ == "__main__" and "g25" in sys.argv[1:]:
+    g25_prep_data()

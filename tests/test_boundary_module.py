@@ -145,3 +145,32 @@ def test_semabs3d_tsdf_network_input_vs_reference(golden):
     assert err <= 2e-4 * max(1.0, float(np.abs(g["out"]).max()))
     with pytest.raises(ValueError, match="tsdf_vol"):
         net(input_xyz_pts=torch.from_numpy(g["xyz"]), input_feature_pts=torch.from_numpy(g["feat"]), tsdf_vol=None, output_xyz_pts=torch.from_numpy(g["q"]))
+
+
+@pytest.mark.gpu
+def test_semabs3d_tsdf_batch_pairing_quirk_vs_oracle():
+    """B = 2 scenes x P = 2 label volumes with "tsdf" input: the reference concatenates `tsdf_vol.unsqueeze(1).repeat(P, 1, 1, 1, 1)` (order
+    b0, b1, b0, b1) to the b-major feature stack (b0p0, b0p1, b1p0, b1p1), net.py:411-419 - volume (b, p) gets tsdf_vol[(b P + p) % B].
+    The oracle restates that line literally (and is pinned to the reference module at B = 1 by g17); the HIP path must pair the same way."""
+    from oracle import semabs3d as os3
+    from semabs_amd.net import SemAbs3D
+    S, L, N, M = 16, 3, 1500, 300
+    kw = dict(KW, voxel_shape=(S, S, S), unet_num_levels=L, network_inputs=["saliency", "tsdf"])
+    sd = make_semabs3d_state_dict(seed=6, unet_num_levels=L)
+    sd["pts_feat_extractor.4.weight"] = sd["pts_feat_extractor.4.weight"][:15].clone()
+    sd["pts_feat_extractor.4.bias"] = sd["pts_feat_extractor.4.bias"][:15].clone()
+    net = SemAbs3D(device="cuda", **kw).to("cuda").eval()
+    net.load_state_dict(sd)
+    rng = np.random.default_rng(3)
+    lo, hi = np.array(BOUNDS[0]), np.array(BOUNDS[1])
+    xyz = torch.from_numpy((lo + (hi - lo) * rng.random((2, N, 3))).astype(np.float32))
+    feat = torch.from_numpy((rng.standard_normal((2, 2, N, 1)) * 0.5).astype(np.float32))
+    q = torch.from_numpy((lo + (hi - lo) * rng.random((2, 2, M, 3))).astype(np.float32))
+    tsdf = torch.from_numpy(rng.uniform(-1, 1, (2, S, S, S)).astype(np.float32))
+    out = net(input_xyz_pts=xyz, input_feature_pts=feat, tsdf_vol=tsdf, output_xyz_pts=q)
+    with torch.no_grad():
+        ref = os3.semabs3d_forward(sd, xyz, feat, q, BOUNDS, (S, S, S), num_levels=L, tsdf_vol=tsdf)
+        own = os3.semabs3d_forward(sd, xyz, feat, q, BOUNDS, (S, S, S), num_levels=L, tsdf_vol=tsdf[[0, 0]])   # what "every volume its own scene" would give for b = 0
+    err = float((out.cpu() - ref).abs().max())
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
+    assert float((ref[0, 1] - own[0, 1]).abs().max()) > 1e-3          # the quirk is visible in this input: (b0, p1) reads scene 1's TSDF

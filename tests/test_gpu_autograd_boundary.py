@@ -1,0 +1,240 @@
+"""The training half of the drop-in boundary: the reference's own loop calls
+
+    outputs = net(**batch); loss = binary_cross_entropy_with_logits(outputs, labels, weight=...)        train_vool.py:118-178
+    optimizer.zero_grad(); loss.backward(); clip_grad_norm_(net.parameters(), grad_max_norm); optimizer.step(); net.steps += 1   utils.py:404-417
+
+on `net = SemAbsVOOL(**kwargs).to(device)` (optionally inside DistributedDataParallel, utils.py:254-258).  Those lines are re-created here
+against `semabs_amd.net.SemAbsVOOL`, whose forward now carries a grad_fn backed by the hand-written HIP backward pass, and checked against the
+unmodified reference's numbers (g20, 64^3), against the fused trainer (`VOOLTrainer.step`), under a real DistributedDataParallel wrapper (RCCL, one
+rank) and with two gloo ranks sharing the GPU (DDP's gradient averaging done by hand on the p.grad the backward left)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import semabs_amd  # noqa: F401
+from _train_inputs import vool_batch
+from semabs_amd.synth import SCENE_BOUNDS
+from semabs_amd.weights import make_semabsvool_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(S, sd, levels=6):
+    from semabs_amd.net import SemAbsVOOL
+    kw = dict(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8, unet_num_levels=levels,
+              network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1,
+              batch_size=1)
+    net = SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cuda", decoder_concat_xyz_pts=True, **kw).to("cuda")
+    net.load_state_dict(sd)
+    return net
+
+
+def _loop_step(net, optimizer, batch, grad_max_norm=2.0):
+    """utils.loop's training branch (utils.py:404-417) with train_vool.get_losses' loss (train_vool.py:171-178; balance_positive_negative=False
+    -> weight of ones)."""
+    batch = {k: (v.to("cuda") if type(v) == torch.Tensor else v) for k, v in batch.items()}
+    outputs = net(**batch)
+    loss = F.binary_cross_entropy_with_logits(outputs, batch["output_label_pts"], weight=torch.ones_like(batch["output_label_pts"]))
+    optimizer.zero_grad()
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(net.parameters(), grad_max_norm)
+    optimizer.step()
+    (net.module if hasattr(net, "module") else net).steps += 1
+    return outputs, loss, total
+
+
+def test_reference_loop_lines_vs_reference_golden_64(golden):
+    from semabs_amd.optim import Lamb
+    g = golden("g20_vool_train64")
+    S, N, M, D, seed, wseed, _ = [int(v) for v in g["meta"]]
+    batch = vool_batch(S, N, M, D, seed, g["label"])
+    before = make_semabsvool_state_dict(seed=wseed)
+    net = _net(S, before)
+    optimizer = Lamb(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, adam=False)
+    batch = {k: (v.to("cuda") if type(v) == torch.Tensor else v) for k, v in batch.items()}
+    outputs = net(**batch)
+    assert outputs.grad_fn is not None and outputs.requires_grad and tuple(outputs.shape) == (1, D, M)
+    loss = F.binary_cross_entropy_with_logits(outputs, batch["output_label_pts"], weight=torch.ones_like(batch["output_label_pts"]))
+    optimizer.zero_grad()
+    loss.backward()
+    names = [str(k) for k in g["names"]]
+    params = dict(net.named_parameters())
+    gtot = float(np.sqrt((g["grad_norm"] ** 2).sum()))
+    worst = 0.0
+    for k, n, has in zip(names, g["grad_norm"], g["has_grad"]):
+        assert (params[k].grad is not None) == bool(has), k            # visual_sampler.*, unused relation embeddings: None, like the reference's autograd
+        if has and n > 1e-4 * gtot:
+            worst = max(worst, abs(float(params[k].grad.double().norm()) - n) / n)
+    total = float(torch.nn.utils.clip_grad_norm_(net.parameters(), 2.0))
+    optimizer.step()
+    net.steps += 1
+    e_loss = abs(float(loss) - float(g["loss"])) / float(g["loss"])
+    e_logit = float(np.abs(outputs.detach().cpu().numpy() - g["logits"]).max())
+    e_total = abs(total - float(g["total_norm"])) / float(g["total_norm"])
+    print(f"reference loop lines on SemAbsVOOL (64^3): loss rel {e_loss:.2e}, logits L-inf {e_logit:.2e}, worst grad-norm rel {worst:.2e}, total norm rel {e_total:.2e}")
+    assert e_loss <= 1e-6 and e_logit <= 2.5e-4 and worst <= 2.8e-2 and e_total <= 4e-4       # the bounds of test_gpu_train.py's trainer test
+    sd = net.state_dict()
+    for k, dn, has in zip(names, g["delta_norm"], g["has_grad"]):
+        mine = float((sd[k].cpu().double() - before[k].double()).norm())
+        assert abs(mine - dn) <= 5e-2 * dn + 1e-12, (k, mine, dn)      # also: tensors without gradient stay put (dn = 0)
+    assert float(sd["steps"]) == 1.0
+    # the next forward sees the updated weights (Lamb.step bumps the parameters' version counters): inference == a fresh module
+    with torch.no_grad():
+        out_a = net(**batch)
+        out_b = _net(S, {k: v.cpu() for k, v in sd.items()})(**batch)
+    assert float((out_a - out_b).abs().max()) <= 1e-5 * float(out_b.abs().max())
+    assert float((out_a - outputs.detach()).abs().max()) > 1e-4
+    with pytest.raises(RuntimeError, match="single-use"):
+        loss2 = outputs.sum()
+        loss2.backward()
+
+
+def test_module_loop_equals_fused_trainer():
+    """Same batch, same weights: `loss.backward()` through the module == `VOOLTrainer.step` (which fuses BCE into the pointer-head kernel)."""
+    from semabs_amd.optim import Lamb
+    from semabs_amd.train import VOOLTrainer
+    S, N, M, D, L = 16, 1500, 700, 3, 4
+    rng = np.random.default_rng(21)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    batch = dict(input_xyz_pts=torch.from_numpy((lo + (hi - lo) * rng.random((2, N, 3))).astype(np.float32)),
+                 input_target_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                 input_reference_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                 output_xyz_pts=torch.from_numpy((lo - 0.05 + (hi - lo + 0.1) * rng.random((2, D, M, 3))).astype(np.float32)),
+                 output_label_pts=torch.from_numpy((rng.random((2, D, M)) < 0.25).astype(np.float32)),
+                 spatial_relation_name=[["on", "behind"], ["in", "[pad]"], ["on the left of", "on"]])
+    sd = make_semabsvool_state_dict(seed=9, unet_num_levels=L)
+    tr = VOOLTrainer(sd, voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_levels=L)
+    ref = tr.step(batch)
+    ref_sd = tr.state_dict()
+    net = _net(S, sd, levels=L)
+    optimizer = Lamb(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    outputs, loss, total = _loop_step(net, optimizer, batch)
+    assert abs(float(loss) - float(ref["loss"])) <= 1e-6 * float(ref["loss"])
+    assert float((outputs.detach() - ref["logits"]).abs().max()) <= 1e-5
+    assert abs(float(total) - float(ref["gradnorm"])) <= 1e-4 * float(ref["gradnorm"])
+    params = dict(net.named_parameters())
+    assert params["relation_embeddings.in front of"].grad is None and params["completion_net.visual_sampler.mlp.0.weight"].grad is None
+    assert params["relation_embeddings.[pad]"].grad is not None
+    new = net.state_dict()
+    gn = float(ref["gradnorm"])
+    for k, v in ref_sd.items():
+        if k in tr.grads and float(tr.grads[k].norm()) > 1e-3 * min(gn, 2.0):       # (clipped) gradient well above the noise floor of a sign-like step
+            step = float((v - sd[k].to(v.device)).abs().max())
+            assert float((new[k] - v).abs().max()) <= 5e-2 * step + 1e-12, k
+        elif k not in tr.grads:
+            assert torch.equal(new[k].cpu(), v.cpu()), k
+
+
+def test_under_distributed_data_parallel_rccl_one_rank():
+    """utils.get_net's wrapper: DistributedDataParallel(module=net, device_ids=[device], find_unused_parameters=True) over RCCL.  One rank (the
+    test box has one GPU): DDP's graph walk for unused parameters, its gradient hooks and its bucket all-reduce all run on what the HIP
+    backward hands to autograd; the step must equal the unwrapped module's."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from semabs_amd.optim import Lamb
+    S, N, M, D, L = 16, 1200, 500, 2, 4
+    rng = np.random.default_rng(5)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    batch = dict(input_xyz_pts=torch.from_numpy((lo + (hi - lo) * rng.random((1, N, 3))).astype(np.float32)),
+                 input_target_saliency_pts=torch.from_numpy(rng.random((1, D, N, 1)).astype(np.float32)),
+                 input_reference_saliency_pts=torch.from_numpy(rng.random((1, D, N, 1)).astype(np.float32)),
+                 output_xyz_pts=torch.from_numpy((lo + (hi - lo) * rng.random((1, D, M, 3))).astype(np.float32)),
+                 output_label_pts=torch.from_numpy((rng.random((1, D, M)) < 0.3).astype(np.float32)),
+                 spatial_relation_name=[["on"], ["behind"]])
+    sd = make_semabsvool_state_dict(seed=4, unet_num_levels=L)
+    plain = _net(S, sd, levels=L)
+    _, loss0, total0 = _loop_step(plain, Lamb(plain.parameters(), lr=1e-3, weight_decay=1e-5), batch)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29650 + os.getpid() % 200)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        net = DistributedDataParallel(module=_net(S, sd, levels=L), device_ids=[torch.device("cuda", 0)], find_unused_parameters=True)
+        optimizer = Lamb(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5, adam=False)
+        for it in range(2):                                                # twice: DDP re-arms its reducer after every backward
+            outputs, loss, total = _loop_step(net, optimizer, batch)
+            if it == 0:
+                assert abs(float(loss) - float(loss0)) <= 1e-6 * float(loss0) and abs(float(total) - float(total0)) <= 1e-4 * float(total0)
+                a, b = net.module.state_dict(), plain.state_dict()
+                for k in a:
+                    step = float((b[k].float() - sd[k].to(b[k].device).float()).abs().max())
+                    assert float((a[k].float() - b[k].float()).abs().max()) <= 5e-2 * step + 1e-12, k
+        assert float(net.module.steps) == 2.0
+        # parameters DDP found unused (visual_sampler.*, relation embeddings no description names) were left alone
+        assert torch.equal(net.module.state_dict()["relation_embeddings.in"].cpu(), sd["relation_embeddings.in"])
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from semabs_amd.optim import Lamb
+    from test_gpu_train_dp import S, L, _batch2, _item
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = _net(S, make_semabsvool_state_dict(seed=9, unet_num_levels=L), levels=L)
+        optimizer = Lamb(net.parameters(), lr=1e-3, weight_decay=1e-5)
+        batch = {k: (v.to("cuda") if type(v) == torch.Tensor else v) for k, v in _item(_batch2(), rank).items()}
+        outputs = net(**batch)
+        loss = F.binary_cross_entropy_with_logits(outputs, batch["output_label_pts"])
+        optimizer.zero_grad()
+        loss.backward()
+        # what DistributedDataParallel(find_unused_parameters=True) does with the p.grad the backward left: parameters used on ANY rank get the
+        # average over ranks (a rank that did not use one contributes zeros); globally unused ones keep grad = None.  gloo has no device
+        # collectives, hence the host staging (RCCL reduces the device buffers in place)
+        ps = list(net.parameters())
+        used = torch.tensor([float(p.grad is not None) for p in ps])
+        dist.all_reduce(used)
+        for p, u in zip(ps, used.tolist()):
+            if u > 0:
+                h = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu()
+                dist.all_reduce(h)
+                p.grad = (h / world).to(p.device)
+        total = float(torch.nn.utils.clip_grad_norm_(net.parameters(), 2.0))
+        optimizer.step()
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), total, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_module_equal_the_fused_single_rank_step():
+    import torch.multiprocessing as mp
+    from test_gpu_train_dp import _batch2, _trainer
+    tr = _trainer()
+    before = {k: v.cpu().numpy().copy() for k, v in tr.state_dict().items()}
+    ref = tr.step(_batch2())
+    torch.cuda.synchronize()
+    ref_sd = {k: v.cpu().numpy() for k, v in tr.state_dict().items()}
+    ref_g = {k: v.cpu().numpy() for k, v in tr.grads.items()}
+    gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ref_g.values()))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=900) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert abs(0.5 * (got[0][1] + got[1][1]) - float(ref["loss"])) <= 1e-5 * float(ref["loss"])
+    for rank, loss, total, sd in got:
+        assert abs(total - float(ref["gradnorm"])) <= 2e-4 * float(ref["gradnorm"]), (rank, total)
+        worst = 0.0
+        for k, v in ref_sd.items():
+            if k not in ref_g or tr.params[k].grad is None:
+                assert np.array_equal(sd[k], v), k
+                continue
+            g = ref_g[k]
+            if float(np.linalg.norm(g.astype(np.float64))) < 1e-3 * gnorm:
+                continue
+            sel = np.abs(g) > 5e-2 * np.abs(g).max()
+            step = np.abs(v - before[k]).max()
+            if sel.any() and step > 0:
+                worst = max(worst, float(np.abs(sd[k] - v)[sel].max() / step))
+        print(f"rank {rank}: worst parameter deviation {worst:.3e} of the tensor's own step")
+        assert worst <= 5e-2, (rank, worst)
+    assert all(np.array_equal(got[0][3][k], got[1][3][k]) for k in ref_sd)

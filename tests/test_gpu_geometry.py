@@ -72,3 +72,28 @@ def test_tsdf(golden, tag, hw, S):
     assert np.array_equal(sha(tv._color_vol_cpu), g[f"{tag}_color_sha"])
     tsdf, col = tv.get_volume()
     assert tsdf.shape == (S, S, S) and col.shape == (3, S, S, S) and col.dtype == np.uint8
+
+
+def test_compact_subsample_matches_nonzero_and_the_oracle_draw():
+    """semabs_compact_subsample: pix = ascending in-bounds pixel ids (== torch.nonzero), n_in on the device, sel = the counter-based seeded
+    draw with replacement the oracle restates (oracle/scene.py:subsample_indices) - incl. an empty mask and a single survivor."""
+    from oracle.scene import subsample_indices
+    from semabs_amd import _lib
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    for n, p, num, seed in [(480 * 480, 0.37, 80000, 7), (1000, 0.5, 333, 0), (1025, 1.0, 64, 123456789), (5000, 0.0, 16, 1), (77, 0.02, 40, 2 ** 40 + 5)]:
+        m = (rng.random(n) < p).astype(np.uint8)
+        if p > 0 and m.sum() == 0:
+            m[n // 2] = 1
+        mask = torch.from_numpy(m).to(dev)
+        pix = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        n_in = torch.zeros(1, dtype=torch.int64, device=dev)
+        sel = torch.full((num,), -1, dtype=torch.int64, device=dev)
+        _lib.call("semabs_compact_subsample", _lib.ptr(mask), n, seed, num, _lib.ptr(pix), _lib.ptr(n_in), _lib.ptr(sel), _lib.stream())
+        ref_pix = np.nonzero(m)[0]
+        assert int(n_in.item()) == len(ref_pix)
+        assert np.array_equal(pix.cpu().numpy()[: len(ref_pix)], ref_pix)
+        if len(ref_pix):
+            assert np.array_equal(sel.cpu().numpy(), ref_pix[subsample_indices(seed, len(ref_pix), num)])
+        else:
+            assert not sel.cpu().numpy().any()

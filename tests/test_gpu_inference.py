@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import semabs_amd  # noqa: F401
+from conftest import sha
 from semabs_amd.synth import SCENE_BOUNDS, synth_ovssc_logits, synth_scene
 from semabs_amd.weights import make_semabs3d_state_dict
 
@@ -83,22 +84,82 @@ def test_process_batch_ovssc_form_chunking_and_logits():
     assert float(np.abs(np.stack(list(v1.values())) - ref_v).mean()) < 1e-3
 
 
-def test_prep_data_batch_keys_and_features():
-    """prep_data's batch (visualize.py:61-154): keys, shapes, x 50 and mean subtraction, in-bounds selection - needs the BPE table for the
-    text tower, which only the build container has."""
+def test_prep_data_vs_executed_reference(golden):
+    """g25 = visualize.prep_data (visualize.py:61-154) compiled from the reference's source and executed with its own get_pointcloud /
+    filter_pts_bounds; the CLIP call is the closed-form stand-in `synth_relevancy` on both sides, so everything prep_data itself does -
+    key set, x 50, mean subtraction, in-bounds selection and order, per-class / per-description stacks, return form - compares exactly."""
+    import pickle
+    from semabs_amd import inference
+    from semabs_amd.synth import synth_relevancy
+    g = golden("g25_prep_data")
+    H, seed = [int(v) for v in g["meta"]]
+    sc = synth_scene(H, H, seed=seed)
+    data = dict(rgb=sc["rgb"], depth=sc["depth"], cam_intr=sc["cam_intr"], cam_extr=sc["cam_pose"],
+                ovssc_obj_classes=["chair", "table", "lamp"], descriptions=[("lamp", "on", "table"), ("cushion", "behind", "chair")])
+    calls = []
+
+    class StandIn:
+        @classmethod
+        def get_clip_saliency(cls, img, text_labels, prompts, **kwargs):
+            calls.append((list(prompts), dict(kwargs)))
+            return torch.from_numpy(synth_relevancy(img, [str(t) for t in text_labels])), None
+
+    real = inference.ClipWrapper
+    inference.ClipWrapper = StandIn
+    try:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            path = d + "/scene_0007.pkl"
+            pickle.dump(data, open(path, "wb"))
+            for sub in (True, False):
+                b = inference.prep_data(path, SCENE_BOUNDS, sub, d)                      # the reference's positional signature
+                tag = f"sub{int(sub)}"
+                assert sorted(b.keys()) == [str(k) for k in g[f"{tag}_batch_keys"]]
+                assert b["scene_id"] == str(g[f"{tag}_scene_id"]) == "scene_0007"
+                assert b["descriptions"] == [str(x) for x in g[f"{tag}_descriptions"]] and b["spatial_relation_name"] == [str(x) for x in g[f"{tag}_relations"]]
+                assert b["tsdf_vol"] is None and b["ovssc_obj_classes"] == data["ovssc_obj_classes"]
+                n = int(g[f"{tag}_n"])
+                assert len(b["input_xyz_pts"]) == n and b["input_xyz_pts"].dtype == torch.float32
+                assert np.array_equal(sha(b["input_xyz_pts"].numpy()), g[f"{tag}_xyz_sha"])       # points, mask and order: bit-exact
+                assert np.array_equal(sha(b["input_rgb_pts"]), g[f"{tag}_rgb_sha"])
+                # `relevancies` rows follow the key order (hash order in the reference, first-seen here): compare by key
+                ref_keys = [str(k) for k in g[f"{tag}_keys"]]
+                mine_keys = list(dict.fromkeys(data["ovssc_obj_classes"] + [d_[0] for d_ in data["descriptions"]] + [d_[2] for d_ in data["descriptions"]]))
+                assert set(ref_keys) == set(mine_keys) and len(b["relevancies"]) == len(ref_keys)
+                for k in mine_keys:
+                    a, r = b["relevancies"][mine_keys.index(k)].numpy(), g[f"{tag}_relevancies"][ref_keys.index(k)]
+                    assert np.abs(a - r).max() <= 1e-7, k                                   # (the mean over rows is summed in a different row order)
+                for k in ("input_feature_pts", "input_target_saliency_pts", "input_reference_saliency_pts"):
+                    assert tuple(b[k].shape) == tuple(g[f"{tag}_{k}"].shape) and np.abs(b[k].numpy() - g[f"{tag}_{k}"]).max() <= 1e-7, k
+    finally:
+        inference.ClipWrapper = real
+    prompts, kw = calls[-1]
+    assert prompts == [str(p) for p in g["call_prompts"]] and sorted(kw.keys()) == [str(k) for k in g["call_kwargs"]]
+    with pytest.raises(NotImplementedError, match="img_shape"):
+        inference.prep_data(dict(data, img_shape=(48, 48)), SCENE_BOUNDS, True)
+    with pytest.raises(KeyError):
+        inference.prep_data({k: v for k, v in data.items() if k != "descriptions"}, SCENE_BOUNDS, True)
+
+
+def test_prep_data_through_the_real_relevancy_path(golden):
+    """The same function with nothing replaced: strings -> tokenizer (fixture ids: the BPE table is not on the GPU box) -> HIP text tower ->
+    HIP relevancy ("ours": 4 scales, flips, 5 jittered copies) -> x 50 -> geometry -> batch."""
     from semabs_amd.clip import ClipWrapper
-    from semabs_amd.clip.tokenizer import find_vocab
-    if find_vocab() is None:
-        pytest.skip("CLIP BPE table not present on this box")
     from semabs_amd.inference import prep_data
     from semabs_amd.weights import make_clip_state_dict
+    from test_gpu_relevancy import _FixtureTokenizer
     ClipWrapper.engine = None
     ClipWrapper("ViT-B/32", state_dict=make_clip_state_dict("ViT-B/32", 0), chunk_tiles=64, max_labels=8)
-    sc = synth_scene(96, 96, seed=2)
-    data = dict(rgb=sc["rgb"], depth=sc["depth"], cam_intr=sc["cam_intr"], cam_extr=sc["cam_pose"], ovssc_obj_classes=["chair", "table"],
-                descriptions=[("lamp", "on", "table")])
-    b = prep_data(data, SCENE_BOUNDS, subtract_mean=True, jittered_images=[sc["rgb"]] * 5)
+    ClipWrapper.tokenizer = _FixtureTokenizer(golden)
+    try:
+        sc = synth_scene(96, 96, seed=2)
+        data = dict(rgb=sc["rgb"], depth=sc["depth"], cam_intr=sc["cam_intr"], cam_extr=sc["cam_pose"], ovssc_obj_classes=["chair", "table"],
+                    descriptions=[("lamp", "on", "table")])
+        b = prep_data(data, SCENE_BOUNDS, subtract_mean=True, jittered_images=[sc["rgb"]] * 5)
+    finally:
+        ClipWrapper.tokenizer = None
     n = len(b["input_xyz_pts"])
-    assert tuple(b["relevancies"].shape) == (3, 96, 96) and float(b["relevancies"].mean(dim=0).abs().max()) < 1e-6
+    assert n > 0 and tuple(b["relevancies"].shape) == (3, 96, 96) and float(b["relevancies"].mean(dim=0).abs().max()) < 1e-6
+    assert float(b["relevancies"].abs().max()) > 1e-3 and torch.isfinite(b["relevancies"]).all()
     assert tuple(b["input_feature_pts"].shape) == (2, n) and tuple(b["input_target_saliency_pts"].shape) == (1, n)
     assert b["spatial_relation_name"] == ["on"] and b["descriptions"] == ["the lamp on the table"] and b["tsdf_vol"] is None

@@ -336,3 +336,35 @@ def test_attention_rising_scores(T, H, causal):
         s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu_(1)
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n, T, D)
     np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
+
+
+def test_imagenet_prompt_ensemble_vs_reference(golden):
+    """`imagenet_prompt_ensemble=True` the way generate_relevancy.py:70-80 runs it - `prompts=imagenet_templates`, 80 templates per label -
+    through the public call: tokenizer (the reference's ids for the 160 strings, g24) -> HIP text tower -> per-template L2 normalise -> mean
+    over templates (clip_gradcam.py:12-27) -> relevancy, against the unmodified reference's (maps, text features)."""
+    from semabs_amd.clip import imagenet_templates, saliency_configs
+    CW, sd = _init_clip("ViT-B/32")
+    g = golden("g24_prompt_ensemble")
+    labels = [str(l) for l in g["labels"]]
+    texts = [t.format(c) for c in labels for t in imagenet_templates]
+
+    class Tok:
+        map = {t: ids for t, ids in zip(texts, g["tokens"].astype(np.int64))}
+
+        def tokenize(self, tx, context_length=77, truncate=False):
+            return torch.from_numpy(np.stack([self.map[t] for t in ([tx] if isinstance(tx, str) else tx)]))
+
+    CW.tokenizer = Tok()
+    try:
+        cfg = dict(saliency_configs["chefer_et_al"](96), imagenet_prompt_ensemble=True)
+        maps, feats = CW.get_clip_saliency(img=synth_rgb(96, 96, seed=42), text_labels=np.array(labels), prompts=imagenet_templates, **cfg)
+    finally:
+        CW.tokenizer = None
+    assert tuple(maps.shape) == (2, 96, 96) and tuple(feats.shape) == (2, 512)
+    e_t = float(np.abs(feats.numpy() - g["text"]).max() / np.abs(g["text"]).max())
+    err = float(np.abs(maps.numpy() - g["maps"]).max())
+    print(f"prompt ensemble (2 labels x 80 templates): text feature rel L-inf {e_t:.2e}, map L-inf {err:.3e} / max|ref| {np.abs(g['maps']).max():.3e}")
+    assert e_t <= 5e-3
+    assert err <= 5.5e-3 * np.abs(g["maps"]).max() and err <= 1.5e-4          # the bounds of the single-template public-API test
+    # the mean over templates is NOT re-normalised (clip_gradcam.py:23-26): the ensemble weight is shorter than a unit vector
+    assert float(np.linalg.norm(feats.numpy(), axis=1).max()) < 0.999

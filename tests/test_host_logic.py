@@ -59,6 +59,29 @@ def test_tokenizer_against_golden(golden):
     assert tk.tokenize("word " * 100, truncate=True).shape == (1, 77)
 
 
+def test_imagenet_templates_table_and_reference_import_line(golden):
+    """`from CLIP.clip import ClipWrapper, saliency_configs, imagenet_templates` (generate_relevancy.py:10) must keep working after the swap;
+    the 80 templates and their order are the interface (the zero-shot weight is their mean): digest pinned to the reference's table (g24)."""
+    import hashlib
+    from semabs_amd.clip import ClipWrapper, imagenet_templates, saliency_configs  # noqa: F401
+    import semabs_amd.clip as pkg
+    g = golden("g24_prompt_ensemble")
+    assert len(imagenet_templates) == int(g["n_templates"]) == 80 and "imagenet_templates" in pkg.__all__
+    assert np.array_equal(np.frombuffer(hashlib.sha256("\n".join(imagenet_templates).encode()).digest(), dtype=np.uint8), g["templates_sha"])
+    assert all(t.count("{}") == 1 for t in imagenet_templates)
+    assert all(cfg(480)["imagenet_prompt_ensemble"] is False for cfg in saliency_configs.values())
+
+
+def test_tokenizer_on_the_prompt_ensemble(golden):
+    from semabs_amd.clip import imagenet_templates
+    from semabs_amd.clip.tokenizer import BPETokenizer, find_vocab
+    if find_vocab() is None:
+        pytest.skip("CLIP BPE merge table not present")
+    g = golden("g24_prompt_ensemble")
+    texts = [t.format(c) for c in [str(l) for l in g["labels"]] for t in imagenet_templates]
+    assert np.array_equal(BPETokenizer().tokenize(texts).numpy(), g["tokens"])
+
+
 def test_shard_range_partitions():
     from semabs_amd.dist import shard_list, shard_range
     for n in (0, 1, 7, 8, 64, 2448):
