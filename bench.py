@@ -198,6 +198,155 @@ def parity_report(pipe, arch, precision):
     return out
 
 
+HBM_PEAK_TBS = 8.0                                                # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
+
+
+def _classify(name, a):
+    """C-ABI entry point + its arguments -> (kernel class, algorithmic flops, algorithmic bytes) of that launch; None = small / host-side."""
+    if name.startswith("semabs_gemm_f16"):
+        M, N, K, epi = a[5], a[6], a[7], a[11]
+        return "fp16 GEMM (k_gemm8 / k_gemm_f16)", 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else (8 if epi == 2 else 4))
+    if name == "semabs_attention":
+        n, T, H = a[3], a[4], a[5]
+        return "attention (k_attention)", 4.0 * n * H * T * T * 64, n * T * H * 64 * 2 * 4
+    if name in ("semabs_layernorm", "semabs_add_layernorm"):
+        M, D = a[4 if name == "semabs_layernorm" else 5], a[5 if name == "semabs_layernorm" else 6]
+        of32 = a[7] if name == "semabs_layernorm" else 0
+        return "LayerNorm (k_layernorm)", 0.0, M * D * (4 + (4 if of32 else 2))
+    if name in ("semabs_conv3d", "semabs_conv3d_stats"):
+        B, D0, D1, D2, cin, cout, k, flags, resid = a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[16], a[7]
+        vox, eb = B * D0 * D1 * D2, 4 if (flags & 1) else 2
+        fl, by = 2.0 * k ** 3 * cin * cout * vox, vox * (cin + cout * (2 if resid else 1)) * eb
+        if k == 3 and cin == 16 and cout == 16 and D0 % 8 == 0 and D1 % 8 == 0 and D2 % 16 == 0:
+            return "Conv3d 128^3 16->16 (k_conv16_lds)", fl, by
+        if k == 3 and cout % 32 == 0 and D0 % 4 == 0 and D1 % 8 == 0 and (D2 % 16 == 0 or (D2 % 8 == 0 and cin % 32 == 0)):
+            return "Conv3d 64^3..8^3 (k_conv_brick)", fl, by
+        return "Conv3d 4^3 / 1x1x1 (k_conv gather)", fl, by
+    if name in ("semabs_convtranspose3d", "semabs_convtranspose3d_stats"):
+        B, D0, D1, D2, cin, cout, flags = a[7], a[8], a[9], a[10], a[11], a[12], a[13]
+        vox, eb = B * D0 * D1 * D2, 4 if (flags & 1) else 2
+        return "ConvTranspose3d (k_convT_brick / gather)", 2.0 * 27 * cin * cout * vox, vox * cin * eb + 8 * vox * cout * eb * 2
+    if name == "semabs_decoder":
+        P, M, f32 = a[10], a[11], a[13]
+        S = a[4]
+        vox = int(S[0]) * int(S[1]) * int(S[2])
+        return "implicit decoder (k_decoder)", 2.0 * P * M * (19 * 16 + 16), P * vox * 16 * (4 if f32 else 2) + P * M * 4
+    if name in ("semabs_gn_stats", "semabs_maxpool3d", "semabs_scatter_mean", "semabs_scatter_mean_stats", "semabs_point_mlp"):
+        return {"semabs_gn_stats": "GroupNorm statistics", "semabs_maxpool3d": "max-pool", "semabs_point_mlp": "point MLP"}.get(name, "scatter-mean"), 0.0, 0
+    if name in ("semabs_tile_patches", "semabs_aggregate", "semabs_color_jitter", "semabs_rollout", "semabs_attention_cls"):
+        return "tiling / aggregation / rollout / CLS attention", 0.0, 0
+    return "other (geometry, TSDF, small element-wise)", 0.0, 0
+
+
+class _CallTimer:
+    """_lib.CALL_HOOK: one torch event pair around every C-ABI launch of a profiled scene (outside the timed region)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def before(self, name, args):
+        cls = _classify(name, args)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return cls, e0
+
+    def after(self, tok):
+        cls, e0 = tok
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((cls, e0, e1))
+
+    def table(self, scenes):
+        torch.cuda.synchronize()
+        agg = {}
+        for (cls, fl, by), e0, e1 in self.rec:
+            d = agg.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by
+        out = {}
+        for cls, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            ms = d["ms"] / scenes
+            row = {"ms_per_scene": round(ms, 3), "launches_per_scene": d["launches"] // scenes}
+            if d["flops"] or d["bytes"]:
+                fl, by = d["flops"] / scenes, d["bytes"] / scenes
+                t_mfma, t_hbm = fl / (PEAK_F16_TFLOPS * 1e12) * 1e3, by / (HBM_PEAK_TBS * 1e12) * 1e3
+                row.update(algorithmic_tflop=round(fl / 1e12, 3), algorithmic_gb=round(by / 1e9, 2), tflops=round(fl / ms / 1e9, 1) if fl else None,
+                           tb_per_s=round(by / ms / 1e9, 2) if by else None, bound="mfma" if t_mfma >= t_hbm else "hbm",
+                           roof_ms=round(max(t_mfma, t_hbm), 3), frac_of_roof=round(max(t_mfma, t_hbm) / ms, 3))
+            out[cls] = row
+        return out
+
+
+def stage_report(pipe, scenes, w_text, arch, precision):
+    """Driver-witnessed numbers for the other BASELINE configs and a per-kernel-class table, measured by this process OUTSIDE the headline timed
+    region (N = 1): config 2 (relevancy stage alone, one 480^2 / 16-label image), config 3 (ResidualUNet3D forward on [16, 16, 128^3], exact and
+    fp16), config 5 (one VOOL optimisation step at 128^3 / 4 descriptions / 80 000 + 400 000 points), and event-timed ms per scene of every
+    kernel class with its algorithmic flops / bytes (conv flops are the reference's 2 * 27 * Cin * Cout per voxel - the exact mode issues 3 x
+    that on the matrix pipe) against max(flops / 2.5 PF, bytes / 8 TB/s)."""
+    from semabs_amd import _lib
+    from semabs_amd.clip import ClipWrapper, saliency_configs
+    cfg = saliency_configs["ours"](IMG)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            a, b = ev(), ev()
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts))
+
+    out = {}
+    sc = scenes[0]
+    def relevancy():
+        images = ClipWrapper.make_images(sc["rgb"], cfg["augmentations"], img_dev=sc.get("rgb_dev"), seed=0)
+        ClipWrapper.relevancy_device(images, w_text, cfg["cropping_augmentations"], cfg["horizontal_flipping"], cfg["positive_attn_only"])
+    out["relevancy_ms"] = round(timed(relevancy), 2)
+    out["relevancy_config"] = f"config 2: {IMG}x{IMG}, {N_LABELS} labels, {arch}, 'ours' (2448 tile forwards): colour jitter + tiling + ViT + rollout + aggregation"
+    # ---- kernel classes over one full scene ----
+    ct = _CallTimer()
+    pipe.run(sc, w_text, seed=0)
+    torch.cuda.synchronize()
+    _lib.CALL_HOOK = ct
+    try:
+        for i in range(2):
+            pipe.run(scenes[i % len(scenes)], w_text, seed=i)
+    finally:
+        _lib.CALL_HOOK = None
+    out["kernel_classes"] = ct.table(2)
+    out["kernel_classes_note"] = ("torch event pairs around every C-ABI launch of 2 profiled scenes (events between launches add ~1-3 % to short kernels); "
+                                  "roof = max(algorithmic flops / 2.5 PF dense fp16 MFMA, algorithmic bytes / 8 TB/s)")
+    # ---- config 3: the UNet alone ----
+    net = pipe.net
+    u = net.vol_feature_extractor
+    x = torch.zeros(N_LABELS, VOXEL, VOXEL, VOXEL, 16, dtype=torch.float32, device="cuda")
+    occ = torch.rand(VOXEL, VOXEL, VOXEL, device="cuda") < 0.03
+    x[:, occ] = torch.randn(N_LABELS, int(occ.sum()), 16, device="cuda")
+    out["unet128x16_ms_" + precision] = round(timed(lambda: u.forward_cl(x.to(u.act_dtype))), 2)
+    from semabs_amd.unet3d import ResidualUNet3D
+    other = "fp16" if precision == "exact" else "exact"
+    u2 = ResidualUNet3D(in_channels=16, out_channels=16, f_maps=16, num_groups=8, num_levels=6, precision=other)
+    u2.load_state_dict(u.state_dict())
+    u2.to("cuda")
+    out["unet128x16_ms_" + other] = round(timed(lambda: u2.forward_cl(x.to(u2.act_dtype))), 2)
+    out["unet_config"] = f"config 3: ResidualUNet3D forward, {N_LABELS} volumes of 16 x {VOXEL}^3, channels-last, incl. the final 1x1x1 convolution"
+    del u2, x
+    torch.cuda.empty_cache()
+    # ---- config 5: one VOOL optimisation step ----
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from train_bench import synth_batch
+    from semabs_amd.synth import SCENE_BOUNDS
+    from semabs_amd.train import VOOLTrainer
+    from semabs_amd.weights import make_semabsvool_state_dict
+    tr = VOOLTrainer(make_semabsvool_state_dict(seed=3), voxel_shape=(VOXEL,) * 3, scene_bounds=SCENE_BOUNDS)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(VOXEL, 80000, 400000, 4, seed=0).items()}
+    out["vool_train_step_ms"] = round(timed(lambda: tr.step(batch), reps=3), 2)
+    out["vool_train_config"] = f"config 5: SemAbsVOOL {VOXEL}^3, batch 1, 4 descriptions, 80000 input / 400000 query points: forward + BCE + backward + clip + LAMB, 1 GPU"
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,6 +366,7 @@ def main():
                     "and 5 gives the same TFLOP/s figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (reference goldens, outside the timed region)")
+    ap.add_argument("--no-stages", action="store_true", help="skip the stage / kernel-class leg (configs 2, 3, 5 and the per-class table, outside the timed region)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -297,7 +447,7 @@ def main():
         # HBM bytes per GEMM launch: PMC counters cannot be read from inside the process that is being timed (rocprofv3 owns them and
         # serialises the kernels), so this figure is IMPORTED from the committed counter run of this same command and labelled as such
         traffic, traffic_src = None, None
-        for name in ("r02_gemm_pmc.json", "r01_gemm_pmc.json"):
+        for name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -317,7 +467,11 @@ def main():
                        "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
             "roofline": {"kernel": "fp16 GEMM: k_gemm8 (large shapes) + k_gemm_f16 (small), all epilogues", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": gs["launches"], "launches_in_timed_region": gs["seen"],
+                         "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": gs["bytes"] / max(1, gs["launches"]),
+                         "traffic_over_algorithmic": (traffic / (gs["bytes"] / max(1, gs["launches"]))) if (traffic and gs["bytes"]) else None,
+                         "algorithmic_bytes_note": "A + W + C per launch (fp16 operands; C fp16 2 B, fp32 4 B, fp32 residual read-modify-write 8 B per element), averaged over the timed launches",
+                         "launches": gs["launches"], "launches_in_timed_region": gs["seen"],
                          "sampling": ("every GEMM launch of the timed region carries start / stop events" if args.time_every == 1 else
                                       f"1 in {args.time_every} GEMM launches of the timed region (hashed launch index) carries start / stop events"),
                          "avg_launch_us": gs["total_ms"] * 1e3 / max(1, gs["launches"]),
@@ -330,6 +484,8 @@ def main():
                                "table is not on the GPU box) and the host->HBM upload of the frame (5 MB, 0.08 ms over PCIe Gen5)")
         if world == 1 and not args.no_parity:
             out["parity"] = parity_report(pipe, args.arch, args.precision)
+        if world == 1 and not args.no_stages:
+            out["stages"] = stage_report(pipe, scenes, w_text, args.arch, args.precision)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, N_LABELS)
         print(json.dumps(out), flush=True)

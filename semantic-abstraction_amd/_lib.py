@@ -141,12 +141,19 @@ def lib():
     return _lib
 
 
+CALL_HOOK = None      # measurement only (bench.py's per-kernel-class table): object with before(name, args) -> token and after(token)
+
+
 def call(name: str, *args) -> None:
     h = lib()
     fn = getattr(h, name, None)
     if fn is None:
         raise RuntimeError(f"libsemabs_hip.so does not export {name}")
+    hook = CALL_HOOK
+    tok = hook.before(name, args) if hook is not None else None
     rc = fn(*args)
+    if hook is not None:
+        hook.after(tok)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {h.semabs_last_error().decode()}")
 

@@ -329,8 +329,181 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
     }
 }
 
+// =================================================================================================
+// k_attention2: the same computation with K AND V staged row-major by direct-to-LDS DMA and V read through the gfx950 transposing LDS read.
+//   * staging: `buffer_load ... lds` (16 B per lane, 1 KB = 8 token rows per wave instruction): no staging VGPRs, no ds_write at all.  The
+//     round-2 kernel bounced every row through registers and scattered V^T with 2-byte ds_write_b16 (4-way bank conflicts, 29 % of the
+//     LDS-active cycles).  Rows >= T fall off the buffer descriptor (extent = this sequence's T rows) and land as zeros.
+//   * LDS images: K [TP][64] with the 16-byte chunk XOR-swizzle of kswz (conflict-free ds_read_b128 fragments, as before); V [TP][64] with
+//     chunk ^= ((row >> 1) & 1) << 2, applied on the DMA SOURCE address (the DMA's LDS image is lane-linear).
+//   * P.V:  O^T += V^T P^T needs, per lane (d = lane & 31, k half = lane >> 5), V[key0 .. key0 + 3][d] - a COLUMN of the row-major image.
+//     `ds_read_b64_tr_b16`: the 16 lanes of a group each address 8 bytes of a [4 keys][16 d] block (lane i: key i / 4, d chunk i % 4) and
+//     get back its column i.  With the swizzle above the four key rows of a group pair occupy four disjoint 16-bank windows: conflict-free.
+// Selected by semabs_attention unless bit 1 of `causal` asks for the round-2 kernel (A/B in tests and tools).
+// =================================================================================================
+__device__ __forceinline__ int vswz_chunk(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NKB, bool CAUSAL>
+__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(const f16* __restrict__ qkv, f16* __restrict__ out,
+                                                    float* __restrict__ stats, int T, int H, int ld, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = 32 * NKB;
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    constexpr int NWAVE = (NKB > 4) ? 8 : 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = blockIdx.x / H, h = blockIdx.x % H;
+    const f16* base = qkv + (long)seq * T * ld + h * 64;
+    const int ql = lane & 31, hi = lane >> 5;
+
+    // query fragments of the wave's first block: ordinary loads, issued BEFORE the LDS-DMA loads (an ordinary load queued behind outstanding
+    // DMA loads can be reported complete early on gfx950 - DESIGN.md 6a - so the two kinds never share the queue in that order)
+    f16x8 fq0[4];
+    {
+        const int q = wid * 32 + ql;
+        const int qc = q < T ? q : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fq0[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+    }
+    {
+        // one resource descriptor per workgroup: this sequence's T token rows; rows >= T read as zeros
+        const long bytes = ((long)(T - 1) * ld + 3L * D) * 2 - (long)h * 128;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+        constexpr int PIECES = TP / 8;                       // 1 KB pieces (8 rows) per operand
+        const int prow = lane >> 3, pc = lane & 7;
+#pragma unroll
+        for (int it = 0; it < (2 * PIECES + NWAVE - 1) / NWAVE; ++it) {
+            const int p = it * NWAVE + wid;                  // wave-uniform piece id: K pieces first, then V
+            if (p < 2 * PIECES) {
+                const bool isv = p >= PIECES;
+                const int row = (isv ? p - PIECES : p) * 8 + prow;
+                const int lc = isv ? vswz_chunk(row, pc) : (pc ^ ((row >> 1) & 7));          // logical chunk that lives at physical chunk pc
+                const unsigned voff = (unsigned)row * (unsigned)ld * 2u + (unsigned)((isv ? 2 * D : D) + lc * 8) * 2u;
+                char* dst = (isv ? sV : sK) + (isv ? p - PIECES : p) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, 0u, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = kswz(ql, ks * 2 + hi);
+    // transposing V reads: lane -> (key row i / 4 + 4 hi of the group's 4-key block, 8-byte piece i % 4 of the 16-d half `dsel`); the swizzle
+    // bit of the row is (i >> 3) & 1 for every block (key0 is a multiple of 4 with bit 1 clear), so the lane's offset inside a row is constant
+    const int gi = lane & 15, dsel = (lane >> 4) & 1;
+    const int vrow_off = ((gi >> 2) + 4 * hi) * 128;
+    const int vcol0 = (((dsel * 2 + ((gi & 3) >> 1)) ^ (((gi >> 3) & 1) << 2)) << 4) + (gi & 1) * 8;         // d block 0; d block 1 = ^ 64
+    auto vfrag = [&](int key0, int db) -> f16x8 {
+        const char* pa = sV + key0 * 128 + vrow_off + (vcol0 ^ (db << 6));
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)pa);
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 8 * 128));
+        f16x8 v;
+        const f16x4 fa = __builtin_bit_cast(f16x4, a), fb = __builtin_bit_cast(f16x4, b);
+        v[0] = fa[0]; v[1] = fa[1]; v[2] = fa[2]; v[3] = fa[3]; v[4] = fb[0]; v[5] = fb[1]; v[6] = fb[2]; v[7] = fb[3];
+        return v;
+    };
+#pragma unroll 1
+    for (int qb = wid; qb < NKB; qb += NWAVE) {
+        const int q = qb * 32 + ql;
+        const int qc = q < T ? q : T - 1;
+        f16x8 fq[4];
+        if (qb == wid) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fq[ks] = fq0[ks];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+        }
+        float mref = 0.f, sum = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = -mref;       // the MFMA accumulator does the subtraction of the reference maximum
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + kb * 4096 + koff[ks]);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fq[ks], sc, 0, 0, 0);
+            }
+            // the V fragments of this key block do not depend on the scores: request them now, they arrive under the softmax arithmetic
+            f16x8 fv[2][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) fv[hf][db] = vfrag(kb * 32 + hf * 16, db);
+            if (CAUSAL || kb * 32 + 31 >= T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool dead = key >= T || (CAUSAL && key > q);
+                    sc[r] = dead ? -INFINITY : sc[r];
+                }
+            }
+            float bm = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) bm = fmaxf(bm, sc[r]);
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const bool raise = kb == 0 || bm > 8.f;
+            if (__ballot(raise) != 0) {
+                const float d = raise ? bm : 0.f;
+                const float alpha = __builtin_amdgcn_exp2f(-d * 1.44269504088896340736f);
+                mref += d;
+                sum *= alpha;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] -= d;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] * 1.44269504088896340736f); sum += sc[r]; }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f16x8 p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = (f16)sc[hf * 8 + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fv[hf][db], p, o[db], 0, 0, 0);
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (stats && q < T && hi == 0) {
+            float* st = stats + (((long)seq * H + h) * T + q) * 2;
+            st[0] = mref; st[1] = inv;
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= inv;
+        if (q < T) {
+            f16* orow = out + ((long)seq * T + q) * D + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f16x4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = (f16)o[db][rq * 4 + j];
+                    *reinterpret_cast<f16x4*>(orow + db * 32 + rq * 8 + 4 * hi) = hv;
+                }
+        }
+    }
+}
+
 // qkv fp16 [n_seq, T, ld] with q | k | v at column offsets 0, D, 2D (q already scaled); out fp16 [n_seq, T, D]
 // row_stats (optional, may be NULL) fp32 [n_seq, H, T, 2] = (reference maximum, 1 / sum) of every query's softmax
+// causal: bit 0 = causal mask (text tower); bit 1 = run the round-2 kernel instead of k_attention2 (same results to fp16 rounding of P.V order)
 extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim,
                                 int ld, int causal, void* stream) {
     if (n_seq == 0) return SEMABS_OK;
@@ -339,6 +512,8 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
     SEMABS_REQUIRE(T <= 288 && ld % 8 == 0, "semabs_attention: T must be <= 288");
     const int D = H * 64;
     const int nkb = (T + 31) / 32;
+    const bool is_causal = (causal & 1) != 0;
+    const bool legacy = (causal & 2) != 0 || (long)T * ld * 2 >= (1L << 31);          // bit 1: the round-2 kernel (register staging, V^T scatter) for A/B
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(n_seq * H);
 #define ATT_LAUNCH(N, C)                                                                                             \
@@ -348,7 +523,14 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
         hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
     }
-#define ATT_CASE(N) { if (causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }
+#define ATT2_LAUNCH(N, C)                                                                                            \
+    {                                                                                                                \
+        size_t lds = (size_t)(32 * N) * 256;                                                                         \
+        static bool set2 = false;                                                                                    \
+        if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention2<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = true; } \
+        hipLaunchKernelGGL((k_attention2<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
+    }
+#define ATT_CASE(N) { if (legacy) { if (is_causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) } else { if (is_causal) ATT2_LAUNCH(N, true) else ATT2_LAUNCH(N, false) } }
     switch (nkb) {
         case 1: case 2: ATT_CASE(2) break;
         case 3: ATT_CASE(3) break;
@@ -361,6 +543,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
     }
 #undef ATT_CASE
 #undef ATT_LAUNCH
+#undef ATT2_LAUNCH
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

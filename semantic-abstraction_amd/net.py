@@ -286,12 +286,14 @@ class SemAbsVOOL(torch.nn.Module):
 
     def forward(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts,
                 tsdf_vol=None, **kwargs):
-        """-> logits [B, D, M] (net.py:506-579).  Under `torch.no_grad()` / `eval`-style use: the fused inference kernels.  With grad mode on and
-        trainable parameters the result carries a `grad_fn`: `loss.backward()` on anything computed from it runs the hand-written backward
+        """-> logits [B, D, M] (net.py:506-579).  Under `torch.no_grad()` or after `net.eval()`: the fused inference kernels (no graph).  In training
+        mode with grad mode on and trainable parameters the result carries a `grad_fn`: `loss.backward()` on anything computed from it runs the hand-written backward
         pass of `semabs_amd.train` and leaves the gradients in `p.grad` of this module's parameters - what `utils.loop` needs
         (utils.py:404-417: `loss.backward(); clip_grad_norm_(net.parameters(), ...); optimizer.step()`), and what DistributedDataParallel's
         gradient hooks listen to."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        # training mode + grad mode (train_vool.py / utils.loop); `net.eval()` (visualize.py:453, which calls the net WITHOUT torch.no_grad() and
+        # detaches the result) and torch.no_grad() (utils.loop's validation branch, utils.py:424) both take the fused inference kernels
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(dict(output_xyz_pts=output_xyz_pts, spatial_relation_name=spatial_relation_name, input_xyz_pts=input_xyz_pts,
                                             input_target_saliency_pts=input_target_saliency_pts,
                                             input_reference_saliency_pts=input_reference_saliency_pts))

@@ -924,7 +924,7 @@ def _spread(a, b):
                 spread_total_rel=np.float64(abs(b.get("total_norm", 0.0) - a.get("total_norm", 0.0)) / max(a.get("total_norm", 1.0), 1e-300)))
 
 
-def g22_vool_train128(S=128, N=80000, M=400000, D=4, name="g22_vool_train128", perturbations=(1,)):
+def g22_vool_train128(S=128, N=80000, M=400000, D=4, name="g22_vool_train128", perturbations=(1, 2, 3)):
     a = _vool_reference_step(S, N, M, D, REL4[:D] if D <= 4 else None)
     res = {"meta": np.asarray([S, N, M, D, 13, 3, 131], np.int32), "label_packed": np.packbits(a["label"].astype(np.uint8).reshape(-1)),
            "loss": np.float64(a["loss"]), "total_norm": np.float64(a["total_norm"]), "names": np.asarray(a["names"]),

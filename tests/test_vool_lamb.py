@@ -66,10 +66,12 @@ def test_gpu_vool_forward(golden, precision, tol):
                    network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128, reduce_method="max",
                    batch_size=1, precision=precision)
     m.load_state_dict(make_semabsvool_state_dict(seed=wseed))
+    m.eval()                                                # like visualize.py:453; in training mode the forward records the backward tape instead
     xyz, feat, q = _inputs(S, N, M, 2 * D, seed)
     out = m(output_xyz_pts=torch.from_numpy(q[:, :D]), spatial_relation_name=REL, input_xyz_pts=torch.from_numpy(xyz),
             input_target_saliency_pts=torch.from_numpy(feat[:, :D]), input_reference_saliency_pts=torch.from_numpy(feat[:, D:]), tsdf_vol=None)
-    err = np.abs(out.cpu().numpy() - g["vool_out"]).max()
+    assert out.grad_fn is None
+    err = np.abs(out.detach().cpu().numpy() - g["vool_out"]).max()
     print(f"{precision}: VOOL logit Linf {err:.3e} (max|ref| {np.abs(g['vool_out']).max():.2f})")
     assert err <= tol * np.abs(g["vool_out"]).max()
 
