@@ -18,3 +18,25 @@ def vool_batch(S, N, M, D, seed, label):
     return dict(input_xyz_pts=torch.from_numpy(xyz), input_target_saliency_pts=torch.from_numpy(feat[:, :D]),
                 input_reference_saliency_pts=torch.from_numpy(feat[:, D:]), output_xyz_pts=torch.from_numpy(q[:, :D]),
                 output_label_pts=torch.from_numpy(np.asarray(label, np.float32)), spatial_relation_name=[list(r) for r in REL_NAMES[:D]])
+
+
+def worst_param_deviation(sd, ref_sd, before, ref_g, noise_floor=1e-3, sel_frac=5e-2):
+    """Two optimisation steps from the same start compared parameter by parameter.  LAMB's first step is sign-like (m / (sqrt(v) + eps) = g / |g|):
+    where a gradient element is within noise of zero its update flips sign on any pair of runs, so compare only where |g| is well above the
+    tensor's noise floor, and skip tensors whose whole gradient is noise.  All arguments: dicts of numpy arrays (ref_g: the reference run's
+    gradients, only for tensors that have one).  -> worst |sd - ref_sd| over the selected elements, as a fraction of the tensor's own max step;
+    tensors without gradient must be bit-identical."""
+    gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ref_g.values()))
+    worst = 0.0
+    for k, v in ref_sd.items():
+        if k not in ref_g:
+            assert np.array_equal(sd[k], v), k
+            continue
+        g = ref_g[k]
+        if float(np.linalg.norm(g.astype(np.float64))) < noise_floor * gnorm or np.abs(g).max() == 0:
+            continue
+        sel = np.abs(g) > sel_frac * np.abs(g).max()
+        step = np.abs(v - before[k]).max()
+        if sel.any() and step > 0:
+            worst = max(worst, float(np.abs(sd[k] - v)[sel].max() / step))
+    return worst

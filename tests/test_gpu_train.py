@@ -320,7 +320,10 @@ def _check_against_reference_with_spread(tr, out, g, sp, label, factor=3.0, floo
         if not has or n <= 1e-4 * gtot:
             continue                                                  # biases in front of a GroupNorm etc.: mathematically zero, numerically noise
         e = abs(float(tr.grads[k].double().norm()) - n) / n
-        bn, bl = max(s_norm[k], floor_norm / factor), max(s_l2[k], floor_l2 / factor)
+        bl = max(s_l2[k], floor_l2 / factor)
+        # a norm cannot be asked to agree better than the vectors do (| |a| - |b| | <= |a - b|): the reference's norm spread of a small tensor
+        # is often several times smaller than its vector spread (the perturbation moves the gradient sideways), the HIP path's need not be
+        bn = max(s_norm[k], s_l2[k] / factor, floor_norm / factor)
         rn.append(e / bn)
         key = "grad/" + k if "grad/" + k in g else "grads/" + k
         mine = tr.grads[k].cpu().numpy()
