@@ -29,9 +29,6 @@ struct GemmArgs {
     int g_in, g_out, g_off;     // EPI_ROWMAP_ADD_F32: out row = (m / g_in) * g_out + g_off + m % g_in
     int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
     int sc_w;                   // column panels per super-column of the raster (see tile_of in k_gemm8); 0 = all of them
-    // LayerNorm folded into the GEMMs around it (k_gemm8 only; see the LNM template parameter):
-    f16* ln_xg; const float* ln_gamma; float* ln_part;      // producer (EPI_BIAS_RESID_F32): fp16 (x * gamma) [M, N], gamma [N], row partials [M, N / 256, 2]
-    const float* ln_rowac; const float* ln_colsum;          // consumer (fp16 outputs): per row (rstd, -mean * rstd) [M, 2], per column sum_k gamma_k W[n, k] [N]
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
@@ -346,15 +343,7 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
-// LNM (LayerNorm fold): 0 = none.
-//   1 (with EPI_BIAS_RESID_F32) = PRODUCER: besides x += acc + bias the epilogue writes xg = fp16(x_new * gamma) - the A operand of the GEMM that
-//     follows the LayerNorm - and, per row, the partial sums (sum x_new, sum x_new^2) over this tile's 256 columns into ln_part[row][tile column]:
-//     reduced across the 8 lanes of a row (DPP), then across the 4 wave columns x 2 B halves through 16 KB of LDS behind the operand buffers, in
-//     a FIXED order (no atomics: the maps stay bit-reproducible and independent of the batch size).
-//   2 (with the fp16-output epilogues) = CONSUMER: C = a_row * acc + c_row * colsum[n] + bias'[n] with (a, c) = (rstd, -mean * rstd) of the row
-//     (semabs_ln_rowstats turns the partials into them) - LN(x) W^T + b without ever materialising LN(x):
-//     sum_k ((x_k - mu) rstd gamma_k + beta_k) W[n,k] = rstd * sum_k xg_k W[n,k] - mu rstd * sum_k gamma_k W[n,k] + sum_k beta_k W[n,k].
-template <int EPI, bool PF, bool PERS = false, int LNM = 0>      // PERS: persistent workgroups, tiles vb = blockIdx.x, + gridDim.x, ... (see the end of the kernel)
+template <int EPI, bool PF, bool PERS = false>      // PERS: persistent workgroups, tiles vb = blockIdx.x, + gridDim.x, ... (see the end of the kernel)
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
@@ -503,7 +492,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         constexpr int PASSB = 64 * ROWB;                    // 4 / 8 KB; two passes alternate inside the wave's 16 KB
         char* const ep = smem + wid * 16384;
         float bia[2][8];
-        [[maybe_unused]] float csv[LNM == 2 ? 2 : 1][8], rowa[LNM == 2 ? 2 : 1][4], rowc[LNM == 2 ? 2 : 1][4];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int ncol = n0 + hb * 128 + wc * 32 + kg * 8;
@@ -513,21 +501,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                 const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
                 bia[hb][0] = b0.x; bia[hb][1] = b0.y; bia[hb][2] = b0.z; bia[hb][3] = b0.w; bia[hb][4] = b1.x; bia[hb][5] = b1.y; bia[hb][6] = b1.z; bia[hb][7] = b1.w;
             }
-            if constexpr (LNM == 2) {
-                const float4 c0 = *reinterpret_cast<const float4*>(g.ln_colsum + ncol), c1 = *reinterpret_cast<const float4*>(g.ln_colsum + ncol + 4);
-                csv[hb][0] = c0.x; csv[hb][1] = c0.y; csv[hb][2] = c0.z; csv[hb][3] = c0.w; csv[hb][4] = c1.x; csv[hb][5] = c1.y; csv[hb][6] = c1.z; csv[hb][7] = c1.w;
-            }
-        }
-        if constexpr (LNM == 2) {                           // (rstd, -mean * rstd) of this lane's 8 accumulator rows
-#pragma unroll
-            for (int ha = 0; ha < 2; ++ha)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long row = m0 + ha * 128 + wr * 64 + i * 16 + l15;
-                    float2 t = make_float2(0.f, 0.f);
-                    if (row < g.M) t = *reinterpret_cast<const float2*>(g.ln_rowac + row * 2);
-                    rowa[ha][i] = t.x; rowc[ha][i] = t.y;
-                }
         }
         // register layout -> LDS (row = i * 16 + l15; this lane's 8 columns = chunk kg (fp16) / chunks 2 kg, 2 kg + 1 (fp32))
         const int wswz = OUT16 ? ((l15 >> 1) & 3) : (l15 & 7);
@@ -546,14 +519,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             for (int i = 0; i < 4; ++i) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if constexpr (LNM == 2) {
-                        v[e] = acc[ha][i][hb][0][e] * rowa[ha][i] + (rowc[ha][i] * csv[hb][e] + bia[hb][e]);
-                        v[4 + e] = acc[ha][i][hb][1][e] * rowa[ha][i] + (rowc[ha][i] * csv[hb][4 + e] + bia[hb][4 + e]);
-                    } else {
-                        v[e] = acc[ha][i][hb][0][e] + bia[hb][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][4 + e];
-                    }
-                }
+                for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[hb][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][4 + e]; }
                 if constexpr (OUT16) {
                     f16x8 h;
 #pragma unroll
@@ -626,20 +592,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) res[pass & 1][it] = buf_load4<EAUX>(rC, voff, soff_of(pass, it));
                 };
-                // LNM == 1: the fp16 (x * gamma) copy and the row partials of the LayerNorm that follows (see the template comment)
-                [[maybe_unused]] __amdgpu_buffer_rsrc_t rG = rC;
-                [[maybe_unused]] f32x4 gam[2];
-                [[maybe_unused]] float* const sred = reinterpret_cast<float*>(smem + 131072);        // [256 rows][4 wave columns][2 B halves][2]
-                [[maybe_unused]] const unsigned ldgb = (unsigned)g.N * 2u;
-                if constexpr (LNM == 1) {
-                    rG = gemm_rsrc(reinterpret_cast<const char*>(g.ln_xg) + (mw * g.N + n0 + wc * 32) * 2,
-                                   rows > 0 ? (rows - 1) * (long)ldgb + (long)(g.N - n0 - wc * 32) * 2 : 0);
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
-                        const float4 t = *reinterpret_cast<const float4*>(g.ln_gamma + n0 + hb * 128 + wc * 32 + cchunk * 4);
-                        gam[hb] = f32x4{t.x, t.y, t.z, t.w};
-                    }
-                }
                 issue(0);
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
@@ -650,38 +602,9 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     for (int it = 0; it < NIT; ++it) {
                         const f32x4 v = lds_read(pass, it);
                         const f32x4 o = res[pass & 1][it];
-                        const f32x4 nw = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
-                        buf_store4<EAUX>(rC, voff, soff_of(pass, it), nw);
-                        if constexpr (LNM == 1) {
-                            const int hb = pass >> 1;
-                            f16x4 hx;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) hx[e] = (f16)(nw[e] * gam[hb][e]);
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hx), rG, (unsigned)crow * ldgb + (unsigned)(cchunk * 8),
-                                                                  (unsigned)((pass & 1) * 128 + it * RPI) * ldgb + (unsigned)(hb * 128 * 2), 0);
-                            float s1 = (nw[0] + nw[1]) + (nw[2] + nw[3]);
-                            float s2 = (nw[0] * nw[0] + nw[1] * nw[1]) + (nw[2] * nw[2] + nw[3] * nw[3]);
-#pragma unroll
-                            for (int sh = 1; sh < 8; sh <<= 1) { s1 += __shfl_xor(s1, sh, 64); s2 += __shfl_xor(s2, sh, 64); }
-                            if (cchunk == 0) {
-                                const int row = (pass & 1) * 128 + wr * 64 + it * RPI + crow;
-                                *reinterpret_cast<float2*>(sred + ((row * 4 + wc) * 2 + hb) * 2) = make_float2(s1, s2);
-                            }
-                        }
+                        buf_store4<EAUX>(rC, voff, soff_of(pass, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (LNM == 1) {
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_s_barrier();
-                    if (tid < 256 && m0 + tid < g.M) {
-                        const float* pr = sred + tid * 16;
-                        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) { s1 += pr[q * 2]; s2 += pr[q * 2 + 1]; }
-                        *reinterpret_cast<float2*>(g.ln_part + ((m0 + tid) * g.n_tiles_n + n0 / 256) * 2) = make_float2(s1, s2);
-                    }
                 }
             } else {
 #pragma unroll
@@ -912,24 +835,6 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         return SEMABS_OK;
     }
 #endif
-    if constexpr (EPI == EPI_BIAS_RESID_F32) {
-        if (g.ln_xg) {                                       // LayerNorm producer: + 16 KB of LDS behind the operand buffers for the row partials
-            static bool lset = false;
-            if (!lset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 16384); lset = true; }
-            gemm_dispatch(k_gemm8<EPI, true, false, 1>, dim3(g.n_blocks), dim3(512), LDS + 16384, s, g, o);
-            SEMABS_CHECK_LAUNCH();
-            return SEMABS_OK;
-        }
-    }
-    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-        if (g.ln_rowac) {                                    // LayerNorm consumer
-            static bool lset = false;
-            if (!lset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); lset = true; }
-            gemm_dispatch(k_gemm8<EPI, true, false, 2>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
-            SEMABS_CHECK_LAUNCH();
-            return SEMABS_OK;
-        }
-    }
     if (GEMM_PREFETCH) gemm_dispatch(k_gemm8<EPI, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     else gemm_dispatch(k_gemm8<EPI, false>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     SEMABS_CHECK_LAUNCH();
@@ -976,7 +881,6 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0;
-    g.ln_xg = nullptr; g.ln_gamma = nullptr; g.ln_part = nullptr; g.ln_rowac = nullptr; g.ln_colsum = nullptr;
     GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
@@ -988,35 +892,6 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     }
     semabs_set_error("semabs_gemm_f16: unknown epilogue");
     return SEMABS_EINVAL;
-}
-
-// LayerNorm folded into the GEMMs on either side of it (large shapes only: M >= 2048, N % 256 == 0, K >= 128; see k_gemm8's LNM parameter).
-//   epi 2 (x += A W^T + b, fp32) with ln_xg / ln_gamma / ln_part: also xg = fp16(x_new * gamma) [M, N] and the row partials [M, N / 256, 2];
-//   epi 0 / 1 (fp16 outputs) with ln_rowac / ln_colsum: C = rstd_row * (A W^T) - mean_row rstd_row * colsum + bias, A being such an xg.
-extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
-                                  void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum,
-                                  void* start_event, void* stop_event, void* stream) {
-    SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16_ln: null operand");
-    SEMABS_REQUIRE(M >= 2048 && N % 256 == 0 && K >= 128 && K % BK == 0, "semabs_gemm_f16_ln: needs M >= 2048, N % 256 == 0, K >= 128 (the phased kernel)");
-    SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (epi > 1 || ldc % 8 == 0) && lda < (1L << 20) && ldb < (1 << 20) && ldc < (1L << 20),
-                   "semabs_gemm_f16_ln: leading dimensions");
-    const bool producer = epi == EPI_BIAS_RESID_F32 && ln_xg && ln_gamma && ln_part && !ln_rowac && !ln_colsum;
-    const bool consumer = (epi == EPI_BIAS_F16 || epi == EPI_BIAS_GELU_F16) && ln_rowac && ln_colsum && !ln_xg && !ln_gamma && !ln_part;
-    SEMABS_REQUIRE(producer || consumer, "semabs_gemm_f16_ln: epi 2 with (xg, gamma, partials) or epi 0 / 1 with (rowac, colsum)");
-    SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ln: start and stop events go together");
-    GemmArgs g;
-    g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = nullptr;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.g_in = 1; g.g_out = 1; g.g_off = 0;
-    g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0;
-    g.ln_xg = (f16*)ln_xg; g.ln_gamma = ln_gamma; g.ln_part = ln_part; g.ln_rowac = ln_rowac; g.ln_colsum = ln_colsum;
-    GemmOpts o{2, (hipEvent_t)start_event, (hipEvent_t)stop_event};
-    hipStream_t s = (hipStream_t)stream;
-    switch (epi) {
-        case EPI_BIAS_F16: return launch_gemm8<EPI_BIAS_F16>(g, s, o);
-        case EPI_BIAS_GELU_F16: return launch_gemm8<EPI_BIAS_GELU_F16>(g, s, o);
-        default: return launch_gemm8<EPI_BIAS_RESID_F32>(g, s, o);
-    }
 }
 
 extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend,

@@ -59,6 +59,28 @@ def _pad32(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _ZeroArena:
+    """One zero-filled device buffer per step for the dozens of small accumulators a step needs (GroupNorm sums, channel reductions,
+    max-|x| words: ~8 per convolution layer, each a separate torch fill launch before) - ONE memset at the start of the step, sub-allocated in
+    order.  Falls back to torch.zeros when exhausted."""
+
+    def __init__(self, dev, nbytes=8 << 20):
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.off = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def zeros(self, shape, dtype):
+        n = int(np.prod(shape)) * {torch.float64: 8, torch.float32: 4, torch.int32: 4, torch.int64: 8}[dtype]
+        o = (self.off + 255) // 256 * 256
+        if o + n > self.buf.numel():
+            return torch.zeros(*shape, dtype=dtype, device=self.buf.device)
+        self.off = o + n
+        return self.buf[o:o + n].view(dtype).view(*shape)
+
+
 class _Rec:
     """Tape entry of one GroupNorm + Conv3d: what the backward pass needs."""
     __slots__ = ("name", "x", "y", "mean", "rstd", "scale", "shift")
@@ -78,6 +100,7 @@ class UNetTrainer:
         self.dev = _lib.require_gpu()
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
+        self.arena = _ZeroArena(self.dev)
 
     # ---- per-step weight layouts (fp16 hi/lo splits for the MFMA kernels) --------------------------------------------------------
     def refresh(self):
@@ -113,15 +136,20 @@ class UNetTrainer:
                                       bwd=_split16p(_pad32(w.reshape(cout, cin).t().contiguous())))
 
     # ---- forward -----------------------------------------------------------------------------------------------------------------
-    def _conv_fwd(self, x, pre, relu, resid=None) -> _Rec:
+    def _conv_fwd(self, x, pre, relu, resid=None, in_sums=None, out_groups=0):
+        """-> (tape record, GroupNorm statistics of the output or None).  in_sums: statistics of x when its producer already has them
+        (scatter / the previous convolution / the transposed convolution: fused into their epilogues, no pass over x);
+        out_groups > 0: have this convolution produce the statistics of ITS output for the layer that follows."""
         m = self.mats[pre]
         key = self.prefix + pre
         B, D0, D1, D2, Cc = x.shape
         nvox, G, st = D0 * D1 * D2, m["groups"], _lib.stream()
         r = _Rec()
         r.name, r.x = pre, x
-        sums = torch.zeros(B, G, 2, dtype=torch.float64, device=self.dev)
-        _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, 1, st)
+        sums = in_sums
+        if sums is None:
+            sums = self.arena.zeros((B, G, 2), torch.float64)
+            _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, 1, st)
         r.scale = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
         r.shift = torch.empty_like(r.scale)
         r.mean = torch.empty(B, G, dtype=torch.float32, device=self.dev)
@@ -130,19 +158,27 @@ class UNetTrainer:
                   _lib.ptr(r.scale), _lib.ptr(r.shift), B, Cc, G, nvox, 1e-5, st)
         _lib.call("semabs_gn_meanrstd", _lib.ptr(sums), _lib.ptr(r.mean), _lib.ptr(r.rstd), B, G, nvox * (Cc // G), 1e-5, st)
         r.y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
-        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(r.y), _lib.ptr(r.scale), _lib.ptr(r.shift),
-                  None, _lib.ptr(resid), B, D0, D1, D2, m["cin"], m["cout"], 3, int(relu), 1 | m["fwd"][2], st)
-        return r
+        args = (_lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(r.y), _lib.ptr(r.scale), _lib.ptr(r.shift),
+                None, _lib.ptr(resid), B, D0, D1, D2, m["cin"], m["cout"], 3, int(relu), 1 | m["fwd"][2])
+        out_sums = None
+        if out_groups:
+            out_sums = self.arena.zeros((B, out_groups, 2), torch.float64)
+            _lib.call("semabs_conv3d_stats", *args, _lib.ptr(out_sums), out_groups, st)
+        else:
+            _lib.call("semabs_conv3d", *args, st)
+        return r, out_sums
 
-    def _block_fwd(self, x, pre, tape):
-        r1 = self._conv_fwd(x, pre + "conv1.", True)
-        r2 = self._conv_fwd(r1.y, pre + "conv2.", True)
-        r3 = self._conv_fwd(r2.y, pre + "conv3.", True, resid=r1.y)
+    def _block_fwd(self, x, pre, tape, in_sums=None):
+        # conv1 / conv2 hand the statistics of their outputs to the GroupNorm of conv2 / conv3 (like unet3d.ResidualUNet3D._block)
+        r1, s1 = self._conv_fwd(x, pre + "conv1.", True, in_sums=in_sums, out_groups=self.mats[pre + "conv2."]["groups"])
+        r2, s2 = self._conv_fwd(r1.y, pre + "conv2.", True, in_sums=s1, out_groups=self.mats[pre + "conv3."]["groups"])
+        r3, _ = self._conv_fwd(r2.y, pre + "conv3.", True, resid=r1.y, in_sums=s2)
         tape.append(("block", r1, r2, r3))
         return r3.y
 
-    def forward(self, x: torch.Tensor):
-        """x fp32 [B, S, S, S, Cin] -> (y [B, S, S, S, Cout], tape)."""
+    def forward(self, x: torch.Tensor, in_sums=None):
+        """x fp32 [B, S, S, S, Cin] -> (y [B, S, S, S, Cout], tape).  in_sums: GroupNorm statistics of x (fp64 [B, groups, 2]) when the
+        producer of x already has them (semabs_scatter_mean_stats)."""
         assert x.dtype == torch.float32 and x.is_contiguous()
         st = _lib.stream()
         tape: List = []
@@ -155,17 +191,21 @@ class UNetTrainer:
                 _lib.call("semabs_maxpool3d", _lib.ptr(x), _lib.ptr(y), B, D0, D1, D2, Cc, 1, st)
                 tape.append(("pool", x, i - 1))
                 x = y
-            x = self._block_fwd(x, f"encoders.{i}.basic_module.", tape)
+            x = self._block_fwd(x, f"encoders.{i}.basic_module.", tape, in_sums=in_sums if i == 0 else None)
             feats.insert(0, x)
         for i, skip in enumerate(feats[1:]):
             pre = f"decoders.{i}.upsampling.upsample."
             m = self.mats[pre]
             B, D0, D1, D2, _ = x.shape
             y = torch.empty_like(skip)
-            _lib.call("semabs_convtranspose3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), m["class_off"], _lib.ptr(y),
-                      _lib.ptr(self.p[self.prefix + pre + "bias"]), _lib.ptr(skip), B, D0, D1, D2, m["cin"], m["cout"], 1 | m["fwd"][2], st)
+            blk = f"decoders.{i}.basic_module."
+            og = self.mats[blk + "conv1."]["groups"]
+            sums = self.arena.zeros((B, og, 2), torch.float64)
+            _lib.call("semabs_convtranspose3d_stats", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), m["class_off"], _lib.ptr(y),
+                      _lib.ptr(self.p[self.prefix + pre + "bias"]), _lib.ptr(skip), B, D0, D1, D2, m["cin"], m["cout"], 1 | m["fwd"][2],
+                      _lib.ptr(sums), og, st)
             tape.append(("up", pre, x, L - 2 - i))
-            x = self._block_fwd(y, f"decoders.{i}.basic_module.", tape)
+            x = self._block_fwd(y, blk, tape, in_sums=sums)
         m = self.mats["final_conv."]
         B, D0, D1, D2, _ = x.shape
         y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
@@ -177,7 +217,7 @@ class UNetTrainer:
     # ---- backward ----------------------------------------------------------------------------------------------------------------
     def _colsum(self, a2d: torch.Tensor, grad: torch.Tensor):
         R, Cc = a2d.shape
-        red = torch.zeros(1, Cc, 2, dtype=torch.float64, device=self.dev)
+        red = self.arena.zeros((1, Cc, 2), torch.float64)
         _lib.call("semabs_chan_reduce", _lib.ptr(a2d), None, None, None, _lib.ptr(red), 1, R, Cc, 1, _lib.stream())
         grad.add_(red[0, :, 0].float())
 
@@ -202,7 +242,7 @@ class UNetTrainer:
 
     def _ew(self, a, b, mode, want_max=False):
         out = torch.empty_like(a)
-        bits = torch.zeros(1, dtype=torch.int32, device=self.dev) if want_max else None
+        bits = self.arena.zeros((1,), torch.int32) if want_max else None
         _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.ptr(bits), _lib.stream())
         if want_max:
             out._semabs_absmax = bits
@@ -229,13 +269,13 @@ class UNetTrainer:
         dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
         _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
                   B, D0, D1, D2, cout, cin, 3, 0, 1 | m["bwd"][2], st)
-        red = torch.zeros(B, cin, 2, dtype=torch.float64, device=self.dev)
+        red = self.arena.zeros((B, cin, 2), torch.float64)
         _lib.call("semabs_chan_reduce", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(red), B, nvox, cin, G, st)
         coef = torch.empty(B, cin, 3, dtype=torch.float32, device=self.dev)
         _lib.call("semabs_gn_bwd_coef", _lib.ptr(red), _lib.ptr(self.p[key + "groupnorm.weight"]), _lib.ptr(r.rstd), _lib.ptr(inv), _lib.ptr(coef),
                   _lib.ptr(self.g[key + "groupnorm.weight"]), _lib.ptr(self.g[key + "groupnorm.bias"]), B, cin, G, nvox, st)
         dX = torch.empty_like(dXn)
-        bits = torch.zeros(1, dtype=torch.int32, device=self.dev) if relu_in else None
+        bits = self.arena.zeros((1,), torch.int32) if relu_in else None
         _lib.call("semabs_gn_bwd_apply", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(coef), _lib.ptr(add1), None,
                   _lib.ptr(r.x if relu_in else None), _lib.ptr(bits), _lib.ptr(dX), B, nvox, cin, G, st)
         if relu_in:
@@ -433,8 +473,14 @@ class VOOLTrainer:
         vol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
         head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
         nxt = torch.empty(N, dtype=torch.int32, device=dev)
-        _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox, 1, st)
-        fv, tape = u.forward(vol)
+        sums = None
+        if self.C == 16 and u.mats["encoders.0.basic_module.conv1."]["groups"] == 8:      # first GroupNorm's statistics come out of the scatter
+            sums = u.arena.zeros((P, 8, 2), torch.float64)
+            _lib.call("semabs_scatter_mean_stats", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox, 1,
+                      _lib.ptr(sums), st)
+        else:
+            _lib.call("semabs_scatter_mean", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox, 1, st)
+        fv, tape = u.forward(vol, in_sums=sums)
         # VOOL head (net.py:556-579)
         off3, sc3, shp = _lib.farr(self.vg.offsets), _lib.farr(self.vg.scales), _lib.iarr(self.vg.grid_shape)
         f = torch.empty(D * M, 36, dtype=torch.float32, device=dev)
@@ -509,6 +555,7 @@ class VOOLTrainer:
     def forward_tape(self, batch: dict):
         """-> (logits [B, D, M], ctx).  No loss: the caller computes it from the logits (the reference's `get_losses`, train_vool.py:118-178)."""
         self.unet.refresh()
+        self.unet.arena.reset()
         xyz, st_, sr_, q, names, B, N, D, M = self._unpack(batch)
         logits = torch.empty(B, D, M, dtype=torch.float32, device=self.dev)
         scenes = []
@@ -547,6 +594,7 @@ class VOOLTrainer:
         assert self.module is None, "module-bound engines hand their gradients to autograd (SemAbsVOOL.forward under grad mode)"
         self.flat_grad.zero_()
         self.unet.refresh()
+        self.unet.arena.reset()
         xyz, st_, sr_, q, names, B, N, D, M = self._unpack(batch)
         label = batch["output_label_pts"].to(dev, torch.float32).contiguous()
         weight = self.bce_weight(label)

@@ -67,7 +67,7 @@ def test_gn_conv_layer_backward_strict(gscale):
         F.conv3d(F.group_norm(xt, 8, ga, be, 1e-5), w, None, padding=1).backward(torch.from_numpy(dz))
         for k in grads:
             grads[k].zero_()
-        r = u._conv_fwd(_cl(x), name, False)
+        r, _ = u._conv_fwd(_cl(x), name, False)
         dx = u._conv_bwd(r, _cl(dz))
         torch.cuda.synchronize()
         assert _rel(_uncl(dx), xt.grad.numpy()) < 1e-5, name
