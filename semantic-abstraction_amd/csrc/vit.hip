@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 __device__ __forceinline__ int vswz_chunk(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int NKB, bool CAUSAL>
+template <int NKB, bool CAUSAL, bool DMA>          // DMA: stage K / V by direct-to-LDS loads; else through registers with 16-byte LDS stores (same images)
 __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(const f16* __restrict__ qkv, f16* __restrict__ out,
                                                     float* __restrict__ stats, int T, int H, int ld, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -367,7 +367,34 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(cons
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fq0[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
     }
-    {
+    if constexpr (!DMA) {
+        // register staging: every K / V row chunk of the thread is requested before the first LDS store (as in the round-2 kernel), then
+        // written with ONE ds_write_b128 each - V row-major in the swizzled image instead of eight 2-byte V^T scatters
+        constexpr int NTHR = 64 * NWAVE;
+        constexpr int NIT_ST = (TP * 8 + NTHR - 1) / NTHR;
+        f16x8 kvs[NIT_ST], vvs[NIT_ST];
+#pragma unroll
+        for (int it = 0; it < NIT_ST; ++it) {
+            const int c = tid + it * NTHR;
+            const int row = c >> 3, kc = c & 7;
+            if (c < TP * 8 && row < T) {
+                kvs[it] = *reinterpret_cast<const f16x8*>(base + (long)row * ld + D + kc * 8);
+                vvs[it] = *reinterpret_cast<const f16x8*>(base + (long)row * ld + 2 * D + kc * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kvs[it][e] = (f16)0.f; vvs[it][e] = (f16)0.f; }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT_ST; ++it) {
+            const int c = tid + it * NTHR;
+            const int row = c >> 3, kc = c & 7;
+            if (c < TP * 8) {
+                *reinterpret_cast<f16x8*>(sK + kswz(row, kc)) = kvs[it];
+                *reinterpret_cast<f16x8*>(sV + row * 128 + (vswz_chunk(row, kc) << 4)) = vvs[it];
+            }
+        }
+    } else {
         // one resource descriptor per workgroup: this sequence's T token rows; rows >= T read as zeros
         const long bytes = ((long)(T - 1) * ld + 3L * D) * 2 - (long)h * 128;
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(base), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
@@ -386,7 +413,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(cons
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int koff[4];
@@ -503,7 +530,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(cons
 
 // qkv fp16 [n_seq, T, ld] with q | k | v at column offsets 0, D, 2D (q already scaled); out fp16 [n_seq, T, D]
 // row_stats (optional, may be NULL) fp32 [n_seq, H, T, 2] = (reference maximum, 1 / sum) of every query's softmax
-// causal: bit 0 = causal mask (text tower); bit 1 = run the round-2 kernel instead of k_attention2 (same results to fp16 rounding of P.V order)
+// causal: bit 0 = causal mask (text tower); bit 1 = run the round-2 kernel, bit 2 = k_attention2 with LDS-DMA staging (A/B; all three give identical results)
 extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim,
                                 int ld, int causal, void* stream) {
     if (n_seq == 0) return SEMABS_OK;
@@ -513,7 +540,8 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
     const int D = H * 64;
     const int nkb = (T + 31) / 32;
     const bool is_causal = (causal & 1) != 0;
-    const bool legacy = (causal & 2) != 0 || (long)T * ld * 2 >= (1L << 31);          // bit 1: the round-2 kernel (register staging, V^T scatter) for A/B
+    const bool legacy = (causal & 2) != 0;                                              // bit 1: the round-2 kernel (register staging, 2-byte V^T scatter) for A/B
+    const bool dma = (causal & 4) != 0 && (long)T * ld * 2 < (1L << 31);                // bit 2: k_attention2 with LDS-DMA staging (measured slower, kept for A/B)
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(n_seq * H);
 #define ATT_LAUNCH(N, C)                                                                                             \
@@ -523,14 +551,16 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
         hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
     }
-#define ATT2_LAUNCH(N, C)                                                                                            \
+#define ATT2_LAUNCH(N, C, DM)                                                                                        \
     {                                                                                                                \
         size_t lds = (size_t)(32 * N) * 256;                                                                         \
         static bool set2 = false;                                                                                    \
-        if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention2<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = true; } \
-        hipLaunchKernelGGL((k_attention2<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
+        if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention2<N, C, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = true; } \
+        hipLaunchKernelGGL((k_attention2<N, C, DM>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
     }
-#define ATT_CASE(N) { if (legacy) { if (is_causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) } else { if (is_causal) ATT2_LAUNCH(N, true) else ATT2_LAUNCH(N, false) } }
+#define ATT_CASE(N) { if (legacy) { if (is_causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }                                 \
+                      else if (dma) { if (is_causal) ATT2_LAUNCH(N, true, true) else ATT2_LAUNCH(N, false, true) }                 \
+                      else { if (is_causal) ATT2_LAUNCH(N, true, false) else ATT2_LAUNCH(N, false, false) } }
     switch (nkb) {
         case 1: case 2: ATT_CASE(2) break;
         case 3: ATT_CASE(3) break;

@@ -123,6 +123,26 @@ def test_module_loop_equals_fused_trainer():
     worst = worst_param_deviation(npy(net.state_dict()), npy(ref_sd), {k: v.numpy() for k, v in sd.items()}, ref_g)
     print(f"module loop vs fused trainer: worst parameter deviation {worst:.3e} of the tensor's own step")
     assert worst <= 5e-2
+    # Checkpoint interchange (utils.py:278-296): an optimizer built the reference's way - Lamb(net.parameters()), EVERY parameter in
+    # state-dict order, the ones the VOOL graph never reaches simply without state - must load into the fused trainer (whose optimizer used to
+    # span only the trainable subset: parameter-group size mismatch) and the resumed second step must match the module loop's second step.
+    n_params = len(list(net.parameters()))
+    assert len(optimizer.state_dict()["param_groups"][0]["params"]) == n_params == len(tr.opt.state_dict()["param_groups"][0]["params"])
+    ckpt = {"net": {"module." + k: v.clone() for k, v in net.state_dict().items()}, "optimizer": optimizer.state_dict(), "epochs": 3}
+    tr2 = VOOLTrainer(sd, voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_levels=L)
+    assert tr2.load_checkpoint(ckpt) == 3 and tr2.steps == 1
+    mid = npy(net.state_dict())
+    out2 = tr2.step(batch)
+    _, loss2, _ = _loop_step(net, optimizer, batch)
+    assert abs(float(loss2.detach()) - float(out2["loss"])) <= 1e-5 * float(out2["loss"])
+    ref_g2 = {k: tr2.grads[k].cpu().numpy() for k in tr2.grads if tr2.params[k].grad is not None}
+    worst2 = worst_param_deviation(npy(net.state_dict()), npy(tr2.state_dict()), mid, ref_g2)
+    print(f"resumed from the module loop's checkpoint: worst parameter deviation of step 2 {worst2:.3e} of the tensor's own step")
+    assert worst2 <= 5e-2
+    # and the other way round: the trainer's checkpoint loads into an optimizer over net.parameters()
+    opt_b = Lamb(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt_b.load_state_dict(tr2.checkpoint()["optimizer"])
+    assert int(opt_b.state[dict(net.named_parameters())["spatial_sampler.mlp.0.weight"]]["step"]) == 2
 
 
 def test_under_distributed_data_parallel_rccl_one_rank():

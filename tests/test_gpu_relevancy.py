@@ -113,9 +113,10 @@ def test_attention(T, H, causal):
     np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
     # the round-2 kernel (register staging + V^T scatter; bit 1 of the causal word) stays selectable for A/B: same scores, same P, the P.V
     # products are summed in the same order -> identical outputs
-    out2 = torch.zeros_like(out)
-    _lib.call("semabs_attention", _lib.ptr(qkv_d), _lib.ptr(out2), None, n, T, H, 64, 3 * D, causal | 2, _lib.stream())
-    assert torch.equal(out, out2)
+    for bit in (2, 4):                                     # 2 = the round-2 kernel, 4 = k_attention2 with LDS-DMA staging
+        out2 = torch.zeros_like(out)
+        _lib.call("semabs_attention", _lib.ptr(qkv_d), _lib.ptr(out2), None, n, T, H, 64, 3 * D, causal | bit, _lib.stream())
+        assert torch.equal(out, out2), bit
 
 
 # ---- tiling front / back -----------------------------------------------------------------------------

@@ -14,8 +14,10 @@ def run(flag, o=out):
     _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(o), None, n, T, H, 64, 3 * D, flag, _lib.stream())
 run(0, out); run(2, out2); torch.cuda.synchronize()
 print("kernels agree:", bool(torch.equal(out, out2)), float((out.float() - out2.float()).abs().max()))
+run(4, out2); torch.cuda.synchronize()
+print("dma variant agrees:", bool(torch.equal(out, out2)))
 for rep in range(2):
-    for flag, name in ((0, "k_attention2"), (2, "round-2 kernel")):
+    for flag, name in ((0, "k_attention2 (reg)"), (4, "k_attention2 (dma)"), (2, "round-2 kernel")):
         for _ in range(3): run(flag)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -23,4 +25,4 @@ for rep in range(2):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         gb = n * T * 4 * D * 2 / 1e9
-        print(f"{name:16s} n={n}: {us:.1f} us  {gb / us * 1e3:.2f} TB/s of q+k+v+out", flush=True)
+        print(f"{name:18s} n={n}: {us:.1f} us  {gb / us * 1e3:.2f} TB/s of q+k+v+out", flush=True)
