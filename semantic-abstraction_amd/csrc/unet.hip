@@ -25,6 +25,24 @@
 //                   for the 8^3 / 4^3 levels in exact mode)
 #include "semabs_common.h"
 
+// The hardware places workgroup b of a launch on XCD b % 8, and each XCD has its own 4 MiB L2.  Tiles that share halo voxels (neighbouring
+// bricks, the output-channel slices of one brick) should therefore NOT have consecutive workgroup ids.  Bijective remap: XCD x runs the
+// contiguous run of tile ids [x * n / 8, (x + 1) * n / 8) in dispatch order, so a tile's neighbours are resident on - or were just run by -
+// the same XCD and its halo re-reads hit that L2 instead of going out to the fabric (round 3; the GEMMs do the same, gemm.hip tile_of).
+__device__ __forceinline__ int xcd_remap(int vb, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = vb & 7, k = vb >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+// the same for persistent workgroups (grid G, G % 8 == 0): iteration `it` of workgroup vb -> tile id, or -1 when this XCD's run is exhausted
+__device__ __forceinline__ int xcd_persistent_tile(int vb, int G, int it, int total) {
+    if (G & 7) { const long t = (long)it * G + vb; return t < total ? (int)t : -1; }
+    const int x = vb & 7, j = vb >> 3, g8 = G >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+    const long o = (long)it * g8 + j;
+    return o < cnt ? lo + (int)o : -1;
+}
+
 static int semabs_num_cus();
 
 // =================================================================================================
@@ -955,21 +973,25 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     // The barriers only order LDS traffic (halo buffers); __syncthreads() would also wait for the consumers' global stores to complete
     // (vmcnt(0)) once per brick.
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // brick of iteration `it`: this XCD's contiguous run of the brick list (xcd_persistent_tile), so that the halo planes neighbouring bricks
+    // share are read through ONE L2
+    auto brick_of = [&](int it) { return xcd_persistent_tile((int)blockIdx.x, (int)gridDim.x, it, total); };
     if (producer) {
-        int brick = blockIdx.x;
-        if (brick < total) produce(brick, 0);
+        int it = 0, brick = brick_of(0);
+        if (brick >= 0) produce(brick, 0);
         lds_barrier();
         int buf = 0;
-        for (; brick < total; brick += gridDim.x, buf ^= 1) {
-            const int next = brick + gridDim.x;
-            if (next < total && !CONV16_ABL(a.ablate == 2 || a.ablate >= 4)) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
+        for (; brick >= 0; buf ^= 1) {
+            const int next = brick_of(++it);
+            if (next >= 0 && !CONV16_ABL(a.ablate == 2 || a.ablate >= 4)) produce(next, buf ^ 1);   // the other buffer: consumed one iteration ago, before the barrier
             lds_barrier();
+            brick = next;
         }
     } else {
         load_weights();
         lds_barrier();
-        int buf = 0;
-        for (int brick = blockIdx.x; brick < total; brick += gridDim.x, buf ^= 1) {
+        int buf = 0, it = 0;
+        for (int brick = brick_of(0); brick >= 0; brick = brick_of(++it), buf ^= 1) {
             if (!CONV16_ABL(a.ablate == 1)) consume(brick, buf);
             lds_barrier();
         }
@@ -1149,7 +1171,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         }
     };
 
-    int tile = blockIdx.x;
+    int tile = PERSIST ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);      // (not persistent: the grid is the tile list)
     if (tile >= total) return;
     BRICK_STAMP(6);
     issue(tile, 0);
@@ -1613,7 +1635,7 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
     const int vl = lane & 15, kg = lane >> 4;
     const int b = blockIdx.y, cout0 = blockIdx.z * 16;
     const int n2 = a.D2 / T2, n1 = a.D1 / T1;
-    int t = blockIdx.x;
+    int t = (gridDim.y * gridDim.z == 1 || gridDim.x % 8 == 0) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // x is the fastest grid axis: with gridDim.x % 8 == 0 the XCD of a workgroup is blockIdx.x % 8
     const int t2 = t % n2; t /= n2;
     const int t1 = t % n1; const int t0 = t / n1;
     const int z0 = t0 * T0, y0 = t1 * T1, x0 = t2 * T2;
@@ -1949,8 +1971,9 @@ __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, cons
     if (LATTICE) {
         const int n2 = G2 / 4, n1 = G1 / 2, n0 = G0 / 32;
         const int per = n0 * n1 * n2;
-        b = blockIdx.x / per;
-        int t = blockIdx.x - b * per;
+        const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);      // neighbouring query tiles read the same voxels: keep them on one XCD's L2
+        b = vb / per;
+        int t = vb - b * per;
         const int t2 = t % n2; t /= n2;
         const int t1 = t % n1; const int t0 = t / n1;
         const int i0 = t0 * 32 + (threadIdx.x & 31), i1 = t1 * 2 + ((threadIdx.x >> 5) & 1), i2 = t2 * 4 + (threadIdx.x >> 6);

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 //   * P.V:  O^T += V^T P^T needs, per lane (d = lane & 31, k half = lane >> 5), V[key0 .. key0 + 3][d] - a COLUMN of the row-major image.
 //     `ds_read_b64_tr_b16`: the 16 lanes of a group each address 8 bytes of a [4 keys][16 d] block (lane i: key i / 4, d chunk i % 4) and
 //     get back its column i.  With the swizzle above the four key rows of a group pair occupy four disjoint 16-bank windows: conflict-free.
-// Selected by semabs_attention unless bit 1 of `causal` asks for the round-2 kernel (A/B in tests and tools).
+// Selected per call by bits 1 / 2 of semabs_attention's `causal` word (A/B in tests and tools); measured slower than k_attention, see the launcher.
 // =================================================================================================
 __device__ __forceinline__ int vswz_chunk(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(cons
 
 // qkv fp16 [n_seq, T, ld] with q | k | v at column offsets 0, D, 2D (q already scaled); out fp16 [n_seq, T, D]
 // row_stats (optional, may be NULL) fp32 [n_seq, H, T, 2] = (reference maximum, 1 / sum) of every query's softmax
-// causal: bit 0 = causal mask (text tower); bit 1 = run the round-2 kernel, bit 2 = k_attention2 with LDS-DMA staging (A/B; all three give identical results)
+// causal: bit 0 = causal mask (text tower); bit 1 = k_attention2 with register staging, bit 2 = k_attention2 with LDS-DMA staging (A/B; all three give identical results)
 extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim,
                                 int ld, int causal, void* stream) {
     if (n_seq == 0) return SEMABS_OK;
@@ -540,8 +540,11 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
     const int D = H * 64;
     const int nkb = (T + 31) / 32;
     const bool is_causal = (causal & 1) != 0;
-    const bool legacy = (causal & 2) != 0;                                              // bit 1: the round-2 kernel (register staging, 2-byte V^T scatter) for A/B
-    const bool dma = (causal & 4) != 0 && (long)T * ld * 2 < (1L << 31);                // bit 2: k_attention2 with LDS-DMA staging (measured slower, kept for A/B)
+    // Default = k_attention (register staging, V^T in LDS).  k_attention2 (row-major V + transposing LDS reads; bit 1: register staging, bit 2:
+    // LDS-DMA staging) removes every LDS bank conflict and 61 % of the LDS-active cycles (profiles/r03_pmc_attention_ab.json) but runs 12 %
+    // SLOWER at the bench shape (797 / 803 vs 707 us per 2 448-tile launch): kept selectable per call for A/B, identical results.
+    const bool legacy = (causal & 6) == 0;
+    const bool dma = (causal & 4) != 0 && (long)T * ld * 2 < (1L << 31);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(n_seq * H);
 #define ATT_LAUNCH(N, C)                                                                                             \

@@ -97,9 +97,6 @@ class SemAbs3D(torch.nn.Module):
         self.C = unet_num_channels
         self.concat_xyz = bool(decoder_concat_xyz_pts)
         self.precision = precision                   # "exact" by default: the reference's fp32 results; "fp16" = opt-in fast mode
-        self.vol_feature_extractor = ResidualUNet3D(in_channels=unet_num_channels, out_channels=unet_num_channels,
-                                                    f_maps=unet_f_maps, num_groups=unet_num_groups,
-                                                    num_levels=unet_num_levels, precision=precision)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         init = make_semabs3d_state_dict(seed=seed, unet_num_channels=unet_num_channels, unet_f_maps=unet_f_maps, unet_num_groups=unet_num_groups,
                                         unet_num_levels=unet_num_levels, pts_feat_extractor_hidden_dim=pts_feat_extractor_hidden_dim,
@@ -107,7 +104,14 @@ class SemAbs3D(torch.nn.Module):
         if self.with_tsdf:                          # the point MLP leaves one UNet input channel to the TSDF volume (net.py:365-367)
             init["pts_feat_extractor.4.weight"] = init["pts_feat_extractor.4.weight"][: unet_num_channels - 1].clone()
             init["pts_feat_extractor.4.bias"] = init["pts_feat_extractor.4.bias"][: unet_num_channels - 1].clone()
-        register_tree(self, {k: v for k, v in init.items() if not k.startswith("vol_feature_extractor.")}, buffers=("steps",))
+        # Registration order = the reference's (net.py:346-381: pts_feat_extractor, vol_feature_extractor, visual_sampler): `net.parameters()` is
+        # positional for everything built on it - Lamb(net.parameters()), optimizer.state_dict() / load_state_dict (utils.py:264-266, 289)
+        own = {k: v for k, v in init.items() if not k.startswith("vol_feature_extractor.")}
+        register_tree(self, {k: v for k, v in own.items() if k.startswith("pts_feat_extractor.")})
+        self.vol_feature_extractor = ResidualUNet3D(in_channels=unet_num_channels, out_channels=unet_num_channels,
+                                                    f_maps=unet_f_maps, num_groups=unet_num_groups,
+                                                    num_levels=unet_num_levels, precision=precision)
+        register_tree(self, {k: v for k, v in own.items() if not k.startswith("pts_feat_extractor.")}, buffers=("steps",))
         self._w = self._dec = self._final = None
         self._sig = None
         self.features_cl = None

@@ -43,6 +43,8 @@ class Lamb(Optimizer):
                 st["exp_avg_sq"] = torch.zeros_like(p.data)
             for k in ("exp_avg", "exp_avg_sq"):                 # moments restored from a CPU checkpoint / another device / non-contiguous
                 m = st[k]
+                if m.shape != p.shape:                           # a positional state dict from a different parameter order / network: fail loudly -
+                    raise ValueError(f"Lamb: loaded state '{k}' has shape {tuple(m.shape)} for a parameter of shape {tuple(p.shape)}")   # the kernels index by raw pointers
                 if m.device != p.device or m.dtype != torch.float32 or not m.is_contiguous():
                     st[k] = m.to(p.device, torch.float32).contiguous()
         # the plan holds raw device pointers: parameters, gradients AND both moment tensors are part of its identity

@@ -192,7 +192,10 @@ def make_semabsvool_state_dict(seed: int = 0, pointing_dim: int = 64, unet_num_c
     extra = {"steps": np.zeros(1, dtype=np.float32),
              "spatial_sampler.mlp.0.weight": u(din, hid, din), "spatial_sampler.mlp.0.bias": u(din, hid),
              "spatial_sampler.mlp.2.weight": u(hid, pointing_dim, hid), "spatial_sampler.mlp.2.bias": u(hid, pointing_dim)}
-    for name in VOOL_RELATIONS:
-        extra["relation_embeddings." + name] = rng.standard_normal(pointing_dim, dtype=np.float32)
+    rel = {}
+    for name in VOOL_RELATIONS:                              # values drawn in this order (the goldens depend on it) ...
+        rel["relation_embeddings." + name] = rng.standard_normal(pointing_dim, dtype=np.float32)
+    for k in sorted(rel):                                    # ... but listed in the reference's parameter order: nn.ParameterDict sorts its keys, and
+        extra[k] = rel[k]                                    # `Lamb(net.parameters())` / optimizer state dicts are positional (utils.py:264-266, 289)
     sd.update({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in extra.items()})
     return sd

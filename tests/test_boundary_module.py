@@ -174,3 +174,18 @@ def test_semabs3d_tsdf_batch_pairing_quirk_vs_oracle():
     err = float((out.cpu() - ref).abs().max())
     assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
     assert float((ref[0, 1] - own[0, 1]).abs().max()) > 1e-3          # the quirk is visible in this input: (b0, p1) reads scene 1's TSDF
+
+
+def test_parameter_order_is_the_references(golden):
+    """`net.parameters()` is positional for everything the reference builds on it - `Lamb(net.parameters())`, `optimizer.state_dict()` /
+    `load_state_dict` in the checkpoint (utils.py:264-266, 278-296).  g20's `names` = `named_parameters()` of the unmodified reference SemAbsVOOL:
+    the drop-in module, the seeded state-dict generator and the fused trainer's optimizer must list the parameters in that order."""
+    from semabs_amd.net import SemAbs3D, SemAbsVOOL
+    ref = [str(k) for k in golden("g20_vool_train64")["names"]]
+    kw = {k: v for k, v in KW.items() if k != "decoder_concat_xyz_pts"}
+    net = SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cpu", decoder_concat_xyz_pts=True, **kw)
+    assert [k for k, _ in net.named_parameters()] == ref
+    sd = make_semabsvool_state_dict(seed=1)
+    assert [k for k, v in sd.items() if torch.is_floating_point(v) and not k.endswith("steps")] == ref
+    inner = SemAbs3D(device="cpu", **dict(KW, decoder_concat_xyz_pts=False))
+    assert ["completion_net." + k for k, _ in inner.named_parameters()] == [k for k in ref if k.startswith("completion_net.")]

@@ -111,9 +111,9 @@ def test_attention(T, H, causal):
         s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu_(1)
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n, T, D)
     np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=3e-3, atol=3e-3)
-    # the round-2 kernel (register staging + V^T scatter; bit 1 of the causal word) stays selectable for A/B: same scores, same P, the P.V
-    # products are summed in the same order -> identical outputs
-    for bit in (2, 4):                                     # 2 = the round-2 kernel, 4 = k_attention2 with LDS-DMA staging
+    # k_attention2 (row-major V read through ds_read_b64_tr_b16; bit 1 = register staging, bit 2 = LDS-DMA staging) stays selectable for A/B: same
+    # scores, same P, the P.V products are summed in the same order -> identical outputs
+    for bit in (2, 4):
         out2 = torch.zeros_like(out)
         _lib.call("semabs_attention", _lib.ptr(qkv_d), _lib.ptr(out2), None, n, T, H, 64, 3 * D, causal | bit, _lib.stream())
         assert torch.equal(out, out2), bit

@@ -17,7 +17,7 @@ print("kernels agree:", bool(torch.equal(out, out2)), float((out.float() - out2.
 run(4, out2); torch.cuda.synchronize()
 print("dma variant agrees:", bool(torch.equal(out, out2)))
 for rep in range(2):
-    for flag, name in ((0, "k_attention2 (reg)"), (4, "k_attention2 (dma)"), (2, "round-2 kernel")):
+    for flag, name in ((2, "k_attention2 (reg)"), (4, "k_attention2 (dma)"), (0, "k_attention")):
         for _ in range(3): run(flag)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
