@@ -128,7 +128,12 @@ def test_module_loop_equals_fused_trainer():
     # span only the trainable subset: parameter-group size mismatch) and the resumed second step must match the module loop's second step.
     n_params = len(list(net.parameters()))
     assert len(optimizer.state_dict()["param_groups"][0]["params"]) == n_params == len(tr.opt.state_dict()["param_groups"][0]["params"])
-    ckpt = {"net": {"module." + k: v.clone() for k, v in net.state_dict().items()}, "optimizer": optimizer.state_dict(), "epochs": 3}
+    import copy
+    import io
+    buf = io.BytesIO()                                       # through torch.save / torch.load like utils.py:278-296 (state_dict() hands out the live moment tensors)
+    torch.save({"net": {"module." + k: v for k, v in net.state_dict().items()}, "optimizer": optimizer.state_dict(), "epochs": 3}, buf)
+    buf.seek(0)
+    ckpt = torch.load(buf, map_location="cuda", weights_only=False)
     tr2 = VOOLTrainer(sd, voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_levels=L)
     assert tr2.load_checkpoint(ckpt) == 3 and tr2.steps == 1
     mid = npy(net.state_dict())
@@ -141,7 +146,7 @@ def test_module_loop_equals_fused_trainer():
     assert worst2 <= 5e-2
     # and the other way round: the trainer's checkpoint loads into an optimizer over net.parameters()
     opt_b = Lamb(net.parameters(), lr=1e-3, weight_decay=1e-5)
-    opt_b.load_state_dict(tr2.checkpoint()["optimizer"])
+    opt_b.load_state_dict(copy.deepcopy(tr2.checkpoint()["optimizer"]))
     assert int(opt_b.state[dict(net.named_parameters())["spatial_sampler.mlp.0.weight"]]["step"]) == 2
 
 
