@@ -58,7 +58,8 @@ int semabs_tsdf_integrate(const unsigned char* color, const float* depth, int H,
 int semabs_frustum_mask(const double* pts, long M, const double* params, int H, int W, unsigned char* mask, void* stream);
 
 /* in-bounds compaction + seeded sub-sample on the device (visualize.py:103-108 boolean indexing, :193 np.random.choice with replacement):
- * pix[0..n_in) = ascending i with mask[i] != 0; sel[j] = pix[mulhi64(splitmix64(seed * 0x9E3779B97F4A7C15 + j), n_in)]; n_in int64 [1] device */
+ * pix[0..n_in) = ascending i with mask[i] != 0; sel[j] = pix[mulhi64(splitmix64(seed * 0x9E3779B97F4A7C15 + j), n_in)]; n_in int64 [1] device.
+ * mask 16-byte aligned; num >= max(1, ceil(n / 4096) / 2): sel doubles as the scratch of the per-block counts between the launches */
 int semabs_compact_subsample(const unsigned char* mask, long n, unsigned long long seed, long num, long long* pix, long long* n_in,
                              long long* sel, void* stream);
 

@@ -8,8 +8,9 @@
 //
 // Two kernels (gfx950):
 //  * k_gemm8 (M >= 2048, N % 256 == 0, K >= 128 - every GEMM of the ViT trunk): 256 x 256 x 64 tile, 8 waves, four phases per K tile with one
-//    half-tile of direct-to-LDS DMA issued per phase and four half-tiles in flight across barriers, skewed wave rows, register-direct
-//    epilogue.  Described in full at its definition below.
+//    half-tile of direct-to-LDS DMA issued per phase and four half-tiles in flight across barriers, skewed wave rows, fragment reads
+//    prefetched inside the MFMA blocks, buffer-descriptor addressing, and an epilogue that transposes each wave's accumulators through its
+//    own slice of LDS so that stores cover whole row segments.  Described in full at its definition below.
 //  * k_gemm_f16 (everything else - small M, N % 256 != 0, K = 64): 128 x 128 x 64 (or 128 x 256 x 32) tile of 32x32x16 MFMAs, operands
 //    global -> LDS by direct DMA (global_load_lds_dwordx4) in a 2-3 stage ring with counted vmcnt + raw barriers, LDS rows XOR-swizzled
 //    (applied on the DMA source address and on the read) so ds_read_b128 fragment reads are bank-conflict-free, fragment ping-pong, and an
@@ -316,8 +317,10 @@ static int launch_cfg(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 //      is staged >= 4 phases before the phase that precedes its first read, so "vmcnt(8)" (four half-tiles = 8 DMA instructions
 //      per lane still in flight) in every phase retires it in time: 64 KB of operands stay in flight per CU across barriers.
 // Operands are swapped in the MFMA (D = B_frag x A_frag) and the B fragment rows are interleaved (n = (i >> 2) * 8 + jt * 4 + (i & 3))
-// so that a lane ends up with 8 CONSECUTIVE columns of one output row: the epilogue stores straight from registers, 16 B (fp16) or
-// 2 x 16 B (fp32) per lane and a full 64 / 128-byte line per row - no LDS round trip.
+// so that a lane ends up with 8 CONSECUTIVE columns of one output row (16 B of fp16 / 2 x 16 B of fp32): the unit the epilogue moves.  The
+// epilogue itself does NOT store those registers directly (round 1 did: row-per-lane 16-byte stores are served at ~1 lane / clk by the
+// texture-address unit); it transposes them through the wave's own 16 KB of the idle operand buffers into row-contiguous order first - see
+// the comment at `epilogue` below.
 // =================================================================================================
 __device__ __forceinline__ int swzA8(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int swzB8(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1))) << 4); }

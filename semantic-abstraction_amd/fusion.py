@@ -14,7 +14,7 @@ from . import _lib
 class TSDFVolume:
     def __init__(self, vol_bnds, voxel_size):
         vol_bnds = np.asarray(vol_bnds)
-        assert vol_bnds.shape == (3, 2), "[!] `vol_bnds` should be of shape (3, 2)."
+        assert vol_bnds.shape == (3, 2), f"vol_bnds must be (3, 2): per-axis (min, max) in metres, got {vol_bnds.shape}"
         assert (vol_bnds[:, 0] < vol_bnds[:, 1]).all()
         self._dev = _lib.require_gpu()
         self._vol_bnds = vol_bnds
