@@ -1963,77 +1963,29 @@ __device__ __forceinline__ float decoder_mlp(const DecArgs& a, float (&f)[16], c
     }
     return o;
 }
-// Round 3: FOUR LANES PER VOXEL READ.  One thread per query used to read each corner voxel's 64 bytes as four 16-byte loads of its own - a wave
-// instruction then touched 64 different voxels, 16 of every 64 bytes each, and that access shape is served by the texture-address unit at
-// ~16 B / clk / CU: 17 GB of corner reads per scene at 8.6 TB/s = the 1.6 ms the kernel took, whatever the caches did.
-// A thread still OWNS one query (coordinates, MLP with the weights in scalar registers, store), but the gathers are done by the quad: in round
-// r (0..3) the four lanes of a quad interpolate the query of quad lane r together - lane q loads quarter q (channels 4q .. 4q + 3) of each
-// corner, so the quad reads one voxel's 64 contiguous bytes and a wave instruction covers 16 whole voxels - then all-gather the 16 features
-// with DPP quad broadcasts and the owner keeps them.  Same loads per lane as before (4 rounds x 8 corners x 16 B), same per-channel corner
-// order, same MLP: results bit-identical to the thread-per-query kernel.
-template <int K> __device__ __forceinline__ float quad_bcast(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
-}
-template <int K> __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true); }
-template <bool F32>
-__device__ __forceinline__ void load4(const void* base, long idx, float (&v)[4]) {
-    if (F32) {
-        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    } else {
-        const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(base) + idx);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (float)h[j];
-    }
-}
-template <typename T, int R>
-__device__ __forceinline__ void decoder_round(const T* __restrict__ vol, const DecArgs& a, float ix, float iy, float iz, int b, int quarter, float (&f)[16]) {
-    // the query of quad lane R: its (already clipped) voxel coordinates and label volume
-    const float rx = quad_bcast<R>(ix), ry = quad_bcast<R>(iy), rz = quad_bcast<R>(iz);
-    const int rb = quad_bcast_i<R>(b);
-    const float fx = floorf(rx), fy = floorf(ry), fz = floorf(rz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    const float wx1 = rx - fx, wy1 = ry - fy, wz1 = rz - fz, wx0 = (fx + 1.f) - rx, wy0 = (fy + 1.f) - ry, wz0 = (fz + 1.f) - rz;
-    float f4[4] = {0.f, 0.f, 0.f, 0.f};
-    const T* vb = vol + (long)rb * a.S0 * a.S1 * a.S2 * 16;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        const int zz = z0 + (d >> 2), yy = y0 + ((d >> 1) & 1), xx = x0 + (d & 1);
-        if (zz > a.S0 - 1 || yy > a.S1 - 1 || xx > a.S2 - 1) continue;       // out-of-bounds corner contributes 0 (its weight is 0 too); quad-uniform
-        const float w = ((d & 1) ? wx1 : wx0) * (((d >> 1) & 1) ? wy1 : wy0) * ((d >> 2) ? wz1 : wz0);
-        float v[4];
-        load4<sizeof(T) == 4>(vb, (((long)zz * a.S1 + yy) * a.S2 + xx) * 16 + quarter * 4, v);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) f4[c] += v[c] * w;
-    }
-    const bool mine = quarter == R;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float g0 = quad_bcast<0>(f4[e]), g1 = quad_bcast<1>(f4[e]), g2 = quad_bcast<2>(f4[e]), g3 = quad_bcast<3>(f4[e]);
-        f[e] = mine ? g0 : f[e]; f[4 + e] = mine ? g1 : f[4 + e]; f[8 + e] = mine ? g2 : f[8 + e]; f[12 + e] = mine ? g3 : f[12 + e];
-    }
-}
+// Round 3 tried FOUR LANES PER VOXEL READ here (a quad interpolating one query together, lane q loading quarter q of each corner voxel so that a
+// quad reads 64 contiguous bytes, DPP all-gather, owner lane runs the MLP; results bit-identical): 1.61 -> 2.44 ms per scene - SLOWER.  The
+// thread-per-query gathers below are not what bounds this kernel; what did help is the XCD-aware tile order (FETCH_SIZE 4.41 -> 2.65 GB for the
+// 2.15 GB volume, L2 hit 82 %), for 1.65 -> 1.61 ms.
 template <typename T, bool LATTICE, bool CXYZ>
 __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, const float* __restrict__ query, DecArgs a, int P, long M,
                                                  long q_stride_p, float* __restrict__ out, int G0, int G1, int G2) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, quarter = lane & 3;
+    __shared__ float s_out[LATTICE ? 256 : 1];
     long i; int b; long m;
-    bool live = true;
     if (LATTICE) {
-        // workgroup = 16 (axis 0: the volume's innermost axis - a wave's 16 quads walk 16 neighbouring voxels) x 4 (axis 1: the waves) x 4 (axis 2: the quad)
-        const int n2 = G2 / 4, n1 = G1 / 4, n0 = G0 / 16;
+        const int n2 = G2 / 4, n1 = G1 / 2, n0 = G0 / 32;
         const int per = n0 * n1 * n2;
         const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);      // neighbouring query tiles read the same voxels: keep them on one XCD's L2
         b = vb / per;
         int t = vb - b * per;
         const int t2 = t % n2; t /= n2;
         const int t1 = t % n1; const int t0 = t / n1;
-        const int i0 = t0 * 16 + (lane >> 2), i1 = t1 * 4 + wid, i2 = t2 * 4 + quarter;
+        const int i0 = t0 * 32 + (threadIdx.x & 31), i1 = t1 * 2 + ((threadIdx.x >> 5) & 1), i2 = t2 * 4 + (threadIdx.x >> 6);
         m = ((long)i0 * G1 + i1) * G2 + i2;
         i = (long)b * M + m;
     } else {
-        i = (long)blockIdx.x * 256 + threadIdx.x;
-        if (i >= (long)P * M) { i = (long)P * M - 1; live = false; }     // (quads stay whole for the DPP exchanges; the duplicate is not stored)
+        i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= (long)P * M) return;
         b = (int)(i / M); m = i % M;
     }
     const float* qp = query + (long)b * q_stride_p + m * 3;
@@ -2049,15 +2001,38 @@ __global__ __launch_bounds__(256) void k_decoder(const T* __restrict__ vol, cons
     // unnormalise (align_corners=True) and clip (border): x -> D2, y -> D1, z -> D0
     float ix = ((qn[0] + 1.f) / 2.f) * (float)(a.S2 - 1), iy = ((qn[1] + 1.f) / 2.f) * (float)(a.S1 - 1), iz = ((qn[2] + 1.f) / 2.f) * (float)(a.S0 - 1);
     ix = fminf(fmaxf(ix, 0.f), (float)(a.S2 - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(a.S1 - 1)); iz = fminf(fmaxf(iz, 0.f), (float)(a.S0 - 1));
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
     float f[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) f[c] = 0.f;
-    decoder_round<T, 0>(vol, a, ix, iy, iz, b, quarter, f);
-    decoder_round<T, 1>(vol, a, ix, iy, iz, b, quarter, f);
-    decoder_round<T, 2>(vol, a, ix, iy, iz, b, quarter, f);
-    decoder_round<T, 3>(vol, a, ix, iy, iz, b, quarter, f);
+    const T* vb = vol + (long)b * a.S0 * a.S1 * a.S2 * 16;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int zz = z0 + (d >> 2), yy = y0 + ((d >> 1) & 1), xx = x0 + (d & 1);
+        if (zz > a.S0 - 1 || yy > a.S1 - 1 || xx > a.S2 - 1) continue;       // out-of-bounds corner contributes 0 (its weight is 0 too)
+        const float w = ((d & 1) ? wx1 : wx0) * (((d >> 1) & 1) ? wy1 : wy0) * ((d >> 2) ? wz1 : wz0);
+        const long idx = (((long)zz * a.S1 + yy) * a.S2 + xx) * 16;
+        float v[8];
+        load8<sizeof(T) == 4>(vb, idx, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] += v[c] * w;
+        load8<sizeof(T) == 4>(vb, idx + 8, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[8 + c] += v[c] * w;
+    }
     const float o = decoder_mlp<CXYZ>(a, f, qn);
-    if (live) out[i] = o;                                   // lattice: the quad's four queries are consecutive along axis 2 -> 16 contiguous bytes per quad
+    if (LATTICE) {
+        s_out[(threadIdx.x & 63) * 4 + (threadIdx.x >> 6)] = o;                 // [(i0, i1) pair][i2]
+        __syncthreads();
+        if (threadIdx.x < 64) {                                                 // one 16-byte store per (i0, i1): 4 consecutive queries along axis 2
+            const float4 v = *reinterpret_cast<const float4*>(s_out + threadIdx.x * 4);
+            *reinterpret_cast<float4*>(out + i) = v;                            // for these threads i2 = t2 * 4: i is the first of the four
+        }
+    } else {
+        out[i] = o;
+    }
 }
 
 // vol [P, S0, S1, S2, 16] (fp16 / fp32); query fp32: label b reads query + b * q_stride_p (0 = shared by all labels),
@@ -2085,7 +2060,7 @@ extern "C" int semabs_decoder(const void* vol, const float* query, const float* 
         for (int i = 0; i < 256; ++i) a.fw[i] = final_w[i];
         for (int i = 0; i < 16; ++i) a.fb[i] = final_b[i];
     }
-    const bool lattice = qgrid3 && (long)qgrid3[0] * qgrid3[1] * qgrid3[2] == M && qgrid3[0] % 16 == 0 && qgrid3[1] % 4 == 0 && qgrid3[2] % 4 == 0 &&
+    const bool lattice = qgrid3 && (long)qgrid3[0] * qgrid3[1] * qgrid3[2] == M && qgrid3[0] % 32 == 0 && qgrid3[1] % 2 == 0 && qgrid3[2] % 4 == 0 &&
                          (long)P * (M / 256) < (1L << 31);
 #define DEC_LAUNCH(KERN, GRID)                                                                                                        \
     do {                                                                                                                              \
