@@ -217,15 +217,16 @@ def _classify(name, a):
         B, D0, D1, D2, cin, cout, k, flags, resid = a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[16], a[7]
         vox, eb = B * D0 * D1 * D2, 4 if (flags & 1) else 2
         fl, by = 2.0 * k ** 3 * cin * cout * vox, vox * (cin + cout * (2 if resid else 1)) * eb
+        iss = 3.0 if (flags & 1) else 1.0                   # exact mode = fp16 hi / lo split: three MFMA products per algorithmic product
         if k == 3 and cin == 16 and cout == 16 and D0 % 8 == 0 and D1 % 8 == 0 and D2 % 16 == 0:
-            return "Conv3d 128^3 16->16 (k_conv16_lds)", fl, by
+            return "Conv3d 128^3 16->16 (k_conv16_lds)", fl, by, iss
         if k == 3 and cout % 32 == 0 and D0 % 4 == 0 and D1 % 8 == 0 and (D2 % 16 == 0 or (D2 % 8 == 0 and cin % 32 == 0)):
-            return "Conv3d 64^3..8^3 (k_conv_brick)", fl, by
-        return "Conv3d 4^3 / 1x1x1 (k_conv gather)", fl, by
+            return "Conv3d 64^3..8^3 (k_conv_brick)", fl, by, iss
+        return "Conv3d 4^3 / 1x1x1 (k_conv gather)", fl, by, iss
     if name in ("semabs_convtranspose3d", "semabs_convtranspose3d_stats"):
         B, D0, D1, D2, cin, cout, flags = a[7], a[8], a[9], a[10], a[11], a[12], a[13]
         vox, eb = B * D0 * D1 * D2, 4 if (flags & 1) else 2
-        return "ConvTranspose3d (k_convT_brick / gather)", 2.0 * 27 * cin * cout * vox, vox * cin * eb + 8 * vox * cout * eb * 2
+        return "ConvTranspose3d (k_convT_brick / gather)", 2.0 * 27 * cin * cout * vox, vox * cin * eb + 8 * vox * cout * eb * 2, (3.0 if (flags & 1) else 1.0)
     if name == "semabs_decoder":
         P, M, f32 = a[10], a[11], a[13]
         S = a[4]
@@ -259,9 +260,10 @@ class _CallTimer:
     def table(self, scenes):
         torch.cuda.synchronize()
         agg = {}
-        for (cls, fl, by), e0, e1 in self.rec:
-            d = agg.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-            d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by
+        for c, e0, e1 in self.rec:
+            cls, fl, by = c[0], c[1], c[2]
+            d = agg.setdefault(cls, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, issued=0.0))
+            d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["flops"] += fl; d["bytes"] += by; d["issued"] += fl * (c[3] if len(c) > 3 else 1.0)
         out = {}
         for cls, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
             ms = d["ms"] / scenes
@@ -272,6 +274,10 @@ class _CallTimer:
                 row.update(algorithmic_tflop=round(fl / 1e12, 3), algorithmic_gb=round(by / 1e9, 2), tflops=round(fl / ms / 1e9, 1) if fl else None,
                            tb_per_s=round(by / ms / 1e9, 2) if by else None, bound="mfma" if t_mfma >= t_hbm else "hbm",
                            roof_ms=round(max(t_mfma, t_hbm), 3), frac_of_roof=round(max(t_mfma, t_hbm) / ms, 3))
+                if d["issued"] > d["flops"]:                 # exact-mode convolutions: the roof of the arithmetic actually chosen (3 MFMA products per product)
+                    t_iss = d["issued"] / scenes / (PEAK_F16_TFLOPS * 1e12) * 1e3
+                    row.update(issued_mfma_tflop=round(d["issued"] / scenes / 1e12, 3), issued_roof_ms=round(max(t_iss, t_hbm), 3),
+                               frac_of_issued_roof=round(max(t_iss, t_hbm) / ms, 3))
             out[cls] = row
         return out
 
