@@ -305,6 +305,10 @@ int semabs_vool_sample_bwd(const float* df, const float* query, const float* off
 int semabs_cos_bce(const float* o, const float* rel, const float* label, const float* weight, int P, long M, float temperature, long n_total,
                    float* logits, float* dO, float* drel, double* loss, void* stream);
 
+/* per-step weight layouts: hi / lo[i] = fp16 hi / lo split of src[idx[i]] (idx < 0: zero) - one launch per matrix instead of torch permute / flip /
+ * cat / cast chains; the index map of a layout (tap-major, flipped + transposed, parity classes, fragment-packed copy) depends on shapes only */
+int semabs_gather_split16(const float* src, const int* idx, long n, void* hi, void* lo, void* stream);
+
 /* the pointer head with the loss left to the caller (autograd boundary of SemAbsVOOL: `loss.backward()` of utils.py:404-417):
  * dlogits == NULL: logits = cos(o, rel) / T only; dlogits = d loss / d logits [P*M]: dO, drel (accumulated) = d loss / d o, d rel   net.py:566-579 */
 int semabs_cos_head(const float* o, const float* rel, const float* dlogits, int P, long M, float temperature, float* logits, float* dO,

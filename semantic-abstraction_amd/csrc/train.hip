@@ -159,6 +159,45 @@ extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scal
 }
 
 // =================================================================================================
+// Per-step weight layouts in ONE launch per matrix: out_hi / out_lo[i] = fp16 hi / lo split of src[idx[i]] (idx < 0: zero padding).
+// The MFMA kernels read every convolution / linear weight as split-fp16 matrices in their own layouts (tap-major rows, flipped + transposed
+// for the data gradient, parity-class matrices of the transposed convolution, each followed by its fragment-packed copy); the weights change
+// every optimisation step, and building those layouts with torch ops was ~830 tiny launches (3.8 ms of GPU time) per step.  The index map of
+// a layout depends on the shapes only: the host builds it once by running the layout code on an index tensor (train.py: _WeightLayouts).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_gather_split16(const float* __restrict__ src, const int* __restrict__ idx, long n, f16* __restrict__ hi,
+                                                        f16* __restrict__ lo) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        const int4 k = *reinterpret_cast<const int4*>(idx + i);
+        const int kk[4] = {k.x, k.y, k.z, k.w};
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = kk[e] >= 0 ? src[kk[e]] : 0.f;
+            h[e] = (f16)v; l[e] = (f16)(v - (float)h[e]);
+        }
+        *reinterpret_cast<f16x4*>(hi + i) = h;
+        *reinterpret_cast<f16x4*>(lo + i) = l;
+    } else {
+        for (long j = i; j < n; ++j) {
+            const float v = idx[j] >= 0 ? src[idx[j]] : 0.f;
+            const f16 h = (f16)v;
+            hi[j] = h; lo[j] = (f16)(v - (float)h);
+        }
+    }
+}
+// src fp32 (any shape, contiguous); idx int32 [n] (16-byte aligned), hi / lo fp16 [n] (8-byte aligned)
+extern "C" int semabs_gather_split16(const float* src, const int* idx, long n, void* hi, void* lo, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(src && idx && hi && lo, "semabs_gather_split16: null pointer");
+    hipLaunchKernelGGL(k_gather_split16, dim3(semabs_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, idx, n, (f16*)hi, (f16*)lo);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
 // Per-(batch, channel) reductions over voxels: Sa = sum dY, Sb = sum dY * xhat (xhat = (X - mean_g) * rstd_g), fp64 atomics.
 // Used for bias gradients (X = null) and GroupNorm backward.
 // =================================================================================================

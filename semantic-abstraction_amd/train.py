@@ -33,23 +33,6 @@ TAPS_CONV3 = _taps([(a - 1, b - 1, c - 1) for a in range(3) for b in range(3) fo
 TAPS_ONE = _taps([(0, 0, 0)])
 
 
-def _split16(w: torch.Tensor):
-    hi = w.to(torch.float16)
-    lo = (w - hi.float()).to(torch.float16)
-    return hi.contiguous(), lo.contiguous()
-
-
-def _split16p(w: torch.Tensor):
-    """fp16 hi / lo split of a [rows, Kp] weight matrix with its fragment-packed copy appended (unet3d._pack_fragments, flag bit 9 of the
-    convolution entry points' flag word) -> (hi, lo, flag)."""
-    from .unet3d import _pack_fragments
-    if w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
-        hi, lo = _split16(torch.cat([w.reshape(-1), _pack_fragments(w)]))
-        return hi, lo, 512
-    hi, lo = _split16(w)
-    return hi, lo, 0
-
-
 def _pad32(w: torch.Tensor) -> torch.Tensor:
     kp = (w.shape[1] + 31) // 32 * 32
     if kp == w.shape[1]:
@@ -57,6 +40,41 @@ def _pad32(w: torch.Tensor) -> torch.Tensor:
     out = torch.zeros(w.shape[0], kp, dtype=w.dtype, device=w.device)
     out[:, : w.shape[1]] = w
     return out
+
+
+def _flat_packed(w: torch.Tensor):
+    """[rows, Kp] -> (flat = the matrix followed by its fragment-packed copy when the shape allows, flag word)."""
+    from .unet3d import _pack_fragments
+    if w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
+        return torch.cat([w.reshape(-1), _pack_fragments(w)]), 512
+    return w.reshape(-1), 0
+
+
+class _WeightLayouts:
+    """Split-fp16 kernel operands of the trainable weights, refreshed every step by ONE gather launch per matrix (semabs_gather_split16).
+    `build(t)` is the layout written with torch data-movement ops (permute / flip / cat / zero padding) - it is run ONCE on an index tensor
+    (1 .. numel, zeros = padding) to obtain the int32 map, and the hi / lo buffers keep their addresses for the lifetime of the trainer."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.maps: Dict[str, tuple] = {}
+
+    def get(self, key: str, w: torch.Tensor, build):
+        m = self.maps.get(key)
+        if m is None or m[3] != tuple(w.shape):
+            ar = torch.arange(1, w.numel() + 1, dtype=torch.int32, device=self.dev).view(w.shape)
+            out = build(ar)
+            flat, extra = (out if isinstance(out, tuple) else (out, None))
+            idx = (flat.reshape(-1) - 1).to(torch.int32).contiguous()
+            hi = torch.empty(idx.numel(), dtype=torch.float16, device=self.dev)
+            lo = torch.empty_like(hi)
+            m = (idx, hi, lo, tuple(w.shape), extra)
+            self.maps[key] = m
+        idx, hi, lo, _, extra = m
+        src = w.detach()
+        assert src.is_contiguous() and src.dtype == torch.float32
+        _lib.call("semabs_gather_split16", _lib.ptr(src), _lib.ptr(idx), idx.numel(), _lib.ptr(hi), _lib.ptr(lo), _lib.stream())
+        return hi, lo, extra
 
 
 class _ZeroArena:
@@ -101,39 +119,45 @@ class UNetTrainer:
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
         self.arena = _ZeroArena(self.dev)
+        self.layouts = _WeightLayouts(self.dev)
 
     # ---- per-step weight layouts (fp16 hi/lo splits for the MFMA kernels) --------------------------------------------------------
     def refresh(self):
+        L = self.layouts
         for pre, kind, cin, cout in self.plan:
             key = self.prefix + pre
             if kind in ("gcr", "gc"):
                 w = self.p[key + "conv.weight"]
                 k = w.shape[2]
-                fwd = _pad32(w.permute(0, 2, 3, 4, 1).reshape(cout, -1))
-                bwd = _pad32(w.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(cin, -1))
-                self.mats[pre] = dict(kind="conv", cin=cin, cout=cout, k=k, groups=self.G if cin >= self.G else 1,
-                                      fwd=_split16p(fwd), bwd=_split16p(bwd))
+                fwd = L.get(key + "fwd", w, lambda t, cout=cout: _flat_packed(_pad32(t.permute(0, 2, 3, 4, 1).reshape(cout, -1))))
+                bwd = L.get(key + "bwd", w, lambda t, cin=cin: _flat_packed(_pad32(t.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(cin, -1))))
+                self.mats[pre] = dict(kind="conv", cin=cin, cout=cout, k=k, groups=self.G if cin >= self.G else 1, fwd=fwd, bwd=bwd)
             elif kind == "convT":
                 w = self.p[key + "weight"]                                             # [cin, cout, 3, 3, 3]
-                from .unet3d import _pack_fragments
-                mats, packs, offs, off = [], [], [], 0
-                for cls in range(8):
-                    pp = (cls >> 2, (cls >> 1) & 1, cls & 1)
-                    cols = []
-                    for t0 in range(pp[0] + 1):
-                        for t1 in range(pp[1] + 1):
-                            for t2 in range(pp[2] + 1):
-                                kk = [1 if q == 0 else (0 if t == 0 else 2) for q, t in zip(pp, (t0, t1, t2))]
-                                cols.append(w[:, :, kk[0], kk[1], kk[2]].t())
-                    m = torch.cat(cols, dim=1).contiguous()
-                    mats.append(m.reshape(-1)); packs.append(_pack_fragments(m)); offs.append(off); off += m.numel()
-                bwd = _pad32(w.permute(0, 2, 3, 4, 1).reshape(cin, -1))               # [cin, (k, cout)]
-                self.mats[pre] = dict(kind="convT", cin=cin, cout=cout, fwd=_split16(torch.cat(mats + packs)) + (512,),
-                                      class_off=(C.c_long * 8)(*offs), bwd=_split16p(bwd))
+
+                def classes(t):
+                    from .unet3d import _pack_fragments
+                    mats, packs, offs, off = [], [], [], 0
+                    for cls in range(8):
+                        pp = (cls >> 2, (cls >> 1) & 1, cls & 1)
+                        cols = []
+                        for t0 in range(pp[0] + 1):
+                            for t1 in range(pp[1] + 1):
+                                for t2 in range(pp[2] + 1):
+                                    kk = [1 if q == 0 else (0 if tt == 0 else 2) for q, tt in zip(pp, (t0, t1, t2))]
+                                    cols.append(t[:, :, kk[0], kk[1], kk[2]].t())
+                        m = torch.cat(cols, dim=1).contiguous()
+                        mats.append(m.reshape(-1)); packs.append(_pack_fragments(m)); offs.append(off); off += m.numel()
+                    return torch.cat(mats + packs), offs
+
+                hi, lo, offs = L.get(key + "fwd", w, classes)
+                bwd = L.get(key + "bwd", w, lambda t, cin=cin: _flat_packed(_pad32(t.permute(0, 2, 3, 4, 1).reshape(cin, -1))))   # [cin, (k, cout)]
+                self.mats[pre] = dict(kind="convT", cin=cin, cout=cout, fwd=(hi, lo, 512), class_off=(C.c_long * 8)(*offs), bwd=bwd)
             else:                                                                      # final 1x1x1 conv with bias
                 w = self.p[key + "weight"]
-                self.mats[pre] = dict(kind="final", cin=cin, cout=cout, k=1, fwd=_split16p(_pad32(w.reshape(cout, cin))),
-                                      bwd=_split16p(_pad32(w.reshape(cout, cin).t().contiguous())))
+                fwd = L.get(key + "fwd", w, lambda t, cin=cin, cout=cout: _flat_packed(_pad32(t.reshape(cout, cin))))
+                bwd = L.get(key + "bwd", w, lambda t, cin=cin, cout=cout: _flat_packed(_pad32(t.reshape(cout, cin).t().contiguous())))
+                self.mats[pre] = dict(kind="final", cin=cin, cout=cout, k=1, fwd=fwd, bwd=bwd)
 
     # ---- forward -----------------------------------------------------------------------------------------------------------------
     def _conv_fwd(self, x, pre, relu, resid=None, in_sums=None, out_groups=0):
@@ -416,12 +440,15 @@ class VOOLTrainer:
         _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
         return y
 
-    def _linear_mfma(self, x, w, b, act, grad_in=False):
-        """The 128 -> 128 MLP layers as 1x1x1 convolutions on the split-fp16 MFMA kernel (fp32-like accuracy).  grad_in: x is a
-        gradient (arbitrarily small): scaled by a power of two on the way in and back on the way out."""
+    def _linear_mfma(self, x, wkey, b, act, grad_in=False, transposed=False):
+        """The 128 -> 128 MLP layers as 1x1x1 convolutions on the split-fp16 MFMA kernel (fp32-like accuracy); wkey names the weight parameter,
+        transposed = multiply by its transpose (the data gradient).  grad_in: x is a gradient (arbitrarily small): scaled by a power of two on
+        the way in and back on the way out."""
         R, Ci = x.shape
-        Co = w.shape[0]
-        hi, lo, pk = _split16p(_pad32(w.contiguous()))
+        w = self.params[wkey]
+        Co = w.shape[1] if transposed else w.shape[0]
+        hi, lo, pk = self.unet.layouts.get(f"lin:{wkey}:{int(transposed)}", w, (lambda t: _flat_packed(_pad32(t.t().contiguous()))) if transposed else
+                                           (lambda t: _flat_packed(_pad32(t.contiguous()))))
         y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
         u = self.unet
         sc = sh = s2 = None
@@ -467,8 +494,8 @@ class VOOLTrainer:
         feat = torch.cat([sal_t, sal_r], dim=0)                                           # [P, N]
         x4 = torch.cat([xyz.unsqueeze(0).expand(P, N, 3), feat.unsqueeze(-1)], dim=-1).reshape(P * N, 4).contiguous()
         h1 = self._linear(x4, p[cn + "0.weight"], p[cn + "0.bias"], 1)
-        h2 = self._linear_mfma(h1, p[cn + "2.weight"], p[cn + "2.bias"], 1)
-        pf = self._linear_mfma(h2, p[cn + "4.weight"], p[cn + "4.bias"], 0)              # [P*N, C]
+        h2 = self._linear_mfma(h1, cn + "2.weight", p[cn + "2.bias"], 1)
+        pf = self._linear_mfma(h2, cn + "4.weight", p[cn + "4.bias"], 0)              # [P*N, C]
         flat = self.vg.flat_idxs(xyz)
         vol = torch.zeros(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
         head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
@@ -489,7 +516,7 @@ class VOOLTrainer:
         w1p = torch.zeros(32, 36, dtype=torch.float32, device=dev)
         w1p[:, :35] = p[ss + "0.weight"]
         h = self._linear(f, w1p, p[ss + "0.bias"], 1)
-        o = self._linear_mfma(h, p[ss + "2.weight"], p[ss + "2.bias"], 0)
+        o = self._linear_mfma(h, ss + "2.weight", p[ss + "2.bias"], 0)
         rel = torch.stack([p["relation_embeddings." + n].detach() for n in rel_names], dim=0).contiguous()
         return dict(D=D, N=N, M=M, P=P, x4=x4, h1=h1, h2=h2, flat=flat, tape=tape, query=query, f=f, w1p=w1p, h=h, o=o, rel=rel,
                     rel_names=list(rel_names))
@@ -508,7 +535,7 @@ class VOOLTrainer:
             g["relation_embeddings." + n].add_(drel[d])
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
         u._colsum(dO, g[ss + "2.bias"])
-        dh = u._ew(self._linear_mfma(dO, p[ss + "2.weight"].detach().t().contiguous(), None, 0, grad_in=True), h, 1)
+        dh = u._ew(self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True), h, 1)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
@@ -523,10 +550,10 @@ class VOOLTrainer:
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
-        dh2 = u._ew(self._linear_mfma(dpf, p[cn + "4.weight"].detach().t().contiguous(), None, 0, grad_in=True), h2, 1)
+        dh2 = u._ew(self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True), h2, 1)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
-        dh1 = u._ew(self._linear_mfma(dh2, p[cn + "2.weight"].detach().t().contiguous(), None, 0, grad_in=True), h1, 1)
+        dh1 = u._ew(self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True), h1, 1)
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
 
