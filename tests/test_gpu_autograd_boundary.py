@@ -140,7 +140,9 @@ def test_module_loop_equals_fused_trainer():
     out2 = tr2.step(batch)
     _, loss2, _ = _loop_step(net, optimizer, batch)
     assert abs(float(loss2.detach()) - float(out2["loss"])) <= 1e-5 * float(out2["loss"])
-    ref_g2 = {k: tr2.grads[k].cpu().numpy() for k in tr2.grads if tr2.params[k].grad is not None}
+    # step 2 is decided by the first MOMENT m = 0.09 g1 + 0.1 g2, not by g2: where the two gradients nearly cancel the update's sign is noise
+    # (seen as a 1.2 x deviation in 2 of 8 runs when the elements were selected by |g2|), so select by |m|
+    ref_g2 = {k: tr2.opt.state[tr2.params[k]]["exp_avg"].cpu().numpy() for k in tr2.grads if tr2.params[k].grad is not None}
     worst2 = worst_param_deviation(npy(net.state_dict()), npy(tr2.state_dict()), mid, ref_g2)
     print(f"resumed from the module loop's checkpoint: worst parameter deviation of step 2 {worst2:.3e} of the tensor's own step")
     assert worst2 <= 5e-2
