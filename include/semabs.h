@@ -278,6 +278,9 @@ int semabs_gn_bwd_apply(const float* dXn, const float* X, const float* mean, con
 /* element-wise over n (% 4 == 0) floats: mode 0 out = a * (b > 0) (ReLU backward from the output), 1 LeakyReLU backward, 2 out = a + b,
  * 3 out = a * b[0] (b = device scalar); absmax_bits (optional, zeroed uint32) receives the bit pattern of max |out| */
 int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, unsigned int* absmax_bits, void* stream);
+/* modes 0 - 2 with a * in_scale[0] (device scalar) as the first operand: the "undo the dynamic gradient scale" pass folded into its consumer */
+int semabs_ew_scaled(const float* a, const float* b, const float* in_scale, float* out, long n, int mode, float slope, unsigned int* absmax_bits,
+                     void* stream);
 /* Dynamic power-of-two scale s for a gradient tensor (max |x| * s in [256, 512)) so the split-fp16 data-gradient convolutions keep fp32-like
  * accuracy for tiny gradients: scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits = uint32 scratch, or with
  * have_bits = 1 the max |x| pattern semabs_ew already produced (x is then not read) */
@@ -285,6 +288,9 @@ int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr
                       void* stream);
 /* MaxPool3d(2) backward: first maximal element of each window takes dY                                   unet3d.py:298-317 */
 int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, int B, int D0, int D1, int D2, int C, void* stream);
+/* + `add` (like dX: the skip connection's gradient) added on the way out, max |dX| -> absmax_bits (optional, zero it first): one pass less per level */
+int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, float* dX, unsigned int* absmax_bits, int B, int D0, int D1, int D2,
+                             int C, void* stream);
 
 /* Y[R, Co] = act(X[R, Ci] . W[Co, Ci]^T + bias), act 0 none / 1 LeakyReLU(slope): the point MLP and sampler MLP layers and, with W
  * transposed by the caller, their data gradients                                                         net.py:358-367, 300-309 */

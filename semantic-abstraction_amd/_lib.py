@@ -89,8 +89,10 @@ SIGNATURES = {
     "semabs_gn_bwd_coef": [P, P, P, P, P, P, P, I, I, I, L, P],
     "semabs_gn_bwd_apply": [P, P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     "semabs_ew": [P, P, P, L, I, F, P, P],
+    "semabs_ew_scaled": [P, P, P, P, L, I, F, P, P],
     "semabs_grad_scale": [P, L, P, P, I, P, P, I, P],
     "semabs_maxpool3d_bwd": [P, P, P, I, I, I, I, I, P],
+    "semabs_maxpool3d_bwd_add": [P, P, P, P, P, I, I, I, I, I, P],
     "semabs_linear_f32": [P, P, P, P, L, I, I, I, F, P],
     "semabs_scatter_mean_bwd": [P, P, P, P, I, L, I, L, P],
     "semabs_vool_sample": [P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P],

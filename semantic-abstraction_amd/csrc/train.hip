@@ -350,11 +350,12 @@ extern "C" int semabs_gn_bwd_apply(const float* dXn, const float* X, const float
 //   mode 3: out = a * b[0]                     (undo the dynamic gradient scale, b = device scalar)
 // =================================================================================================
 __global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ out, long n4, int mode, float slope,
-                     unsigned int* __restrict__ bits) {
+                     unsigned int* __restrict__ bits, const float* __restrict__ in_scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
-        const float4 d = ld_nt4(dY + i * 4);
+        float4 d = ld_nt4(dY + i * 4);
+        if (in_scale) { const float k = in_scale[0]; d.x *= k; d.y *= k; d.z *= k; d.w *= k; }     // the producer's dynamic gradient scale undone on the way in (a power of two: exact)
         if (mode == 3) { const float k = Y[0]; o = make_float4(d.x * k, d.y * k, d.z * k, d.w * k); }
         else {
             const float4 y = ld_nt4(Y + i * 4);
@@ -374,16 +375,27 @@ __global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, 
 extern "C" int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, unsigned int* absmax_bits, void* stream) {
     if (n == 0) return SEMABS_OK;
     SEMABS_REQUIRE(a && b && out && n % 4 == 0 && mode >= 0 && mode <= 3, "semabs_ew: bad args (n % 4 == 0)");
-    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits);
+    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits, (const float*)nullptr);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+// the same with the first operand multiplied by the device scalar in_scale[0] first (modes 0 - 2): folds the separate "undo the dynamic gradient
+// scale" pass (mode 3) of a data-gradient convolution's output into the element-wise pass that consumes it
+extern "C" int semabs_ew_scaled(const float* a, const float* b, const float* in_scale, float* out, long n, int mode, float slope, unsigned int* absmax_bits,
+                                void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(a && b && in_scale && out && n % 4 == 0 && mode >= 0 && mode <= 2, "semabs_ew_scaled: bad args (n % 4 == 0, mode 0..2)");
+    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits, in_scale);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
 
 // MaxPool3d(2) backward, channels-last fp32: the FIRST maximal element of each 2x2x2 window (scan order d, h, w) gets dY
-__global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX, int B, int O0, int O1, int O2, int C) {
+__global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX, int B, int O0, int O1, int O2, int C,
+                              const float* __restrict__ add, unsigned int* __restrict__ bits) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long tot = (long)B * O0 * O1 * O2 * C;
-    if (i >= tot) return;
+    if (i >= tot) { if (bits) absmax_commit(bits, 0.f); return; }      // (every lane takes part in the wave-level maximum)
     const int c = (int)(i % C); long v = i / C;
     const int o2 = (int)(v % O2); v /= O2;
     const int o1 = (int)(v % O1); v /= O1;
@@ -397,14 +409,32 @@ __global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restri
         if (x > best) { best = x; arg = d; }
     }
     const float g = dY[i];
+    float m = 0.f;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) dX[idx[d]] = (d == arg) ? g : 0.f;
+    for (int d = 0; d < 8; ++d) {
+        float o = (d == arg) ? g : 0.f;
+        if (add) o += add[idx[d]];                           // the skip connection's gradient (the pooled tensor is also a decoder input): one pass less
+        dX[idx[d]] = o;
+        m = fmaxf(m, fabsf(o));
+    }
+    if (bits) absmax_commit(bits, m);
 }
 extern "C" int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, int B, int D0, int D1, int D2, int C, void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && dY && dX && D0 % 2 == 0 && D1 % 2 == 0 && D2 % 2 == 0, "semabs_maxpool3d_bwd: bad args");
     const long tot = (long)B * (D0 / 2) * (D1 / 2) * (D2 / 2) * C;
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C);
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C,
+                       (const float*)nullptr, (unsigned int*)nullptr);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+// the same + `add` (like dX, e.g. the skip connection's gradient) added on the way out, and (optional) max |dX| -> absmax_bits (zero it first)
+extern "C" int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, float* dX, unsigned int* absmax_bits, int B, int D0, int D1,
+                                        int D2, int C, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(X && dY && add && dX && D0 % 2 == 0 && D1 % 2 == 0 && D2 % 2 == 0, "semabs_maxpool3d_bwd_add: bad args");
+    const long tot = (long)B * (D0 / 2) * (D1 / 2) * (D2 / 2) * C;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C, add, absmax_bits);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -258,16 +258,26 @@ class UNetTrainer:
         _lib.call("semabs_grad_scale", _lib.ptr(dz), dz.numel(), _lib.ptr(sc), _lib.ptr(sh), B * Cc, _lib.ptr(s2), _lib.ptr(bits), int(have), _lib.stream())
         return sc, sh, s2
 
+    def _unscale_by(self, a, inv):
+        out = torch.empty_like(a)
+        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(inv), _lib.ptr(out), a.numel(), 3, 0.0, None, _lib.stream())
+        return out
+
     def _unscale(self, a, s2):
         out = torch.empty_like(a)
         inv = s2[1:]
         _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(inv), _lib.ptr(out), a.numel(), 3, 0.0, None, _lib.stream())
         return out
 
-    def _ew(self, a, b, mode, want_max=False):
+    def _ew(self, a, b, mode, want_max=False, in_scale=None):
+        """in_scale (device scalar): a still carries a producer's dynamic gradient scale; multiply by in_scale[0] on the way in (saves the
+        separate un-scaling pass over a)."""
         out = torch.empty_like(a)
         bits = self.arena.zeros((1,), torch.int32) if want_max else None
-        _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.ptr(bits), _lib.stream())
+        if in_scale is not None:
+            _lib.call("semabs_ew_scaled", _lib.ptr(a), _lib.ptr(b), _lib.ptr(in_scale), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.ptr(bits), _lib.stream())
+        else:
+            _lib.call("semabs_ew", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.numel(), mode, SLOPE, _lib.ptr(bits), _lib.stream())
         if want_max:
             out._semabs_absmax = bits
         return out
@@ -306,14 +316,14 @@ class UNetTrainer:
             dX._semabs_absmax = bits
         return dX
 
-    def _block_bwd(self, recs, dOut):
+    def _block_bwd(self, recs, dOut, in_scale=None):
         r1, r2, r3 = recs
-        dS = self._ew(dOut, r3.y, 0, want_max=True)         # through the final ReLU of relu(conv3 + out1)
+        dS = self._ew(dOut, r3.y, 0, want_max=True, in_scale=in_scale)         # through the final ReLU of relu(conv3 + out1)
         dz2 = self._conv_bwd(r3, dS, relu_in=True)          # d out2, already through conv2's ReLU (r3.x = out2)
         dz1 = self._conv_bwd(r2, dz2, add1=dS, relu_in=True)   # d out1 = via conv2 + the residual branch, through conv1's ReLU
         return self._conv_bwd(r1, dz1)
 
-    def _up_bwd(self, pre: str, xin: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    def _up_bwd(self, pre: str, xin: torch.Tensor, g: torch.Tensor):
         """ConvTranspose3d k3 s2 p1 op1 backward: g = gradient w.r.t. its output [B, 2D, 2D, 2D, cout] -> gradient w.r.t. xin."""
         m = self.mats[pre]
         key = self.prefix + pre
@@ -327,7 +337,7 @@ class UNetTrainer:
         sc, sh, s2 = self._scale(g, B, cout)
         _lib.call("semabs_conv3d_gather", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh),
                   B, 2 * D0, 2 * D1, 2 * D2, D0, D1, D2, 2, cout, cin, 27, TAPS_CONV3, 1 | m["bwd"][2], st)
-        return self._unscale(dx, s2)
+        return dx, s2[1:]                                    # still scaled: the block that consumes it multiplies by 1 / s in its first pass
 
     def backward(self, tape, dy: torch.Tensor) -> torch.Tensor:
         """dy fp32 [B, S, S, S, Cout] -> gradient w.r.t. the UNet input; parameter gradients are accumulated into `grads`."""
@@ -335,6 +345,7 @@ class UNetTrainer:
         L = len(self.f_maps)
         d_skip: Dict[int, torch.Tensor] = {}
         g = dy.contiguous()
+        g_scale = None                                       # device scalar: g still carries a dynamic gradient scale (undone by its consumer)
         for item in reversed(tape):
             kind = item[0]
             if self.debug is not None:
@@ -352,20 +363,26 @@ class UNetTrainer:
                 sc, sh, s2 = self._scale(g, B, cout)
                 _lib.call("semabs_conv3d", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh), None, None,
                           B, D0, D1, D2, cout, cin, 1, 0, 1 | m["bwd"][2], st)
-                g = self._unscale(dx, s2)
+                g, g_scale = dx, s2[1:]
             elif kind == "block":
-                g = self._block_bwd(item[1:], g)
+                g = self._block_bwd(item[1:], g, in_scale=g_scale)
+                g_scale = None
             elif kind == "up":
                 _, pre, xin, level = item
+                assert g_scale is None
                 d_skip[level] = g                                   # y = skip + convT(x) + bias: the skip gets the same gradient
-                g = self._up_bwd(pre, xin, g)
+                g, g_scale = self._up_bwd(pre, xin, g)
             elif kind == "pool":
                 _, x, level = item                                  # x = output of encoder `level`, also used as a skip
+                assert g_scale is None
                 B, D0, D1, D2, Cc = x.shape
                 dx = torch.empty_like(x)
-                _lib.call("semabs_maxpool3d_bwd", _lib.ptr(x), _lib.ptr(g), _lib.ptr(dx), B, D0, D1, D2, Cc, st)
-                g = self._ew(dx, d_skip.pop(level), 2)
+                # route the gradient to the arg-max AND add the skip's gradient, in one pass
+                _lib.call("semabs_maxpool3d_bwd_add", _lib.ptr(x), _lib.ptr(g), _lib.ptr(d_skip.pop(level)), _lib.ptr(dx), None, B, D0, D1, D2, Cc, st)
+                g = dx
         assert not d_skip
+        if g_scale is not None:                              # (a network whose first tape entry is not a block)
+            g = self._unscale_by(g, g_scale)
         return g
 
 
@@ -456,7 +473,7 @@ class VOOLTrainer:
             sc, sh, s2 = u._scale(x, 1, Ci)
         _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(y), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(b), None,
                   1, 1, 1, R, Ci, Co, 1, 2 if act else 0, 1 | pk, _lib.stream())
-        return u._unscale(y, s2) if grad_in else y
+        return (y, s2[1:]) if grad_in else y                   # grad_in: still scaled; the caller's LeakyReLU-mask pass multiplies by 1 / s
 
     def _wgrad_linear(self, dOut, x, grad_w, cols=None):
         R, Co = dOut.shape
@@ -535,7 +552,8 @@ class VOOLTrainer:
             g["relation_embeddings." + n].add_(drel[d])
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
         u._colsum(dO, g[ss + "2.bias"])
-        dh = u._ew(self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True), h, 1)
+        y_, inv_ = self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True)
+        dh = u._ew(y_, h, 1, in_scale=inv_)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
@@ -550,10 +568,12 @@ class VOOLTrainer:
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
-        dh2 = u._ew(self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True), h2, 1)
+        y_, inv_ = self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True)
+        dh2 = u._ew(y_, h2, 1, in_scale=inv_)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
-        dh1 = u._ew(self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True), h1, 1)
+        y_, inv_ = self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True)
+        dh1 = u._ew(y_, h1, 1, in_scale=inv_)
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
 

@@ -89,7 +89,8 @@ def test_convtranspose_backward_strict():
     b = sd[pre + name + "bias"].clone().requires_grad_(True)
     xt = torch.from_numpy(x).requires_grad_(True)
     (torch.from_numpy(skip) + F.conv_transpose3d(xt, w, b, stride=2, padding=1, output_padding=1)).backward(torch.from_numpy(dy))
-    dx = u._up_bwd(name, _cl(x), _cl(dy))
+    dx, inv = u._up_bwd(name, _cl(x), _cl(dy))               # still carries the dynamic gradient scale; its consumer multiplies by inv[0]
+    dx = u._unscale_by(dx, inv)
     torch.cuda.synchronize()
     assert _rel(_uncl(dx), xt.grad.numpy()) < 1e-5
     assert _rel(grads[pre + name + "weight"].cpu().numpy(), w.grad.numpy()) < 1e-5
