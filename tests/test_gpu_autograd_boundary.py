@@ -145,7 +145,7 @@ def test_module_loop_equals_fused_trainer():
     ref_g2 = {k: tr2.opt.state[tr2.params[k]]["exp_avg"].cpu().numpy() for k in tr2.grads if tr2.params[k].grad is not None}
     worst2 = worst_param_deviation(npy(net.state_dict()), npy(tr2.state_dict()), mid, ref_g2)
     print(f"resumed from the module loop's checkpoint: worst parameter deviation of step 2 {worst2:.3e} of the tensor's own step")
-    assert worst2 <= 5e-2
+    assert worst2 <= 0.2                                     # measured 8e-4 .. 7.5e-2 over ten runs (the maximum over elements of a ratio of two noisy steps); a mis-mapped moment gives > 1
     # and the other way round: the trainer's checkpoint loads into an optimizer over net.parameters()
     opt_b = Lamb(net.parameters(), lr=1e-3, weight_decay=1e-5)
     opt_b.load_state_dict(copy.deepcopy(tr2.checkpoint()["optimizer"]))
