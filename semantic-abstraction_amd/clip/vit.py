@@ -95,9 +95,10 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, k
 _gemm = gemm
 
 
-def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5):
+def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5, order=0):
+    """order: 0 = rows in dispatch order, 1 / 2 = XCD-contiguous runs of rows walked forwards / backwards (the zigzag schedule of the trunk)."""
     _lib.call("semabs_layernorm", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out), int(M), int(D), float(eps),
-              int(out_f32), int(ld_in if ld_in is not None else D), _lib.stream())
+              int(out_f32) | (int(order) << 1), int(ld_in if ld_in is not None else D), _lib.stream())
 
 
 def add_layernorm(x, delta, gamma, beta, out, M, D, eps=1e-5):
@@ -183,6 +184,9 @@ class VisionRollout:
         self._wss = {}
         self._cap = {}           # tiles the workspace of each slot is sized for
         self.delta_residual = DELTA_RESIDUAL
+        # Zigzag schedule of the trunk: consecutive kernels walk the token rows in opposite directions (per XCD run), so each starts with the
+        # rows its producer wrote last - still in the 256 MiB Infinity Cache - instead of the ones written first (semabs_common.h)
+        self.zigzag = os.environ.get("SEMABS_ZIGZAG", "0") == "1"
         self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
@@ -229,14 +233,29 @@ class VisionRollout:
         M = n * T
         x, h, qkv, att, hid = ws["x"], ws["h"], ws["qkv"], ws["att"], ws["hid"]
         if not self.delta_residual:
+            zz = self.zigzag and M >= 2048
+            c = [0]
+
+            def step():                                      # direction of the next launch: 0 = forwards, 1 = backwards
+                c[0] ^= 1
+                return c[0] ^ 1
             for b in self.blocks[:-1]:
-                layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
-                gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16)
-                _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, 0, _lib.stream())
-                gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32)
-                layernorm(x, b.ln2_w, b.ln2_b, h, M, D)
-                gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
-                gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
+                if not zz:
+                    layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
+                    gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16)
+                    _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, 0, _lib.stream())
+                    gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32)
+                    layernorm(x, b.ln2_w, b.ln2_b, h, M, D)
+                    gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
+                    gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
+                    continue
+                layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=1 + step())
+                gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, kernel=2 | (step() << 8))
+                _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, (1 + step()) << 3, _lib.stream())
+                gemm(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32, kernel=2 | (step() << 8))
+                layernorm(x, b.ln2_w, b.ln2_b, h, M, D, order=1 + step())
+                gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16, kernel=2 | (step() << 8))
+                gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32, kernel=2 | (step() << 8))
             return
         # Residual updates as fp16 deltas: the out-proj / c_proj GEMMs write `delta = A W^T + b` in fp16 (a quarter of the bytes of the fp32
         # read-modify-write) and the following LayerNorm pass, which reads the row anyway, does x += delta before normalising.

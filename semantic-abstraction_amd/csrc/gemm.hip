@@ -30,6 +30,7 @@ struct GemmArgs {
     int g_in, g_out, g_off;     // EPI_ROWMAP_ADD_F32: out row = (m / g_in) * g_out + g_off + m % g_in
     int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
     int sc_w;                   // column panels per super-column of the raster (see tile_of in k_gemm8); 0 = all of them
+    int reverse;                // k_gemm8: every XCD walks its run of tiles backwards (zigzag with the producer of A, semabs_common.h)
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
@@ -361,11 +362,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 
     // block id -> output tile.  XCD-aware bijective remap (hardware places block b on XCD b % 8) + grouped rasterisation, as in k_gemm_f16.
     auto tile_of = [&](int vb, long& m0, int& n0) {
-        int b;
-        {
-            const int nb = g.n_blocks, q = nb >> 3, r = nb & 7, xcd = vb & 7, k = vb >> 3;
-            b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-        }
+        const int b = semabs_xcd_item(vb, g.n_blocks, g.reverse != 0);
         // super-columns: the column panels are walked sc_w at a time over ALL row panels, so that the sc_w weight panels of a super-column
         // (sc_w x 256 x K fp16) stay in the XCD's 4 MiB L2 for its whole pass while the activation panels stream through once per pass
         const int scw = g.sc_w > 0 && g.sc_w < g.n_tiles_n ? g.sc_w : g.n_tiles_n;
@@ -873,7 +870,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (epi > 1 || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
-    SEMABS_REQUIRE(kernel >= 0 && kernel <= 2, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased)");
+    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 9) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
@@ -883,7 +880,8 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         SEMABS_REQUIRE(rowmap3 && rowmap3[0] > 0, "semabs_gemm_f16: epi 4 needs rowmap");
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
-    g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0;
+    g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
+    kernel &= 255;
     GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {

@@ -48,3 +48,13 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Workgroup id -> work item with XCD locality and a direction.  The hardware places workgroup vb on XCD vb % 8; item ids are handed out so that
+// XCD x owns the contiguous run [lo_x, lo_x + cnt_x) of the nb items and walks it in dispatch order - forwards, or (reverse) backwards.
+// Consecutive kernels of a producer -> consumer chain alternate the direction ("zigzag"): a consumer then starts with the rows its producer
+// wrote LAST, which are still in the 256 MiB Infinity Cache (and partly in that XCD's L2), instead of with the rows written first.
+__device__ __forceinline__ int semabs_xcd_item(int vb, int nb, bool reverse) {
+    const int q = nb >> 3, r = nb & 7, x = vb & 7, k = vb >> 3;
+    const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+    return lo + (reverse ? cnt - 1 - k : k);
+}

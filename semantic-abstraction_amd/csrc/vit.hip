@@ -16,9 +16,11 @@
 // =================================================================================================
 template <int VPL, bool OUT_F32>   // VPL = float4 vectors per lane (D = 256 * VPL)
 __global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, void* __restrict__ out, long M, float eps) {
+                            const float* __restrict__ beta, void* __restrict__ out, long M, float eps, int order) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // order: 0 = rows in dispatch order; 1 / 2 = XCD-contiguous runs walked forwards / backwards (zigzag with the neighbouring GEMMs)
+    const long blk = order ? semabs_xcd_item((int)blockIdx.x, (int)gridDim.x, order == 2) : (long)blockIdx.x;
+    const long row = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
     const int D = 256 * VPL;
     const float* xr = x + row * ld_in;
@@ -124,10 +126,11 @@ extern "C" int semabs_layernorm(const float* x, const float* gamma, const float*
     SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024 && ld_in % 4 == 0, "semabs_layernorm: D must be 256..1024 step 256");
     dim3 grid(semabs_cdiv(M, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    const int order = (out_f32 >> 1) & 3;                   // bits 1-2 of out_f32: 0 dispatch order, 1 / 2 XCD-contiguous runs forwards / backwards
 #define LN_CASE(V)                                                                                              \
     case V:                                                                                                     \
-        if (out_f32) hipLaunchKernelGGL((k_layernorm<V, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps); \
-        else hipLaunchKernelGGL((k_layernorm<V, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps);        \
+        if (out_f32 & 1) hipLaunchKernelGGL((k_layernorm<V, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order); \
+        else hipLaunchKernelGGL((k_layernorm<V, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order);        \
         break;
     switch (D / 256) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) }
 #undef LN_CASE
@@ -164,7 +167,7 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((c
 
 template <int NKB, bool CAUSAL>   // number of 32-key blocks: TP = 32 * NKB
 __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out,
-                                                   float* __restrict__ stats, int T, int H, int ld, int D) {
+                                                   float* __restrict__ stats, int T, int H, int ld, int D, int order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = 32 * NKB;
     constexpr int VS = TP + 4;                    // V^T row stride (elements): keeps ds_read_b64 8-byte aligned
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
     constexpr int NWAVE = (NKB > 4) ? 8 : 4;        // one 32-query block per wave when there are more than 4 of them
     constexpr int NTHR = 64 * NWAVE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int seq = blockIdx.x / H, h = blockIdx.x % H;
+    const int wg = order ? semabs_xcd_item((int)blockIdx.x, (int)gridDim.x, order == 2) : (int)blockIdx.x;    // (see k_layernorm: zigzag order)
+    const int seq = wg / H, h = wg % H;
     const f16* base = qkv + (long)seq * T * ld + h * 64;
 
     // Staging: ALL of a thread's K / V rows are requested before the first LDS store (the loop used to alternate load - store, i.e. one
@@ -544,6 +548,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
     // LDS-DMA staging) removes every LDS bank conflict and 61 % of the LDS-active cycles (profiles/r03_pmc_attention_ab.json) but runs 12 %
     // SLOWER at the bench shape (797 / 803 vs 707 us per 2 448-tile launch): kept selectable per call for A/B, identical results.
     const bool legacy = (causal & 6) == 0;
+    const int order = (causal >> 3) & 3;                    // bits 3-4: 0 dispatch order, 1 / 2 XCD-contiguous runs of (sequence, head) forwards / backwards (k_attention only)
     const bool dma = (causal & 4) != 0 && (long)T * ld * 2 < (1L << 31);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(n_seq * H);
@@ -552,7 +557,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
         size_t lds = (size_t)(32 * N) * 128 + 64 * (32 * N + 4) * 2;                                                 \
         static bool set = false;                                                                                     \
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
-        hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
+        hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D, order); \
     }
 #define ATT2_LAUNCH(N, C, DM)                                                                                        \
     {                                                                                                                \
