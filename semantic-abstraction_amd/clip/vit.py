@@ -186,7 +186,7 @@ class VisionRollout:
         self.delta_residual = DELTA_RESIDUAL
         # Zigzag schedule of the trunk: consecutive kernels walk the token rows in opposite directions (per XCD run), so each starts with the
         # rows its producer wrote last - still in the 256 MiB Infinity Cache - instead of the ones written first (semabs_common.h)
-        self.zigzag = os.environ.get("SEMABS_ZIGZAG", "0") == "1"
+        self.zigzag = os.environ.get("SEMABS_ZIGZAG", "1") == "1"
         self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
