@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 // One tap, 16 x 16 outputs, millions of rows (the final 1x1x1 convolution: dW[16][16] += sum_r g[r][:]^T x[r][:] over 16.7 M voxels): a pure
 // streaming reduction.  The tiled kernel above took 1.82 ms for it (every row chunk goes through LDS for 256 outputs); here a lane pair owns
 // a row - lane parity h takes output rows 8 h .. 8 h + 7, i.e. 8 x 16 accumulators in registers - reads its 96 bytes with 16-byte loads (a wave
-// covers 32 consecutive rows of both operands), and the partial sums meet in a wave reduction + one fp32 atomic per output per wave.
+// covers 32 consecutive rows of both operands), and the partial sums meet in a wave reduction, an LDS reduction over the four waves and one fp32 atomic per output per workgroup.
 __global__ __launch_bounds__(256) void k_wgrad_rows16(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ dW, long R) {
     const int h = threadIdx.x & 1;
     float acc[8][16];
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_wgrad_rows16(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[i][j] += av[i] * xv[j];
     }
+    __shared__ float sred[4][256];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -165,8 +166,11 @@ __global__ __launch_bounds__(256) void k_wgrad_rows16(const float* __restrict__ 
             float v = acc[i][j];
 #pragma unroll
             for (int o = 2; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);      // over the 32 lanes of the same parity
-            if ((threadIdx.x & 63) < 2) atomicAdd(&dW[(h * 8 + i) * 16 + j], v);
+            if ((threadIdx.x & 63) < 2) sred[threadIdx.x >> 6][(h * 8 + i) * 16 + j] = v;
         }
+    __syncthreads();
+    // one atomic per output per WORKGROUP (per wave it was 2 M atomics on 256 addresses: 3.6 ms of serialised read-modify-writes)
+    atomicAdd(&dW[threadIdx.x], (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]));
 }
 
 extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0,
@@ -183,7 +187,7 @@ extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scal
     const long R = (long)B * M0 * M1 * M2;
     if (ntaps == 1 && Ca == 16 && Cx == 16 && !gn_scale && in_stride == 1 && taps[0] == 0 && taps[1] == 0 && taps[2] == 0 && I0 == M0 && I1 == M1 &&
         I2 == M2 && R >= (1L << 18)) {
-        int nb = semabs_cdiv(R, 128 * 64); if (nb > 2048) nb = 2048;
+        int nb = semabs_cdiv(R, 128 * 64); if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(k_wgrad_rows16, dim3(nb), dim3(256), 0, (hipStream_t)stream, A, X, dW, R);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
