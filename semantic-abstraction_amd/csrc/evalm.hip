@@ -32,7 +32,7 @@ extern "C" int semabs_voxelize_eval(const long long* flat, const unsigned char* 
     if (BP == 0) return SEMABS_OK;
     SEMABS_REQUIRE(flat && pred && label && ignore && vol_scratch && out_pred && out_label && out_ignore && N >= 0 && nvox > 0, "semabs_voxelize_eval: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(vol_scratch, 0, sizeof(int) * 3 * BP * nvox, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    semabs_fill32(vol_scratch, sizeof(int) * 3 * BP * nvox, 0u, s);
     if (N > 0) hipLaunchKernelGGL(k_voxelize_eval, dim3(semabs_cdiv(BP * N, 256)), dim3(256), 0, s, flat, pred, label, ignore, vol_scratch, BP, N, nvox);
     hipLaunchKernelGGL(k_voxelize_finish, dim3(semabs_cdiv(BP * nvox, 256)), dim3(256), 0, s, vol_scratch, out_pred, out_label, out_ignore, BP * nvox);
     SEMABS_CHECK_LAUNCH();
@@ -67,7 +67,7 @@ extern "C" int semabs_prediction_counts(const unsigned char* pred, const unsigne
     if (BP == 0) return SEMABS_OK;
     SEMABS_REQUIRE(pred && label && ignore && counts && M >= 0 && BP < 65536, "semabs_prediction_counts: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 6 * BP, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    semabs_fill32(counts, sizeof(unsigned long long) * 6 * BP, 0u, s);
     if (M > 0) {
         int bx = semabs_cdiv(M, 256 * 8); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
         hipLaunchKernelGGL(k_pred_counts, dim3(bx, (unsigned)BP), dim3(256), 0, s, pred, label, ignore, counts, M);

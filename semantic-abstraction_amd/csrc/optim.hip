@@ -71,7 +71,7 @@ extern "C" int semabs_lamb_step(const long long* chunks, int n_chunks, const lon
     hipStream_t s = (hipStream_t)stream;
     // the reference forms 1 - beta in python doubles and lets torch cast the scalar to fp32
     LambHyper h{(float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay};
-    if (hipMemsetAsync(norms, 0, sizeof(double) * 2 * n_tensors, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    semabs_fill32(norms, sizeof(double) * 2 * n_tensors, 0u, s);
     hipLaunchKernelGGL(k_lamb_moments, dim3(n_chunks), dim3(256), 0, s, chunks, ptrs, n_tensors, h, norms);
     hipLaunchKernelGGL(k_lamb_apply, dim3(n_chunks), dim3(256), 0, s, chunks, ptrs, n_tensors, h, norms, stats, adam);
     SEMABS_CHECK_LAUNCH();

@@ -58,3 +58,15 @@ __device__ __forceinline__ int semabs_xcd_item(int vb, int nb, bool reverse) {
     const int lo = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
     return lo + (reverse ? cnt - 1 - k : k);
 }
+
+// Fill nbytes (a multiple of 4, pointer 4-byte aligned) with a 32-bit pattern.  A kernel launch, not hipMemsetAsync: on this runtime a memset
+// queued between kernels costs ~1.5 ms of stream time (measured on the 4-byte fill of semabs_grad_scale: 78.8 -> 77.1 ms per training step).
+static __global__ __launch_bounds__(256) void semabs_k_fill32(unsigned int* __restrict__ p, long n, unsigned int v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+static inline void semabs_fill32(void* p, size_t nbytes, unsigned int v, hipStream_t s) {
+    const long n = (long)(nbytes / 4);
+    if (n == 0) return;
+    long nb = (n + 1023) / 1024; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(semabs_k_fill32, dim3((unsigned)nb), dim3(256), 0, s, (unsigned int*)p, n, v);
+}

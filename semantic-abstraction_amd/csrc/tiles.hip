@@ -342,7 +342,7 @@ extern "C" int semabs_color_jitter(unsigned char* img, int H, int W, const int* 
         const int op = order4[k];
         SEMABS_REQUIRE(op >= 0 && op < 4, "semabs_color_jitter: op must be 0..3");
         if (op == 1) {
-            if (hipMemsetAsync(scratch8, 0, 8, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+            semabs_fill32(scratch8, 8, 0u, s);
             hipLaunchKernelGGL(k_grey_sum, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, n, (unsigned long long*)scratch8);
         }
         hipLaunchKernelGGL(k_jitter_op, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, img, n, op, factors4[op],

@@ -294,7 +294,10 @@ extern "C" int semabs_chan_reduce(const float* dY, const float* X, const float* 
     if (B == 0 || nvox == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dY && out && C % 4 == 0 && C <= 512 && (!X || (mean && rstd && G > 0 && C % G == 0)), "semabs_chan_reduce: bad args");
     long chunks = nvox * (C / 4);
-    int bx = semabs_cdiv(chunks, 256 * 16); if (bx < 1) bx = 1; if (bx > 128) bx = 128;
+    // ~2048 workgroups in all (8 per CU keep enough loads in flight; 128 x B left half the chip idle for the B = 1 bias-gradient sums:
+    // 0.84 ms for 1 GB); every workgroup ends with 2 C fp64 atomics
+    int cap = 2048 / B; if (cap < 16) cap = 16;
+    int bx = semabs_cdiv(chunks, 256 * 16); if (bx < 1) bx = 1; if (bx > cap) bx = cap;
     hipLaunchKernelGGL(k_chan_reduce, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, dY, X, mean, rstd, out, nvox, C, G > 0 ? G : 1);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
@@ -661,7 +664,7 @@ extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const
     SampArgs a; fill_samp(a, off3, sc3, shape3);
     hipStream_t s = (hipStream_t)stream;
     const long nvox = (long)a.S0 * a.S1 * a.S2;
-    if (hipMemsetAsync(head, 0xff, sizeof(int) * P * nvox, s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    semabs_fill32(head, sizeof(int) * P * nvox, 0xffffffffu, s);
     if (M > 0) hipLaunchKernelGGL(k_vool_cells, dim3(semabs_cdiv((long)P * M, 256)), dim3(256), 0, s, query, a, P, M, head, next);
     hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * nvox * 2, 256)), dim3(256), 0, s, df, query, a, P, M, head, next, dvol_t, dvol_r);
     SEMABS_CHECK_LAUNCH();
@@ -787,13 +790,14 @@ __global__ void k_scale_fill(const unsigned int* __restrict__ bits, float* __res
     if (i == 0) { s2[0] = s; s2[1] = 1.f / s; }
 }
 // x fp32 [n] (n % 4 == 0) -> scale_arr[n_arr] = s, shift_arr[n_arr] = 0 (the conv's input affine), s2 = (s, 1 / s); bits: uint32 scratch, or
-// (have_bits = 1) the max |x| bit pattern already produced by semabs_ew, in which case x is not read again
+// (have_bits = 1) the max |x| bit pattern already produced by semabs_ew, in which case x is not read again; have_bits = 2: bits is already zero
+// (sub-allocated from the step's zeroed arena), so no memset is queued
 extern "C" int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr, int n_arr, float* s2, unsigned int* bits, int have_bits,
                                  void* stream) {
-    SEMABS_REQUIRE(scale_arr && shift_arr && s2 && bits && n_arr > 0 && (have_bits || (x && n > 0 && n % 4 == 0)), "semabs_grad_scale: bad args");
+    SEMABS_REQUIRE(scale_arr && shift_arr && s2 && bits && n_arr > 0 && (have_bits == 1 || (x && n > 0 && n % 4 == 0)), "semabs_grad_scale: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (!have_bits) {
-        if (hipMemsetAsync(bits, 0, sizeof(unsigned int), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    if (have_bits != 1) {
+        if (!have_bits) semabs_fill32(bits, sizeof(unsigned int), 0u, s);
         int bx = semabs_cdiv(n / 4, 256 * 8); if (bx > 2048) bx = 2048;
         hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, x, n / 4, bits);
     }
@@ -833,7 +837,7 @@ extern "C" int semabs_clip_grad_norm(const long long* chunks, int n_chunks, cons
     if (n_chunks == 0) return SEMABS_OK;
     SEMABS_REQUIRE(chunks && ptrs && sq && max_norm > 0.f, "semabs_clip_grad_norm: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sq, 0, sizeof(double), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+    semabs_fill32(sq, sizeof(double), 0u, s);
     hipLaunchKernelGGL(k_grad_sqsum, dim3(n_chunks), dim3(256), 0, s, chunks, ptrs, n_tensors, sq);
     hipLaunchKernelGGL(k_grad_scale, dim3(n_chunks), dim3(256), 0, s, chunks, ptrs, n_tensors, sq, max_norm, extra_scale);
     SEMABS_CHECK_LAUNCH();

@@ -1488,7 +1488,7 @@ static int conv_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
         if (ks > 27) ks = 27;
         if (ks >= 3) {
             a.ksplit = ks;
-            if (hipMemsetAsync(a.y, 0, (size_t)Mtot * a.Cout * sizeof(float), s) != hipSuccess) { semabs_set_error("hipMemsetAsync failed"); return SEMABS_EHIP; }
+            semabs_fill32(a.y, (size_t)Mtot * a.Cout * sizeof(float), 0u, s);
             dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / 64, ks), block(256);
             hipLaunchKernelGGL((k_conv<4, true, false, true>), grid, block, 0, s, a);
             const long n4 = Mtot * a.Cout / 4;

@@ -252,10 +252,10 @@ class UNetTrainer:
         sh = torch.empty_like(sc)
         s2 = torch.empty(2, dtype=torch.float32, device=self.dev)
         bits = getattr(dz, "_semabs_absmax", None)
-        have = bits is not None
-        if not have:
-            bits = torch.empty(1, dtype=torch.int32, device=self.dev)
-        _lib.call("semabs_grad_scale", _lib.ptr(dz), dz.numel(), _lib.ptr(sc), _lib.ptr(sh), B * Cc, _lib.ptr(s2), _lib.ptr(bits), int(have), _lib.stream())
+        have = 1
+        if bits is None:
+            bits, have = self.arena.zeros((1,), torch.int32), 2
+        _lib.call("semabs_grad_scale", _lib.ptr(dz), dz.numel(), _lib.ptr(sc), _lib.ptr(sh), B * Cc, _lib.ptr(s2), _lib.ptr(bits), have, _lib.stream())
         return sc, sh, s2
 
     def _unscale_by(self, a, inv):

@@ -86,6 +86,12 @@ if "base" in what:
             tune(3, pf)
             log[f"base_pf{pf}_{rep}"] = line(f"fragment prefetch {pf} (rep {rep})")
     tune(3, 1)
+if "cfgs" in what:
+    for rep in range(2):
+        for c in (0, 7, 4, 5):
+            tune(0, c)
+            log[f"cfg{c}_{rep}"] = line(f"ring-kernel configuration {c} (0 = production) rep {rep}")
+    tune(0, 0)
 if "persist" in what:
     for rep in range(2):
         for ps in (0, 1):
