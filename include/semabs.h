@@ -258,6 +258,15 @@ int semabs_conv3d_gather(const void* x, const void* w_hi, const void* w_lo, void
 int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0, int M1, int M2,
                  int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps, int tap_minor, void* stream);
 
+/* semabs_wgrad on the matrix cores (split fp16 operands = fp32-like accuracy, transposing LDS reads) for the shapes semabs_wgrad_conv3 does not
+ * take: the 8^3 / 4^3 levels, ConvTranspose3d (stride 2), Linear.  Additionally Cx % 16 == 0 and fewer than 2^31 - 64 rows.  sA2 / sX2 =
+ * (s, 1 / s) device scalars of semabs_grad_scale for the operand that is a gradient, or NULL.  scratch (scratch_floats fp32) or NULL: room for
+ * the row chunks' partial sums - with it they are combined by a second deterministic pass, without it by fp32 atomics.  Replaces the weight-gradient half of
+ * loss.backward() for these layers (reference: train_vool.py / utils.py loop -> torch autograd of unet3d.py:63-118, 296-331). */
+int semabs_wgrad_mfma(const float* A, const float* X, const float* gn_scale, const float* gn_shift, const float* sA2, const float* sX2, float* dW,
+                      int B, int M0, int M1, int M2, int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps,
+                      int tap_minor, float* scratch, long scratch_floats, void* stream);
+
 /* The same for Conv3d 3x3x3 on MFMA (split fp16, LDS-transposed 4 x 8 x 16 bricks): dW[ca][tap * Cx + cx] += sum_vox dZ[vox][ca] * GN(X)[vox + tap][cx].
  * s2 = (s, 1 / s) of semabs_grad_scale(dZ) or NULL.  Needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0, Ca % 16 == 0, Cx % 16 == 0. */
 int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B, int D0,

@@ -83,6 +83,7 @@ SIGNATURES = {
     # training step (train.hip, unet.hip)
     "semabs_conv3d_gather": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],
     "semabs_wgrad": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P],
+    "semabs_wgrad_mfma": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P, L, P],
     "semabs_wgrad_conv3": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "semabs_chan_reduce": [P, P, P, P, P, I, L, I, I, P],
     "semabs_gn_meanrstd": [P, P, P, I, I, L, F, P],

@@ -209,6 +209,233 @@ extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scal
 }
 
 // =================================================================================================
+// The same reduction on the matrix cores (split fp16: Ahi Xhi + Ahi Xlo + Alo Xhi, fp32 accumulate) for the shapes the brick kernel
+// (k_wgrad16_lds) does not take: the 8^3 / 4^3 levels, the transposed convolutions (stride 2) and the linear layers.  The contraction runs
+// over ROWS, which is the slow index of both operands in memory, so a 32-row batch of A [rows][16 CAB channels] and of the gathered
+// X [rows][16 n-blocks of 16 (tap, cx) columns] goes through LDS in its natural row-major form - planes of [32 rows][16 channels] fp16,
+// 32 B per row - and the fragments come back through the transposing LDS read (ds_read_b64_tr_b16: the 16 lanes of a group address a
+// [4 rows][16 channels] block and each receives one channel's 4 rows).  Which rows form a lane's 8 k values is free as long as both
+// operands agree: k group g takes rows 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3, so a half wave reads 8 consecutive rows = 256
+// contiguous bytes of a plane (conflict-free), and the plane pitch of 1088 B spreads the 8-byte staging stores over all banks.
+// Workgroup = 4 waves: tile CAB x 16 output channels x 16 n-blocks, wave w owns n-blocks 4 w .. 4 w + 3; the global loads of batch i + 1 are
+// in flight while batch i is multiplied; row chunks meet in fp32 atomics.  Gradient operands arrive with their dynamic power-of-two scale
+// (sA2 / sX2 = (s, 1 / s) device scalars or null): multiplied by s on the way into fp16, the sums by 1 / s on the way out.
+// =================================================================================================
+struct WgradMArgs {
+    const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* sA2; const float* sX2; float* dW;
+    float* part;                // row-chunk partial sums [chunk][Ca][npad] (reduced by k_wgrad_mfma_reduce), or null: fp32 atomics on dW
+    int B, M0, M1, M2, I0, I1, I2, is, Ca, Cx, ntaps, tap_minor, npad;
+    unsigned R, rows_per_block;
+    signed char td0[28], td1[28], td2[28];
+};
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+
+template <int CAB>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradMArgs a) {
+    constexpr int PP = 1088;                                // plane pitch (bytes)
+    constexpr int NA = (CAB * 128 + 255) / 256;             // float4 of A per thread per batch
+    __shared__ __attribute__((aligned(16))) char sA[2][CAB * PP];      // [hi / lo][channel block][32 rows][16 channels] fp16
+    __shared__ __attribute__((aligned(16))) char sX[2][16 * PP];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ca0 = blockIdx.y * CAB * 16, nb0 = blockIdx.z * 16;
+    const int cpb = a.Cx >> 4, NB = a.ntaps * cpb;
+    const unsigned r_begin = blockIdx.x * a.rows_per_block;
+    unsigned r_end = r_begin + a.rows_per_block; if (r_end > a.R) r_end = a.R;
+    const float sa = a.sA2 ? a.sA2[0] : 1.f, sx = a.sX2 ? a.sX2[0] : 1.f;
+
+    // X slots of this thread: row xr of the batch, quarter xq of n-blocks 2 i + (xs >> 2), i = 0 .. 7
+    const int xr = t >> 3, xs = t & 7, xq = xs & 3;
+    int xtd[8], xcx[8];                                     // packed tap offsets, first channel (-1: past the last n-block)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int nb = nb0 + 2 * i + (xs >> 2);
+        xtd[i] = 0; xcx[i] = -1;
+        if (nb < NB) {
+            const int tap = nb / cpb;
+            xcx[i] = (nb - tap * cpb) * 16 + xq * 4;
+            xtd[i] = (a.td0[tap] & 0xff) | ((a.td1[tap] & 0xff) << 8) | ((a.td2[tap] & 0xff) << 16);
+        }
+    }
+    float4 pa[NA], px[8];
+    auto fetch = [&](unsigned rb) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int e = t + k * 256, rr = e / (CAB * 4), q = e % (CAB * 4);
+            const unsigned row = rb + rr;
+            pa[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < CAB * 128 && row < r_end) pa[k] = *reinterpret_cast<const float4*>(a.A + (long)row * a.Ca + ca0 + q * 4);
+        }
+        const unsigned row = rb + xr;
+        unsigned m = row;
+        const int m2 = (int)(m % (unsigned)a.M2); m /= (unsigned)a.M2;
+        const int m1 = (int)(m % (unsigned)a.M1); m /= (unsigned)a.M1;
+        const int m0 = (int)(m % (unsigned)a.M0); const int b = (int)(m / (unsigned)a.M0);
+        const int j0 = m0 * a.is, j1 = m1 * a.is, j2 = m2 * a.is;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r_end && xcx[i] >= 0) {
+                const int i0 = j0 + (int)(signed char)(xtd[i] & 0xff), i1 = j1 + (int)(signed char)((xtd[i] >> 8) & 0xff),
+                          i2 = j2 + (int)(signed char)((xtd[i] >> 16) & 0xff);
+                if (i0 >= 0 && i0 < a.I0 && i1 >= 0 && i1 < a.I1 && i2 >= 0 && i2 < a.I2) {
+                    v = *reinterpret_cast<const float4*>(a.X + ((((long)b * a.I0 + i0) * a.I1 + i1) * a.I2 + i2) * a.Cx + xcx[i]);
+                    if (a.gn_scale) {
+                        const float4 sc = *reinterpret_cast<const float4*>(a.gn_scale + (long)b * a.Cx + xcx[i]);
+                        const float4 sh = *reinterpret_cast<const float4*>(a.gn_shift + (long)b * a.Cx + xcx[i]);
+                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    }
+                }
+            }
+            px[i] = v;
+        }
+    };
+    auto split_store = [&](float4 v, float s, char* hi, char* lo) {
+        const float f[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (f16)f[e]; l[e] = (f16)(f[e] - (float)h[e]); }
+        *reinterpret_cast<f16x4*>(hi) = h; *reinterpret_cast<f16x4*>(lo) = l;
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int e = t + k * 256, rr = e / (CAB * 4), q = e % (CAB * 4);
+            if (e < CAB * 128) { const int o = (q >> 2) * PP + rr * 32 + (q & 3) * 8; split_store(pa[k], sa, sA[0] + o, sA[1] + o); }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int o = (2 * i + (xs >> 2)) * PP + xr * 32 + xq * 8; split_store(px[i], sx, sX[0] + o, sX[1] + o); }
+    };
+    const int g16 = lane >> 4, li = lane & 15;
+    const int fo = (g16 * 4 + (li >> 2)) * 32 + (li & 3) * 8;
+    auto frag = [&](const char* plane) -> f16x8 {
+        const wg_s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3)))*)(plane + fo));
+        const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3)))*)(plane + fo + 512));
+        const f16x4 fu = __builtin_bit_cast(f16x4, u), fv = __builtin_bit_cast(f16x4, v);
+        f16x8 r;
+        r[0] = fu[0]; r[1] = fu[1]; r[2] = fu[2]; r[3] = fu[3]; r[4] = fv[0]; r[5] = fv[1]; r[6] = fv[2]; r[7] = fv[3];
+        return r;
+    };
+    f32x4 acc[CAB][4];
+#pragma unroll
+    for (int c = 0; c < CAB; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool active = nb0 + w * 4 < NB;                   // wave-uniform: this wave has columns to compute
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (unsigned rb = r_begin; rb < r_end; rb += 32) {
+        store();
+        __syncthreads();
+        if (rb + 32 < r_end) fetch(rb + 32);
+        if (active) {
+            f16x8 ah[CAB], al[CAB];
+#pragma unroll
+            for (int c = 0; c < CAB; ++c) { ah[c] = frag(sA[0] + c * PP); al[c] = frag(sA[1] + c * PP); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x8 xh = frag(sX[0] + (w * 4 + j) * PP), xl = frag(sX[1] + (w * 4 + j) * PP);
+#pragma unroll
+                for (int c = 0; c < CAB; ++c) {
+                    acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], xh, acc[c][j], 0, 0, 0);
+                    acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], xl, acc[c][j], 0, 0, 0);
+                    acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], xh, acc[c][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const float os = (a.sA2 ? a.sA2[1] : 1.f) * (a.sX2 ? a.sX2[1] : 1.f);
+    const int N = a.ntaps * a.Cx;
+    if (a.part) {                                           // plain 64-byte-run stores of this row chunk's tile; summed (and laid out) by the reduce pass
+        float* dst = a.part + (long)blockIdx.x * a.Ca * a.npad;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < CAB; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[(long)(ca0 + c * 16 + g16 * 4 + r) * a.npad + (nb0 + w * 4 + j) * 16 + li] = acc[c][j][r] * os;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nb = nb0 + w * 4 + j;
+        if (nb >= NB) break;
+        const int tap = nb / cpb, cx = (nb - tap * cpb) * 16 + li;
+#pragma unroll
+        for (int c = 0; c < CAB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ca = ca0 + c * 16 + g16 * 4 + r;
+                const long idx = a.tap_minor ? ((long)ca * a.Cx + cx) * a.ntaps + tap : (long)ca * N + tap * a.Cx + cx;
+                if (gridDim.x == 1) a.dW[idx] += acc[c][j][r] * os;       // the only workgroup with this tile
+                else atomicAdd(&a.dW[idx], acc[c][j][r] * os);
+            }
+    }
+}
+// dW[layout(ca, n)] += sum_chunks part[chunk][ca][n]   (thread = one (ca, n): reads are coalesced over n, 4 partial sums in flight)
+__global__ __launch_bounds__(256) void k_wgrad_mfma_reduce(const float* __restrict__ part, float* __restrict__ dW, int chunks, int Ca, int N, int npad,
+                                                           int Cx, int ntaps, int tap_minor) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)Ca * N) return;
+    const int ca = (int)(e / N), n = (int)(e - (long)ca * N);
+    const float* p = part + (long)ca * npad + n;
+    const long cs = (long)Ca * npad;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= chunks; c += 4) { s0 += p[c * cs]; s1 += p[(c + 1) * cs]; s2 += p[(c + 2) * cs]; s3 += p[(c + 3) * cs]; }
+    for (; c < chunks; ++c) s0 += p[c * cs];
+    const int tap = n / Cx, cx = n - tap * Cx;
+    const long idx = tap_minor ? ((long)ca * Cx + cx) * ntaps + tap : e;
+    dW[idx] += (s0 + s1) + (s2 + s3);
+}
+
+// semabs_wgrad on the matrix cores; additionally Cx % 16 == 0, fewer than 2^31 rows.  sA2 / sX2: (s, 1 / s) of semabs_grad_scale for the operand that
+// is a gradient (A for Conv3d / Linear, X for ConvTranspose3d), or NULL.  scratch (scratch_floats fp32, or NULL): room for the row chunks'
+// partial tiles - with it the chunks are combined by a second, deterministic pass instead of fp32 atomics (measured at 16 G atomics / s on
+// scattered addresses: the 8^3 level's 12 M atomics took 0.6 of its 0.75 ms).
+extern "C" int semabs_wgrad_mfma(const float* A, const float* X, const float* gn_scale, const float* gn_shift, const float* sA2, const float* sX2,
+                                 float* dW, int B, int M0, int M1, int M2, int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps,
+                                 const signed char* taps, int tap_minor, float* scratch, long scratch_floats, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(A && X && dW && taps, "semabs_wgrad_mfma: null pointer");
+    SEMABS_REQUIRE(Ca % 16 == 0 && Cx % 16 == 0 && ntaps >= 1 && ntaps <= 28, "semabs_wgrad_mfma: Ca % 16, Cx % 16, 1 <= ntaps <= 28");
+    SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_mfma: gn_scale and gn_shift go together");
+    const long R = (long)B * M0 * M1 * M2;
+    SEMABS_REQUIRE(R > 0 && R < (1L << 31) - 64, "semabs_wgrad_mfma: row count out of range");
+    WgradMArgs a;
+    a.A = A; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.sA2 = sA2; a.sX2 = sX2; a.dW = dW;
+    a.B = B; a.M0 = M0; a.M1 = M1; a.M2 = M2; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.is = in_stride; a.Ca = Ca; a.Cx = Cx; a.ntaps = ntaps;
+    a.tap_minor = tap_minor; a.R = (unsigned)R;
+    for (int i = 0; i < ntaps; ++i) { a.td0[i] = taps[i * 3]; a.td1[i] = taps[i * 3 + 1]; a.td2[i] = taps[i * 3 + 2]; }
+    const int CAB = (Ca % 64 == 0) ? 4 : (Ca % 32 == 0 ? 2 : 1);
+    const int ytiles = Ca / (16 * CAB), ztiles = semabs_cdiv((long)ntaps * (Cx / 16), 16);
+    a.npad = ztiles * 256;
+    // row chunks: ~1024 workgroups in all, at least 128 rows each
+    long chunks = 1024 / ((long)ytiles * ztiles); if (chunks < 1) chunks = 1;
+    const long tile_floats = (long)Ca * a.npad;
+    if (scratch && chunks > scratch_floats / tile_floats) chunks = scratch_floats / tile_floats;
+    if (chunks < 1) chunks = 1;
+    long rpb = (R + chunks - 1) / chunks; if (rpb < 128) rpb = 128;
+    rpb = (rpb + 31) / 32 * 32;
+    a.rows_per_block = (unsigned)rpb;
+    chunks = semabs_cdiv(R, rpb);
+    a.part = (scratch && chunks > 1 && chunks * tile_floats <= scratch_floats) ? scratch : nullptr;
+    dim3 grid((unsigned)chunks, ytiles, ztiles);
+    hipStream_t s = (hipStream_t)stream;
+    if (CAB == 4) hipLaunchKernelGGL(k_wgrad_mfma<4>, grid, dim3(256), 0, s, a);
+    else if (CAB == 2) hipLaunchKernelGGL(k_wgrad_mfma<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_wgrad_mfma<1>, grid, dim3(256), 0, s, a);
+    if (a.part)
+        hipLaunchKernelGGL(k_wgrad_mfma_reduce, dim3(semabs_cdiv((long)Ca * ntaps * Cx, 256)), dim3(256), 0, s, a.part, dW, (int)chunks, Ca, ntaps * Cx,
+                           a.npad, Cx, ntaps, tap_minor);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
 // Per-step weight layouts in ONE launch per matrix: out_hi / out_lo[i] = fp16 hi / lo split of src[idx[i]] (idx < 0: zero padding).
 // The MFMA kernels read every convolution / linear weight as split-fp16 matrices in their own layouts (tap-major rows, flipped + transposed
 // for the data gradient, parity-class matrices of the transposed convolution, each followed by its fragment-packed copy); the weights change

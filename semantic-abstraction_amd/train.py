@@ -116,6 +116,7 @@ class UNetTrainer:
         self.plan = unet_layer_plan(in_channels, out_channels, self.f_maps[0], len(self.f_maps))
         self.mats: Dict[str, dict] = {}
         self.dev = _lib.require_gpu()
+        self._wgs = None
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
         self.arena = _ZeroArena(self.dev)
@@ -245,6 +246,12 @@ class UNetTrainer:
         _lib.call("semabs_chan_reduce", _lib.ptr(a2d), None, None, None, _lib.ptr(red), 1, R, Cc, 1, _lib.stream())
         grad.add_(red[0, :, 0].float())
 
+    def _wg_scratch(self):
+        """(pointer, capacity in floats) of the buffer semabs_wgrad_mfma parks its row chunks' partial sums in (64 MB, allocated once)."""
+        if self._wgs is None:
+            self._wgs = torch.empty(16 << 20, dtype=torch.float32, device=self.dev)
+        return _lib.ptr(self._wgs), self._wgs.numel()
+
     def _scale(self, dz: torch.Tensor, B: int, Cc: int):
         """Dynamic power-of-two scale of a gradient tensor (csrc/train.hip, semabs_grad_scale): -> (scale_arr, shift_arr, s2).
         When dz came out of `_ew(..., want_max=True)` its max |.| is already known and the tensor is not read again."""
@@ -297,6 +304,9 @@ class UNetTrainer:
         if D0 % 4 == 0 and D1 % 8 == 0 and D2 % 16 == 0 and self.mfma_wgrad:
             _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
                       B, D0, D1, D2, cout, cin, 1, st)
+        elif cin % 16 == 0 and self.mfma_wgrad:                  # 8^3 / 4^3 levels: rows through LDS, transposing reads (k_wgrad_mfma)
+            _lib.call("semabs_wgrad_mfma", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), None, _lib.ptr(dW),
+                      B, D0, D1, D2, D0, D1, D2, 1, cout, cin, 27, TAPS_CONV3, 1, *self._wg_scratch(), st)
         else:
             _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
                       cout, cin, 27, TAPS_CONV3, 1, st)
@@ -331,10 +341,14 @@ class UNetTrainer:
         B, D0, D1, D2, cin = xin.shape
         cout = m["cout"]
         self._colsum(g.view(-1, cout), self.g[key + "bias"])
-        _lib.call("semabs_wgrad", _lib.ptr(xin), _lib.ptr(g), None, None, _lib.ptr(self.g[key + "weight"]), B, D0, D1, D2, 2 * D0, 2 * D1, 2 * D2, 2,
-                  cin, cout, 27, TAPS_CONV3, 1, st)                      # [cin, cout, 3, 3, 3] directly
-        dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
         sc, sh, s2 = self._scale(g, B, cout)
+        if cout % 16 == 0 and self.mfma_wgrad:
+            _lib.call("semabs_wgrad_mfma", _lib.ptr(xin), _lib.ptr(g), None, None, None, _lib.ptr(s2), _lib.ptr(self.g[key + "weight"]),
+                      B, D0, D1, D2, 2 * D0, 2 * D1, 2 * D2, 2, cin, cout, 27, TAPS_CONV3, 1, *self._wg_scratch(), st)      # [cin, cout, 3, 3, 3] directly
+        else:
+            _lib.call("semabs_wgrad", _lib.ptr(xin), _lib.ptr(g), None, None, _lib.ptr(self.g[key + "weight"]), B, D0, D1, D2, 2 * D0, 2 * D1, 2 * D2, 2,
+                      cin, cout, 27, TAPS_CONV3, 1, st)
+        dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
         _lib.call("semabs_conv3d_gather", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh),
                   B, 2 * D0, 2 * D1, 2 * D2, D0, D1, D2, 2, cout, cin, 27, TAPS_CONV3, 1 | m["bwd"][2], st)
         return dx, s2[1:]                                    # still scaled: the block that consumes it multiplies by 1 / s in its first pass
@@ -482,7 +496,12 @@ class VOOLTrainer:
             dW = grad_w                                           # [Co, Ci]: accumulate in place
         else:
             dW = torch.zeros(Co, Ci, dtype=torch.float32, device=self.dev)
-        _lib.call("semabs_wgrad", _lib.ptr(dOut), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, TAPS_ONE, 1, _lib.stream())
+        if Ci % 16 == 0 and self.unet.mfma_wgrad:
+            s2 = self.unet._scale(dOut, 1, Co)[2]
+            _lib.call("semabs_wgrad_mfma", _lib.ptr(dOut), _lib.ptr(x), None, None, _lib.ptr(s2), None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1,
+                      TAPS_ONE, 1, *self.unet._wg_scratch(), _lib.stream())
+        else:
+            _lib.call("semabs_wgrad", _lib.ptr(dOut), _lib.ptr(x), None, None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1, Co, Ci, 1, TAPS_ONE, 1, _lib.stream())
         if cols is not None:
             grad_w.add_(dW[:, :cols])
 
@@ -553,7 +572,7 @@ class VOOLTrainer:
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
         u._colsum(dO, g[ss + "2.bias"])
         y_, inv_ = self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True)
-        dh = u._ew(y_, h, 1, in_scale=inv_)
+        dh = u._ew(y_, h, 1, want_max=True, in_scale=inv_)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
@@ -569,11 +588,11 @@ class VOOLTrainer:
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
         y_, inv_ = self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True)
-        dh2 = u._ew(y_, h2, 1, in_scale=inv_)
+        dh2 = u._ew(y_, h2, 1, want_max=True, in_scale=inv_)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
         y_, inv_ = self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True)
-        dh1 = u._ew(y_, h1, 1, in_scale=inv_)
+        dh1 = u._ew(y_, h1, 1, want_max=True, in_scale=inv_)
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
 

@@ -146,6 +146,76 @@ def test_linear_wgrad_colsum_vs_torch():
         assert _rel(red[0, :, 0].cpu().numpy(), dOut.double().sum(0).numpy()) < 1e-6
 
 
+def test_wgrad_mfma_vs_torch_autograd():
+    """semabs_wgrad_mfma (split-fp16 MFMA, transposing LDS reads) against torch's fp64 autograd of Conv3d / ConvTranspose3d / Linear weights
+    (unet3d.py:63-118 conv + GroupNorm order, :296-331 transposed convolution) and against the fp32 VALU kernel it replaces.  Gradient operands are
+    drawn at 1e-7 scale so the dynamic power-of-two scale is exercised (unscaled they would flush in fp16)."""
+    from semabs_amd import _lib
+    from semabs_amd.train import TAPS_CONV3, TAPS_ONE
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    F = torch.nn.functional
+
+    scratch = torch.empty(1 << 22, device=dev)
+
+    def scale_of(t):
+        sc = torch.empty(1, device=dev); sh = torch.empty(1, device=dev); s2 = torch.empty(2, device=dev)
+        bits = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("semabs_grad_scale", _lib.ptr(t), t.numel(), _lib.ptr(sc), _lib.ptr(sh), 1, _lib.ptr(s2), _lib.ptr(bits), 2, _lib.stream())
+        return s2
+
+    # Conv3d 3x3x3 with the GroupNorm affine folded into the gather: 8^3 / 4^3 levels (+ a ragged size)
+    for B, D, cin, cout in [(2, (8, 8, 8), 32, 64), (3, (4, 4, 4), 64, 32), (1, (3, 5, 6), 16, 16)]:
+        x = rng.standard_normal((B, cin) + D)
+        gsc, gsh = rng.uniform(0.5, 1.5, (B, cin)), rng.standard_normal((B, cin))
+        dz = rng.standard_normal((B, cout) + D) * 1e-7
+        xn = torch.from_numpy(x * gsc[:, :, None, None, None] + gsh[:, :, None, None, None])
+        wt = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv3d(xn, wt, padding=1).backward(torch.from_numpy(dz))
+        xd = torch.from_numpy(x).float().to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        dzd = torch.from_numpy(dz).float().to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        scd, shd = torch.from_numpy(gsc).float().to(dev).contiguous(), torch.from_numpy(gsh).float().to(dev).contiguous()
+        dW = torch.zeros(cout, cin, 27, device=dev)
+        _lib.call("semabs_wgrad_mfma", _lib.ptr(dzd), _lib.ptr(xd), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(scale_of(dzd)), None, _lib.ptr(dW),
+                  B, *D, *D, 1, cout, cin, 27, TAPS_CONV3, 1, _lib.ptr(scratch), scratch.numel(), _lib.stream())
+        old = torch.zeros_like(dW)
+        _lib.call("semabs_wgrad", _lib.ptr(dzd), _lib.ptr(xd), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(old), B, *D, *D, 1, cout, cin, 27, TAPS_CONV3, 1,
+                  _lib.stream())
+        ref = wt.grad.reshape(cout, cin, 27).numpy()
+        assert _rel(dW.cpu().numpy(), ref) < 2e-6, (D, _rel(dW.cpu().numpy(), ref))
+        assert _rel(old.cpu().numpy(), ref) < 2e-6
+
+    # ConvTranspose3d k3 s2 p1 op1: A = the layer input, X = the output gradient (the scaled operand), rows over the INPUT voxels
+    for B, D, cin, cout in [(2, (4, 4, 4), 64, 32), (1, (8, 8, 8), 32, 16), (2, (2, 3, 4), 128, 64)]:
+        x = rng.standard_normal((B, cin) + D)
+        D2 = tuple(2 * d for d in D)
+        g = rng.standard_normal((B, cout) + D2) * 1e-7
+        wt = torch.zeros(cin, cout, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv_transpose3d(torch.from_numpy(x), wt, stride=2, padding=1, output_padding=1).backward(torch.from_numpy(g))
+        xd = torch.from_numpy(x).float().to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        gd = torch.from_numpy(g).float().to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        dW = torch.zeros(cin, cout, 27, device=dev)
+        _lib.call("semabs_wgrad_mfma", _lib.ptr(xd), _lib.ptr(gd), None, None, None, _lib.ptr(scale_of(gd)), _lib.ptr(dW),
+                  B, *D, *D2, 2, cin, cout, 27, TAPS_CONV3, 1, None, 0, _lib.stream())
+        ref = wt.grad.reshape(cin, cout, 27).numpy()
+        assert _rel(dW.cpu().numpy(), ref) < 2e-6, (D, _rel(dW.cpu().numpy(), ref))
+
+    # Linear: one tap, rows = points; accumulates into dW (second call doubles it); both layouts
+    for R, Ci, Co in [(5000, 128, 128), (777, 32, 64), (2050, 128, 16), (31, 16, 16)]:
+        x = rng.standard_normal((R, Ci)); d = rng.standard_normal((R, Co)) * 1e-7
+        xd, dd = torch.from_numpy(x).float().to(dev), torch.from_numpy(d).float().to(dev)
+        ref = d.T @ x
+        for tap_minor in (0, 1):
+            dW = torch.zeros(Co, Ci, device=dev)
+            for rep in range(2):                            # once through the partial-sum scratch, once through atomics
+                _lib.call("semabs_wgrad_mfma", _lib.ptr(dd), _lib.ptr(xd), None, None, _lib.ptr(scale_of(dd)), None, _lib.ptr(dW), 1, 1, 1, R, 1, 1, R, 1,
+                          Co, Ci, 1, TAPS_ONE, tap_minor, _lib.ptr(scratch) if rep == 0 else None, scratch.numel() if rep == 0 else 0, _lib.stream())
+            assert _rel(dW.cpu().numpy(), 2 * ref) < 2e-6, (R, Ci, Co, _rel(dW.cpu().numpy(), 2 * ref))
+    with pytest.raises(RuntimeError):
+        _lib.call("semabs_wgrad_mfma", _lib.ptr(dd), _lib.ptr(xd), None, None, None, None, _lib.ptr(dW), 1, 1, 1, 31, 1, 1, 31, 1, 16, 36, 1, TAPS_ONE, 1,
+                  None, 0, _lib.stream())
+
+
 def test_maxpool_bwd_ties_first_max():
     from semabs_amd import _lib
     dev = torch.device("cuda:0")
