@@ -267,10 +267,12 @@ int semabs_wgrad_mfma(const float* A, const float* X, const float* gn_scale, con
                       int B, int M0, int M1, int M2, int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps,
                       int tap_minor, float* scratch, long scratch_floats, void* stream);
 
-/* The same for Conv3d 3x3x3 on MFMA (split fp16, LDS-transposed 4 x 8 x 16 bricks): dW[ca][tap * Cx + cx] += sum_vox dZ[vox][ca] * GN(X)[vox + tap][cx].
- * s2 = (s, 1 / s) of semabs_grad_scale(dZ) or NULL.  Needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0, Ca % 16 == 0, Cx % 16 == 0. */
+/* The same for Conv3d 3x3x3 on MFMA (split fp16, bricks of the volume staged in LDS): dW[ca][tap * Cx + cx] += sum_vox dZ[vox][ca] * GN(X)[vox + tap][cx].
+ * s2 = (s, 1 / s) of semabs_grad_scale(dZ) or NULL.  Needs D0 % 4 == 0, D1 % 4 == 0, D2 % 16 == 0, Ca % 16 == 0, Cx % 16 == 0.
+ * scratch (scratch_floats fp32, >= (Ca / 16) (Cx / 16) 6912): partial sums of the transposing-read kernel, reduced deterministically;
+ * scratch = NULL: the round-2 kernel (4 x 8 x 16 bricks transposed while staging, D1 % 8 == 0, fp32 atomics). */
 int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B, int D0,
-                       int D1, int D2, int Ca, int Cx, int tap_minor, void* stream);
+                       int D1, int D2, int Ca, int Cx, int tap_minor, float* scratch, long scratch_floats, void* stream);
 
 /* out fp64 [B, C, 2] += (sum_v dY, sum_v dY * xhat) per (batch, channel); X = NULL gives plain column sums (bias gradients) */
 int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const float* rstd, double* out, int B, long nvox, int C, int G,

@@ -1242,24 +1242,240 @@ __global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
     }
 }
 
+// =================================================================================================
+// The same weight gradient with the operands in their NATURAL order in LDS ([voxel][16 channels] fp16, 32 B per voxel, hi and lo planes)
+// and the voxel-major fragments produced by the transposing LDS read (ds_read_b64_tr_b16, as in k_wgrad_mfma): staging is an 8-byte store per
+// (voxel, 4 channels) instead of sixteen 4-byte scatter stores per voxel pair, a fragment read of 16 consecutive x is one contiguous 512 B
+// (conflict-free at any dx shift, so the three dx taps are plain address offsets - no v_alignbit), and 4 x 4 x 16 bricks (58 KB) leave room for
+// the accumulators.  A workgroup = 8 waves, one per CU: wave w multiplies k-steps 2 (w & 3), 2 (w & 3) + 1 of a brick (k-step = two x rows =
+// 32 voxels) against taps 13 (w >> 2) .. + 13 (14 accumulators; the dZ fragment is read once per k-step and tap half); the next brick's global
+// loads are issued before the MFMAs of the current one and land in registers meanwhile.  The workgroup's 27 x 16 x 16 sums meet in LDS and go to a partial-sum buffer,
+// one row per workgroup; k_wgrad3_reduce adds the rows into dW (no atomics: deterministic, and 16 G atomics / s was a third of the old kernel).
+// =================================================================================================
+struct Wgrad3Args {
+    const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* s2; float* part;
+    int B, D0, D1, D2, Ca, Cx;
+};
+#define W3_HV (6 * 6 * 18)
+#define W3_LDS (2 * W3_HV * 32 + 2 * 256 * 32)
+
+__global__ __launch_bounds__(512) void k_wgrad3_tr(Wgrad3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sXh = smem; char* const sXl = sXh + W3_HV * 32; char* const sAh = sXl + W3_HV * 32; char* const sAl = sAh + 256 * 32;
+    float* const sG = reinterpret_cast<float*>(smem + W3_LDS);      // [B][scale 16 | shift 16] of this channel slice (no global loads per brick)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kp = w & 3, half = w >> 2;                    // k-steps 2 kp, 2 kp + 1; taps 13 half .. 13 half + 13
+    const int ca0 = blockIdx.y * 16, cx0 = blockIdx.z * 16;
+    const int n0 = a.D0 / 4, n1 = a.D1 / 4, n2 = a.D2 / 16;
+    const int nbricks = a.B * n0 * n1 * n2;
+    const float s_in = a.s2 ? a.s2[0] : 1.f;
+    const int q = tid & 3;                                  // this thread's 4-channel quarter in every staging slot
+    f32x4 acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int e = tid; e < a.B * 32; e += 512) {
+        const int b = e >> 5, c = e & 15;
+        sG[e] = a.gn_scale ? ((e & 16) ? a.gn_shift[(long)b * a.Cx + cx0 + c] : a.gn_scale[(long)b * a.Cx + cx0 + c]) : ((e & 16) ? 0.f : 1.f);
+    }
+    float4 px[6], pa[2];
+    unsigned okmask = 0;
+    // Staging addresses: the slot -> (hz, hy, hx) split is the same for every brick, so it is done once; per brick a slot costs three
+    // add + clamp (v_med3) pairs, the in-volume test and three 24-bit multiplies for a 32-bit byte offset into a buffer descriptor (the
+    // launcher guarantees B D0 D1 < 2^24 and < 4 GB per tensor).  With 64-bit pointer arithmetic and the divisions inside the loop the
+    // fetch alone was 2 us of VALU work per brick - as long as the brick's MFMAs.
+    int hpos[6], apos[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int hv = (i * 512 + tid) >> 2; hv = hv < W3_HV ? hv : W3_HV - 1;
+        hpos[i] = (hv / 108) | (((hv / 18) % 6) << 8) | ((hv % 18) << 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int av = (i * 512 + tid) >> 2; apos[i] = (av >> 6) | (((av >> 4) & 3) << 8) | ((av & 15) << 16); }
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7fffffff, 0x00020000);
+    const unsigned xq = (unsigned)(cx0 + q * 4) * 4u, aq = (unsigned)(ca0 + q * 4) * 4u, xvb = (unsigned)a.Cx * 4u, avb = (unsigned)a.Ca * 4u;
+    auto fetch = [&](int brick) {
+        int t = brick;
+        const int t2 = t % n2; t /= n2;
+        const int t1 = t % n1; t /= n1;
+        const int t0 = t % n0; const int b = t / n0;
+        const int z0 = t0 * 4, y0 = t1 * 4, x0 = t2 * 16, bz = b * a.D0;
+        unsigned m = 0, xo[6], ao[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                      // branch-free: out-of-volume slots read a clamped address and are zeroed in store()
+            const int gz = z0 - 1 + (hpos[i] & 0xff), gy = y0 - 1 + ((hpos[i] >> 8) & 0xff), gx = x0 - 1 + (hpos[i] >> 16);
+            const int cz = min(max(gz, 0), a.D0 - 1), cy = min(max(gy, 0), a.D1 - 1), cxx = min(max(gx, 0), a.D2 - 1);      // v_med3_i32
+            m |= ((cz == gz && cy == gy && cxx == gx) ? 1u : 0u) << i;
+            const unsigned vox = __umul24(__umul24((unsigned)(bz + cz), (unsigned)a.D1) + (unsigned)cy, (unsigned)a.D2) + (unsigned)cxx;
+            xo[i] = __umul24(vox, xvb) + xq;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int z = z0 + (apos[i] & 0xff), y = y0 + ((apos[i] >> 8) & 0xff), x = x0 + (apos[i] >> 16);
+            const unsigned vox = __umul24(__umul24((unsigned)(bz + z), (unsigned)a.D1) + (unsigned)y, (unsigned)a.D2) + (unsigned)x;
+            ao[i] = __umul24(vox, avb) + aq;
+        }
+        okmask = m;
+        // all addresses and the mask FIRST, then nothing but loads (otherwise the register allocator parks mask arithmetic in a load's
+        // destination registers and waits for that load - the full memory latency - before the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xo[i], 0, 0)); px[i] = make_float4(v[0], v[1], v[2], v[3]); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, ao[i], 0, 0)); pa[i] = make_float4(v[0], v[1], v[2], v[3]); }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto split_store = [&](const float f[4], char* hi, char* lo) {
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (f16)f[e]; l[e] = (f16)(f[e] - (float)h[e]); }
+        *reinterpret_cast<f16x4*>(hi) = h; *reinterpret_cast<f16x4*>(lo) = l;
+    };
+    auto store = [&](int brick) {
+        const int b = brick / (n0 * n1 * n2);
+        const float4 gsc = *reinterpret_cast<const float4*>(sG + b * 32 + q * 4), gsh = *reinterpret_cast<const float4*>(sG + b * 32 + 16 + q * 4);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int hv = (i * 512 + tid) >> 2;
+            if (hv < W3_HV) {
+                const bool ok = (okmask >> i) & 1u;          // the affine applies to voxels inside the volume only: the padding is zero AFTER GroupNorm
+                const float f[4] = {ok ? px[i].x * gsc.x + gsh.x : 0.f, ok ? px[i].y * gsc.y + gsh.y : 0.f, ok ? px[i].z * gsc.z + gsh.z : 0.f,
+                                    ok ? px[i].w * gsc.w + gsh.w : 0.f};
+                split_store(f, sXh + hv * 32 + q * 8, sXl + hv * 32 + q * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int av = (i * 512 + tid) >> 2;
+            const float f[4] = {pa[i].x * s_in, pa[i].y * s_in, pa[i].z * s_in, pa[i].w * s_in};
+            split_store(f, sAh + av * 32 + q * 8, sAl + av * 32 + q * 8);
+        }
+    };
+    const int g16 = lane >> 4, li = lane & 15;
+    const int fo = (g16 * 4 + (li >> 2)) * 32 + (li & 3) * 8;      // rows = x 0 .. 15 of one x row; the second read takes the next y row
+    auto frag = [&](const char* p0, int second) -> f16x8 {
+        const wg_s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3)))*)(p0));
+        const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3)))*)(p0 + second));
+        const f16x4 fu = __builtin_bit_cast(f16x4, u), fv = __builtin_bit_cast(f16x4, v);
+        f16x8 r;
+        r[0] = fu[0]; r[1] = fu[1]; r[2] = fu[2]; r[3] = fu[3]; r[4] = fv[0]; r[5] = fv[1]; r[6] = fv[2]; r[7] = fv[3];
+        return r;
+    };
+
+    int brick = blockIdx.x;
+    if (brick < nbricks) fetch(brick);
+    for (; brick < nbricks; brick += gridDim.x) {
+        __syncthreads();                                    // the previous brick's fragments are no longer being read
+        store(brick);
+        __syncthreads();
+        // unconditional (the last iteration re-reads its own brick): a conditional fetch makes the staging registers a merge of old and new
+        // values, and the copies the compiler inserts for it wait for the loads right here
+        fetch(brick + (int)gridDim.x < nbricks ? brick + (int)gridDim.x : brick);
+        __builtin_amdgcn_sched_barrier(0);                  // the loads are ISSUED here, before the MFMAs (left alone, the scheduler sinks them to their first use)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ks = kp * 2 + kk, z = ks >> 1, y0 = (ks & 1) * 2;
+            const int ab = ((z * 4 + y0) * 16) * 32 + fo;
+            const f16x8 ah = frag(sAh + ab, 512), al = frag(sAl + ab, 512);
+            const int xb = ((z * 6 + y0) * 18) * 32 + fo;  // halo voxel (z, y0, 0); a tap adds ((dz + 1) 6 + dy + 1) 18 + dx + 1 voxels
+            // taps in pairs: the fragments of pair p + 1 are requested before the MFMAs of pair p, and the two taps' accumulators alternate so
+            // that no MFMA waits for the result of the one before it.  tap = 13 half + tt (wave-uniform); tap 13 is computed by both halves
+            // (branch-free loop), half 1 drops it at the end
+            auto xoff = [&](int tt) { const int tap = half * 13 + tt; return xb + (((tap / 9) * 6 + (tap / 3) % 3) * 18 + tap % 3) * 32; };
+            f16x8 xh[2][2], xl[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int bb = xoff(u); xh[0][u] = frag(sXh + bb, 576); xl[0][u] = frag(sXl + bb, 576); }
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const int cur = p & 1, nxt = cur ^ 1;
+                if (p + 1 < 7) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { const int bb = xoff(2 * p + 2 + u); xh[nxt][u] = frag(sXh + bb, 576); xl[nxt][u] = frag(sXl + bb, 576); }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[2 * p + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[cur][u], acc[2 * p + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[2 * p + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[cur][u], acc[2 * p + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[2 * p + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[cur][u], acc[2 * p + u], 0, 0, 0);
+            }
+        }
+    }
+    // acc[tt][r] = this wave's share of dW[ca = 4 g16 + r][tap][cx = li]: the four k-step waves of a tap half meet in LDS, ordered [ca][cx][tap]
+    const float inv = a.s2 ? a.s2[1] : 1.f;
+    float* sOut = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    for (int e = tid; e < 6912; e += 512) sOut[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 14; ++tt) {
+        const int tap = half * 13 + tt;
+        if (tt > 0 || half == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&sOut[((4 * g16 + r) * 16 + li) * 27 + tap], acc[tt][r] * inv);
+        }
+    }
+    __syncthreads();
+    float* dst = a.part + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 6912;
+    for (int e = tid; e < 6912; e += 512) dst[e] = sOut[e];
+}
+// part [nx][Ca / 16][Cx / 16][16 ca][16 cx][27] -> dW += sum over nx
+__global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__ part, float* __restrict__ dW, int nx, int ny, int nz, int Cx, int tap_minor) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)ny * nz * 6912;
+    if (i >= per) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= nx; c += 4) { s0 += part[c * per + i]; s1 += part[(c + 1) * per + i]; s2 += part[(c + 2) * per + i]; s3 += part[(c + 3) * per + i]; }
+    for (; c < nx; ++c) s0 += part[c * per + i];
+    const int e = (int)(i % 6912); const int yz = (int)(i / 6912);
+    const int ca = (yz / nz) * 16 + e / 432, rem = e % 432, cx = (yz % nz) * 16 + rem / 27, tap = rem % 27;
+    const long idx = tap_minor ? ((long)ca * Cx + cx) * 27 + tap : ((long)ca * 27 + tap) * Cx + cx;
+    dW[idx] += (s0 + s1) + (s2 + s3);
+}
+
 // dZ fp32 [B, D0, D1, D2, Ca], X fp32 [B, D0, D1, D2, Cx] (+ GroupNorm affine [B, Cx]); dW fp32 [Ca, 27, Cx] or (tap_minor) [Ca, Cx, 27], accumulated.
-// s2 = (s, 1 / s) device scalars of semabs_grad_scale for dZ, or null.  Needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0, Ca % 16 == Cx % 16 == 0.
+// s2 = (s, 1 / s) device scalars of semabs_grad_scale for dZ, or null.  Needs D0 % 4 == 0, D1 % 4 == 0, D2 % 16 == 0, Ca % 16 == Cx % 16 == 0.
+// scratch (scratch_floats fp32): partial sums of the transposing-read kernel k_wgrad3_tr; NULL selects the round-2 kernel (D1 % 8 == 0, atomics).
 extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B,
-                                  int D0, int D1, int D2, int Ca, int Cx, int tap_minor, void* stream) {
+                                  int D0, int D1, int D2, int Ca, int Cx, int tap_minor, float* scratch, long scratch_floats, void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dZ && X && dW, "semabs_wgrad_conv3: null pointer");
-    SEMABS_REQUIRE(D0 % WG_T0 == 0 && D1 % WG_T1 == 0 && D2 % WG_T2 == 0 && Ca % 16 == 0 && Cx % 16 == 0,
-                   "semabs_wgrad_conv3: needs D0 % 4 == 0, D1 % 8 == 0, D2 % 16 == 0 and channel counts that are multiples of 16");
+    SEMABS_REQUIRE(D0 % 4 == 0 && D1 % 4 == 0 && D2 % WG_T2 == 0 && Ca % 16 == 0 && Cx % 16 == 0,
+                   "semabs_wgrad_conv3: needs D0 % 4 == 0, D1 % 4 == 0, D2 % 16 == 0 and channel counts that are multiples of 16");
     SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_conv3: gn_scale and gn_shift go together");
+    const int combos = (Ca / 16) * (Cx / 16);
+    hipStream_t s = (hipStream_t)stream;
+    if (scratch) {
+        // transposing-read kernel: one persistent workgroup per CU in all, every workgroup leaves one 27 x 16 x 16 partial sum in scratch
+        const int nbricks = B * (D0 / 4) * (D1 / 4) * (D2 / 16);
+        int bx = 256 / combos; if (bx < 1) bx = 1; if (bx > nbricks) bx = nbricks;
+        if ((long)bx * combos * 6912 > scratch_floats) bx = (int)(scratch_floats / ((long)combos * 6912));
+        SEMABS_REQUIRE(B <= 64, "semabs_wgrad_conv3: at most 64 volumes per call");
+        const long vox = (long)B * D0 * D1 * D2;
+        SEMABS_REQUIRE((long)B * D0 * D1 < (1L << 24) && D2 < (1 << 24) && vox < (1L << 24) + 1 && vox * Ca * 4 < (1L << 31) && vox * Cx * 4 < (1L << 31),
+                       "semabs_wgrad_conv3: tensors of at most 2^24 voxels and 2 GB each (32-bit staging offsets)");
+        SEMABS_REQUIRE(bx >= 1, "semabs_wgrad_conv3: scratch too small (needs (Ca / 16) * (Cx / 16) * 6912 floats at least)");
+        Wgrad3Args a;
+        a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.part = scratch; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
+        static bool set3 = false;
+        if (!set3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3_tr), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS + 64 * 128); set3 = true; }
+        hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(512), W3_LDS + (size_t)B * 128, s, a);
+        hipLaunchKernelGGL(k_wgrad3_reduce, dim3(semabs_cdiv((long)combos * 6912, 256)), dim3(256), 0, s, scratch, dW, bx, Ca / 16, Cx / 16, Cx, tap_minor);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
+    SEMABS_REQUIRE(D1 % WG_T1 == 0, "semabs_wgrad_conv3: without scratch (4 x 8 x 16 bricks, atomics) D1 % 8 == 0 is needed");
     Wgrad16Args a;
     a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx; a.tap_minor = tap_minor;
     const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + 8 + WG_T0 * WG_T1 * WG_AYROW) * 2 * 2;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nbricks = B * (D0 / WG_T0) * (D1 / WG_T1) * (D2 / WG_T2);
-    const int combos = (Ca / 16) * (Cx / 16);
     int bx = 768 / combos; if (bx < 8) bx = 8; if (bx > nbricks) bx = nbricks;
-    hipLaunchKernelGGL(k_wgrad16_lds, dim3(bx, Ca / 16, Cx / 16), dim3(WG_NTHR), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_wgrad16_lds, dim3(bx, Ca / 16, Cx / 16), dim3(WG_NTHR), lds, s, a);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -10,6 +10,7 @@ the `Lamb` optimiser of optim.py.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -117,6 +118,7 @@ class UNetTrainer:
         self.mats: Dict[str, dict] = {}
         self.dev = _lib.require_gpu()
         self._wgs = None
+        self.wgrad_tr = os.environ.get("SEMABS_WGRAD_TR", "1") == "1"      # A/B: 0 = the round-2 brick kernel (transposes while staging, atomics)
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
         self.arena = _ZeroArena(self.dev)
@@ -301,9 +303,10 @@ class UNetTrainer:
         sc, sh, s2 = self._scale(dZ, B, cout)                # dynamic power-of-two scale of dZ, shared by the weight and data gradients
         inv = s2[1:]
         dW = self.g[key + "conv.weight"]                     # [cout, cin, 3, 3, 3]: the kernels accumulate in this layout directly
-        if D0 % 4 == 0 and D1 % 8 == 0 and D2 % 16 == 0 and self.mfma_wgrad:
+        if D0 % 4 == 0 and D1 % 4 == 0 and D2 % 16 == 0 and cin % 16 == 0 and self.mfma_wgrad:
+            scr = self._wg_scratch() if self.wgrad_tr else (None, 0)
             _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
-                      B, D0, D1, D2, cout, cin, 1, st)
+                      B, D0, D1, D2, cout, cin, 1, *scr, st)
         elif cin % 16 == 0 and self.mfma_wgrad:                  # 8^3 / 4^3 levels: rows through LDS, transposing reads (k_wgrad_mfma)
             _lib.call("semabs_wgrad_mfma", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), None, _lib.ptr(dW),
                       B, D0, D1, D2, D0, D1, D2, 1, cout, cin, 27, TAPS_CONV3, 1, *self._wg_scratch(), st)

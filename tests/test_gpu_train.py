@@ -185,6 +185,29 @@ def test_wgrad_mfma_vs_torch_autograd():
         assert _rel(dW.cpu().numpy(), ref) < 2e-6, (D, _rel(dW.cpu().numpy(), ref))
         assert _rel(old.cpu().numpy(), ref) < 2e-6
 
+    # the brick kernels (semabs_wgrad_conv3): transposing-read kernel with partial-sum scratch, and the round-2 kernel (scratch = NULL)
+    for B, D, cin, cout in [(2, (4, 4, 16), 16, 16), (1, (8, 8, 32), 32, 16), (3, (4, 12, 16), 16, 32), (2, (16, 16, 16), 16, 16)]:
+        x = rng.standard_normal((B, cin) + D)
+        gsc, gsh = rng.uniform(0.5, 1.5, (B, cin)), rng.standard_normal((B, cin))
+        dz = rng.standard_normal((B, cout) + D) * 1e-7
+        xn = torch.from_numpy(x * gsc[:, :, None, None, None] + gsh[:, :, None, None, None])
+        wt = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv3d(xn, wt, padding=1).backward(torch.from_numpy(dz))
+        xd = torch.from_numpy(x).float().to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        dzd = torch.from_numpy(dz).float().to(dev).permute(0, 2, 3, 4, 1).contiguous()
+        scd, shd = torch.from_numpy(gsc).float().to(dev).contiguous(), torch.from_numpy(gsh).float().to(dev).contiguous()
+        ref = wt.grad.reshape(cout, cin, 27).numpy()
+        for use_scratch in (True, False):
+            if not use_scratch and D[1] % 8:
+                continue
+            for tap_minor in (1, 0):
+                dW = torch.zeros(cout, cin, 27, device=dev) if tap_minor else torch.zeros(cout, 27, cin, device=dev)
+                for _ in range(2):                          # accumulates
+                    _lib.call("semabs_wgrad_conv3", _lib.ptr(dzd), _lib.ptr(xd), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(scale_of(dzd)), _lib.ptr(dW),
+                              B, *D, cout, cin, tap_minor, _lib.ptr(scratch) if use_scratch else None, scratch.numel() if use_scratch else 0, _lib.stream())
+                got = dW.cpu().numpy() if tap_minor else dW.permute(0, 2, 1).cpu().numpy()
+                assert _rel(got, 2 * ref) < 2e-6, (D, use_scratch, tap_minor, _rel(got, 2 * ref))
+
     # ConvTranspose3d k3 s2 p1 op1: A = the layer input, X = the output gradient (the scaled operand), rows over the INPUT voxels
     for B, D, cin, cout in [(2, (4, 4, 4), 64, 32), (1, (8, 8, 8), 32, 16), (2, (2, 3, 4), 128, 64)]:
         x = rng.standard_normal((B, cin) + D)
