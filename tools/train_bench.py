@@ -27,7 +27,7 @@ def synth_batch(S, N, M, D, seed=0):
     lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
     # points on a few random planes (a depth-camera-like surface sample), not a uniform cloud: ~3 % of the voxels occupied
     base = rng.random((N, 3))
-    base[:, rng.integers(0, 3, N)] *= 0.05
+    base[np.arange(N), rng.integers(0, 3, N)] *= 0.05      # one coordinate PER POINT (until round 3 this line scaled every column: 80 000 points in a 6^3-voxel cube)
     xyz = (lo + (hi - lo) * np.clip(base, 0, 1)).astype(np.float32)[None]
     sal = rng.random((1, 2 * D, N, 1)).astype(np.float32)
     q = (lo + (hi - lo) * rng.random((1, D, M, 3))).astype(np.float32)
