@@ -1448,26 +1448,31 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_conv3: gn_scale and gn_shift go together");
     const int combos = (Ca / 16) * (Cx / 16);
     hipStream_t s = (hipStream_t)stream;
-    if (scratch) {
-        // transposing-read kernel: one persistent workgroup per CU in all, every workgroup leaves one 27 x 16 x 16 partial sum in scratch
-        const int nbricks = B * (D0 / 4) * (D1 / 4) * (D2 / 16);
-        int bx = 256 / combos; if (bx < 1) bx = 1; if (bx > nbricks) bx = nbricks;
-        if ((long)bx * combos * 6912 > scratch_floats) bx = (int)(scratch_floats / ((long)combos * 6912));
-        SEMABS_REQUIRE(B <= 64, "semabs_wgrad_conv3: at most 64 volumes per call");
-        const long vox = (long)B * D0 * D1 * D2;
-        SEMABS_REQUIRE((long)B * D0 * D1 < (1L << 24) && D2 < (1 << 24) && vox < (1L << 24) + 1 && vox * Ca * 4 < (1L << 31) && vox * Cx * 4 < (1L << 31),
-                       "semabs_wgrad_conv3: tensors of at most 2^24 voxels and 2 GB each (32-bit staging offsets)");
-        SEMABS_REQUIRE(bx >= 1, "semabs_wgrad_conv3: scratch too small (needs (Ca / 16) * (Cx / 16) * 6912 floats at least)");
-        Wgrad3Args a;
-        a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.part = scratch; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
+    // volumes per launch of the transposing-read kernel: its GroupNorm table holds 64 volumes and its staging offsets are 32-bit
+    const long vpv = (long)D0 * D1 * D2;                    // voxels per volume
+    long bmax = 64;
+    if ((1L << 24) / vpv < bmax) bmax = (1L << 24) / vpv;
+    if (((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4) < bmax) bmax = ((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4);
+    if (scratch && bmax >= 1 && (long)D0 * D1 < (1L << 24) / bmax && scratch_floats >= (long)combos * 6912) {
         static bool set3 = false;
         if (!set3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3_tr), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS + 64 * 128); set3 = true; }
-        hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(512), W3_LDS + (size_t)B * 128, s, a);
-        hipLaunchKernelGGL(k_wgrad3_reduce, dim3(semabs_cdiv((long)combos * 6912, 256)), dim3(256), 0, s, scratch, dW, bx, Ca / 16, Cx / 16, Cx, tap_minor);
+        for (int b0 = 0; b0 < B; b0 += (int)bmax) {          // (one launch for every call of the 128^3 training step)
+            const int Bc = B - b0 < bmax ? B - b0 : (int)bmax;
+            // one persistent workgroup per CU in all, every workgroup leaves one 27 x 16 x 16 partial sum in scratch
+            const int nbricks = Bc * (D0 / 4) * (D1 / 4) * (D2 / 16);
+            int bx = 256 / combos; if (bx < 1) bx = 1; if (bx > nbricks) bx = nbricks;
+            if ((long)bx * combos * 6912 > scratch_floats) bx = (int)(scratch_floats / ((long)combos * 6912));
+            Wgrad3Args a;
+            a.A = dZ + (long)b0 * vpv * Ca; a.X = X + (long)b0 * vpv * Cx;
+            a.gn_scale = gn_scale ? gn_scale + (long)b0 * Cx : nullptr; a.gn_shift = gn_shift ? gn_shift + (long)b0 * Cx : nullptr;
+            a.s2 = s2; a.part = scratch; a.B = Bc; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
+            hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(512), W3_LDS + (size_t)Bc * 128, s, a);
+            hipLaunchKernelGGL(k_wgrad3_reduce, dim3(semabs_cdiv((long)combos * 6912, 256)), dim3(256), 0, s, scratch, dW, bx, Ca / 16, Cx / 16, Cx, tap_minor);
+        }
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
     }
-    SEMABS_REQUIRE(D1 % WG_T1 == 0, "semabs_wgrad_conv3: without scratch (4 x 8 x 16 bricks, atomics) D1 % 8 == 0 is needed");
+    SEMABS_REQUIRE(D1 % WG_T1 == 0, "semabs_wgrad_conv3: without (enough) scratch, or for volumes above 2^24 voxels, the 4 x 8 x 16 brick kernel runs and needs D1 % 8 == 0");
     Wgrad16Args a;
     a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx; a.tap_minor = tap_minor;
     const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + 8 + WG_T0 * WG_T1 * WG_AYROW) * 2 * 2;

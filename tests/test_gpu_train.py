@@ -186,7 +186,7 @@ def test_wgrad_mfma_vs_torch_autograd():
         assert _rel(old.cpu().numpy(), ref) < 2e-6
 
     # the brick kernels (semabs_wgrad_conv3): transposing-read kernel with partial-sum scratch, and the round-2 kernel (scratch = NULL)
-    for B, D, cin, cout in [(2, (4, 4, 16), 16, 16), (1, (8, 8, 32), 32, 16), (3, (4, 12, 16), 16, 32), (2, (16, 16, 16), 16, 16)]:
+    for B, D, cin, cout in [(2, (4, 4, 16), 16, 16), (1, (8, 8, 32), 32, 16), (3, (4, 12, 16), 16, 32), (2, (16, 16, 16), 16, 16), (70, (4, 4, 16), 16, 16)]:      # 70 volumes: two launches
         x = rng.standard_normal((B, cin) + D)
         gsc, gsh = rng.uniform(0.5, 1.5, (B, cin)), rng.standard_normal((B, cin))
         dz = rng.standard_normal((B, cout) + D) * 1e-7
