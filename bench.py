@@ -348,6 +348,18 @@ def stage_report(pipe, scenes, w_text, arch, precision):
     batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(VOXEL, 80000, 400000, 4, seed=0).items()}
     out["vool_train_step_ms"] = round(timed(lambda: tr.step(batch), reps=3), 2)
     out["vool_train_config"] = f"config 5: SemAbsVOOL {VOXEL}^3, batch 1, 4 descriptions, 80000 input / 400000 query points: forward + BCE + backward + clip + LAMB, 1 GPU"
+    if VOXEL == 128:
+        # roof of the step: the UNet on 8 volumes (2 per description) dominates.  Forward 0.34081 TFLOP / 0.838 G activation elements per volume
+        # (tools/unet_bench.py); the backward pass is a data-gradient and a weight-gradient convolution per layer (2 x the forward flops) and
+        # ~3 x its tensor passes (dZ read twice, X read for the weight gradient and twice by the GroupNorm backward, dXn written and read
+        # twice, dX written).  Exact mode issues 3 MFMAs per product.
+        vols, f_tf, f_gb = 8, 0.34081, 0.838 * 4
+        alg_tf, issued_tf, gb = 3 * vols * f_tf, 9 * vols * f_tf, 4 * vols * f_gb
+        mfma_ms, hbm_ms = issued_tf / PEAK_F16_TFLOPS * 1e3, gb / (HBM_PEAK_TBS * 1e3) * 1e3
+        out["vool_train_roof"] = {"algorithmic_tflop": round(alg_tf, 2), "issued_mfma_tflop": round(issued_tf, 2), "compulsory_gb_estimate": round(gb, 1),
+                                  "mfma_floor_ms": round(mfma_ms, 2), "hbm_floor_ms": round(hbm_ms, 2), "bound": "hbm" if hbm_ms > mfma_ms else "mfma",
+                                  "frac_of_roof": round(max(mfma_ms, hbm_ms) / out["vool_train_step_ms"], 3),
+                                  "note": "UNet forward + backward on 8 volumes only (point MLPs, sampler, head, optimiser are < 10 % of the step); bytes = 4 x the forward's compulsory activation traffic"}
     del tr
     torch.cuda.empty_cache()
     return out
