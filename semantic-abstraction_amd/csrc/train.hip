@@ -575,44 +575,74 @@ extern "C" int semabs_gn_bwd_coef(const double* red, const float* gamma, const f
 }
 
 // dX = (k1 * dXn - k2 - xhat * k3 [+ add1] [+ add2]) [* (mask_y > 0)]; optionally max |dX| -> bits (for the next dynamic gradient scale)
-__global__ void k_gn_bwd_apply(const float* __restrict__ dXn, const float* __restrict__ X, const float* __restrict__ mean,
+// grid = (chunks of 256 * 4 float4 per volume, B): a thread's four channels - hence its mean / rstd / coefficients - are the same for every
+// element it touches when C / 4 divides 256 (every channel count of the network), so they are loaded once; 4 independent float4 per operand
+// in flight per thread.  (One float4 per thread with the (b, channel) decode and nine scalar coefficient loads per element ran at 4.7 TB/s.)
+template <bool FIXED>                                       // FIXED: C / 4 divides 256
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ dXn, const float* __restrict__ X, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ coef, const float* __restrict__ add1,
                                const float* __restrict__ add2, const float* __restrict__ mask_y, unsigned int* __restrict__ bits,
-                               float* __restrict__ dX, int B, long nvox, int C, int G) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long tot = (long)B * nvox * (C / 4);
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (i < tot) {
-        const int c0 = (int)(i % (C / 4)) * 4; const int b = (int)(i / (nvox * (C / 4)));
-        const float4 d = ld_nt4(dXn + i * 4);
-        const float4 x = ld_nt4(X + i * 4);
-        const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
+                               float* __restrict__ dX, long per_vol, int C, int G) {
+    const int b = blockIdx.y;
+    const int cpv = C / 4;
+    const long vbase = (long)b * per_vol;                   // in float4 units
+    float mu[4], rs[4], k0[4], k1[4], k2[4];
+    auto setup = [&](int c0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + j, g = c / (C / G);
-            const float xh = (xv[j] - mean[b * G + g]) * rstd[b * G + g];
+            mu[j] = mean[b * G + g]; rs[j] = rstd[b * G + g];
             const float* k = coef + ((long)b * C + c) * 3;
-            o[j] = k[0] * dv[j] - k[1] - xh * k[2];
+            k0[j] = k[0]; k1[j] = k[1]; k2[j] = k[2];
         }
-        if (add1) { const float4 a = ld_nt4(add1 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
-        if (add2) { const float4 a = ld_nt4(add2 + i * 4); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
-        if (mask_y) {                                          // X is the post-ReLU output of the previous layer only when the caller says so
-            const float4 y = ld_nt4(mask_y + i * 4);
-            o[0] = y.x > 0.f ? o[0] : 0.f; o[1] = y.y > 0.f ? o[1] : 0.f; o[2] = y.z > 0.f ? o[2] : 0.f; o[3] = y.w > 0.f ? o[3] : 0.f;
+    };
+    if (FIXED) setup((threadIdx.x % cpv) * 4);
+    float m = 0.f;
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    float4 d[4], x[4], a1[4], a2[4], y[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        ok[u] = i < per_vol;
+        const long e = (vbase + (ok[u] ? i : 0)) * 4;
+        d[u] = ld_nt4(dXn + e); x[u] = ld_nt4(X + e);
+        if (add1) a1[u] = ld_nt4(add1 + e);
+        if (add2) a2[u] = ld_nt4(add2 + e);
+        if (mask_y) y[u] = ld_nt4(mask_y + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        if (!FIXED) setup((int)(i % cpv) * 4);
+        const float dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w}, xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = k0[j] * dv[j] - k1[j] - ((xv[j] - mu[j]) * rs[j]) * k2[j];
+        if (add1) { o[0] += a1[u].x; o[1] += a1[u].y; o[2] += a1[u].z; o[3] += a1[u].w; }
+        if (add2) { o[0] += a2[u].x; o[1] += a2[u].y; o[2] += a2[u].z; o[3] += a2[u].w; }
+        if (mask_y) {                                      // X is the post-ReLU output of the previous layer only when the caller says so
+            o[0] = y[u].x > 0.f ? o[0] : 0.f; o[1] = y[u].y > 0.f ? o[1] : 0.f; o[2] = y[u].z > 0.f ? o[2] : 0.f; o[3] = y[u].w > 0.f ? o[3] : 0.f;
         }
-        *reinterpret_cast<float4*>(dX + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (ok[u]) {
+            *reinterpret_cast<float4*>(dX + (vbase + i) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
     }
-    if (bits) {
-        absmax_commit(bits, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-    }
+    if (bits) absmax_commit(bits, m);
 }
 extern "C" int semabs_gn_bwd_apply(const float* dXn, const float* X, const float* mean, const float* rstd, const float* coef, const float* add1,
                                    const float* add2, const float* mask_y, unsigned int* absmax_bits, float* dX, int B, long nvox, int C, int G,
                                    void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dXn && X && mean && rstd && coef && dX && C % 4 == 0 && C % G == 0, "semabs_gn_bwd_apply: bad args");
-    hipLaunchKernelGGL(k_gn_bwd_apply, dim3(semabs_cdiv((long)B * nvox * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, dXn, X, mean, rstd, coef,
-                       add1, add2, mask_y, absmax_bits, dX, B, nvox, C, G);
+    const long per_vol = nvox * (C / 4);
+    SEMABS_REQUIRE(B < 65536 && semabs_cdiv(per_vol, 1024) < (1L << 31), "semabs_gn_bwd_apply: grid too large");
+    const dim3 grid((unsigned)semabs_cdiv(per_vol, 1024), B);
+    if (256 % (C / 4) == 0)
+        hipLaunchKernelGGL(k_gn_bwd_apply<true>, grid, dim3(256), 0, (hipStream_t)stream, dXn, X, mean, rstd, coef, add1, add2, mask_y, absmax_bits, dX, per_vol, C, G);
+    else
+        hipLaunchKernelGGL(k_gn_bwd_apply<false>, grid, dim3(256), 0, (hipStream_t)stream, dXn, X, mean, rstd, coef, add1, add2, mask_y, absmax_bits, dX, per_vol, C, G);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -624,33 +654,41 @@ extern "C" int semabs_gn_bwd_apply(const float* dXn, const float* X, const float
 //   mode 2: out = a + b                        (gradient fan-in;  Y = second addend)
 //   mode 3: out = a * b[0]                     (undo the dynamic gradient scale, b = device scalar)
 // =================================================================================================
-__global__ void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ out, long n4, int mode, float slope,
+__global__ __launch_bounds__(256) void k_ew(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ out, long n4, int mode, float slope,
                      unsigned int* __restrict__ bits, const float* __restrict__ in_scale) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n4) {
-        float4 d = ld_nt4(dY + i * 4);
-        if (in_scale) { const float k = in_scale[0]; d.x *= k; d.y *= k; d.z *= k; d.w *= k; }     // the producer's dynamic gradient scale undone on the way in (a power of two: exact)
-        if (mode == 3) { const float k = Y[0]; o = make_float4(d.x * k, d.y * k, d.z * k, d.w * k); }
-        else {
-            const float4 y = ld_nt4(Y + i * 4);
-            if (mode == 2) { o.x = d.x + y.x; o.y = d.y + y.y; o.z = d.z + y.z; o.w = d.w + y.w; }
-            else {
-                const float s = mode == 0 ? 0.f : slope;
-                o.x = d.x * (y.x > 0.f ? 1.f : s); o.y = d.y * (y.y > 0.f ? 1.f : s); o.z = d.z * (y.z > 0.f ? 1.f : s); o.w = d.w * (y.w > 0.f ? 1.f : s);
-            }
+    // four float4 per operand in flight per thread (one per thread ran at 5.2 TB/s)
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    const float kin = in_scale ? in_scale[0] : 1.f;        // the producer's dynamic gradient scale undone on the way in (a power of two: exact)
+    const float k3 = mode == 3 ? Y[0] : 0.f;
+    const float s = mode == 0 ? 0.f : slope;
+    float4 d[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256 < n4 ? i0 + u * 256 : 0;
+        d[u] = ld_nt4(dY + i * 4);
+        if (mode != 3) y[u] = ld_nt4(Y + i * 4);
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        float4 o;
+        const float4 dd = make_float4(d[u].x * kin, d[u].y * kin, d[u].z * kin, d[u].w * kin);
+        if (mode == 3) o = make_float4(dd.x * k3, dd.y * k3, dd.z * k3, dd.w * k3);
+        else if (mode == 2) o = make_float4(dd.x + y[u].x, dd.y + y[u].y, dd.z + y[u].z, dd.w + y[u].w);
+        else o = make_float4(dd.x * (y[u].x > 0.f ? 1.f : s), dd.y * (y[u].y > 0.f ? 1.f : s), dd.z * (y[u].z > 0.f ? 1.f : s), dd.w * (y[u].w > 0.f ? 1.f : s));
+        if (i < n4) {
+            *reinterpret_cast<float4*>(out + i * 4) = o;
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
-        *reinterpret_cast<float4*>(out + i * 4) = o;
     }
-    if (bits) {                                             // max |out| for the dynamic gradient scale of the next convolution
-        absmax_commit(bits, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-    }
+    if (bits) absmax_commit(bits, m);                       // max |out| for the dynamic gradient scale of the next convolution
 }
 // absmax_bits: optional uint32 (zero it first) receiving the bit pattern of max |out| - feeds semabs_grad_scale(have_bits = 1)
 extern "C" int semabs_ew(const float* a, const float* b, float* out, long n, int mode, float slope, unsigned int* absmax_bits, void* stream) {
     if (n == 0) return SEMABS_OK;
     SEMABS_REQUIRE(a && b && out && n % 4 == 0 && mode >= 0 && mode <= 3, "semabs_ew: bad args (n % 4 == 0)");
-    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits, (const float*)nullptr);
+    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits, (const float*)nullptr);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -660,7 +698,7 @@ extern "C" int semabs_ew_scaled(const float* a, const float* b, const float* in_
                                 void* stream) {
     if (n == 0) return SEMABS_OK;
     SEMABS_REQUIRE(a && b && in_scale && out && n % 4 == 0 && mode >= 0 && mode <= 2, "semabs_ew_scaled: bad args (n % 4 == 0, mode 0..2)");
-    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits, in_scale);
+    hipLaunchKernelGGL(k_ew, dim3(semabs_cdiv(n / 4, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, mode, slope, absmax_bits, in_scale);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
