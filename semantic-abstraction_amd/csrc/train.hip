@@ -497,7 +497,21 @@ __global__ __launch_bounds__(256) void k_chan_reduce(const float* __restrict__ d
         }
         float sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
         const float* dyb = dY + (long)b * nvox * C; const float* xb = X ? X + (long)b * nvox * C : nullptr;
-        for (long i = start; i < chunks; i += stride) {
+        long i = start;
+        for (; i + 3 * stride < chunks; i += 4 * stride) {      // four independent loads per operand in flight
+            float4 d[4], x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { d[u] = ld_nt4(dyb + (i + u * stride) * 4); if (xb) x[u] = ld_nt4(xb + (i + u * stride) * 4); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sa[0] += d[u].x; sa[1] += d[u].y; sa[2] += d[u].z; sa[3] += d[u].w;
+                if (xb) {
+                    sb[0] += d[u].x * ((x[u].x - mu[0]) * rs[0]); sb[1] += d[u].y * ((x[u].y - mu[1]) * rs[1]);
+                    sb[2] += d[u].z * ((x[u].z - mu[2]) * rs[2]); sb[3] += d[u].w * ((x[u].w - mu[3]) * rs[3]);
+                }
+            }
+        }
+        for (; i < chunks; i += stride) {
             const float4 d = ld_nt4(dyb + i * 4);
             sa[0] += d.x; sa[1] += d.y; sa[2] += d.z; sa[3] += d.w;
             if (xb) {

@@ -36,5 +36,5 @@ tot = {}
 for ms, name, _ in rows:
     tot[name] = tot.get(name, 0.0) + ms
 print("per entry point:", {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]})
-for ms, name, ints in rows[:40]:
+for ms, name, ints in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print(f"{ms * 1e3:9.1f} us  {name:28s} {[i for i in ints if i < (1 << 31)]}")
