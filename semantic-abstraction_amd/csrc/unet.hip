@@ -493,6 +493,8 @@ struct ConvArgs {
     int ablate;                 // tuning only (k_conv16_lds): 1 producers only, 2 consumers only, 4 consumers without epilogue
     long long* trace;           // tuning only (k_conv_brick, tools/conv_probe.py): [workgroup][8] s_memtime stamps of wave 0
     const f16* wp_hi; const f16* wp_lo;   // optional (k_conv_brick): fragment-packed copy of the weights, see SEMABS_CONV_PACKED
+    int ncls; long cls_off[8];            // k_conv only: > 0 = ConvTranspose3d, all 8 output parity classes in ONE launch (blockIdx.z = class:
+                                          // taps, weight block and output parity are derived from it in the kernel)
 };
 
 template <bool F32>
@@ -512,8 +514,18 @@ __device__ __forceinline__ void load8(const void* base, long idx, float (&v)[8])
 // LDSW (the deep levels, NW = 4): the four waves of a workgroup share their output-channel tiles, i.e. their weight fragments - 8 KB per
 // k-step that each of them used to pull through the vector L1 on its own (the kernel is bound by L1 bandwidth there: 12 KB of operands per
 // wave per 24 MFMAs).  Wave w loads tile w, parks it in a double-buffered LDS slab, and all four read the k-step's four tiles from there.
-template <int NW, bool F32, bool CIN16, bool LDSW = false>
+template <int NW, bool F32, bool CIN16, bool LDSW = false, bool CLS = false>      // CLS: ConvTranspose3d, blockIdx.z = output parity class
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+    // the class-dependent launch parameters as locals (the kernel argument itself is never written: a modified by-value struct moves to
+    // scratch and slowed every instantiation by 25 %)
+    const int ccls = CLS ? (int)blockIdx.z : 0;
+    const int cp0 = CLS ? ccls >> 2 : 0, cp1 = CLS ? (ccls >> 1) & 1 : 0, cp2 = CLS ? ccls & 1 : 0;
+    const int k_ntaps = CLS ? (cp0 + 1) * (cp1 + 1) * (cp2 + 1) : a.ntaps;
+    const int k_Kp = CLS ? k_ntaps * a.Cin : a.Kp;
+    const int k_op0 = CLS ? cp0 : a.op0, k_op1 = CLS ? cp1 : a.op1, k_op2 = CLS ? cp2 : a.op2;
+    const long k_woff = CLS ? a.cls_off[ccls] : 0;
+    const f16* const k_w_hi = a.w_hi + k_woff; const f16* const k_w_lo = a.w_lo ? a.w_lo + k_woff : nullptr;
+    const f16* const k_wp_hi = a.wp_hi ? a.wp_hi + k_woff : nullptr; const f16* const k_wp_lo = a.wp_lo ? a.wp_lo + k_woff : nullptr;
     constexpr int MW = 2;
     static_assert(!LDSW || (NW == 4 && !CIN16), "LDSW: four waves x four output-channel tiles");
     __shared__ __attribute__((aligned(16))) f16x8 s_w[LDSW ? 2 : 1][LDSW ? 4 : 1][2][LDSW ? 64 : 1];
@@ -554,7 +566,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             }
     }
     const int cin_steps = CIN16 ? 1 : a.Cin / 32;
-    const int nsteps = CIN16 ? (a.ntaps + 1) / 2 : a.ntaps * cin_steps;
+    const int nsteps = CIN16 ? (k_ntaps + 1) / 2 : k_ntaps * cin_steps;
     // The k-loop is software-pipelined by hand: the gathered activations and the weight rows of k-step ks + 1 are requested before
     // the MFMAs of k-step ks.  On the deep levels a wave walks 200-400 k-steps of L2 / HBM weight rows with nothing else to hide their
     // latency (few workgroups exist there), and the compiler does not pipeline a loop with a run-time trip count by itself.
@@ -563,8 +575,14 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         int tap, c0;
         if (CIN16) { tap = 2 * ks + (kg >> 1); c0 = 8 * (kg & 1); }
         else { tap = ks / cin_steps; c0 = (ks - tap * cin_steps) * 32 + 8 * kg; }
-        const bool tap_ok = tap < a.ntaps;
-        const int d0 = tap_ok ? a.td0[tap] : 0, d1 = tap_ok ? a.td1[tap] : 0, d2 = tap_ok ? a.td2[tap] : 0;
+        const bool tap_ok = tap < k_ntaps;
+        int d0 = 0, d1 = 0, d2 = 0;
+        if (tap_ok) {
+            if (CLS) {                                      // taps of a parity class in (t0, t1, t2) order: offset 1 for the first tap of an odd dimension
+                const int t2 = tap % (cp2 + 1), r = tap / (cp2 + 1), t1 = r % (cp1 + 1), t0 = r / (cp1 + 1);
+                d0 = (cp0 && t0 == 0) ? 1 : 0; d1 = (cp1 && t1 == 0) ? 1 : 0; d2 = (cp2 && t2 == 0) ? 1 : 0;
+            } else { d0 = a.td0[tap]; d1 = a.td1[tap]; d2 = a.td2[tap]; }
+        }
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             const int i0 = v0[mi] * a.is + d0, i1 = v1[mi] * a.is + d1, i2 = v2[mi] * a.is + d2;
@@ -580,9 +598,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         for (int ni = 0; ni < NW; ++ni) {
             if (LDSW && ni != 0) continue;                  // this wave's own tile only (tile wid), kept in slot 0
             const int cb = (n0 >> 4) + (LDSW ? wid : ni);
-            const long widx = a.wp_hi ? ((long)(ks * (a.Cout >> 4) + cb) * 64 + lane) * 8 : (long)(cb * 16 + vl) * a.Kp + ks * 32 + kg * 8;
-            R.wh[ni] = *reinterpret_cast<const f16x8*>((a.wp_hi ? a.wp_hi : a.w_hi) + widx);
-            if (F32) R.wl[ni] = *reinterpret_cast<const f16x8*>((a.wp_hi ? a.wp_lo : a.w_lo) + widx);
+            const long widx = k_wp_hi ? ((long)(ks * (a.Cout >> 4) + cb) * 64 + lane) * 8 : (long)(cb * 16 + vl) * k_Kp + ks * 32 + kg * 8;
+            R.wh[ni] = *reinterpret_cast<const f16x8*>((k_wp_hi ? k_wp_hi : k_w_hi) + widx);
+            if (F32) R.wl[ni] = *reinterpret_cast<const f16x8*>((k_wp_hi ? k_wp_lo : k_w_lo) + widx);
         }
     };
     auto park = [&](int ks, Raw& R) {                       // LDSW: this wave's tile of k-step ks -> LDS, then the workgroup barrier
@@ -672,7 +690,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         if (!vok[mi]) continue;
-        const long ovox = (((long)vb[mi] * a.O0 + (v0[mi] * a.os + a.op0)) * a.O1 + (v1[mi] * a.os + a.op1)) * a.O2 + (v2[mi] * a.os + a.op2);
+        const long ovox = (((long)vb[mi] * a.O0 + (v0[mi] * a.os + k_op0)) * a.O1 + (v1[mi] * a.os + k_op1)) * a.O2 + (v2[mi] * a.os + k_op2);
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
             const int co = n0 + ni * 16 + 4 * kg;
@@ -1501,10 +1519,19 @@ static int conv_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
     // output channels per wave: 64 / 32 / 16.  Wide slices reuse each gathered input fragment more, but the deep UNet levels have only
     // a few thousand voxels: there the k-loop (up to 432 steps of dependent L2 weight loads) is latency-bound and the chip is filled
     // by slicing Cout finer instead (4^3 x 512 channels: 32 -> 128 workgroups).
+    const int ncls = a.ncls > 0 ? a.ncls : 1;
     int nw = a.Cout >= 64 ? 4 : (a.Cout >= 32 ? 2 : 1);
-    while (nw > 1 && (long)semabs_cdiv(Mtot, 4 * 32) * (a.Cout / (nw * 16)) < 1024) nw >>= 1;
-    dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / (nw * 16)), block(256);
+    while (nw > 1 && (long)semabs_cdiv(Mtot, 4 * 32) * (a.Cout / (nw * 16)) * ncls < 1024) nw >>= 1;
+    dim3 grid(semabs_cdiv(Mtot, 4 * 32), a.Cout / (nw * 16), ncls), block(256);
     const bool c16 = a.Cin == 16;
+    if (a.ncls > 0) {                                       // ConvTranspose3d, eight parity classes in grid z (Cin % 32 == 0)
+#define CONVC_GO(NW_, F_) hipLaunchKernelGGL((k_conv<NW_, F_, false, false, true>), grid, block, 0, s, a)
+        if (f32) { if (nw == 4) CONVC_GO(4, true); else if (nw == 2) CONVC_GO(2, true); else CONVC_GO(1, true); }
+        else { if (nw == 4) CONVC_GO(4, false); else if (nw == 2) CONVC_GO(2, false); else CONVC_GO(1, false); }
+#undef CONVC_GO
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
 #define CONV_GO(NW_, F_, C_) hipLaunchKernelGGL((k_conv<NW_, F_, C_>), grid, block, 0, s, a)
 #define CONV_NW(F_, C_) { if (nw == 4) CONV_GO(4, F_, C_); else if (nw == 2) CONV_GO(2, F_, C_); else CONV_GO(1, F_, C_); }
     if (nw == 4 && !c16) {                                  // four waves x four shared weight tiles: weights through LDS
@@ -1550,7 +1577,7 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
     a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.ntaps = ksize * ksize * ksize;
     a.Kp = ((a.ntaps * Cin + 31) / 32) * 32;
-    a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr;
+    a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr; a.ncls = 0;
     if (act_flags & SEMABS_CONV_PACKED) {
         a.wp_hi = a.w_hi + (long)Cout * a.Kp;
         if (w_lo) a.wp_lo = a.w_lo + (long)Cout * a.Kp;
@@ -1602,7 +1629,7 @@ extern "C" int semabs_conv3d_gather(const void* x, const void* w_hi, const void*
     ConvArgs a;
     SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gather: in_scale and in_shift go together");
     a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
-    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
+    a.bias = nullptr; a.resid = nullptr; a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr; a.ncls = 0; a.B = B; a.I0 = I0; a.I1 = I1; a.I2 = I2; a.O0 = M0; a.O1 = M1; a.O2 = M2;
     a.M0 = M0; a.M1 = M1; a.M2 = M2; a.os = 1; a.is = in_stride; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
     a.ntaps = ntaps; a.Kp = ((ntaps * Cin + 31) / 32) * 32;
     if (act_flags & SEMABS_CONV_PACKED) { a.wp_hi = a.w_hi + (long)Cout * a.Kp; if (a.w_lo) a.wp_lo = a.w_lo + (long)Cout * a.Kp; }
@@ -1836,22 +1863,18 @@ static int convT_impl(const void* x, const void* w_hi, const void* w_lo, const l
         if (rc == SEMABS_OK && out_sums && !fused) rc = semabs_gn_stats(y, out_sums, B, 8L * D0 * D1 * D2, Cout, out_groups, act_f32, stream);
         return rc;
     }
-    for (int cls = 0; cls < 8; ++cls) {
-        const int p0 = cls >> 2, p1 = (cls >> 1) & 1, p2 = cls & 1;
+    {   // the small (deep) levels: the eight output parity classes as ONE launch of the gather kernel, blockIdx.z = class (eight launches of
+        // 16 - 64 workgroups each were 50 us apiece: 0.48 ms for the 4^3 -> 8^3 layer, whose arithmetic is 4 us)
         ConvArgs a;
-        a.x = x; a.y = y; a.w_hi = (const f16*)w_hi + class_off[cls]; a.w_lo = w_lo ? (const f16*)w_lo + class_off[cls] : nullptr;
+        a.x = x; a.y = y; a.w_hi = (const f16*)w_hi; a.w_lo = w_lo ? (const f16*)w_lo : nullptr;
         a.gn_scale = nullptr; a.gn_shift = nullptr; a.bias = bias; a.resid = skip; a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr;
         if (act_flags & SEMABS_CONV_PACKED) { a.wp_hi = a.w_hi + 27L * Cin * Cout; if (a.w_lo) a.wp_lo = a.w_lo + 27L * Cin * Cout; }
         a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = 2 * D0; a.O1 = 2 * D1; a.O2 = 2 * D2;
-        a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.is = 1; a.op0 = p0; a.op1 = p1; a.op2 = p2; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
-        int t = 0;
-        for (int t0 = 0; t0 <= p0; ++t0)
-            for (int t1 = 0; t1 <= p1; ++t1)
-                for (int t2 = 0; t2 <= p2; ++t2, ++t) {
-                    a.td0[t] = p0 ? (t0 == 0 ? 1 : 0) : 0; a.td1[t] = p1 ? (t1 == 0 ? 1 : 0) : 0; a.td2[t] = p2 ? (t2 == 0 ? 1 : 0) : 0;
-                }
-        a.ntaps = t;
-        a.Kp = a.ntaps * Cin;
+        a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 2; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
+        a.ntaps = 8; a.Kp = 8 * Cin;                        // (per class in the kernel)
+        for (int t = 0; t < 28; ++t) { a.td0[t] = 0; a.td1[t] = 0; a.td2[t] = 0; }
+        a.ncls = 8;
+        for (int c = 0; c < 8; ++c) a.cls_off[c] = class_off[c];
         rc = conv_launch(a, act_f32, (hipStream_t)stream);
         if (rc) return rc;
     }
