@@ -202,8 +202,7 @@ struct AggArgs {
     int L, N, g, H, W, n_img, tiles_per_img, n_scales;
 };
 
-__device__ __forceinline__ void bil_setup(int d, int ts, int g, int& i0, int& i1, float& l0, float& l1) {
-    const float scale = (float)g / (float)ts;
+__device__ __forceinline__ void bil_setup(int d, float scale, int g, int& i0, int& i1, float& l0, float& l1) {      // scale = (float)g / (float)tile size
     float s = scale * ((float)d + 0.5f) - 0.5f;
     if (s < 0.f) s = 0.f;
     i0 = (int)s;
@@ -231,13 +230,14 @@ __global__ __launch_bounds__(256) void k_aggregate(const float* __restrict__ rel
         int iy_lo = c - ts + 1 <= 0 ? 0 : (c - ts + 1 + stride - 1) / stride;
         __half acc = __float2half(0.f);
         float cnt = 1e-5f;
+        const float bscale = (float)g / (float)ts;       // one division per scale, not per covering tile (~300 per pixel)
         for (int im = 0; im < a.n_img; ++im) {
             for (int iy = iy_lo; iy <= iy_hi; ++iy) {
                 int w0, w1; float lw0, lw1;
-                bil_setup(c - iy * stride, ts, g, w0, w1, lw0, lw1);
+                bil_setup(c - iy * stride, bscale, g, w0, w1, lw0, lw1);
                 for (int ix = ix_lo; ix <= ix_hi; ++ix) {
                     int h0, h1; float lh0, lh1;
-                    bil_setup(r - ix * stride, ts, g, h0, h1, lh0, lh1);
+                    bil_setup(r - ix * stride, bscale, g, h0, h1, lh0, lh1);
                     const long tile = (long)im * a.tiles_per_img + base + iy * nx + ix;
                     const float* p = rel + ((long)l * a.N + tile) * gg;
                     float v00 = p[h0 * g + w0], v01 = p[h0 * g + w1], v10 = p[h1 * g + w0], v11 = p[h1 * g + w1];
