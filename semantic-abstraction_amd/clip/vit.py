@@ -147,7 +147,9 @@ def make_vision_engine(state_dict, chunk_tiles: int = 2448, max_labels: int = 16
     layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
     if layers <= ROLLOUT_SKIP + 2:
         return VisionRollout(state_dict, chunk_tiles=chunk_tiles, max_labels=max_labels)
-    return VisionRolloutDeep(state_dict, chunk_tiles=min(chunk_tiles, 16), max_labels=max_labels)
+    # tiles per chunk of the deep rollout: the backward pass runs labels x tiles sequences (16 x 63 x 257 rows = 1 012 row panels: 15.8 waves of
+    # 256 x 256 GEMM tiles at N = 1 024, where 16 tiles gave 4.02 waves, i.e. a fifth round for four tiles); 21 GB of tape at 16 labels
+    return VisionRolloutDeep(state_dict, chunk_tiles=min(chunk_tiles, int(os.environ.get("SEMABS_DEEP_CHUNK", "63"))), max_labels=max_labels)
 
 
 ROLLOUT_SKIP = 10      # ClipGradcam(num_layers=10): blocks with index <= 10 do not enter the rollout (clip_gradcam.py:37, 85-87)

@@ -806,21 +806,38 @@ extern "C" int semabs_ln_bwd(const float* x, const float* gamma, const float* gy
 }
 
 // quick-GELU VJP: dfc[m, :] = dact[m, :] * (s (1 + 1.702 fc (1 - s))),  s = sigmoid(1.702 fc[m % n_x, :])   -> fp16
-__global__ void k_gelu_bwd(const float* __restrict__ dact, const float* __restrict__ fc, f16* __restrict__ dfc, long M, int W, int n_x) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * (W / 4)) return;
-    long m = i / (W / 4); int c = (int)(i % (W / 4)) * 4;
-    float4 a = *reinterpret_cast<const float4*>(dact + m * W + c);
-    float4 f = *reinterpret_cast<const float4*>(fc + (m % n_x) * W + c);
+// One workgroup per row m: the pre-activation row m % n_x is a scalar decision, 4 float4 per operand in flight per thread (one float4 per
+// thread with two 64-bit divisions per element ran at 3.7 TB/s: 1.79 ms per ViT-L block at 16 labels x 63 tiles).
+__global__ __launch_bounds__(256) void k_gelu_bwd(const float* __restrict__ dact, const float* __restrict__ fc, f16* __restrict__ dfc, long M, int W, int n_x) {
+    const long m = blockIdx.x;
+    const float* a_row = dact + m * W;
+    const float* f_row = fc + (m % n_x) * W;
+    f16* o_row = dfc + m * W;
     auto d = [](float x) { float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); };
-    f16x4 h;
-    h[0] = (f16)(a.x * d(f.x)); h[1] = (f16)(a.y * d(f.y)); h[2] = (f16)(a.z * d(f.z)); h[3] = (f16)(a.w * d(f.w));
-    *reinterpret_cast<f16x4*>(dfc + m * W + c) = h;
+    for (int c0 = threadIdx.x * 4; c0 < W; c0 += 4096) {
+        float4 a[4], f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 1024 < W ? c0 + u * 1024 : c0;
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_row + c));
+            a[u] = make_float4(t[0], t[1], t[2], t[3]);
+            f[u] = *reinterpret_cast<const float4*>(f_row + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 1024;
+            if (c < W) {
+                f16x4 h;
+                h[0] = (f16)(a[u].x * d(f[u].x)); h[1] = (f16)(a[u].y * d(f[u].y)); h[2] = (f16)(a[u].z * d(f[u].z)); h[3] = (f16)(a[u].w * d(f[u].w));
+                *reinterpret_cast<f16x4*>(o_row + c) = h;
+            }
+        }
+    }
 }
 extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, void* stream) {
     if (M == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(dact && fc && dfc && M > 0 && W % 4 == 0 && n_x > 0, "semabs_gelu_bwd: bad args");
-    hipLaunchKernelGGL(k_gelu_bwd, dim3(semabs_cdiv(M * (W / 4), 256)), dim3(256), 0, (hipStream_t)stream, dact, fc, (f16*)dfc, M, W, n_x);
+    SEMABS_REQUIRE(dact && fc && dfc && M > 0 && M < (1L << 31) && W % 4 == 0 && n_x > 0, "semabs_gelu_bwd: bad args");
+    hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, dact, fc, (f16*)dfc, M, W, n_x);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
