@@ -109,6 +109,8 @@ int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, con
  * auxiliary.py:129,340; model_explainability.py:210-217,253-254,325,353; clip_gradcam.py:90-97 (VJP chain)
  * epi: 0 fp16 = acc+bias | 1 fp16 = quickgelu(acc+bias) | 2 fp32 += acc+bias | 3 fp32 = acc+bias |
  *      4 fp32 row-remapped: out row = (m / g_in) * g_out + g_off + m % g_in, plus addend[(g_off + m % g_in), :]
+ *      5 fp16 = (acc+bias) * quickgelu'(addend[m % g_in, :]): the QuickGELU VJP of the multi-layer rollout (clip_gradcam.py:90-97 differentiating
+ *        model_explainability.py:199-201); addend = fp32 pre-activations [g_in, N]; M >= 2048, N % 256 == 0, K >= 128 (phased kernel only)
  * rowmap3 HOST {g_in, g_out, g_off}; N % 128 == 0, K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0. */
 int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
                     long lda, int ldb, long ldc, int epi, const int* rowmap3, void* stream);

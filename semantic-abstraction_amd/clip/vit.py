@@ -25,7 +25,7 @@ import torch
 
 from .. import _lib
 
-EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP = 0, 1, 2, 3, 4
+EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_F32, EPI_ROWMAP, EPI_GELUBWD = 0, 1, 2, 3, 4, 5
 
 
 class GemmTimer:
@@ -76,6 +76,7 @@ GEMM_TIMER: "GemmTimer | None" = None
 # epilogue) but the LayerNorm passes get slower by the same bytes - 149.9 vs 149.0 ms per scene - and every residual update is rounded to
 # fp16 once more, so the fused read-modify-write epilogue stays the default.
 DELTA_RESIDUAL = os.environ.get("SEMABS_DELTA_RESIDUAL", "0") == "1"
+FUSE_GELU_BWD = os.environ.get("SEMABS_FUSE_GELU_BWD", "1") == "1"      # A/B: 0 = fp32 GEMM output + k_gelu_bwd
 
 
 def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, kernel=0):
@@ -86,7 +87,7 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, k
         t.seen += 1
         if t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0:     # hashed: no phase lock with the launch pattern
             e0, e1 = t._pair()
-            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else (8 if epi == 2 else 4))))   # A + W + C (fp32 residual: read + write)
+            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4))))   # A + W + C (fp32 residual: read + write)
     _lib.call("semabs_gemm_f16_ex", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
               int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, int(kernel), e0, e1,
               _lib.stream())
@@ -499,8 +500,11 @@ class VisionRolloutDeep:
         for i in range(self.layers - 1, self.first_roll - 1, -1):
             b, sv = self.blocks[i], ws["saved"][i]
             # MLP sub-layer: g_mid = g_out + LN2^T( W_fc^T( gelu'(fc) * (W_pr^T g_out) ) )
-            gemm(g16, b.w_pr_t, ws["dact"], None, M, 4 * D, D, D, D, 4 * D, EPI_F32)
-            _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(sv["fc"]), _lib.ptr(ws["dfc"]), M, 4 * D, NT, st)
+            if M >= 2048 and FUSE_GELU_BWD:                      # the QuickGELU derivative in the GEMM's epilogue: no fp32 dact written and re-read
+                gemm(g16, b.w_pr_t, ws["dfc"], None, M, 4 * D, D, D, D, 4 * D, EPI_GELUBWD, addend=sv["fc"], rowmap=(NT, 1, 0))
+            else:
+                gemm(g16, b.w_pr_t, ws["dact"], None, M, 4 * D, D, D, D, 4 * D, EPI_F32)
+                _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(sv["fc"]), _lib.ptr(ws["dfc"]), M, 4 * D, NT, st)
             gemm(ws["dfc"], b.w_fc_t, ws["dh"], None, M, D, 4 * D, 4 * D, 4 * D, D, EPI_F32)
             _lib.call("semabs_ln_bwd", _lib.ptr(sv["x_mid"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh"]), _lib.ptr(g32), _lib.ptr(ws["gmid32"]),
                       _lib.ptr(ws["gmid16"]), M, D, NT, D, 1e-5, st)

@@ -22,7 +22,7 @@
 #include <type_traits>
 
 #define BK 64   // K granularity required by the ABI (both K-tile sizes divide it)
-enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4 };
+enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4, EPI_GELUBWD_F16 = 5 };
 
 struct GemmArgs {
     const f16* A; const f16* B; void* C; const float* bias; const float* addend;
@@ -586,7 +586,49 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                                                         rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * ES : 0);
             const unsigned voff = (unsigned)crow * ldcb + (unsigned)(cchunk * 16);
             auto soff_of = [&](int pass, int it) { return (unsigned)((pass & 1) * 128 + it * RPI) * ldcb + (unsigned)((pass >> 1) * 128 * ES); };
-            if constexpr (EPI == EPI_BIAS_RESID_F32) {
+            if constexpr (EPI == EPI_GELUBWD_F16) {
+                // C fp16 = (acc + bias) * quickgelu'(fc[m % g_in, :]): the QuickGELU VJP of the ViT-L rollout (vit.hip k_gelu_bwd) in the epilogue of
+                // the W_pr^T GEMM - the fp32 product (4.2 GB per block at 16 labels x 63 tiles) is neither written nor read back.  The tile goes through
+                // LDS in fp32 like the other fp32 epilogues; the pre-activation rows are loaded in the same coalesced layout one pass ahead; a lane
+                // ends up with 4 consecutive columns = one 8-byte store.
+                const unsigned ldob = (unsigned)g.ldc * 2u;
+                const __amdgpu_buffer_rsrc_t rO = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * 2,
+                                                            rows > 0 ? (rows - 1) * (long)ldob + (long)(g.N - n0 - wc * 32) * 2 : 0);
+                const unsigned ovoff = (unsigned)crow * ldob + (unsigned)(cchunk * 8);
+                const float* fcol = g.addend + (n0 + wc * 32 + cchunk * 4);
+                f32x4 fc[2][NIT];
+                auto issue = [&](int pass) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const unsigned m = (unsigned)(mw + (pass & 1) * 128 + it * RPI + crow);
+                        const unsigned fr = m % (unsigned)g.g_in;
+                        const float4 t = *reinterpret_cast<const float4*>(fcol + (long)fr * g.N + (pass >> 1) * 128);
+                        fc[pass & 1][it] = f32x4{t.x, t.y, t.z, t.w};
+                    }
+                };
+                issue(0);
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    lds_write(pass);
+                    if (pass + 1 < 4) issue(pass + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const f32x4 v = lds_read(pass, it);
+                        const f32x4 x = fc[pass & 1][it];
+                        f16x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x[e]));
+                            h[e] = (f16)(v[e] * (sg * (1.f + 1.702f * x[e] * (1.f - sg))));
+                        }
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rO, ovoff,
+                                                              (unsigned)((pass & 1) * 128 + it * RPI) * ldob + (unsigned)((pass >> 1) * 128 * 2), 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
                 f32x4 res[2][NIT];
                 auto issue = [&](int pass) {
 #pragma unroll
@@ -862,6 +904,7 @@ static int launch(const GemmArgs& g, hipStream_t s, const GemmOpts& o) {
 // C ABI.  A fp16 [M, K] (row stride lda elements), B fp16 [N, K] (row stride ldb), C per `epi`:
 //   0 fp16 = acc + bias        1 fp16 = quickgelu(acc + bias)      2 fp32 += acc + bias (in place)
 //   3 fp32 = acc + bias        4 fp32 row-remapped store + addend  (rowmap = {g_in, g_out, g_off})
+//   5 fp16 = (acc + bias) * quickgelu'(addend[m % rowmap[0], :])   (addend = fp32 pre-activations [rowmap[0], N]; phased kernel only)
 // bias fp32 [N] or NULL.  Requires N % 128 == 0, K % 64 == 0, 16-byte aligned rows.
 extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias, const float* addend,
                                   long M, int N, int K, long lda, int ldb, long ldc, int epi, const int* rowmap3,
@@ -869,15 +912,15 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16: null operand");
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
-    SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (epi > 1 || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
+    SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((epi > 1 && epi != 5) || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
     SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 9) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.g_in = 1; g.g_out = 1; g.g_off = 0;
-    if (epi == EPI_ROWMAP_ADD_F32) {
-        SEMABS_REQUIRE(rowmap3 && rowmap3[0] > 0, "semabs_gemm_f16: epi 4 needs rowmap");
+    if (epi == EPI_ROWMAP_ADD_F32 || epi == EPI_GELUBWD_F16) {
+        SEMABS_REQUIRE(rowmap3 && rowmap3[0] > 0, "semabs_gemm_f16: epi 4 / 5 need rowmap");
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
@@ -890,6 +933,11 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(g, s, o);
         case EPI_BIAS_F32: return launch<EPI_BIAS_F32>(g, s, o);
         case EPI_ROWMAP_ADD_F32: return launch<EPI_ROWMAP_ADD_F32>(g, s, o);
+        case EPI_GELUBWD_F16: {
+            const bool big_ok = g.N % 256 == 0 && g.K >= 128 && g.lda < (1L << 20) && g.ldb < (1 << 20) && g.ldc < (1L << 20);
+            SEMABS_REQUIRE(big_ok && g.M >= 2048 && g.M < (1L << 31) && addend && g.g_in > 0, "semabs_gemm_f16: epi 5 (QuickGELU VJP) needs the phased kernel's shapes (M >= 2048, N % 256 == 0, K >= 128), the pre-activations in addend and their row count in rowmap[0]");
+            return launch_gemm8<EPI_GELUBWD_F16>(g, s, o);
+        }
     }
     semabs_set_error("semabs_gemm_f16: unknown epilogue");
     return SEMABS_EINVAL;

@@ -110,6 +110,31 @@ def test_gemm_rowmap_epilogue(kernel):
     assert bool((got[:, 0] == -7.0).all())                                       # class-token rows are left to semabs_embed_finish
 
 
+def test_gemm_quickgelu_vjp_epilogue():
+    """epi 5 (phased kernel): C fp16 = (A B^T + bias) * quickgelu'(pre[m % n_x, :]) - the QuickGELU VJP of the ViT-L rollout
+    (model_explainability.py:199-201 QuickGELU, differentiated by torch.autograd in clip_gradcam.py:90-97) fused into the W_pr^T GEMM; against
+    fp64 and against the unfused pair (fp32 GEMM + semabs_gelu_bwd)."""
+    from semabs_amd import _lib
+    from semabs_amd.clip.vit import gemm
+    for M, N, K, n_x in [(2381, 1024, 256, 700), (4100, 768, 768, 4100), (2048, 256, 128, 257)]:
+        A, B, bias, ref = _operands(M, N, K, K, K, seed=M)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        pre = torch.randn(n_x, N, device="cuda", generator=g) * 2.0
+        x = pre.double()[torch.arange(M, device="cuda") % n_x]
+        sg = torch.sigmoid(1.702 * x)
+        ref5 = ref * (sg * (1.0 + 1.702 * x * (1.0 - sg)))
+        out = torch.full((M, N), 7.0, dtype=torch.float16, device="cuda")
+        gemm(A, B, out, bias, M, N, K, K, K, N, 5, addend=pre, rowmap=(n_x, 1, 0))
+        _check16(out, ref5, f"epi 5 {M}x{N}x{K}")
+        d32 = torch.empty(M, N, device="cuda")
+        gemm(A, B, d32, bias, M, N, K, K, K, N, EPI_F32, kernel=2)
+        two = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        _lib.call("semabs_gelu_bwd", _lib.ptr(d32), _lib.ptr(pre), _lib.ptr(two), M, N, n_x, _lib.stream())
+        assert float((out.float() - two.float()).abs().max()) <= 2e-3 * float(ref5.abs().max())      # two fp16 roundings of nearly equal fp32 values
+    with pytest.raises(RuntimeError):                                            # small M: the ring kernel has no such epilogue
+        gemm(A[:300], B, out[:300], bias, 300, N, K, K, K, N, 5, addend=pre, rowmap=(n_x, 1, 0))
+
+
 def test_gemm_kernels_agree_and_heuristic_picks_the_phased_kernel():
     """Both kernels compute the same sums (fp32 accumulation order differs); the heuristic (kernel 0) must give exactly the phased kernel's
     result for a trunk-sized problem and exactly the ring kernel's for a small one."""
