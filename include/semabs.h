@@ -109,8 +109,8 @@ int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, con
  * auxiliary.py:129,340; model_explainability.py:210-217,253-254,325,353; clip_gradcam.py:90-97 (VJP chain)
  * epi: 0 fp16 = acc+bias | 1 fp16 = quickgelu(acc+bias) | 2 fp32 += acc+bias | 3 fp32 = acc+bias |
  *      4 fp32 row-remapped: out row = (m / g_in) * g_out + g_off + m % g_in, plus addend[(g_off + m % g_in), :]
- *      5 fp16 = (acc+bias) * quickgelu'(addend[m % g_in, :]): the QuickGELU VJP of the multi-layer rollout (clip_gradcam.py:90-97 differentiating
- *        model_explainability.py:199-201); addend = fp32 pre-activations [g_in, N]; M >= 2048, N % 256 == 0, K >= 128 (phased kernel only)
+ *      5 fp16 = (acc+bias) * addend[m % g_in, :]: addend = fp32 table [g_in, N] - with semabs_quickgelu_grad's table the QuickGELU VJP of the multi-layer
+ *        rollout (clip_gradcam.py:90-97 differentiating model_explainability.py:199-201); M >= 2048, N % 256 == 0, K >= 128 (phased kernel only)
  * rowmap3 HOST {g_in, g_out, g_off}; N % 128 == 0, K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0. */
 int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
                     long lda, int ldb, long ldc, int epi, const int* rowmap3, void* stream);
@@ -145,6 +145,8 @@ int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int
 int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
 int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
 int semabs_quickgelu(const float* fc, void* act, long n, void* stream);                 /* model_explainability.py:197-199 */
+/* gd = d quickgelu(x) / dx on fp32 pre-activations (fp32, n % 4 == 0): the derivative table of semabs_gemm_f16 epi 5 */
+int semabs_quickgelu_grad(const float* fc, float* gd, long n, void* stream);
 /* logits = 100 f/|f| . w_l and d logit / d f, rows normalised to max-abs 1            clip_gradcam.py:62-67 */
 int semabs_logit_grad(const float* feat, const float* w_text, int n, int L, int E, float* logits, void* dfeat, float* scale, void* stream);
 int semabs_ln_bwd(const float* x, const float* gamma, const float* gy, const float* resid, float* out32, void* out16,

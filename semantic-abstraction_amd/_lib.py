@@ -55,6 +55,7 @@ SIGNATURES = {
     "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, P],
     "semabs_rows_gather": [P, P, L, I, L, L, P],
     "semabs_quickgelu": [P, P, L, P],
+    "semabs_quickgelu_grad": [P, P, L, P],
     "semabs_logit_grad": [P, P, I, I, I, P, P, P, P],
     "semabs_ln_bwd": [P, P, P, P, P, P, L, I, I, L, F, P],
     "semabs_gelu_bwd": [P, P, P, L, I, I, P],

@@ -501,7 +501,8 @@ class VisionRolloutDeep:
             b, sv = self.blocks[i], ws["saved"][i]
             # MLP sub-layer: g_mid = g_out + LN2^T( W_fc^T( gelu'(fc) * (W_pr^T g_out) ) )
             if M >= 2048 and FUSE_GELU_BWD:                      # the QuickGELU derivative in the GEMM's epilogue: no fp32 dact written and re-read
-                gemm(g16, b.w_pr_t, ws["dfc"], None, M, 4 * D, D, D, D, 4 * D, EPI_GELUBWD, addend=sv["fc"], rowmap=(NT, 1, 0))
+                _lib.call("semabs_quickgelu_grad", _lib.ptr(sv["fc"]), _lib.ptr(ws["dact"]), NT * 4 * D, st)      # derivative table, shared by the labels (dact = scratch)
+                gemm(g16, b.w_pr_t, ws["dfc"], None, M, 4 * D, D, D, D, 4 * D, EPI_GELUBWD, addend=ws["dact"], rowmap=(NT, 1, 0))
             else:
                 gemm(g16, b.w_pr_t, ws["dact"], None, M, 4 * D, D, D, D, 4 * D, EPI_F32)
                 _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(sv["fc"]), _lib.ptr(ws["dfc"]), M, 4 * D, NT, st)

@@ -22,7 +22,7 @@
 #include <type_traits>
 
 #define BK 64   // K granularity required by the ABI (both K-tile sizes divide it)
-enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4, EPI_GELUBWD_F16 = 5 };
+enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4, EPI_MULROW_F16 = 5 };
 
 struct GemmArgs {
     const f16* A; const f16* B; void* C; const float* bias; const float* addend;
@@ -586,11 +586,13 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                                                         rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * ES : 0);
             const unsigned voff = (unsigned)crow * ldcb + (unsigned)(cchunk * 16);
             auto soff_of = [&](int pass, int it) { return (unsigned)((pass & 1) * 128 + it * RPI) * ldcb + (unsigned)((pass >> 1) * 128 * ES); };
-            if constexpr (EPI == EPI_GELUBWD_F16) {
-                // C fp16 = (acc + bias) * quickgelu'(fc[m % g_in, :]): the QuickGELU VJP of the ViT-L rollout (vit.hip k_gelu_bwd) in the epilogue of
-                // the W_pr^T GEMM - the fp32 product (4.2 GB per block at 16 labels x 63 tiles) is neither written nor read back.  The tile goes through
-                // LDS in fp32 like the other fp32 epilogues; the pre-activation rows are loaded in the same coalesced layout one pass ahead; a lane
-                // ends up with 4 consecutive columns = one 8-byte store.
+            if constexpr (EPI == EPI_MULROW_F16) {
+                // C fp16 = (acc + bias) * addend[m % g_in, :] (addend fp32 [g_in, N]): the QuickGELU VJP of the ViT-L rollout in the epilogue of the
+                // W_pr^T GEMM, with the derivative as a per-tile-row table (vit.hip k_quickgelu_grad: the 16 labels of a tile share it) - the fp32
+                // product (4.2 GB per block at 16 labels x 63 tiles) is neither written nor read back.  The tile goes through LDS in fp32 like the
+                // other fp32 epilogues; the table rows are loaded in the same coalesced layout one pass ahead; a lane ends up with 4 consecutive
+                // columns = one 8-byte store.  (With the sigmoid evaluated here - v_exp + v_rcp per element and label - this GEMM took 2.48 ms
+                // against 1.33 ms for the plain fp32-output GEMM of the same shape.)
                 const unsigned ldob = (unsigned)g.ldc * 2u;
                 const __amdgpu_buffer_rsrc_t rO = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * 2,
                                                             rows > 0 ? (rows - 1) * (long)ldob + (long)(g.N - n0 - wc * 32) * 2 : 0);
@@ -618,10 +620,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                         const f32x4 x = fc[pass & 1][it];
                         f16x4 h;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x[e]));
-                            h[e] = (f16)(v[e] * (sg * (1.f + 1.702f * x[e] * (1.f - sg))));
-                        }
+                        for (int e = 0; e < 4; ++e) h[e] = (f16)(v[e] * x[e]);
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rO, ovoff,
                                                               (unsigned)((pass & 1) * 128 + it * RPI) * ldob + (unsigned)((pass >> 1) * 128 * 2), 0);
@@ -904,7 +903,7 @@ static int launch(const GemmArgs& g, hipStream_t s, const GemmOpts& o) {
 // C ABI.  A fp16 [M, K] (row stride lda elements), B fp16 [N, K] (row stride ldb), C per `epi`:
 //   0 fp16 = acc + bias        1 fp16 = quickgelu(acc + bias)      2 fp32 += acc + bias (in place)
 //   3 fp32 = acc + bias        4 fp32 row-remapped store + addend  (rowmap = {g_in, g_out, g_off})
-//   5 fp16 = (acc + bias) * quickgelu'(addend[m % rowmap[0], :])   (addend = fp32 pre-activations [rowmap[0], N]; phased kernel only)
+//   5 fp16 = (acc + bias) * addend[m % rowmap[0], :]   (addend = fp32 table [rowmap[0], N], e.g. semabs_quickgelu_grad's; phased kernel only)
 // bias fp32 [N] or NULL.  Requires N % 128 == 0, K % 64 == 0, 16-byte aligned rows.
 extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias, const float* addend,
                                   long M, int N, int K, long lda, int ldb, long ldc, int epi, const int* rowmap3,
@@ -919,7 +918,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.g_in = 1; g.g_out = 1; g.g_off = 0;
-    if (epi == EPI_ROWMAP_ADD_F32 || epi == EPI_GELUBWD_F16) {
+    if (epi == EPI_ROWMAP_ADD_F32 || epi == EPI_MULROW_F16) {
         SEMABS_REQUIRE(rowmap3 && rowmap3[0] > 0, "semabs_gemm_f16: epi 4 / 5 need rowmap");
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
@@ -933,10 +932,10 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(g, s, o);
         case EPI_BIAS_F32: return launch<EPI_BIAS_F32>(g, s, o);
         case EPI_ROWMAP_ADD_F32: return launch<EPI_ROWMAP_ADD_F32>(g, s, o);
-        case EPI_GELUBWD_F16: {
+        case EPI_MULROW_F16: {
             const bool big_ok = g.N % 256 == 0 && g.K >= 128 && g.lda < (1L << 20) && g.ldb < (1 << 20) && g.ldc < (1L << 20);
-            SEMABS_REQUIRE(big_ok && g.M >= 2048 && g.M < (1L << 31) && addend && g.g_in > 0, "semabs_gemm_f16: epi 5 (QuickGELU VJP) needs the phased kernel's shapes (M >= 2048, N % 256 == 0, K >= 128), the pre-activations in addend and their row count in rowmap[0]");
-            return launch_gemm8<EPI_GELUBWD_F16>(g, s, o);
+            SEMABS_REQUIRE(big_ok && g.M >= 2048 && g.M < (1L << 31) && addend && g.g_in > 0, "semabs_gemm_f16: epi 5 (row-table multiply) needs the phased kernel's shapes (M >= 2048, N % 256 == 0, K >= 128), the table in addend and its row count in rowmap[0]");
+            return launch_gemm8<EPI_MULROW_F16>(g, s, o);
         }
     }
     semabs_set_error("semabs_gemm_f16: unknown epilogue");

@@ -685,6 +685,29 @@ extern "C" int semabs_quickgelu(const float* fc, void* act, long n, void* stream
     return SEMABS_OK;
 }
 
+// quick-GELU derivative table: gd = s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x), fp32 -> fp32.  The multi-layer rollout differentiates the same
+// pre-activations for every label: the table is built once per (block, tile chunk) and the W_pr^T GEMM's epilogue (semabs_gemm_f16 epi 5)
+// multiplies by its rows - no transcendental work per (label, element).
+__global__ __launch_bounds__(256) void k_quickgelu_grad(const float* __restrict__ fc, float* __restrict__ gd, long n4) {
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long i = i0 + u * 256 < n4 ? i0 + u * 256 : 0; x[u] = *reinterpret_cast<const float4*>(fc + i * 4); }
+    auto d = [](float v) { const float sg = 1.f / (1.f + __expf(-1.702f * v)); return sg * (1.f + 1.702f * v * (1.f - sg)); };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256;
+        if (i < n4) *reinterpret_cast<float4*>(gd + i * 4) = make_float4(d(x[u].x), d(x[u].y), d(x[u].z), d(x[u].w));
+    }
+}
+extern "C" int semabs_quickgelu_grad(const float* fc, float* gd, long n, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(fc && gd && n > 0 && n % 4 == 0, "semabs_quickgelu_grad: bad args (n % 4 == 0)");
+    hipLaunchKernelGGL(k_quickgelu_grad, dim3(semabs_cdiv(n / 4, 1024)), dim3(256), 0, (hipStream_t)stream, fc, gd, n / 4);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // logits + d logit / d feat, one wave per tile (clip_gradcam.py:63-67 and the head of the analytic VJP):
 //   fh = f / |f|;  logit[i, l] = 100 fh . w_l;  dfeat[l, i, :] = 100 (w_l - fh (fh . w_l)) / |f|
 // Each gradient row is normalised to max-abs 1 before the fp16 GEMM chain (the VJP is linear, the rollout

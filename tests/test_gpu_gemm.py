@@ -111,7 +111,7 @@ def test_gemm_rowmap_epilogue(kernel):
 
 
 def test_gemm_quickgelu_vjp_epilogue():
-    """epi 5 (phased kernel): C fp16 = (A B^T + bias) * quickgelu'(pre[m % n_x, :]) - the QuickGELU VJP of the ViT-L rollout
+    """epi 5 (phased kernel): C fp16 = (A B^T + bias) * table[m % n_x, :] with table = semabs_quickgelu_grad(pre) - the QuickGELU VJP of the ViT-L rollout
     (model_explainability.py:199-201 QuickGELU, differentiated by torch.autograd in clip_gradcam.py:90-97) fused into the W_pr^T GEMM; against
     fp64 and against the unfused pair (fp32 GEMM + semabs_gelu_bwd)."""
     from semabs_amd import _lib
@@ -124,7 +124,9 @@ def test_gemm_quickgelu_vjp_epilogue():
         sg = torch.sigmoid(1.702 * x)
         ref5 = ref * (sg * (1.0 + 1.702 * x * (1.0 - sg)))
         out = torch.full((M, N), 7.0, dtype=torch.float16, device="cuda")
-        gemm(A, B, out, bias, M, N, K, K, K, N, 5, addend=pre, rowmap=(n_x, 1, 0))
+        table = torch.empty_like(pre)
+        _lib.call("semabs_quickgelu_grad", _lib.ptr(pre), _lib.ptr(table), pre.numel(), _lib.stream())
+        gemm(A, B, out, bias, M, N, K, K, K, N, 5, addend=table, rowmap=(n_x, 1, 0))
         _check16(out, ref5, f"epi 5 {M}x{N}x{K}")
         d32 = torch.empty(M, N, device="cuda")
         gemm(A, B, d32, bias, M, N, K, K, K, N, EPI_F32, kernel=2)
@@ -132,7 +134,7 @@ def test_gemm_quickgelu_vjp_epilogue():
         _lib.call("semabs_gelu_bwd", _lib.ptr(d32), _lib.ptr(pre), _lib.ptr(two), M, N, n_x, _lib.stream())
         assert float((out.float() - two.float()).abs().max()) <= 2e-3 * float(ref5.abs().max())      # two fp16 roundings of nearly equal fp32 values
     with pytest.raises(RuntimeError):                                            # small M: the ring kernel has no such epilogue
-        gemm(A[:300], B, out[:300], bias, 300, N, K, K, K, N, 5, addend=pre, rowmap=(n_x, 1, 0))
+        gemm(A[:300], B, out[:300], bias, 300, N, K, K, K, N, 5, addend=table, rowmap=(n_x, 1, 0))
 
 
 def test_gemm_kernels_agree_and_heuristic_picks_the_phased_kernel():
