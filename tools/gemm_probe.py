@@ -98,6 +98,13 @@ if "persist" in what:
             tune(5, ps)
             log[f"persist{ps}_{rep}"] = line(f"persistent {ps} (rep {rep})")
     tune(5, 0)
+if "ablate2" in what:
+    # components of the steady-state loop, epilogue always off (bit 3): bit 0 no in-loop DMA, bit 1 no in-loop LDS fragment reads, bit 2 no DMA waits
+    for ab, label in [(8, "no epilogue"), (9, "no epilogue, no DMA"), (10, "no epilogue, no LDS reads"), (11, "no epilogue, no DMA, no LDS reads"),
+                      (12, "no epilogue, no DMA waits"), (15, "MFMA + barriers only")]:
+        tune(2, ab)
+        log[f"ablate2_{ab}"] = line(label)
+    tune(2, 0)
 if "ablate" in what:
     for ab, label in [(8, "no epilogue"), (16, "no B staging / B reads"), (24, "no B staging / reads, no epilogue"), (9, "no DMA, no epilogue")]:
         tune(2, ab)
