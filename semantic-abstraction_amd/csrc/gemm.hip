@@ -34,6 +34,7 @@ struct GemmArgs {
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
+    unsigned long long* ptrace; int ptrace_wg;   // tuning build only: s_memtime stamps of every phase of ONE workgroup (waves 0 and 4 = one per wave row), see GEMM8_STAMP
 #endif
 };
 // Ablation switches exist only in the tuning build (build.py --tuning -> libsemabs_hip_tune.so, used by tools/); in the production library
@@ -253,6 +254,7 @@ struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
 static int g_group_m = 0, g_ablate = 0, g_force_cfg = 0, g_prefetch = 1, g_persist = 0, g_sc_w = 0;
 static unsigned long long* g_trace = nullptr;
+static unsigned long long* g_ptrace = nullptr; static int g_ptrace_wg = 0;
 extern "C" int semabs_gemm_tune(int key, long long value) {
     switch (key) {
         case 0: g_force_cfg = (int)value; break;     // alternative ring-kernel tile configurations (see launch())
@@ -261,6 +263,8 @@ extern "C" int semabs_gemm_tune(int key, long long value) {
         case 3: g_prefetch = (int)value; break;
         case 5: g_persist = (int)value; break;        // 1 = persistent workgroups (one per CU)       // 1 = fragment reads in the MFMA shadow (production), 0 = read block before the barrier
         case 4: g_trace = (unsigned long long*)value; break;
+        case 7: g_ptrace = (unsigned long long*)value; break;      // phase trace buffer: 2 rows x 1024 stamps (8 B each), zero = off
+        case 8: g_ptrace_wg = (int)value; break;                   // which workgroup (virtual block id) is traced
         case 6: g_sc_w = (int)value; break;           // column panels per super-column (0 = one super-column)
         default: return SEMABS_EINVAL;
     }
@@ -269,7 +273,7 @@ extern "C" int semabs_gemm_tune(int key, long long value) {
 #define GEMM_GROUP_M g_group_m
 #define GEMM_SC_W g_sc_w
 #define GEMM_PREFETCH g_prefetch
-#define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).trace = g_trace; } while (0)
+#define GEMM_TUNE_ARGS(g) do { (g).ablate = g_ablate; (g).trace = g_trace; (g).ptrace = g_ptrace; (g).ptrace_wg = g_ptrace_wg; } while (0)
 #else
 #define GEMM_GROUP_M 0
 #define GEMM_SC_W 0
@@ -701,11 +705,24 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 16 - (nread), 0);            \
     } while (0)
 
+#ifdef SEMABS_TUNING
+    // phase trace (tools/gemm_probe.py phases): lane 0 of waves 0 and 4 writes the shader clock to the spare LDS behind the operand buffers at four
+    // points of every phase: 0 phase start (before the DMA issue), 1 past the SYNC barrier, 2 MFMA block issued, 3 past the END barrier
+#define GEMM8_STAMP(t_, ph_, pt_)                                                                                             \
+    do {                                                                                                                      \
+        if (ptr_on) *reinterpret_cast<unsigned long long*>(smem + 2 * BUFSZ + (wid >> 2) * 8192 + (((t_) * 4 + (ph_)) * 4 + (pt_)) * 8) = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GEMM8_STAMP(t_, ph_, pt_) do { } while (0)
+#endif
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
     for (int vb = blockIdx.x; vb < g.n_blocks; vb += PERS ? (int)gridDim.x : g.n_blocks) {
     long m0; int n0;
     tile_of(vb, m0, n0);
     set_tile(m0, n0);
+#ifdef SEMABS_TUNING
+    const bool ptr_on = g.ptrace && vb == g.ptrace_wg && lane == 0 && (wid == 0 || wid == 4) && g.K / 64 <= 64;
+#endif
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -739,37 +756,53 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         for (int t = 0; t < nk; ++t) {
             const int par = t & 1;
             const bool s1 = t + 1 < nk && !GEMM_ABL(1), s2 = t + 2 < nk && !GEMM_ABL(1);
+            GEMM8_STAMP(t, 0, 0);
             if (s1) stage_a(1, t + 1);
             GEMM8_SYNC(s1);
+            GEMM8_STAMP(t, 0, 1);
             __builtin_amdgcn_s_setprio(1);
             if (!GEMM_ABL(16)) read_b(1, par);          // tuning bit 4: no B staging, no B fragment reads (wrong results: what would B from registers buy?)
             mma_a0(0);
             GEMM8_INTERLEAVE(4);
             __builtin_amdgcn_s_setprio(0);
+            GEMM8_STAMP(t, 0, 2);
             GEMM8_END();
+            GEMM8_STAMP(t, 0, 3);
+            GEMM8_STAMP(t, 1, 0);
             if (s2) stage_a(0, t + 2);
             GEMM8_SYNC(s2);
+            GEMM8_STAMP(t, 1, 1);
             __builtin_amdgcn_s_setprio(1);
             read_a1(par); mma_a0(1);
             GEMM8_INTERLEAVE(8);
             __builtin_amdgcn_s_setprio(0);
+            GEMM8_STAMP(t, 1, 2);
             GEMM8_END();
+            GEMM8_STAMP(t, 1, 3);
+            GEMM8_STAMP(t, 2, 0);
             if (s2 && !GEMM_ABL(16)) stage_b(0, t + 2);
             GEMM8_SYNC(s2);
+            GEMM8_STAMP(t, 2, 1);
             __builtin_amdgcn_s_setprio(1);
             read_a(0, par ^ 1);                      // (last K tile: reads a stale slot, never used - keeps the block branch-free)
             mma_a1(1);
             GEMM8_INTERLEAVE(8);
             __builtin_amdgcn_s_setprio(0);
+            GEMM8_STAMP(t, 2, 2);
             GEMM8_END();
+            GEMM8_STAMP(t, 2, 3);
+            GEMM8_STAMP(t, 3, 0);
             if (s2 && !GEMM_ABL(16)) stage_b(1, t + 2);
             GEMM8_SYNC(s2);
+            GEMM8_STAMP(t, 3, 1);
             __builtin_amdgcn_s_setprio(1);
             if (!GEMM_ABL(16)) read_b0n(par ^ 1);
             mma_a1(0);
             GEMM8_INTERLEAVE(4);
             __builtin_amdgcn_s_setprio(0);
+            GEMM8_STAMP(t, 3, 2);
             GEMM8_END();
+            GEMM8_STAMP(t, 3, 3);
             __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -814,6 +847,17 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #endif
     if (!GEMM_ABL(8)) epilogue(m0, n0);
 #ifdef SEMABS_TUNING
+    if (g.ptrace && vb == g.ptrace_wg) {                    // every wave of the traced workgroup takes part in the barrier; waves 0 and 4 copy their rows out
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (wid == 0 || wid == 4) {
+            const int nst = g.K / 64 * 16;
+            for (int i = lane; i < nst && i < 1024; i += 64)
+                g.ptrace[(wid >> 2) * 1024 + i] = *reinterpret_cast<unsigned long long*>(smem + 2 * BUFSZ + (wid >> 2) * 8192 + i * 8);
+        }
+    }
+#endif
+#ifdef SEMABS_TUNING
     if (g.trace) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
@@ -838,6 +882,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #undef GEMM8_SYNC
 #undef GEMM8_END
 #undef GEMM8_INTERLEAVE
+#undef GEMM8_STAMP
 }
 
 // Raster group size (row panels walked fastest) by the number of 256-wide column panels.  An XCD runs 32 tiles at a time = group_m row
@@ -851,7 +896,11 @@ static inline int gemm8_group_m(int n_tiles_n) { return n_tiles_n <= 3 ? 2 : (n_
 
 template <int EPI>
 static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
+#ifdef SEMABS_TUNING
+    constexpr int LDS = 2 * 4 * 16384 + 16384;             // + the phase-trace rows (GEMM8_STAMP)
+#else
     constexpr int LDS = 2 * 4 * 16384;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

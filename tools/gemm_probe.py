@@ -98,6 +98,24 @@ if "persist" in what:
             tune(5, ps)
             log[f"persist{ps}_{rep}"] = line(f"persistent {ps} (rep {rep})")
     tune(5, 0)
+if "phases" in what:
+    # per-phase timeline of ONE workgroup in the middle of the grid (tuning build, GEMM8_STAMP): for both wave rows, averaged over the inner K tiles,
+    # shader-clock cycles from phase start to: past the SYNC barrier (DMA issue + vmcnt wait + barrier), MFMA block issued, past the END barrier
+    for name, n, k, epi in SHAPES[:4]:
+        A, B, bias, C = operands(n, k, epi)
+        nb = ((M + 255) // 256) * (n // 256)
+        tr = torch.zeros(2, 1024, dtype=torch.int64, device="cuda")
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi); torch.cuda.synchronize()
+        tune(8, nb // 2 + 3); tune(7, tr.data_ptr())
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi); torch.cuda.synchronize()
+        tune(7, 0)
+        t = tr.cpu().numpy().reshape(2, 64, 4, 4)[:, :k // 64]          # [row, K tile, phase, point]
+        for row in range(2):
+            x = t[row, 1:-2].astype(np.float64)                          # inner K tiles
+            sync = (x[:, :, 1] - x[:, :, 0]).mean(0); mma = (x[:, :, 2] - x[:, :, 1]).mean(0); end = (x[:, :, 3] - x[:, :, 2]).mean(0)
+            per_kt = (t[row, 2:-1, 0, 0] - t[row, 1:-2, 0, 0]).mean()
+            print(f"phases {name} row {row}: cycles per K tile {per_kt:7.0f} | per phase (0-3): to SYNC {np.round(sync)}  MFMA issue {np.round(mma)}  to END {np.round(end)}", flush=True)
+        log[f"phases_{name}"] = t.tolist()
 if "ablate2" in what:
     # components of the steady-state loop, epilogue always off (bit 3): bit 0 no in-loop DMA, bit 1 no in-loop LDS fragment reads, bit 2 no DMA waits
     for ab, label in [(8, "no epilogue"), (9, "no epilogue, no DMA"), (10, "no epilogue, no LDS reads"), (11, "no epilogue, no DMA, no LDS reads"),
