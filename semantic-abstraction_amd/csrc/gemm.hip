@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
 //   kernel      : 0 = heuristic, 1 = the 128 x 128 ring kernel, 2 = the 256 x 256 phased kernel (when the shape allows it)
 //   ev_start/stop: optional HIP events filled by the launch's own dispatch packet (hipExtLaunchKernelGGL) - no extra barrier packets
 //                  around the kernel, unlike hipEventRecord before and after it
-struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; };
+struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
@@ -351,7 +351,7 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
-template <int EPI, bool PF, bool PERS = false>      // PERS: persistent workgroups, tiles vb = blockIdx.x, + gridDim.x, ... (see the end of the kernel)
+template <int EPI, bool PF, bool PERS = false, bool RING = false>      // PERS: persistent workgroups (see the end of the kernel); RING: the K = 32 ring schedule (see `ring`)
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
@@ -735,6 +735,88 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     unsigned long long t_start = 0, t_main = 0;
     if (g.trace) t_start = __builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (RING) {
+        // ---- K tiles of 32 in a ring of four 32 KB buffers [A: 256 rows x 64 B | B: 256 rows x 64 B] ----------------------------------------------
+        // The phased schedule above hands the matrix pipe from one wave row to the other eight times per 64 of K, and every hand-over is a
+        // workgroup barrier's ~90 - 100 ticks (tools/gemm_probe.py phases): 18 % of a K tile.  Here a phase is a whole K tile of 32 = 32 MFMAs per
+        // wave (all 32 accumulators once, no dependencies inside the block), i.e. half the hand-overs per flop.  Phase t of a wave row:
+        //   { ds_read the 12 fragments of tile t | issue tile t + 3 (4 x 1 KB of LDS-DMA per wave) | vmcnt: tile t + 1 retired | lgkmcnt(0) |
+        //     barrier | 32 MFMAs | barrier },   the two rows one barrier apart as before.
+        // Hazards: tile t + 3 overwrites the buffer of tile t - 1, whose fragment reads every wave COMPLETED (lgkmcnt(0)) before its phase t - 1
+        // barrier, i.e. before the other row's phase-(t - 1) END barrier that precedes this stage; tile t is read at the start of phase t, after
+        // the END barrier of phase t - 1, which the other row reaches only after the vmcnt wait that retired ITS share of tile t (three tiles =
+        // 96 KB per CU stay in flight across barriers).  Rows are 64 B: chunk ^= {0, 2, 3, 1}[(row >> 2) & 3] puts the 16 lanes a ds_read_b128 is
+        // served with ({rows 0-3, 12-15} of one k group + {rows 4-11} of the next) on 16 different 16-byte slots, for the A rows and for the
+        // interleaved B rows alike; the swizzle is applied on the DMA source address.
+        constexpr int RB = 32768;
+        auto g4 = [](int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; };
+        unsigned raoff[2], rboff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wid + 8 * j) * 16 + (lane >> 2);
+            const int sc = (lane & 3) ^ g4(row);
+            raoff[j] = (unsigned)(row * (int)g.lda * 2 + sc * 16);
+            rboff[j] = (unsigned)(row * g.ldb * 2 + sc * 16);
+        }
+        auto stage_r = [&](int kt) {
+            char* dst = smem + (kt & 3) * RB + wid * 1024;
+            const unsigned soff = (unsigned)kt * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, raoff[j], soff, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(dst + 16384 + j * 8192), 16, rboff[j], soff, 0, 0);
+        };
+        const int roffA = (wr * 64 + l15) * 64 + ((kg ^ g4(l15)) << 4);
+        int roffB[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int rowb = wc * 32 + (l15 >> 2) * 8 + jt * 4 + (l15 & 3);
+            roffB[jt] = 16384 + rowb * 64 + ((kg ^ g4(rowb)) << 4);
+        }
+        f16x8 fra[2][4], frb[2][2];
+        const int nk32 = g.K / 32;                           // >= 4 (K >= 128)
+        stage_r(0); stage_r(1); stage_r(2);
+        wait_vmcnt<8>();                                     // this wave's share of tile 0
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();           // skew the second wave row by one barrier
+        for (int t = 0; t < nk32; ++t) {
+            const char* buf = smem + (t & 3) * RB;
+            if (t + 3 < nk32) stage_r(t + 3);               // (DMA first: its issue slots are the long part of the segment, the reads' latency hides behind them)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fra[ha][i] = *reinterpret_cast<const f16x8*>(buf + ha * 8192 + i * 1024 + roffA);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) frb[hb][jt] = *reinterpret_cast<const f16x8*>(buf + hb * 8192 + roffB[jt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 3 < nk32) wait_vmcnt<8>();
+            else if (t + 2 < nk32) wait_vmcnt<4>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the fragment reads are COMPLETE before the barrier (see the hazards above)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[ha][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frb[hb][j], fra[ha][i], acc[ha][i][hb][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     prologue();
     if constexpr (PF) stage_b(1, 1);                        // the prefetching loop stages one phase earlier (below)
     wait_vmcnt<8>();                                        // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
@@ -837,6 +919,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         mma(1, 0);
         GEMM8_END();
     }
+    }                                                       // (RING / phased)
     if (wr == 0) __builtin_amdgcn_s_barrier();              // balance the skew barrier
     // Every DMA has been waited for (vmcnt(0) in the last K tile's phases): the epilogue's ordinary loads (bias, residual) never share the
     // vmcnt queue with LDS-DMA loads.  That matters: counted vmcnt waits assume in-order return, and on gfx950 an ordinary load issued
@@ -925,6 +1008,13 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         return SEMABS_OK;
     }
 #endif
+    if (o.ring) {
+        static bool rset = false;
+        if (!rset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); rset = true; }
+        gemm_dispatch(k_gemm8<EPI, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
     if (GEMM_PREFETCH) gemm_dispatch(k_gemm8<EPI, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     else gemm_dispatch(k_gemm8<EPI, false>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
     SEMABS_CHECK_LAUNCH();
@@ -961,7 +1051,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((epi > 1 && epi != 5) || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
-    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 9) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order)");
+    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 10) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
@@ -972,8 +1062,9 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
+    const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
     kernel &= 255;
-    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event};
+    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
         case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s, o);

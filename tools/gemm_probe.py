@@ -29,14 +29,17 @@ def operands(n, k, epi):
     return bufs[key]
 
 
+KERNEL = 0
+
+
 def time_shape(n, k, epi, reps=6):
     A, B, bias, C = operands(n, k, epi)
     for _ in range(2):
-        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=KERNEL)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=KERNEL)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return ms, 2.0 * M * n * k / ms / 1e9
@@ -86,9 +89,15 @@ if "base" in what:
             tune(3, pf)
             log[f"base_pf{pf}_{rep}"] = line(f"fragment prefetch {pf} (rep {rep})")
     tune(3, 1)
+if "ring" in what:
+    for rep in range(3):
+        for kern, label in ((2, "phased, 4 phases per K = 64"), (2 | 512, "ring, 1 phase per K = 32")):
+            KERNEL = kern
+            log[f"ring{kern}_{rep}"] = line(f"{label} (rep {rep})")
+    KERNEL = 0
 if "cfgs" in what:
     for rep in range(2):
-        for c in (0, 7, 4, 5):
+        for c in (0, 9, 3, 7, 4, 5):
             tune(0, c)
             log[f"cfg{c}_{rep}"] = line(f"ring-kernel configuration {c} (0 = production) rep {rep}")
     tune(0, 0)
