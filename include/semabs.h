@@ -116,7 +116,8 @@ int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, co
                     long lda, int ldb, long ldc, int epi, const int* rowmap3, void* stream);
 
 /* Same contraction with per-call launch options (the library keeps no process-global launch state):
- * kernel: 0 = heuristic, 1 = the 128x128 ring kernel, 2 = the 256x256 phased kernel (needs N % 256 == 0, K >= 128);
+ * kernel: 0 = heuristic, 1 = the 128x128 ring kernel, 2 = the 256x256 phased kernel (needs N % 256 == 0, K >= 128); | 256 = every XCD walks its run of
+ *   tiles backwards (zigzag with the producer of A); | 512 = the phased kernel's K = 32 ring schedule (A/B, slower: DESIGN section 11);
  * start_event / stop_event: optional hipEvent_t pair filled by the launch's own dispatch packet (both or neither) - how bench.py times
  * the GEMM launches of the timed region without inserting barrier packets around them. */
 int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias, const float* addend, long M, int N, int K,
