@@ -493,7 +493,11 @@ def main():
                          "sampling": ("every GEMM launch of the timed region carries start / stop events" if args.time_every == 1 else
                                       f"1 in {args.time_every} GEMM launches of the timed region (hashed launch index) carries start / stop events"),
                          "avg_launch_us": gs["total_ms"] * 1e3 / max(1, gs["launches"]),
-                         "gemm_share_of_step": gs["total_ms"] * 1e-3 * gs["seen"] / max(1, gs["launches"]) / dt if world == 1 else None},
+                         "gemm_share_of_step": gs["total_ms"] * 1e-3 * gs["seen"] / max(1, gs["launches"]) / dt if world == 1 else None,
+                         # context, not the judged fraction: what back-to-back MFMAs reach on this part (imported probe results, profiles/r03_mfma_probes.txt)
+                         "mfma_probe": {"constant_operands_tflops": 2414.0, "random_fp16_operands_tflops": 2081.0,
+                                        "frac_of_random_operand_probe": ach / 2081.0,
+                                        "source": "tools/mfma_peak.cpp, 16x16x32 f16, 16 accumulators, 2 waves per SIMD, no memory traffic; measured once in round 3, not in this run"}},
         }
         out["timed_region"] = ("per scene, everything from the uint8 frame + fp32 depth resident in HBM to the label volume: colour jitter, tiling, "
                                "ViT + rollout, aggregation, unprojection + compaction + sub-sample, point MLP, scatter, UNet, decoder, TSDF, frustum "
