@@ -34,7 +34,7 @@ class GemmTimer:
     packets are inserted between consecutive kernels, so timing does not perturb the step being timed."""
 
     def __init__(self, every: int = 1):
-        self.records = []          # (start_event, stop_event, flops, algorithmic bytes); raw hipEvent_t handles
+        self.records = []          # (start_event, stop_event, flops, algorithmic bytes, (N, K, epilogue)); raw hipEvent_t handles
         self._free = []
         self.every = max(1, int(every))    # time one launch in `every` (hashed launch index: a uniform sample of the launch sequence)
         self.seen = 0
@@ -52,18 +52,21 @@ class GemmTimer:
         import ctypes as C
         torch.cuda.synchronize()
         ms, tmp = 0.0, C.c_float()
-        for a, b, _, _ in self.records:
+        shapes = {}                # (N, K, epilogue) -> [launches, ms, flops, algorithmic bytes]
+        for a, b, f, by, key in self.records:
             _lib.call("semabs_event_elapsed_ms", a, b, C.byref(tmp))
             ms += tmp.value
-        fl = sum(f for _, _, f, _ in self.records)
-        out = dict(launches=len(self.records), total_ms=ms, flops=fl, seen=self.seen, bytes=sum(b_ for _, _, _, b_ in self.records))
-        self._free.extend((a, b) for a, b, _, _ in self.records)
+            d = shapes.setdefault(key, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += tmp.value; d[2] += f; d[3] += by
+        fl = sum(r[2] for r in self.records)
+        out = dict(launches=len(self.records), total_ms=ms, flops=fl, seen=self.seen, bytes=sum(r[3] for r in self.records), shapes=shapes)
+        self._free.extend((r[0], r[1]) for r in self.records)
         self.records = []
         return out
 
     def __del__(self):
         try:
-            for a, b in self._free + [(x, y) for x, y, _, _ in self.records]:
+            for a, b in self._free + [(r[0], r[1]) for r in self.records]:
                 _lib.call("semabs_event_destroy", a)
                 _lib.call("semabs_event_destroy", b)
         except Exception:
@@ -87,7 +90,7 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, k
         t.seen += 1
         if t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0:     # hashed: no phase lock with the launch pattern
             e0, e1 = t._pair()
-            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4))))   # A + W + C (fp32 residual: read + write)
+            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4)), (int(N), int(K), int(epi))))   # A + W + C (fp32 residual: read + write)
     _lib.call("semabs_gemm_f16_ex", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
               int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, int(kernel), e0, e1,
               _lib.stream())

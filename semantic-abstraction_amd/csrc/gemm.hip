@@ -20,6 +20,7 @@
 #include "semabs_common.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
+#include <mutex>
 
 #define BK 64   // K granularity required by the ABI (both K-tile sizes divide it)
 enum { EPI_BIAS_F16 = 0, EPI_BIAS_GELU_F16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_BIAS_F32 = 3, EPI_ROWMAP_ADD_F32 = 4, EPI_MULROW_F16 = 5 };
@@ -32,7 +33,7 @@ struct GemmArgs {
     int sc_w;                   // column panels per super-column of the raster (see tile_of in k_gemm8); 0 = all of them
     int reverse;                // k_gemm8: every XCD walks its run of tiles backwards (zigzag with the producer of A, semabs_common.h)
 #ifdef SEMABS_TUNING
-    int ablate;     // tuning build only: bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
+    int ablate;     // tuning build only (k_gemm_f16; k_gemm8 takes its ablations as the template parameter ABL): bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
     unsigned long long* ptrace; int ptrace_wg;   // tuning build only: s_memtime stamps of every phase of ONE workgroup (waves 0 and 4 = one per wave row), see GEMM8_STAMP
 #endif
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
 //   kernel      : 0 = heuristic, 1 = the 128 x 128 ring kernel, 2 = the 256 x 256 phased kernel (when the shape allows it)
 //   ev_start/stop: optional HIP events filled by the launch's own dispatch packet (hipExtLaunchKernelGGL) - no extra barrier packets
 //                  around the kernel, unlike hipEventRecord before and after it
-struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; };
+struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; int v2; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
@@ -351,8 +352,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
-template <int EPI, bool PF, bool PERS = false, bool RING = false>      // PERS: persistent workgroups (see the end of the kernel); RING: the K = 32 ring schedule (see `ring`)
+template <int EPI, bool PF, bool PERS = false, bool RING = false, bool V2 = false, int ABL = 0>      // ABL: compile-time ablation bits (tuning build only; 0 in the product)
+//       // PERS: persistent workgroups (see the end of the kernel); RING: the K = 32 ring schedule (see `ring`); V2: the deep schedule (see `v2`)
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
+#define GABL(bit) ((ABL & (bit)) != 0)      /* 1 no in-loop DMA, 2 no in-loop LDS reads, 4 no DMA waits, 8 no epilogue, 16 no B staging */
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
     constexpr bool OUT16 = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
@@ -392,6 +395,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         aoff[j] = (unsigned)(row * (int)g.lda * 2 + (swzA8(row, scp) - row * 128));
         boff[j] = (unsigned)(row * g.ldb * 2 + (swzB8(row, scp) - row * 128));
     }
+    // (the swizzle terms of rows r and r + 64 are equal, so piece j = 1 is piece 0 + 64 rows: the deep schedule passes that through the scalar offset)
+    const unsigned a_q = (unsigned)(64 * (int)g.lda * 2), b_q = (unsigned)(64 * g.ldb * 2);
     const unsigned a_half = (unsigned)(128 * (int)g.lda * 2), b_half = (unsigned)(128 * g.ldb * 2);
     __amdgpu_buffer_rsrc_t rA, rB;                          // per tile: rows past M read as zeros (they only feed output rows that are never stored)
     auto set_tile = [&](long m0, int n0) {
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     // between the read / DMA-issue block and the MFMA block of a phase
 #define GEMM8_SYNC(staged)                                                       \
     do {                                                                         \
-        if (!GEMM_ABL(4)) { if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>(); } /* tuning: bit 2 = no DMA waits (wrong results) */ \
+        if (!GABL(4)) { if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>(); } /* tuning: bit 2 = no DMA waits (wrong results) */ \
         __builtin_amdgcn_sched_barrier(0);                                       \
         __builtin_amdgcn_s_barrier();                                            \
         __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0); the builtin (not inline asm) so that the compiler's own counter model sees it */ \
@@ -489,6 +494,17 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     // Output addressing: one resource descriptor per (tile, wave) whose extent ends with the last valid row - accesses of the ragged last row
     // panel fall off it - plus a per-lane byte offset and a scalar offset per pass / instruction.
     auto epilogue = [&](const long m0, const int n0) {
+        // Store-data hazard (found in round 4, gfx950 / ROCm 7.2): a VALU write to the data registers of a 16-byte buffer store issued a few instructions
+        // earlier can still reach the store - the last four lanes of each 16-lane group of the LAST store of a pass carried the next pass's first
+        // v_pk_add_f32 result in their second dword (non-deterministic, 0.3 % of the QuickGELU outputs, only in the instantiation whose register
+        // allocation put that VALU write right behind the store).  The compiler pads this hazard only for stores WITHOUT a scalar offset register
+        // (its hazard table assumes an SGPR offset makes the store issue late enough); these stores have one.  So every pass ends with 16 wait states
+        // before the next pass's arithmetic may touch a register.
+        auto store_pad = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
         constexpr int ROWB = OUT16 ? 64 : 128;              // bytes of a pass row (32 columns)
         constexpr int LPR = ROWB / 16;                      // lanes (16-byte chunks) per row in the coalesced layout: 4 / 8
         constexpr int RPI = 64 / LPR;                       // rows per wave instruction: 16 / 8
@@ -548,6 +564,11 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     *reinterpret_cast<f32x4*>(row + (((2 * kg + 1) ^ wswz) << 4)) = w[i][OUT16 ? 0 : 1];
                 }
             }
+            // ... and the stores are COMPLETE (the LDS has fetched their data registers) before anything else is issued: with the fences alone the first
+            // VALU instructions behind them (the read addresses of this pass) could still be given a store's data register - round 4's deep schedule
+            // changed the allocation of the QuickGELU instantiation and the same corruption reappeared in the last store of pass 1 (rows l15 = 3 mod 4,
+            // second dword, non-deterministic).  ~100 cycles per pass against an epilogue of several thousand.
+            __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
         };
         // coalesced layout: instruction `it` of a pass covers rows it * RPI + lane / LPR, this lane's chunk = lane % LPR
@@ -582,7 +603,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     }
                     buf_store4<EAUX>(rC, (unsigned)(orow - orow0) * ldcb + (unsigned)(cchunk * 16), (unsigned)(hb * 128 * ES), v);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                store_pad();
             }
         } else {
             const long rows = g.M - mw;                     // valid rows from the strip's first row on (may be <= 0: nothing is stored)
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rO, ovoff,
                                                               (unsigned)((pass & 1) * 128 + it * RPI) * ldob + (unsigned)((pass >> 1) * 128 * 2), 0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    store_pad();
                 }
             } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
                 f32x4 res[2][NIT];
@@ -649,7 +670,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                         const f32x4 o = res[pass & 1][it];
                         buf_store4<EAUX>(rC, voff, soff_of(pass, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    store_pad();
                 }
             } else {
 #pragma unroll
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     lds_write(pass);
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) buf_store4<EAUX>(rC, voff, soff_of(pass, it), lds_read(pass, it));
-                    __builtin_amdgcn_sched_barrier(0);
+                    store_pad();
                 }
             }
         }
@@ -716,7 +737,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #define GEMM8_STAMP(t_, ph_, pt_) do { } while (0)
 #endif
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
-    for (int vb = blockIdx.x; vb < g.n_blocks; vb += PERS ? (int)gridDim.x : g.n_blocks) {
+    int vb = blockIdx.x;                                    // (a do-while whose condition is the constant false unless PERS: written as a for loop the compiler could not prove the single trip and
+    do {                                                    //  kept every invariant of the epilogue live across the K loop - in a kernel with no register to spare)
     long m0; int n0;
     tile_of(vb, m0, n0);
     set_tile(m0, n0);
@@ -732,8 +754,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef SEMABS_TUNING
-    unsigned long long t_start = 0, t_main = 0;
-    if (g.trace) t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_start = 0, t_main = 0, c_start = 0, c_main = 0;
+    if (g.trace) { t_start = __builtin_amdgcn_s_memrealtime(); c_start = __builtin_amdgcn_s_memtime(); }
 #endif
     if constexpr (RING) {
         // ---- K tiles of 32 in a ring of four 32 KB buffers [A: 256 rows x 64 B | B: 256 rows x 64 B] ----------------------------------------------
@@ -819,9 +841,122 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     } else {
     prologue();
     if constexpr (PF) stage_b(1, 1);                        // the prefetching loop stages one phase earlier (below)
-    wait_vmcnt<8>();                                        // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
+    if constexpr (V2) { stage_a(1, 1); wait_vmcnt<10>(); }  // the deep schedule another one: K tiles 0 and 1 whole, the first three half-tiles retired
+    else wait_vmcnt<8>();                                   // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
     __builtin_amdgcn_s_barrier();
+    if constexpr (PF && V2) {
+        // The deep schedule re-stages the slots of A0(0) / B0(0) in phases 0 / 1 of the first K tile, so their reads - which precede the loop - must
+        // be complete in EVERY wave before the first wave enters phase 0: read here, before the skew, and close with a barrier of all eight waves
+        // (found the hard way: with the reads behind the skew barrier the second wave row read A0(2) where it expected A0(0)).
+        read_b(0, 0); read_a(0, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();              // skew the second wave row by one barrier
+    if constexpr (PF && V2) {
+        // ---- "deep" schedule: the PF schedule below with FIVE half-tiles (80 KB) of DMA in flight per CU instead of four, in the same eight slots, and
+        // exact counted waits while the queue drains.  Stage index s = 4 t + {A0: 0, B0: 1, B1: 2, A1: 3}; stage s is ISSUED in global phase s - 8 (the
+        // prologue issues stages 0 - 7), READ in phase s - 2 (inside that phase's MFMA block, for the next phase) and its slot is re-staged in phase s:
+        // exactly two phases after the last read of the slot's previous occupant - the PF schedule re-stages after three, that slack is the fifth
+        // half-tile.  Per K tile t: phase 0 stages A0(t + 2), phase 1 B0(t + 2), phase 2 B1(t + 2), phase 3 A1(t + 2); reads as in the PF schedule.
+        //   landed: a wave's wait in phase P leaves its five newest stage calls (P + 4 .. P + 8) in flight, so its share of stages <= P + 3 has landed;
+        //           the reader of stage P + 2 in phase P has passed a barrier that the other wave row reached after ITS wait of phase P - 1 (<= P + 2).
+        //   free  : the slot of stage s - 8 was read in phase s - 10; every wave completes those reads (lgkmcnt(0) IN FRONT of the barrier here) before
+        //           its SYNC barrier of phase s - 9, which precedes - for either wave row - the END barrier that opens phase s - 8.
+        //   drain : K tile nk - 2 stages nothing and waits vmcnt 8 / 6 / 4 / 2 (the last K tile's half-tiles, one read per phase from the next phase
+        //           on), K tile nk - 1 vmcnt(0) once - the PF schedule waits vmcnt(0) as soon as nothing is staged and exposes a full memory latency
+        //           per output tile there.
+        // The priority raise and the LDS-read completion wait sit in front of the SYNC barrier: what follows the barrier is matrix-pipe idle time.
+        // Lean load segments: what a wave executes between its END barrier and its next SYNC barrier runs beside the other row's MFMA block, but what
+        // sits between the SYNC barrier and the first MFMA is matrix-pipe idle time on all four SIMDs, eight times per K tile - so the fragment
+        // addresses of the coming block (base + parity offset: two VALU adds) are computed in front of the barrier and pinned there with an empty asm,
+        // the LDS-read completion wait and the priority raise sit in front of it too, the steady-state K tiles (t + 2 < nk) carry no scalar branch, and
+        // the second column tile of a B fragment pair is the first one + 512 bytes (four rows further, same swizzle term): an immediate offset.
+        typedef const __attribute__((address_space(3))) char* lds_cptr;
+        typedef const __attribute__((address_space(3))) f16x8* lds_frag;
+        auto pin = [&](int x) { lds_cptr p = (lds_cptr)smem + x; asm volatile("" : "+v"(p)); return p; };
+        auto ktile = [&](auto steady_c, const int t) {
+            constexpr bool STEADY = decltype(steady_c)::value;
+            const int pb = (t & 1) * BUFSZ, pn = pb ^ BUFSZ;
+            const bool pen = t + 2 == nk;
+            lds_cptr r0, r1;
+#define GEMM8_SYNCD(k_)                                                          \
+    do {                                                                         \
+        if (!GABL(4)) {                                                          \
+            if (STEADY) wait_vmcnt<10>();                                        \
+            else if (pen) wait_vmcnt<8 - 2 * (k_)>();                            \
+            else if ((k_) == 0) wait_vmcnt<0>();                                 \
+        }                                                                        \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_setprio(1);                                           \
+        __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#define GEMM8_ENDD()                                                             \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_setprio(0);                                           \
+        __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+            // phase 0: quadrant (A0, B0); reads B1(t)
+            if (STEADY && !GABL(1)) stage_a(0, t + 2);
+            r0 = pin(offB[0][0] + pb); r1 = pin(offB[0][1] + pb);
+            GEMM8_SYNCD(0);
+            if (!GABL(2)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { fb[1][j][0] = *(lds_frag)(r0 + (OFF_B1 + j * 512)); fb[1][j][1] = *(lds_frag)(r1 + (OFF_B1 + j * 512)); }
+            }
+            mma_a0(0);
+            if (!GABL(2)) GEMM8_INTERLEAVE(4);
+            GEMM8_ENDD();
+            // phase 1: quadrant (A0, B1); reads A1(t)
+            if (STEADY && !GABL(1)) stage_b(0, t + 2);
+            r0 = pin(offA[0] + pb); r1 = pin(offA[1] + pb);
+            GEMM8_SYNCD(1);
+            if (!GABL(2)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fa1[PF ? i : 0][0] = *(lds_frag)(r0 + (OFF_A1 + i * 2048)); fa1[PF ? i : 0][1] = *(lds_frag)(r1 + (OFF_A1 + i * 2048)); }
+            }
+            mma_a0(1);
+            if (!GABL(2)) GEMM8_INTERLEAVE(8);
+            GEMM8_ENDD();
+            // phase 2: quadrant (A1, B1); reads A0(t + 1) (last K tile: a stale slot, never used - keeps the block branch-free)
+            if (STEADY && !GABL(1)) stage_b(1, t + 2);
+            r0 = pin(offA[0] + pn); r1 = pin(offA[1] + pn);
+            GEMM8_SYNCD(2);
+            if (!GABL(2)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fa[i][0] = *(lds_frag)(r0 + (OFF_A0 + i * 2048)); fa[i][1] = *(lds_frag)(r1 + (OFF_A0 + i * 2048)); }
+            }
+            mma_a1(1);
+            if (!GABL(2)) GEMM8_INTERLEAVE(8);
+            GEMM8_ENDD();
+            // phase 3: quadrant (A1, B0); reads B0(t + 1) into the spare set
+            if (STEADY && !GABL(1)) stage_a(1, t + 2);
+            r0 = pin(offB[0][0] + pn); r1 = pin(offB[0][1] + pn);
+            GEMM8_SYNCD(3);
+            if (!GABL(2)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { fb0n[PF ? j : 0][0] = *(lds_frag)(r0 + (OFF_B0 + j * 512)); fb0n[PF ? j : 0][1] = *(lds_frag)(r1 + (OFF_B0 + j * 512)); }
+            }
+            mma_a1(0);
+            if (!GABL(2)) GEMM8_INTERLEAVE(4);
+            GEMM8_ENDD();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) if (!GABL(2)) fb[0][j][kk] = fb0n[PF ? j : 0][kk];
+        };
+        if (GABL(2)) { read_b(1, 0); read_a1(0); }      // ablation: every fragment register holds real data once
+        int t = 0;
+        for (; t + 2 < nk; ++t) ktile(std::integral_constant<bool, true>{}, t);
+        for (; t < nk; ++t) ktile(std::integral_constant<bool, false>{}, t);
+#undef GEMM8_SYNCD
+#undef GEMM8_ENDD
+    } else
     if constexpr (PF) {
         // Fragment reads one phase ahead, inside the MFMA blocks (see the register comment above).  What is read where, K tile t:
         //   phase 0 (A0, B0): B1(t)      phase 1 (A0, B1): A1(t)      phase 2 (A1, B1): A0(t + 1)      phase 3 (A1, B0): B0(t + 1) -> spare set
@@ -837,13 +972,13 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         for (int t = 0; t < nk; ++t) {
             const int par = t & 1;
-            const bool s1 = t + 1 < nk && !GEMM_ABL(1), s2 = t + 2 < nk && !GEMM_ABL(1);
+            const bool s1 = t + 1 < nk && !GABL(1), s2 = t + 2 < nk && !GABL(1);
             GEMM8_STAMP(t, 0, 0);
             if (s1) stage_a(1, t + 1);
             GEMM8_SYNC(s1);
             GEMM8_STAMP(t, 0, 1);
             __builtin_amdgcn_s_setprio(1);
-            if (!GEMM_ABL(16)) read_b(1, par);          // tuning bit 4: no B staging, no B fragment reads (wrong results: what would B from registers buy?)
+            if (!GABL(16)) read_b(1, par);          // tuning bit 4: no B staging, no B fragment reads (wrong results: what would B from registers buy?)
             mma_a0(0);
             GEMM8_INTERLEAVE(4);
             __builtin_amdgcn_s_setprio(0);
@@ -862,7 +997,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             GEMM8_END();
             GEMM8_STAMP(t, 1, 3);
             GEMM8_STAMP(t, 2, 0);
-            if (s2 && !GEMM_ABL(16)) stage_b(0, t + 2);
+            if (s2 && !GABL(16)) stage_b(0, t + 2);
             GEMM8_SYNC(s2);
             GEMM8_STAMP(t, 2, 1);
             __builtin_amdgcn_s_setprio(1);
@@ -874,11 +1009,11 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             GEMM8_END();
             GEMM8_STAMP(t, 2, 3);
             GEMM8_STAMP(t, 3, 0);
-            if (s2 && !GEMM_ABL(16)) stage_b(1, t + 2);
+            if (s2 && !GABL(16)) stage_b(1, t + 2);
             GEMM8_SYNC(s2);
             GEMM8_STAMP(t, 3, 1);
             __builtin_amdgcn_s_setprio(1);
-            if (!GEMM_ABL(16)) read_b0n(par ^ 1);
+            if (!GABL(16)) read_b0n(par ^ 1);
             mma_a1(0);
             GEMM8_INTERLEAVE(4);
             __builtin_amdgcn_s_setprio(0);
@@ -894,21 +1029,21 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     } else
     for (int t = 0; t < nk; ++t) {
         const int par = t & 1;
-        const bool s1 = t + 1 < nk && !GEMM_ABL(1), s2 = t + 2 < nk && !GEMM_ABL(1);
+        const bool s1 = t + 1 < nk && !GABL(1), s2 = t + 2 < nk && !GABL(1);
         // phase 0: quadrant (A0, B0)
-        if (!GEMM_ABL(2) || t == 0) { read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par); }
+        if (!GABL(2) || t == 0) { read_b(0, par); __builtin_amdgcn_sched_barrier(0); read_a(0, par); }
         if (s1) stage_b(1, t + 1);
         GEMM8_SYNC(s1);
         mma(0, 0);
         GEMM8_END();
         // phase 1: quadrant (A0, B1)
-        if (!GEMM_ABL(2) || t == 0) read_b(1, par);
+        if (!GABL(2) || t == 0) read_b(1, par);
         if (s1) stage_a(1, t + 1);
         GEMM8_SYNC(s1);
         mma(0, 1);
         GEMM8_END();
         // phase 2: quadrant (A1, B1)
-        if (!GEMM_ABL(2) || t == 0) read_a(1, par);
+        if (!GABL(2) || t == 0) read_a(1, par);
         if (s2) stage_a(0, t + 2);
         GEMM8_SYNC(s2);
         mma(1, 1);
@@ -926,9 +1061,21 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     // BEHIND outstanding LDS-DMA loads was observed to be reported complete too early (a persistent variant that issued the next tile's
     // first half-tiles before the epilogue returned garbage in lanes 12-15 of the first bias fragment, non-deterministically).
 #ifdef SEMABS_TUNING
-    if (g.trace) t_main = __builtin_amdgcn_s_memrealtime();
+    if (g.trace) { t_main = __builtin_amdgcn_s_memrealtime(); c_main = __builtin_amdgcn_s_memtime(); }
 #endif
-    if (!GEMM_ABL(8)) epilogue(m0, n0);
+    if (!GABL(8)) epilogue(m0, n0);
+    else {                                                  // ablation: keep the accumulators (and with them the whole K loop) alive
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) keep += acc[a][i][c][j][0] + acc[a][i][c][j][1] + acc[a][i][c][j][2] + acc[a][i][c][j][3];
+        if (keep == 12345.678f) reinterpret_cast<float*>(g.C)[tid] = keep;
+    }
 #ifdef SEMABS_TUNING
     if (g.ptrace && vb == g.ptrace_wg) {                    // every wave of the traced workgroup takes part in the barrier; waves 0 and 4 copy their rows out
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -948,8 +1095,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* tr = g.trace + (size_t)vb * 4;
-            tr[0] = t_start; tr[1] = t_main; tr[2] = t_end; tr[3] = ((unsigned long long)xcc << 32) | hw;
+            unsigned long long* tr = g.trace + (size_t)vb * 8;       // 100 MHz stamps, hardware id, shader-clock stamps (effective clock = cycles / time)
+            tr[0] = t_start; tr[1] = t_main; tr[2] = t_end; tr[3] = ((unsigned long long)xcc << 32) | hw; tr[4] = c_start; tr[5] = c_main;
         }
     }
 #endif
@@ -961,7 +1108,9 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
     }
-    }
+    vb += (int)gridDim.x;
+    } while (PERS && vb < g.n_blocks);
+#undef GABL
 #undef GEMM8_SYNC
 #undef GEMM8_END
 #undef GEMM8_INTERLEAVE
@@ -1008,6 +1157,32 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         return SEMABS_OK;
     }
 #endif
+#ifdef SEMABS_TUNING
+    // compile-time ablations (no run-time branches in the loops they measure): g_ablate picks an instantiation, for the QKV / out-proj epilogues only
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_RESID_F32) {
+        if (g_ablate) {
+            auto go = [&](auto kern) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                gemm_dispatch(kern, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
+            };
+#define GEMM8_ABL_CASE(n) case n: if (o.v2) go(k_gemm8<EPI, true, false, false, true, n>); else go(k_gemm8<EPI, true, false, false, false, n>); break;
+            switch (g_ablate) {
+                GEMM8_ABL_CASE(8) GEMM8_ABL_CASE(9) GEMM8_ABL_CASE(10) GEMM8_ABL_CASE(11) GEMM8_ABL_CASE(12) GEMM8_ABL_CASE(13) GEMM8_ABL_CASE(15)
+                default: semabs_set_error("semabs_gemm_tune: this ablation mask is not instantiated"); return SEMABS_EINVAL;
+            }
+#undef GEMM8_ABL_CASE
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
+    }
+#endif
+    if (o.v2) {
+        static std::once_flag vset;
+        std::call_once(vset, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+        gemm_dispatch(k_gemm8<EPI, true, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
     if (o.ring) {
         static bool rset = false;
         if (!rset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); rset = true; }
@@ -1051,7 +1226,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((epi > 1 && epi != 5) || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
-    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 10) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order)");
+    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 12) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order) | 512 (K = 32 ring schedule) | 2048 (round-3 PF schedule)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
@@ -1063,8 +1238,9 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
     const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
+    const int v2 = ((kernel >> 11) & 1) == 0;               // the deep schedule of the phased kernel is the default since round 4; bit 11 selects the round-3 PF schedule (A/B), bit 10 is accepted and ignored
     kernel &= 255;
-    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring};
+    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring, v2};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
         case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s, o);

@@ -95,6 +95,12 @@ if "ring" in what:
             KERNEL = kern
             log[f"ring{kern}_{rep}"] = line(f"{label} (rep {rep})")
     KERNEL = 0
+if "deep" in what:
+    for rep in range(3):
+        for kern, label in ((2 | 2048, "phased PF (4 half-tiles in flight)"), (2, "deep (5 in flight, lean load segments)")):
+            KERNEL = kern
+            log[f"deep{kern}_{rep}"] = line(f"{label} (rep {rep})")
+    KERNEL = 0
 if "cfgs" in what:
     for rep in range(2):
         for c in (0, 9, 3, 7, 4, 5):
@@ -127,25 +133,57 @@ if "phases" in what:
         log[f"phases_{name}"] = t.tolist()
 if "ablate2" in what:
     # components of the steady-state loop, epilogue always off (bit 3): bit 0 no in-loop DMA, bit 1 no in-loop LDS fragment reads, bit 2 no DMA waits
-    for ab, label in [(8, "no epilogue"), (9, "no epilogue, no DMA"), (10, "no epilogue, no LDS reads"), (11, "no epilogue, no DMA, no LDS reads"),
-                      (12, "no epilogue, no DMA waits"), (15, "MFMA + barriers only")]:
-        tune(2, ab)
-        log[f"ablate2_{ab}"] = line(label)
-    tune(2, 0)
+    SH = SHAPES
+    for kern in (2 | 2048, 2):
+        KERNEL = kern
+        SHAPES = [x for x in SH if x[3] in (0, 2)]            # the instantiated epilogues
+        for ab, label in [(0, "full kernel"), (8, "no epilogue"), (9, "no epilogue, no DMA"), (10, "no epilogue, no LDS reads"), (11, "no epilogue, no DMA, no LDS reads"),
+                          (12, "no epilogue, no DMA waits"), (15, "MFMA + barriers only")]:
+            tune(2, ab)
+            log[f"ablate2_{kern}_{ab}"] = line(("PF   " if kern & 2048 else "deep ") + label)
+        tune(2, 0)
+    SHAPES = SH; KERNEL = 0
 if "ablate" in what:
     for ab, label in [(8, "no epilogue"), (16, "no B staging / B reads"), (24, "no B staging / reads, no epilogue"), (9, "no DMA, no epilogue")]:
         tune(2, ab)
         log[f"ablate{ab}"] = line(label)
     tune(2, 0)
+if "abltrace" in what:
+    # per ablation (compile-time instantiations): wall time AND the in-kernel main-loop clock / cycles per K tile of the QKV and c_proj shapes
+    for kern in (2 | 2048, 2):
+        for ab, label in [(0, "full kernel"), (8, "no epilogue"), (9, "no epilogue, no DMA"), (10, "no epilogue, no LDS reads"), (12, "no epilogue, no DMA waits"), (15, "MFMA + barriers only")]:
+            tune(2, ab)
+            for name, n, k, epi in (SHAPES[0], SHAPES[3]):
+                A, B, bias, C = operands(n, k, epi)
+                nb = ((M + 255) // 256) * (n // 256)
+                tr = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
+                for _ in range(4):
+                    gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=kern)
+                torch.cuda.synchronize()
+                tune(4, tr.data_ptr())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=kern)
+                e1.record(); torch.cuda.synchronize()
+                tune(4, 0)
+                t = tr.cpu().numpy()
+                us = e0.elapsed_time(e1) / 4 * 1e3
+                ghz = ((t[:, 5] - t[:, 4]) / np.maximum(1, t[:, 1] - t[:, 0])).mean() * 0.1
+                print(f"{'PF  ' if kern & 2048 else 'deep'} {label:28s} {name:5s} {us:7.1f}us {2.0 * M * n * k / us / 1e6:6.0f}TF  main loop {((t[:, 1] - t[:, 0]) / 100.0).mean():6.2f}us = "
+                      f"{(t[:, 5] - t[:, 4]).mean() / (k // 64):6.0f} cycles per K tile at {ghz:.3f} GHz; tile end - start {((t[:, 2] - t[:, 0]) / 100.0).mean():6.2f}us", flush=True)
+    tune(2, 0)
+if "tracepf" in what:
+    KERNEL = 2 | 2048; what = what + ["trace"]
 if "trace" in what:
     for name, n, k, epi in SHAPES[:4]:
         A, B, bias, C = operands(n, k, epi)
         nb = ((M + 255) // 256) * (n // 256)
-        tr = torch.zeros(nb, 4, dtype=torch.int64, device="cuda")
-        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+        tr = torch.zeros(nb, 8, dtype=torch.int64, device="cuda")
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=KERNEL)
         torch.cuda.synchronize()
         tune(4, tr.data_ptr())
-        gemm(A, B, C, bias, M, n, k, k, k, n, epi)
+        gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=KERNEL)
         torch.cuda.synchronize()
         tune(4, 0)
         t = tr.cpu().numpy()
@@ -161,6 +199,8 @@ if "trace" in what:
             o = idx[np.argsort(start[idx])]
             gaps += list(start[o][1:] - end[o][:-1])
         gaps = np.asarray(gaps)
+        ghz = ((t[:, 5] - t[:, 4]) / np.maximum(1, t[:, 1] - t[:, 0])).mean() * 0.1
+        print(f"trace {name}: clock in the main loop {ghz:.3f} GHz, {(t[:, 5] - t[:, 4]).mean() / (k // 64):.0f} shader cycles per K tile (2048 = matrix pipe back to back)")
         print(f"trace {name}: total {total:.0f}us  tiles {nb}  CUs {len(np.unique(cuid))}  main loop mean {(main - start).mean():.1f}  epilogue (to stores complete) mean {(end - main).mean():.1f}  "
               f"gap to next tile mean {gaps.mean():.2f} p90 {np.percentile(gaps, 90):.2f}  per-tile period {total / (nb / 256):.1f}", flush=True)
 json.dump(log, open(os.path.join(OUT, "probe.json"), "w"))
