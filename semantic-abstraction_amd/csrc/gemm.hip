@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
 //   kernel      : 0 = heuristic, 1 = the 128 x 128 ring kernel, 2 = the 256 x 256 phased kernel (when the shape allows it)
 //   ev_start/stop: optional HIP events filled by the launch's own dispatch packet (hipExtLaunchKernelGGL) - no extra barrier packets
 //                  around the kernel, unlike hipEventRecord before and after it
-struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; int v2; };
+struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; int v2; int pers; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
@@ -361,6 +361,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr bool OUT16 = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
     constexpr int ES = OUT16 ? 2 : 4;                       // bytes per output element
     constexpr int EAUX = OUT16 ? 0 : 2;                     // epilogue cache policy: nt for the fp32 tiles (see buf_store4)
+    // V3 = persistent workgroups with cross-tile prefetch (fp16-output epilogues, deep schedule): see the end of the tile loop
+    constexpr bool V3 = PERS && V2 && PF && OUT16 && (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,14 +512,15 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         constexpr int RPI = 64 / LPR;                       // rows per wave instruction: 16 / 8
         constexpr int NIT = 64 / RPI;                       // instructions per pass: 4 / 8
         constexpr int PASSB = 64 * ROWB;                    // 4 / 8 KB; two passes alternate inside the wave's 16 KB
-        char* const ep = smem + wid * 16384;
+        char* const ep = V3 ? smem + 2 * BUFSZ + wid * 4096 : smem + wid * 16384;      // V3: behind the operand slots, which are being refilled
+        constexpr int PALT = V3 ? 0 : 1;                    // passes alternate between two buffers (V3: one 4 KB buffer; LDS is in order per wave)
         float bia[2][8];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int ncol = n0 + hb * 128 + wc * 32 + kg * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) bia[hb][e] = 0.f;
-            if (g.bias) {
+            if (!V3 && g.bias) {
                 const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
                 bia[hb][0] = b0.x; bia[hb][1] = b0.y; bia[hb][2] = b0.z; bia[hb][3] = b0.w; bia[hb][4] = b1.x; bia[hb][5] = b1.y; bia[hb][6] = b1.z; bia[hb][7] = b1.w;
             }
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         // stores' operands are only overwritten by the NEXT pass, after this pass's LDS reads have returned.
         auto lds_write = [&](int pass) {
             const int hb = pass >> 1, ha = pass & 1;
-            char* buf = ep + (pass & 1) * PASSB;
+            char* buf = ep + (pass & PALT) * PASSB;
             f32x4 w[4][OUT16 ? 1 : 2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         auto lds_read = [&](int pass, int it) {
             const int row = it * RPI + crow;
             const int rswz = OUT16 ? ((row >> 1) & 3) : (row & 7);
-            return *reinterpret_cast<const f32x4*>(ep + (pass & 1) * PASSB + row * ROWB + ((cchunk ^ rswz) << 4));
+            return *reinterpret_cast<const f32x4*>(ep + (pass & PALT) * PASSB + row * ROWB + ((cchunk ^ rswz) << 4));
         };
         const long mw = m0 + wr * 64;                       // first row of this wave's 64-row strip of A half 0 (half 1: + 128)
         const unsigned ldcb = (unsigned)g.ldc * ES;         // output row pitch in bytes
@@ -737,22 +740,40 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #define GEMM8_STAMP(t_, ph_, pt_) do { } while (0)
 #endif
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
+    // ---- V3 state: next tile's coordinates and bias (the accumulators start at the bias: a lane's 8 columns of a (B half, column tile pair)) ----
+    bool v3_first = true; long v3_m0 = 0; int v3_n0 = 0;
+    f32x4 v3_bias[V3 ? 2 : 1][2];
+    auto v3_load_bias = [&](const int n0_) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int ncol = n0_ + hb * 128 + wc * 32 + kg * 8;
+            if (g.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
+                v3_bias[V3 ? hb : 0][0] = f32x4{b0.x, b0.y, b0.z, b0.w}; v3_bias[V3 ? hb : 0][1] = f32x4{b1.x, b1.y, b1.z, b1.w};
+            } else { v3_bias[V3 ? hb : 0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; v3_bias[V3 ? hb : 0][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+    };
     int vb = blockIdx.x;                                    // (a do-while whose condition is the constant false unless PERS: written as a for loop the compiler could not prove the single trip and
     do {                                                    //  kept every invariant of the epilogue live across the K loop - in a kernel with no register to spare)
     long m0; int n0;
-    tile_of(vb, m0, n0);
-    set_tile(m0, n0);
+    if (!V3 || v3_first) {
+        tile_of(vb, m0, n0);
+        set_tile(m0, n0);
+        if constexpr (V3) v3_load_bias(n0);                 // (ahead of the first tile's DMA in the queue)
+    } else { m0 = v3_m0; n0 = v3_n0; }                      // V3: the descriptors already point at this tile, its first two K tiles are in flight
 #ifdef SEMABS_TUNING
     const bool ptr_on = g.ptrace && vb == g.ptrace_wg && lane == 0 && (wid == 0 || wid == 4) && g.K / 64 <= 64;
 #endif
+    if constexpr (!V3) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #ifdef SEMABS_TUNING
     unsigned long long t_start = 0, t_main = 0, c_start = 0, c_main = 0;
     if (g.trace) { t_start = __builtin_amdgcn_s_memrealtime(); c_start = __builtin_amdgcn_s_memtime(); }
@@ -839,10 +860,28 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-    prologue();
-    if constexpr (PF) stage_b(1, 1);                        // the prefetching loop stages one phase earlier (below)
-    if constexpr (V2) { stage_a(1, 1); wait_vmcnt<10>(); }  // the deep schedule another one: K tiles 0 and 1 whole, the first three half-tiles retired
-    else wait_vmcnt<8>();                                   // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
+    if (!V3 || v3_first) {
+        prologue();
+        if constexpr (PF) stage_b(1, 1);                    // the prefetching loop stages one phase earlier (below)
+        if constexpr (V2) { stage_a(1, 1); wait_vmcnt<10>(); }  // the deep schedule another one: K tiles 0 and 1 whole, the first three half-tiles retired
+        else wait_vmcnt<8>();                               // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
+    } else {
+        // V3, every tile but the first: the eight half-tiles were requested before the previous tile's epilogue, whose stores sit BEHIND them in the
+        // queue - counted waits are only trusted while the queue holds nothing but LDS-DMA loads, so wait for everything (the DMA landed long ago; what
+        // this waits for is the acknowledgement of the last pass's stores, partly covered by the accumulator initialisation below)
+        wait_vmcnt<0>();
+    }
+    if constexpr (V3) {
+        // accumulators start at the bias (a lane holds the same 8 columns in every row tile of a quadrant)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][i][c][j] = v3_bias[V3 ? c : 0][j];
+    }
     __builtin_amdgcn_s_barrier();
     if constexpr (PF && V2) {
         // The deep schedule re-stages the slots of A0(0) / B0(0) in phases 0 / 1 of the first K tile, so their reads - which precede the loop - must
@@ -1063,6 +1102,27 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #ifdef SEMABS_TUNING
     if (g.trace) { t_main = __builtin_amdgcn_s_memrealtime(); c_main = __builtin_amdgcn_s_memtime(); }
 #endif
+    if constexpr (V3) {
+        // ---- persistent workgroups with cross-tile prefetch ------------------------------------------------------------------------------------------
+        // A 256 x 256 x 768 tile is ~16 us of steady-state K loop between ~8 us of fixed cost: ~2 us until the first half-tiles of its prologue arrive,
+        // the epilogue, 1 - 2 us until the stores are acknowledged (a workgroup is not retired before that) and ~1 us until the next workgroup runs
+        // (tools/gemm_probe.py abltrace / trace).  Here the workgroup stays, and the NEXT tile's first two K tiles (all eight slots = 128 KB) are
+        // requested right after the K loop, before the epilogue: they land while the epilogue runs.  The epilogue therefore transposes through the 32 KB
+        // of LDS behind the operand slots (4 KB per wave = one fp16 pass, single-buffered), and issues no load at all: the bias is in the
+        // accumulators from the start, and the NEXT tile's bias is fetched here, AHEAD of the DMA in the queue (an ordinary load behind outstanding
+        // LDS-DMA is the combination round 1 saw misbehave).  Every wave has finished its LDS reads of the last K tile (lgkmcnt(0) at the end of
+        // ktile, then the barriers above), so the slots are free.
+        const int nvb = vb + (int)gridDim.x;
+        if (nvb < g.n_blocks) {
+            tile_of(nvb, v3_m0, v3_n0);
+            v3_load_bias(v3_n0);
+            __builtin_amdgcn_sched_barrier(0);
+            set_tile(v3_m0, v3_n0);
+            stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1); stage_b(1, 1); stage_a(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        v3_first = false;
+    }
     if (!GABL(8)) epilogue(m0, n0);
     else {                                                  // ablation: keep the accumulators (and with them the whole K loop) alive
         float keep = 0.f;
@@ -1100,7 +1160,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         }
     }
 #endif
-    if (PERS) {
+    if (PERS && !V3) {
         // Persistent workgroups (one per CU): the next tile's first half-tiles are requested while this tile's stores drain - a workgroup is
         // not retired before its stores complete, and the next one cannot start before it is (the operand buffers take 128 of the 160 KB):
         // 0.9 - 5 us per tile (tools/gemm_probe.py trace).  Every wave is done with its epilogue slice of LDS before the DMA overwrites it;
@@ -1176,6 +1236,24 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         }
     }
 #endif
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+        // fp16-output epilogues: persistent workgroups (one per CU) with cross-tile prefetch - see V3 in the kernel.  Selectable (kernel | 4096), NOT
+        // the default: measured on MI355X (tools/gemm_probe.py deep, round 4) QKV 1 626 us against 1 528 us for one workgroup per tile, c_fc 2 275
+        // against 2 245 - the 128 DMA instructions of the next tile's prologue take ~1.2 us of the CU's memory pipeline in front of the epilogue's
+        // stores, and the vmcnt(0) that opens the next tile waits for the acknowledgement of those stores; what is saved (prologue latency, the
+        // launch gap) is smaller than that.
+        if (o.v2 && o.pers) {
+            constexpr int LDS3 = 2 * 4 * 16384 + 8 * 4096;  // operand slots + 4 KB of epilogue scratch per wave = all 160 KB
+            static std::once_flag pset; static int ncu = 256;
+            std::call_once(pset, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+                int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+            });
+            gemm_dispatch(k_gemm8<EPI, true, true, false, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS3, s, g, o);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
+    }
     if (o.v2) {
         static std::once_flag vset;
         std::call_once(vset, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
@@ -1226,7 +1304,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((epi > 1 && epi != 5) || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
-    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 12) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order) | 512 (K = 32 ring schedule) | 2048 (round-3 PF schedule)");
+    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 13) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order) | 512 (K = 32 ring schedule) | 2048 (round-3 PF schedule) | 4096 (persistent workgroups with cross-tile prefetch, fp16 outputs)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
@@ -1239,8 +1317,9 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
     const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
     const int v2 = ((kernel >> 11) & 1) == 0;               // the deep schedule of the phased kernel is the default since round 4; bit 11 selects the round-3 PF schedule (A/B), bit 10 is accepted and ignored
+    const int pers = (kernel >> 12) & 1;                    // bit 12: persistent workgroups with cross-tile prefetch for the fp16-output epilogues (A/B; slower, see launch_gemm8)
     kernel &= 255;
-    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring, v2};
+    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring, v2, pers};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
         case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s, o);

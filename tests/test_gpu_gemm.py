@@ -44,7 +44,7 @@ SHAPES = [(2048, 768, 768), (2381, 768, 768), (2381, 2304, 768), (2381, 3072, 76
           (50432, 2304, 768), (50432, 768, 3072), (256, 768, 768), (300, 3072, 768)]
 
 
-@pytest.mark.parametrize("kernel", [2, 1, 2 | 512, 2 | 2048])          # 2: the phased kernel (deep schedule, the default), | 512: its K = 32 ring schedule, | 2048: its round-3 PF schedule
+@pytest.mark.parametrize("kernel", [2, 1, 2 | 512, 2 | 2048, 2 | 4096])          # 2: the phased kernel (deep schedule), | 512: its K = 32 ring schedule, | 2048: its round-3 PF schedule, | 4096: persistent workgroups with cross-tile prefetch (fp16 outputs)
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_gemm_kernels_all_epilogues(kernel, M, N, K):
     from semabs_amd.clip.vit import gemm
