@@ -153,7 +153,14 @@ def make_vision_engine(state_dict, chunk_tiles: int = 2448, max_labels: int = 16
         return VisionRollout(state_dict, chunk_tiles=chunk_tiles, max_labels=max_labels)
     # tiles per chunk of the deep rollout: the backward pass runs labels x tiles sequences (16 x 63 x 257 rows = 1 012 row panels: 15.8 waves of
     # 256 x 256 GEMM tiles at N = 1 024, where 16 tiles gave 4.02 waves, i.e. a fifth round for four tiles); 21 GB of tape at 16 labels
-    return VisionRolloutDeep(state_dict, chunk_tiles=min(chunk_tiles, int(os.environ.get("SEMABS_DEEP_CHUNK", "63"))), max_labels=max_labels)
+    # The default chunk follows the FREE device memory (a fixed 63 is a hard out-of-memory regression on smaller parts or next to a
+    # resident training engine): ~0.35 GB of tape + workspaces per tile at 16 labels, keep half of what is free for everything else.
+    deep = os.environ.get("SEMABS_DEEP_CHUNK")
+    if deep is None:
+        free, _ = torch.cuda.mem_get_info()
+        per_tile = 0.35e9 * max(1, max_labels) / 16
+        deep = max(4, min(63, int(0.5 * free / per_tile)))
+    return VisionRolloutDeep(state_dict, chunk_tiles=min(chunk_tiles, int(deep)), max_labels=max_labels)
 
 
 ROLLOUT_SKIP = 10      # ClipGradcam(num_layers=10): blocks with index <= 10 do not enter the rollout (clip_gradcam.py:37, 85-87)

@@ -291,11 +291,8 @@ static inline void gemm_dispatch(Kern kernel, dim3 grid, dim3 block, size_t lds,
 template <int EPI, int BM, int BN, int BKT, int WGM, int WGN, int STAGES>
 static int launch_cfg(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     constexpr int LDS = STAGES * (BM + BN) * BKT * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static SemabsLdsAttr attr;
+    semabs_ensure_lds(&k_gemm_f16<EPI, BM, BN, BKT, WGM, WGN, STAGES>, LDS, attr);
     g.n_tiles_n = g.N / BN;
     long mt = (g.M + BM - 1) / BM;
     g.n_tiles_m = (int)mt;
@@ -1193,12 +1190,9 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 #else
     constexpr int LDS = 2 * 4 * 16384;
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static SemabsLdsAttr attr_pf, attr_nopf;
+    semabs_ensure_lds(&k_gemm8<EPI, true>, LDS, attr_pf);
+    semabs_ensure_lds(&k_gemm8<EPI, false>, LDS, attr_nopf);
     g.n_tiles_n = g.N / 256;
     const long mt = (g.M + 255) / 256;
     g.n_tiles_m = (int)mt;
@@ -1209,8 +1203,8 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     g.n_blocks = (int)(mt * g.n_tiles_n);
 #ifdef SEMABS_TUNING
     if (g_persist) {
-        static bool pset = false;
-        if (!pset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); pset = true; }
+        static SemabsLdsAttr attr_p;
+        semabs_ensure_lds(&k_gemm8<EPI, true, true>, LDS, attr_p);
         int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
         gemm_dispatch(k_gemm8<EPI, true, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS, s, g, o);
         SEMABS_CHECK_LAUNCH();
@@ -1244,26 +1238,24 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         // launch gap) is smaller than that.
         if (o.v2 && o.pers) {
             constexpr int LDS3 = 2 * 4 * 16384 + 8 * 4096;  // operand slots + 4 KB of epilogue scratch per wave = all 160 KB
-            static std::once_flag pset; static int ncu = 256;
-            std::call_once(pset, [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-                int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-            });
+            static SemabsLdsAttr attr3;
+            semabs_ensure_lds(&k_gemm8<EPI, true, true, false, true>, LDS3, attr3);
+            int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
             gemm_dispatch(k_gemm8<EPI, true, true, false, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS3, s, g, o);
             SEMABS_CHECK_LAUNCH();
             return SEMABS_OK;
         }
     }
     if (o.v2) {
-        static std::once_flag vset;
-        std::call_once(vset, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+        static SemabsLdsAttr attr_v;
+        semabs_ensure_lds(&k_gemm8<EPI, true, false, false, true>, LDS, attr_v);
         gemm_dispatch(k_gemm8<EPI, true, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
     }
     if (o.ring) {
-        static bool rset = false;
-        if (!rset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm8<EPI, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); rset = true; }
+        static SemabsLdsAttr attr_r;
+        semabs_ensure_lds(&k_gemm8<EPI, false, false, true>, LDS, attr_r);
         gemm_dispatch(k_gemm8<EPI, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <mutex>
 
 #define SEMABS_OK 0
 #define SEMABS_EINVAL (-1)   // bad argument (null pointer, unsupported shape)
@@ -29,6 +30,18 @@ void semabs_set_error(const char* msg);
     } while (0)
 
 static inline int semabs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-kernel "maximum dynamic LDS" attribute, raised on demand.  One of these per launch site (a function-local static): thread-safe, and - unlike a
+// set-once flag - correct when a later call needs MORE than the first one did (sizes that depend on the problem shape).
+struct SemabsLdsAttr { std::mutex m; int have = 0; };
+template <typename Kern>
+static inline void semabs_ensure_lds(Kern kern, int bytes, SemabsLdsAttr& st) {
+    std::lock_guard<std::mutex> lock(st.m);
+    if (bytes > st.have) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        st.have = bytes;
+    }
+}
 
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -1506,8 +1506,8 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     if ((1L << 24) / vpv < bmax) bmax = (1L << 24) / vpv;
     if (((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4) < bmax) bmax = ((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4);
     if (scratch && bmax >= 1 && (long)D0 * D1 < (1L << 24) / bmax && scratch_floats >= (long)combos * 6912) {
-        static bool set3 = false;
-        if (!set3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3_tr), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS + 64 * 128); set3 = true; }
+        static SemabsLdsAttr attr3;
+        semabs_ensure_lds(&k_wgrad3_tr, W3_LDS + 64 * 128, attr3);
         for (int b0 = 0; b0 < B; b0 += (int)bmax) {          // (one launch for every call of the 128^3 training step)
             const int Bc = B - b0 < bmax ? B - b0 : (int)bmax;
             // one persistent workgroup per CU in all, every workgroup leaves one 27 x 16 x 16 partial sum in scratch
@@ -1528,8 +1528,8 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     Wgrad16Args a;
     a.A = dZ; a.X = X; a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.s2 = s2; a.dW = dW; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx; a.tap_minor = tap_minor;
     const size_t lds = (size_t)(WG_H0 * WG_H1 * 16 * WG_XROW + 8 + WG_T0 * WG_T1 * WG_AYROW) * 2 * 2;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    static SemabsLdsAttr attr16;
+    semabs_ensure_lds(&k_wgrad16_lds, (int)lds, attr16);
     const int nbricks = B * (D0 / WG_T0) * (D1 / WG_T1) * (D2 / WG_T2);
     int bx = 768 / combos; if (bx < 8) bx = 8; if (bx > nbricks) bx = nbricks;
     hipLaunchKernelGGL(k_wgrad16_lds, dim3(bx, Ca / 16, Cx / 16), dim3(WG_NTHR), lds, s, a);

@@ -239,8 +239,8 @@ extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float
     SEMABS_REQUIRE(xyz && feat && w1 && b1 && w2 && b2 && w3 && b3 && out, "semabs_point_mlp: null pointer");
     SEMABS_REQUIRE(hidden == 128 && cout == 16, "semabs_point_mlp: built for hidden 128 -> 16 channels (net.py:358-367 defaults)");
     const size_t lds2 = (size_t)(2 * 128 * PM_ROW + 2 * 4 * 4 * 16 * 8) * 2 + (size_t)(128 * 4 + 2 * 128) * 4;
-    static bool set2 = false;
-    if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); set2 = true; }
+    static SemabsLdsAttr attr2;
+    semabs_ensure_lds(&k_point_mlp_mfma, (int)lds2, attr2);
     const long groups = ((long)P * N + 63) / 64;
     long grid2 = (groups + 7) / 8; if (grid2 > semabs_num_cus()) grid2 = semabs_num_cus();
     hipLaunchKernelGGL(k_point_mlp_mfma, dim3((unsigned)grid2), dim3(512), lds2, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
@@ -256,8 +256,8 @@ extern "C" int semabs_point_mlp_fma(const float* xyz, const float* feat, const f
     SEMABS_REQUIRE(xyz && feat && w1 && b1 && w2 && b2 && w3 && b3 && out, "semabs_point_mlp_fma: null pointer");
     SEMABS_REQUIRE(hidden == 128 && cout == 16, "semabs_point_mlp_fma: built for hidden 128 -> 16 channels (net.py:358-367 defaults)");
     size_t lds = (size_t)(128 * 128 + 16 * 128 + 128 * 4 + 2 * 128 + 16) * 4;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_mlp<128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    static SemabsLdsAttr attr;
+    semabs_ensure_lds(&k_point_mlp<128, 16>, (int)lds, attr);
     long total = (long)P * N;
     int grid = semabs_cdiv(total, 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL((k_point_mlp<128, 16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
@@ -1054,16 +1054,16 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2 * 2;   // two half-voxel planes (256-B padded), hi + lo, two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
         long nb = semabs_num_cus(); if (nb > total) nb = total;
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<true, T0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        static SemabsLdsAttr attr;
+        semabs_ensure_lds(&k_conv16_lds<true, T0>, (int)lds, attr);
         hipLaunchKernelGGL((k_conv16_lds<true, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
     } else {
         constexpr int T0 = 8;
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2;       // two half-voxel planes (256-B padded), two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
         long nb = semabs_num_cus(); if (nb > total) nb = total;
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv16_lds<false, T0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+        static SemabsLdsAttr attr;
+        semabs_ensure_lds(&k_conv16_lds<false, T0>, (int)lds, attr);
         hipLaunchKernelGGL((k_conv16_lds<false, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
     }
     SEMABS_CHECK_LAUNCH();
@@ -1824,12 +1824,9 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
 template <bool F32>
 static int convT_brick_launch(const ConvTArgs& a, hipStream_t s) {
     const size_t lds = (size_t)5 * 9 * 17 * 32 * 2 * (F32 ? 2 : 1);
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convT_brick<F32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convT_brick<F32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        set = true;
-    }
+    static SemabsLdsAttr attr0, attr1;
+    semabs_ensure_lds(&k_convT_brick<F32, 0>, (int)lds, attr0);
+    semabs_ensure_lds(&k_convT_brick<F32, 1>, (int)lds, attr1);
     dim3 grid((a.D0 / 4) * (a.D1 / 8) * (a.D2 / 16), a.B, a.Cout / 16);
     hipLaunchKernelGGL((k_convT_brick<F32, 0>), grid, dim3(512), lds, s, a);
     hipLaunchKernelGGL((k_convT_brick<F32, 1>), grid, dim3(512), lds, s, a);

@@ -555,15 +555,15 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
 #define ATT_LAUNCH(N, C)                                                                                             \
     {                                                                                                                \
         size_t lds = (size_t)(32 * N) * 128 + 64 * (32 * N + 4) * 2;                                                 \
-        static bool set = false;                                                                                     \
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<N, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; } \
+        static SemabsLdsAttr attr;                                                                                   \
+        semabs_ensure_lds(&k_attention<N, C>, (int)lds, attr);                                                       \
         hipLaunchKernelGGL((k_attention<N, C>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D, order); \
     }
 #define ATT2_LAUNCH(N, C, DM)                                                                                        \
     {                                                                                                                \
         size_t lds = (size_t)(32 * N) * 256;                                                                         \
-        static bool set2 = false;                                                                                    \
-        if (!set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention2<N, C, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = true; } \
+        static SemabsLdsAttr attr2;                                                                                  \
+        semabs_ensure_lds(&k_attention2<N, C, DM>, (int)lds, attr2);                                                 \
         hipLaunchKernelGGL((k_attention2<N, C, DM>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
     }
 #define ATT_CASE(N) { if (legacy) { if (is_causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }                                 \

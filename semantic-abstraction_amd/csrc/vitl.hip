@@ -310,13 +310,10 @@ extern "C" int semabs_attention_bwd(const void* qkv, const void* att, const floa
     {                                                                                                                                \
         constexpr int TPc = 32 * N, VSc = TPc + 4;                                                                                   \
         const size_t lq = (size_t)TPc * 256 + 64 * VSc * 2, lkv = (size_t)TPc * 256 + TPc * 16 + 2 * 64 * VSc * 2, lr = (size_t)TPc * 256 + TPc * 16; \
-        static bool set = false;                                                                                                     \
-        if (!set) {                                                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_dq<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_dkv<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lkv); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd_dkv<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr); \
-            set = true;                                                                                                              \
-        }                                                                                                                            \
+        static SemabsLdsAttr attr_q, attr_kv, attr_r;                                                                                \
+        semabs_ensure_lds(&k_attn_bwd_dq<N, true>, (int)lq, attr_q);                                                                 \
+        semabs_ensure_lds(&k_attn_bwd_dkv<N, true>, (int)lkv, attr_kv);                                                              \
+        semabs_ensure_lds(&k_attn_bwd_dkv<N, false>, (int)lr, attr_r);                                                               \
         if (dqkv) {                                                                                                                  \
             hipLaunchKernelGGL((k_attn_bwd_dq<N, true>), grid, dim3(64 * N), lq, s, (const f16*)qkv, (const f16*)att, fwd_stats, (const f16*)dO, rvec, stats, (f16*)dqkv, n, T, H); \
             hipLaunchKernelGGL((k_attn_bwd_dkv<N, true>), grid, dim3(64 * N), lkv, s, (const f16*)qkv, (const f16*)dO, stats, gscale, c, (f16*)dqkv, n, T, H, positive_only);     \

@@ -13,14 +13,11 @@ _CHUNK = 16384
 
 class Lamb(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0, adam=False):
-        if not 0.0 <= lr:
-            raise ValueError("Invalid learning rate: {}".format(lr))
-        if not 0.0 <= eps:
-            raise ValueError("Invalid epsilon value: {}".format(eps))
-        if not 0.0 <= betas[0] < 1.0:
-            raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
-        if not 0.0 <= betas[1] < 1.0:
-            raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
+        # same argument domain as the reference's constructor (arm/optim/lamb.py:47-54): a ValueError outside it
+        for name, value, ok in (("lr", lr, lr >= 0.0), ("eps", eps, eps >= 0.0), ("betas[0]", betas[0], 0.0 <= betas[0] < 1.0),
+                                ("betas[1]", betas[1], 0.0 <= betas[1] < 1.0)):
+            if not ok:
+                raise ValueError(f"Lamb: {name} = {value} is outside its domain (lr, eps >= 0; 0 <= beta < 1)")
         self.adam = adam
         self._plan = None
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -76,7 +73,7 @@ class Lamb(Optimizer):
                 continue
             for p in ps:
                 if p.grad.is_sparse:
-                    raise RuntimeError("Lamb does not support sparse gradients, consider SparseAdam instad.")
+                    raise RuntimeError("Lamb: sparse gradients are not supported (the step runs dense multi-tensor kernels)")
                 assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
             plan = self._build_plan(ps, dev)
             beta1, beta2 = group["betas"]
@@ -85,7 +82,11 @@ class Lamb(Optimizer):
                       _lib.ptr(plan["stats"]), _lib.stream())
             # The kernels wrote through raw device pointers: tell torch the parameters changed, so that everything keyed on a tensor's
             # version counter - the derived kernel operands of the nn.Modules (module.signature), autograd's saved-tensor checks - sees the step
-            torch._C._increment_version(ps)
+            try:
+                torch._C._increment_version(ps)                  # iterable overload (recent torch)
+            except TypeError:                                    # older builds take one tensor at a time
+                for p in ps:
+                    torch._C._increment_version(p)
             stats = plan["stats"]
             for t, p in enumerate(ps):
                 st = self.state[p]

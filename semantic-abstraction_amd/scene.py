@@ -46,7 +46,9 @@ class SceneResult:
     @property
     def n_in_bounds(self) -> int:
         """Host value (synchronises).  Zero in-bounds points is an error in the reference (np.random.choice on an empty population,
-        visualize.py:193); the device path cannot raise at launch time, so it is raised here, on first read."""
+        visualize.py:193); the device path cannot raise at launch time, so it is raised here, on first read - and `ScenePipeline.run` has
+        already poisoned that scene's `logits` (NaN) and `labels` (-1) on the device, so a caller that never reads this still cannot mistake the
+        result for a valid one."""
         n = int(self.n_in.item())
         if n == 0:
             raise RuntimeError("no point of the depth image falls inside scene_bounds")
@@ -191,6 +193,13 @@ class ScenePipeline:
             tsdf_flat = tsdf.reshape(-1)
             _lib.call("semabs_ovssc_labels", _lib.ptr(logits), _lib.ptr(fr), _lib.ptr(tsdf_flat), L, int(logits.shape[1]), float(self.cutoff),
                       _lib.ptr(labels), st)
+        # An empty in-bounds cloud is an error in the reference (np.random.choice on an empty population, visualize.py:193).  The device path learns the
+        # count without a host synchronisation, so it cannot raise here; it must not hand back plausible-looking output either (the sub-sample would be
+        # 80 000 copies of pixel 0): the outputs are poisoned on the device - NaN logits, label -1 everywhere - and `n_in_bounds` raises on first read.
+        empty = (n_in == 0)
+        logits.masked_fill_(empty, float("nan"))
+        if labels is not None:
+            labels.masked_fill_(empty, -1)
         # `relevancies` = the raw relevancy maps; prep_data's x 50 / mean subtraction (visualize.py:100-112) lives in semabs_gather_point_features
         return SceneResult(relevancies=maps, logits=logits, labels=labels, tsdf=tsdf, n_in=n_in)
 

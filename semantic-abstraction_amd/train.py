@@ -303,7 +303,9 @@ class UNetTrainer:
         sc, sh, s2 = self._scale(dZ, B, cout)                # dynamic power-of-two scale of dZ, shared by the weight and data gradients
         inv = s2[1:]
         dW = self.g[key + "conv.weight"]                     # [cout, cin, 3, 3, 3]: the kernels accumulate in this layout directly
-        if D0 % 4 == 0 and D1 % 4 == 0 and D2 % 16 == 0 and cin % 16 == 0 and self.mfma_wgrad:
+        # (the transposing-read kernel takes D1 % 4 == 0; without its scratch, or above 2^24 voxels, the entry point runs the 4 x 8 x 16 brick kernel, which
+        #  needs D1 % 8 == 0 - route anything else to the row kernel below instead of into its SEMABS_REQUIRE: ADVICE round 3)
+        if D0 % 4 == 0 and D1 % (4 if (self.wgrad_tr and D0 * D1 * D2 <= (1 << 24)) else 8) == 0 and D2 % 16 == 0 and cin % 16 == 0 and self.mfma_wgrad:
             scr = self._wg_scratch() if self.wgrad_tr else (None, 0)
             _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
                       B, D0, D1, D2, cout, cin, 1, *scr, st)
@@ -625,6 +627,10 @@ class VOOLTrainer:
         """-> (logits [B, D, M], ctx).  No loss: the caller computes it from the logits (the reference's `get_losses`, train_vool.py:118-178)."""
         self.unet.refresh()
         self.unet.arena.reset()
+        # One outstanding tape per engine (ADVICE round 3): refresh() rewrites the persistent weight layouts in place and reset() recycles the arena
+        # the saved activations live in, so a tape is only valid until the next forward and only while the parameters it was taken with are
+        # unchanged.  The tape carries a generation number and the parameters' version counters; backward_tape refuses a stale one.
+        self._tape_gen = getattr(self, "_tape_gen", 0) + 1
         xyz, st_, sr_, q, names, B, N, D, M = self._unpack(batch)
         logits = torch.empty(B, D, M, dtype=torch.float32, device=self.dev)
         scenes = []
@@ -632,12 +638,21 @@ class VOOLTrainer:
             c = self._scene_fwd(xyz[b].contiguous(), st_[b].contiguous(), sr_[b].contiguous(), q[b].contiguous(), list(names[b]))
             _lib.call("semabs_cos_head", _lib.ptr(c["o"]), _lib.ptr(c["rel"]), None, D, M, self.temperature, _lib.ptr(logits[b]), None, None, _lib.stream())
             scenes.append(c)
-        return logits, dict(scenes=scenes, used=sorted(set(names.reshape(-1).tolist()), key=RELATIONS.index))
+        return logits, dict(scenes=scenes, used=sorted(set(names.reshape(-1).tolist()), key=RELATIONS.index), gen=self._tape_gen, versions=self._param_versions())
+
+    def _param_versions(self):
+        return tuple(int(t._version) for t in self.params.values())
 
     @torch.no_grad()
     def backward_tape(self, ctx: dict, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
         """dlogits = d loss / d logits [B, D, M] -> {parameter name: gradient} for every parameter the graph reached (views of ONE fresh flat
         buffer; autograd accumulates them into `.grad`, where DistributedDataParallel's hooks pick them up)."""
+        if ctx.get("gen") != getattr(self, "_tape_gen", None) or not ctx.get("scenes") or any(len(c) == 0 for c in ctx["scenes"]):
+            raise RuntimeError("SemAbsVOOL backward: this forward's tape is stale - a later forward of the same module has recycled its buffers, or it "
+                               "was already back-propagated (one outstanding forward per engine, single-use tape; see INTEGRATION.md)")
+        if ctx.get("versions") != self._param_versions():
+            raise RuntimeError("SemAbsVOOL backward: parameters were modified (optimizer.step / in-place edit) between this forward and its backward; "
+                               "the data gradients would be computed with the updated weights")
         self._bind_grads(torch.zeros(self.total + len(RELATIONS), dtype=torch.float32, device=self.dev), attach=False)
         dl = dlogits.to(self.dev, torch.float32).contiguous()
         for b, c in enumerate(ctx["scenes"]):

@@ -36,3 +36,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert 0.05 < rf["frac"] < 1.0 and rf["launches"] > 0
+    # nothing in the line may claim more than the hardware has: no class above its roof, no stream above the HBM peak (round 3 shipped a LayerNorm row at
+    # 1.02 of its roof / 8.18 TB/s because a flag word was read without its mask)
+    for cls, row in d.get("stages", {}).get("kernel_classes", {}).items():
+        assert row.get("frac_of_roof") is None or row["frac_of_roof"] <= 1.0, (cls, row)
+        assert row.get("tb_per_s") is None or row["tb_per_s"] <= 8.0, (cls, row)
+        assert row.get("tflops") is None or row["tflops"] <= 2500.0, (cls, row)
+    for name, row in rf.get("per_shape", {}).items():
+        assert row["frac_of_roof"] <= 1.0, (name, row)
+    # imported counter / probe figures must come from THIS round's profiles and say that they are imported
+    assert "profiles/r04_" in (rf.get("traffic_source") or "profiles/r04_"), rf.get("traffic_source")
+    assert rf["mfma_probe"] is None or "imported" in rf["mfma_probe"]["source"]
+    assert d.get("text_tower_in_timed_region") is True

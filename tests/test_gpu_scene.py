@@ -44,3 +44,23 @@ def test_scene_end_to_end(precision):
     assert ((lab == -1) == (lab_ref == -1)).mean() > 0.999
     both = (lab >= 0) & (lab_ref >= 0)
     assert (lab[both] == lab_ref[both]).mean() > 0.97                                      # argmax flips only on near-ties
+
+
+def test_scene_with_no_point_in_bounds_is_loud():
+    """The reference fails on an empty in-bounds cloud (np.random.choice on an empty population, visualize.py:193).  The device path draws the
+    sub-sample without a host synchronisation, so it must poison the result instead of returning the UNet's answer for 4 000 copies of pixel 0
+    (ADVICE round 3): NaN logits, label -1 everywhere, and `n_in_bounds` raises on first read."""
+    from semabs_amd.scene import build_default
+    S, H, L, npts = 32, 96, 2, 4000
+    pipe = build_default("ViT-B/32", precision="fp16", chunk_tiles=64, max_labels=L, voxel=S, text_tower=False, num_input_pts=npts, config="chefer_et_al")
+    sc = synth_scene(H, H, seed=8)
+    sc["depth"] = np.full_like(sc["depth"], 50.0)                                          # every pixel far outside scene_bounds
+    w = torch.randn(L, 512, generator=torch.Generator().manual_seed(0))
+    res = pipe.run(pipe.upload(sc), (w / w.norm(dim=1, keepdim=True)).cuda(), seed=1)
+    assert bool(torch.isnan(res.logits).all())
+    assert bool((res.labels == -1).all())
+    with pytest.raises(RuntimeError, match="scene_bounds"):
+        res.n_in_bounds
+    # ... and a valid scene through the same pipeline afterwards is untouched
+    ok = pipe.run(pipe.upload(synth_scene(H, H, seed=8)), (w / w.norm(dim=1, keepdim=True)).cuda(), seed=1)
+    assert not bool(torch.isnan(ok.logits).any()) and ok.n_in_bounds > 0
