@@ -365,7 +365,7 @@ def stage_report(pipe, scenes, w_text, arch, precision):
     if trunk:
         fl = sum(v.get("algorithmic_tflop") or 0.0 for v in trunk); gb = sum(v.get("algorithmic_gb") or 0.0 for v in trunk); ms = sum(v["ms_per_scene"] for v in trunk)
         counted = None
-        for name in ("r04_pmc_kernels.json", "r03_pmc_kernels.json"):
+        for name in ("r04_gemm_pmc.json",):
             pth = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pth):
                 try:

@@ -1,5 +1,6 @@
-"""Reference-shaped OVSSC inference entry points: `prep_data` and `process_batch_ovssc` of visualize.py (:61-154, :157-248), same
-argument meaning and the same RETURN FORM - a dict class label -> fp32 {0, 1} volume at `sampling_shape` - computed on the GPU.
+"""Reference-shaped inference entry points: `prep_data`, `process_batch_ovssc` and `process_batch_vool` of visualize.py (:61-154, :157-248,
+:354-419), same argument meaning and the same RETURN FORM - a dict class label -> fp32 {0, 1} volume at `sampling_shape` (OVSSC), a dict
+description -> fp32 logit volume plus the lattice points (VOOL) - computed on the GPU.
 
 What differs from the reference, with identical outputs for identical sub-samples:
   * the reference re-runs point MLP + scatter + UNet for every 2^20-point chunk of query points and draws a new `np.random.choice`
@@ -7,6 +8,8 @@ What differs from the reference, with identical outputs for identical sub-sample
     chunk against the cached volume (14 x fewer UNet passes at 240^3).  The sub-sample is one seeded draw per call (`seed`) or the caller's
     `indices`;
   * TSDF integration, frustum test and the argmax / cutoff / frustum / tsdf post-mask run as HIP kernels, no host round trips in between.
+  * `process_batch_vool` likewise: the reference re-runs the whole SemAbsVOOL (two feature volumes = two UNet passes) for every chunk of every
+    description (visualize.py:373-412); here both feature volumes of all descriptions are computed once and the sampler + pointer head runs per chunk.
 `ScenePipeline` (scene.py) is the device-resident throughput path bench.py times; this module is the drop-in for the reference's callers.
 """
 from __future__ import annotations
@@ -93,10 +96,7 @@ def process_batch_ovssc(net, batch: Dict[str, Any], scene_bounds, device: str = 
     classes = list(batch["ovssc_obj_classes"])
     xyz_all = batch["input_xyz_pts"]
     n_in = int(xyz_all.shape[-2])
-    if indices is None:
-        rng = np.random.default_rng(seed) if seed is not None else np.random
-        indices = rng.choice(n_in, size=num_input_pts) if seed is None else rng.integers(0, n_in, size=num_input_pts)
-    idx_t = torch.as_tensor(np.asarray(indices), dtype=torch.int64)
+    idx_t = _subsample(n_in, num_input_pts, seed, indices)
     xyz = xyz_all.reshape(-1, 3)[idx_t].float().to(dev).contiguous()
     feat = batch["input_feature_pts"].reshape(len(classes), -1)[:, idx_t].float().to(dev).contiguous()          # [C, num_input_pts]
     features = net.feature_volume(xyz, feat)                                   # [C, S, S, S, 16]: once per class, not once per chunk
@@ -108,6 +108,46 @@ def process_batch_ovssc(net, batch: Dict[str, Any], scene_bounds, device: str = 
     if return_logits:
         return out, logits.view(len(classes), *sampling_shape), lab
     return out
+
+
+def _subsample(n_in: int, num_input_pts: int, seed: Optional[int], indices):
+    if indices is None:
+        rng = np.random.default_rng(seed) if seed is not None else np.random
+        indices = rng.choice(n_in, size=num_input_pts) if seed is None else rng.integers(0, n_in, size=num_input_pts)
+    return torch.as_tensor(np.asarray(indices), dtype=torch.int64)
+
+
+@torch.no_grad()
+def process_batch_vool(net, batch: Dict[str, Any], scene_bounds, device: str = "cuda", num_input_pts: int = 80000,
+                       sampling_shape: Tuple[int, int, int] = (240, 240, 240), num_pts_per_pass: int = int(2 ** 20),
+                       seed: Optional[int] = 0, indices: Optional[np.ndarray] = None):
+    """visualize.process_batch_vool (:354-419) -> ({description: fp32 logit tensor of `sampling_shape` on the host}, lattice points [prod, 3]).
+    `net`: a `SemAbsVOOL` (anything with its `feature_volumes` / `point` pair).  Per description the reference selects row `desc_idx` of
+    `input_target_saliency_pts` / `input_reference_saliency_pts` and `[[spatial_relation_name[desc_idx]]]`, re-runs the whole network for every
+    chunk of `num_pts_per_pass` lattice points with a fresh `np.random.choice` sub-sample, and concatenates; here the sub-sample is one seeded draw
+    per call (`seed` / `indices`), the two feature volumes of every description are computed once, and only sampler + head run per chunk
+    (at 240^3 / 2^20: 14 chunks -> 1/14 of the UNet passes)."""
+    _lib.require_gpu()
+    grid_points = get_sample_points(sampling_shape, scene_bounds)
+    lo, hi = np.asarray(scene_bounds[0], np.float32), np.asarray(scene_bounds[1], np.float32)
+    gp = grid_points.cpu().numpy()
+    assert bool(((gp >= lo) & (gp <= hi)).all()), "sampling lattice leaves scene_bounds"          # visualize.py:367-369, in the points' own dtype
+    Mq = int(grid_points.shape[0])
+    descs = list(batch["descriptions"])
+    D = len(descs)
+    relations = [str(r) for r in batch["spatial_relation_name"]]
+    assert len(relations) == D
+    xyz_all = batch["input_xyz_pts"].reshape(-1, 3)
+    idx_t = _subsample(int(xyz_all.shape[0]), num_input_pts, seed, indices)
+    xyz = xyz_all[idx_t].float()
+    tgt = batch["input_target_saliency_pts"].reshape(D, -1)[:, idx_t].float()
+    ref = batch["input_reference_saliency_pts"].reshape(D, -1)[:, idx_t].float()
+    ft, fr = net.feature_volumes(xyz, tgt, ref)                                # once, not once per chunk
+    out = torch.empty(D, Mq, dtype=torch.float32, device=grid_points.device)
+    for j in range(0, Mq, num_pts_per_pass):
+        out[:, j:j + num_pts_per_pass] = net.point(ft, fr, relations, grid_points[j:j + num_pts_per_pass].contiguous())
+    host = out.cpu()
+    return {desc: host[d].view(*sampling_shape) for d, desc in enumerate(descs)}, grid_points
 
 
 @torch.no_grad()

@@ -329,25 +329,51 @@ class SemAbsVOOL(torch.nn.Module):
         return _VOOLFunction.apply(eng, batch, pnames, *[eng.params[k] for k in pnames])
 
     @torch.no_grad()
-    def _forward_infer(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts):
+    def feature_volumes(self, xyz: torch.Tensor, target_saliency: torch.Tensor, reference_saliency: torch.Tensor):
+        """The part of the forward pass that does not depend on the query points (net.py:521-549): point MLP + scatter + UNet on the target and on
+        the reference saliency of every description.  xyz fp32 [N, 3], saliencies fp32 [D, N] -> (ft, fr), each [D, S, S, S, C] channels-last.
+        `process_batch_vool` computes these ONCE per description and re-uses them for every chunk of query points."""
         dev = _lib.require_gpu()
         self._sync()
         net = self.completion_net
+        xyz = xyz.to(dev, torch.float32).contiguous()
+        D, N = int(target_saliency.shape[0]), int(xyz.shape[0])
+        ft = net.feature_volume(xyz, target_saliency.to(dev, torch.float32).reshape(D, N).contiguous())
+        fr = net.feature_volume(xyz, reference_saliency.to(dev, torch.float32).reshape(D, N).contiguous())
+        return ft, fr
+
+    @torch.no_grad()
+    def point(self, ft: torch.Tensor, fr: torch.Tensor, relation_names, query_xyz: torch.Tensor) -> torch.Tensor:
+        """Sampler + spatial MLP + cosine pointer (net.py:550-579) against cached feature volumes.  relation_names: one per description;
+        query_xyz fp32 [D, M, 3] (or [M, 3], shared by all descriptions) -> logits fp32 [D, M]."""
+        dev = _lib.require_gpu()
+        self._sync()
+        net = self.completion_net
+        D = int(ft.shape[0])
+        q = query_xyz.to(dev, torch.float32)
+        if q.dim() == 2:
+            q = q[None].expand(D, -1, -1)
+        q = q.contiguous()
+        M = int(q.shape[1])
+        rel = torch.stack([self._rel[str(n)] for n in relation_names], dim=0).contiguous()
+        out = torch.empty(D, M, dtype=torch.float32, device=dev)
+        _lib.call("semabs_vool_head", _lib.ptr(ft), _lib.ptr(fr), _lib.ptr(q), _lib.ptr(self._prm), _lib.ptr(rel), _lib.farr(net.vg.offsets),
+                  _lib.farr(net.vg.scales), _lib.iarr(net.vg.grid_shape), float(self.pointing_temperature), D, M,
+                  net.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
+        return out
+
+    @torch.no_grad()
+    def _forward_infer(self, output_xyz_pts, spatial_relation_name, input_xyz_pts, input_target_saliency_pts, input_reference_saliency_pts):
         batch_size, num_descs = np.array(spatial_relation_name).T.shape
         M = int(output_xyz_pts.shape[-2])
+        if input_xyz_pts.dim() == 2:                            # visualize.py:387-412 hands over the cloud without a batch dimension
+            input_xyz_pts = input_xyz_pts[None]
         outs = []
         for b in range(batch_size):
-            xyz = input_xyz_pts[b].to(dev, torch.float32)
-            N = xyz.shape[0]
-            ft = net.feature_volume(xyz, input_target_saliency_pts[b].to(dev, torch.float32).reshape(num_descs, N))
-            fr = net.feature_volume(xyz, input_reference_saliency_pts[b].to(dev, torch.float32).reshape(num_descs, N))
-            rel = torch.stack([self._rel[spatial_relation_name[d][b]] for d in range(num_descs)], dim=0).contiguous()
-            q = output_xyz_pts[b].to(dev, torch.float32).reshape(num_descs, M, 3).contiguous()
-            out = torch.empty(num_descs, M, dtype=torch.float32, device=dev)
-            _lib.call("semabs_vool_head", _lib.ptr(ft), _lib.ptr(fr), _lib.ptr(q), _lib.ptr(self._prm), _lib.ptr(rel), _lib.farr(net.vg.offsets),
-                      _lib.farr(net.vg.scales), _lib.iarr(net.vg.grid_shape), float(self.pointing_temperature), num_descs, M,
-                      net.vol_feature_extractor.f32, _lib.ptr(out), _lib.stream())
-            outs.append(out)
+            N = int(input_xyz_pts[b].shape[0])
+            ft, fr = self.feature_volumes(input_xyz_pts[b], input_target_saliency_pts[b].reshape(num_descs, N),
+                                          input_reference_saliency_pts[b].reshape(num_descs, N))
+            outs.append(self.point(ft, fr, [spatial_relation_name[d][b] for d in range(num_descs)], output_xyz_pts[b].reshape(num_descs, M, 3)))
         return torch.stack(outs, dim=0).view(batch_size, num_descs, M)
 
 

@@ -87,6 +87,21 @@ def synth_ovssc_logits(points, n_classes: int):
     return torch.stack(out, dim=0)
 
 
+VOOL_RELATIONS = ["in", "behind", "in front of", "on the left of", "on the right of", "on", "[pad]"]
+
+
+def synth_vool_logits(points, target_first: float, reference_first: float, relation: str):
+    """Closed-form stand-in for the network inside `process_batch_vool` (parity fixture g26): a pure fp32 multiply / add function of the query points
+    and of WHAT the caller selected for this description - the first target / reference saliency value it passed and the relation name - so that the
+    reference's plumbing (per-description row selection, relation list nesting, 2^k chunking with a ragged tail, concatenation, return form) can be
+    compared bit for bit.  points torch fp32 [M, 3] -> [M]."""
+    r = float(VOOL_RELATIONS.index(relation))
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    q = x * (1.0 + 0.25 * r) + y * (0.5 - 0.125 * r)
+    q = q + z * 0.75
+    return q * float(target_first) + (q * q) * float(reference_first) + (r - 2.0)
+
+
 def synth_relevancy(img: np.ndarray, labels) -> np.ndarray:
     """Closed-form stand-in for `ClipWrapper.get_clip_saliency(...)[0]` (parity fixture g25: `prep_data` executed from the reference's source):
     one fp32 map [H, W] per label STRING, a pure function of the label's bytes and the image - so that the reference's data plumbing around

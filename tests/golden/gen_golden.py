@@ -1075,3 +1075,141 @@ if __name__ == "__main__" and "g24" in sys.argv[1:]:
     g24_prompt_ensemble()
 if __name__ == "__main__" and "g25" in sys.argv[1:]:
     g25_prep_data()
+
+
+# ---- appended (round 4): process_batch_vool executed from the reference's source (g26) --------------------------------------------------------
+def g26_process_batch_vool():
+    """visualize.process_batch_vool + get_sample_points (visualize.py:354-419, 283-298), EXECUTED: compiled from the reference's source and run with
+    the reference's own filter_pts_bounds; the network call is the closed-form stand-in `semabs_amd.synth.synth_vool_logits`, which reads what the
+    reference selected for each description (saliency rows by description index, `[[relation]]`).  Pins the sampling lattice, the 2^k chunking incl.
+    the ragged tail, per-description selection, concatenation and the return form ({description: tensor of sampling_shape}, grid points)."""
+    from semabs_amd.synth import synth_vool_logits
+    fusion, pc = refimport.load_reference_geometry()
+
+    class Progress:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def add_task(self, *a, **k):
+            return 0
+
+        def update(self, *a, **k):
+            pass
+
+    fpb = lambda xyz, bounds: pc.filter_pts_bounds(xyz, np.asarray(bounds).astype(np.asarray(xyz).dtype))      # numpy-1.22 typing (see g18)
+    ns = {"np": np, "torch": torch, "filter_pts_bounds": fpb, "Progress": Progress}
+    _ref_functions("visualize.py", ["get_sample_points", "process_batch_vool"], ns)
+    S, n_in = 36, 300
+    descs = [("lamp", "on", "table"), ("cushion", "behind", "chair"), ("mug", "on the left of", "lamp")]
+    D = len(descs)
+    rng = np.random.default_rng(26)
+    tgt = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).repeat(1, n_in)         # constant along the points: whichever
+    ref = torch.from_numpy(rng.standard_normal((D, 1)).astype(np.float32)).repeat(1, n_in)         # sub-sample is drawn, the first value is row d's
+    seen = []
+
+    def net(output_xyz_pts, spatial_relation_name, input_target_saliency_pts, input_reference_saliency_pts, **kw):
+        # what the reference hands over: [None, None, [desc_idx], indices, None] on a [D, N] tensor -> (1, 1, num_input_pts, 1); [[relation]]
+        assert tuple(input_target_saliency_pts.shape) == (1, 1, 64, 1) == tuple(input_reference_saliency_pts.shape)
+        assert np.array(spatial_relation_name).shape == (1, 1) and tuple(output_xyz_pts.shape[:2]) == (1, 1) and tuple(kw["input_xyz_pts"].shape) == (64, 3)
+        seen.append(int(output_xyz_pts.shape[-2]))
+        v = synth_vool_logits(output_xyz_pts.reshape(-1, 3).float(), float(input_target_saliency_pts.reshape(-1)[0]),
+                              float(input_reference_saliency_pts.reshape(-1)[0]), spatial_relation_name[0][0])
+        return v[None, None]
+
+    batch = {"descriptions": [f"the {a} {r} the {b}" for a, r, b in descs], "spatial_relation_name": [r for _, r, _ in descs],
+             "input_xyz_pts": torch.zeros(n_in, 3), "input_target_saliency_pts": tgt, "input_reference_saliency_pts": ref}
+    preds, pts = ns["process_batch_vool"](net=net, batch=batch, scene_bounds=SCENE_BOUNDS, device="cpu", num_input_pts=64,
+                                          sampling_shape=(S, S, S), num_pts_per_pass=2 ** 13)
+    assert list(preds.keys()) == batch["descriptions"] and all(tuple(v.shape) == (S, S, S) and v.dtype == torch.float32 for v in preds.values())
+    stack = torch.stack([preds[d] for d in batch["descriptions"]]).numpy()
+    save("g26_process_batch_vool", meta=np.asarray([S, D, n_in, 2 ** 13], np.int64), volumes=stack, tgt=tgt[:, 0].numpy(), ref=ref[:, 0].numpy(),
+         relations=np.asarray(batch["spatial_relation_name"]), descriptions=np.asarray(batch["descriptions"]), points_sha=digest(pts.numpy()),
+         chunks=np.asarray(seen[: len(seen) // D], np.int64))
+    print("    chunks per description", seen[: len(seen) // D], " value range", float(stack.min()), float(stack.max()))
+
+
+if __name__ == "__main__" and "g26" in sys.argv[1:]:
+    g26_process_batch_vool()
+
+
+# ---- appended (round 4): the reference's only REAL input, scene_files/arkit_vn_poster.pkl, through prep_data -> CLIP relevancy -> SemAbs3D (g27) ---
+def g27_real_scene():
+    """scene_files/arkit_vn_poster.pkl (256 x 192 RGB-D of an ARKit capture: non-square, real depth, 14 OVSSC classes + 3 descriptions -> 17 relevancy
+    keys) through the reference end to end: `visualize.prep_data` compiled from its source and run with the UNMODIFIED `ClipWrapper.get_clip_saliency`
+    (ViT-B/32, seeded weights; "ours" with augmentations = 0 so that no random colour jitter enters - everything else of the config as shipped),
+    the reference's own get_pointcloud / filter_pts_bounds, then the reference's `SemAbs3D` (seeded weights, 64^3) on four of the classes with a
+    fixed sub-sample and fixed query points.  The scene itself (a data file of the reference) travels in the fixture; so do the token ids of the 17
+    prompts (the BPE table is not on the GPU box)."""
+    import pickle
+    import tempfile
+    fusion, pc = refimport.load_reference_geometry()
+    rc = refimport.load_reference_clip("ViT-B/32", seed=0)
+    import CLIP.clip.clip_explainability as rexp
+    net_mod, _ = refimport.load_reference_net()
+    src = os.path.join(refimport.REF, "scene_files", "arkit_vn_poster.pkl")
+    data = pickle.load(open(src, "rb"))
+    calls = []
+
+    class Wrapper:                                              # records the call, forwards it unchanged to the reference's ClipWrapper
+        @classmethod
+        def get_clip_saliency(cls, img, text_labels, prompts, **kwargs):
+            calls.append(dict(labels=[str(t) for t in text_labels], prompts=list(prompts), kwargs=dict(kwargs)))
+            return rc.ClipWrapper.get_clip_saliency(img=img, text_labels=text_labels, prompts=prompts, **kwargs)
+
+    class _Path:
+        def __init__(self, p):
+            pass
+
+        def mkdir(self, **k):
+            pass
+
+    fpb = lambda xyz, bounds: pc.filter_pts_bounds(xyz, np.asarray(bounds).astype(np.float32))      # numpy-1.22 typing of the comparison (see g18)
+    cfgs = {"ours": lambda h: dict(rc.saliency_configs["ours"](h), augmentations=0)}
+    ns = {"np": np, "torch": torch, "pickle": pickle, "os": os, "Path": _Path, "ClipWrapper": Wrapper, "saliency_configs": cfgs,
+          "get_pointcloud": pc.get_pointcloud, "filter_pts_bounds": fpb, "visualize_relevancies": lambda **k: None}
+    _ref_functions("visualize.py", ["prep_data"], ns)
+    t = time.time()
+    with tempfile.TemporaryDirectory() as d:
+        b = ns["prep_data"](data_pickle_path=src, scene_bounds=SCENE_BOUNDS, subtract_mean=True, dump_path=d)
+    keys = calls[-1]["labels"]
+    print(f"    prep_data on the real scene: {time.time() - t:.1f}s, {len(keys)} relevancy keys, {len(b['input_xyz_pts'])} in-bounds points", flush=True)
+    rel = b["relevancies"].numpy()                              # [17, 256, 192], x 50, mean-subtracted
+    prompt = calls[-1]["prompts"][0]
+    tokens = rexp.tokenize([prompt.format(k) for k in keys]).numpy().astype(np.int32)
+    # ---- SemAbs3D (the reference's module, seeded weights) on four classes, fixed sub-sample / query points ----
+    S, npts, M = 64, 20000, 4096
+    m = net_mod.SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8, unet_num_levels=6,
+                         network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1,
+                         device="cpu", decoder_concat_xyz_pts=True, batch_size=1)
+    m.load_state_dict(make_semabs3d_state_dict(seed=3), strict=True)
+    m.eval()
+    rng = np.random.default_rng(27)
+    n_in = len(b["input_xyz_pts"])
+    idx = rng.integers(0, n_in, size=npts)
+    lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+    q = (lo + (hi - lo) * rng.random((M, 3))).astype(np.float32)
+    cls_idx = [0, 3, 6, 11]                                     # poster of vietnam, light switch, lamp, wall
+    logits = []
+    t = time.time()
+    with torch.no_grad():
+        for c in cls_idx:
+            out = m(input_xyz_pts=b["input_xyz_pts"][None, idx].float(), input_feature_pts=b["input_feature_pts"][None, [c]][:, :, idx, None].float(),
+                    tsdf_vol=None, output_xyz_pts=torch.from_numpy(q)[None, None])
+            logits.append(out.reshape(-1).numpy())
+    print(f"    SemAbs3D 64^3 x {len(cls_idx)} classes: {time.time() - t:.1f}s", flush=True)
+    rows = np.asarray([0, 37, 101, 128, 200, 255])
+    save("g27_real_scene", rgb=data["rgb"], depth=data["depth"], cam_intr=np.asarray(data["cam_intr"]), cam_extr=np.asarray(data["cam_extr"]),
+         ovssc_obj_classes=np.asarray(data["ovssc_obj_classes"]), descriptions=np.asarray([list(x) for x in data["descriptions"]]),
+         keys=np.asarray(keys), prompt=np.asarray(prompt), tokens=tokens, rel_sub=rel[:, ::2, ::2].copy(), rel_rows_idx=rows, rel_rows=rel[:, rows, :].copy(),
+         rel_absmax=np.abs(rel).reshape(len(keys), -1).max(1), n_in=np.int64(n_in), xyz_sha=digest(b["input_xyz_pts"].numpy()),
+         xyz_sub=b["input_xyz_pts"].numpy()[::211].copy(), feat_sub=b["input_feature_pts"].numpy()[:, ::211].copy(),
+         tgt_sub=b["input_target_saliency_pts"].numpy()[:, ::211].copy(), ref_sub=b["input_reference_saliency_pts"].numpy()[:, ::211].copy(),
+         idx=idx.astype(np.int64), q=q, cls_idx=np.asarray(cls_idx), logits=np.stack(logits), meta=np.asarray([S, npts, M, 3], np.int64),
+         cfg_keys=np.asarray(sorted(calls[-1]["kwargs"].keys())))
+
+
+if __name__ == "__main__" and "g27" in sys.argv[1:]:
+    g27_real_scene()

@@ -163,3 +163,72 @@ def test_prep_data_through_the_real_relevancy_path(golden):
     assert float(b["relevancies"].abs().max()) > 1e-3 and torch.isfinite(b["relevancies"]).all()
     assert tuple(b["input_feature_pts"].shape) == (2, n) and tuple(b["input_target_saliency_pts"].shape) == (1, n)
     assert b["spatial_relation_name"] == ["on"] and b["descriptions"] == ["the lamp on the table"] and b["tsdf_vol"] is None
+
+
+# ---- f5: process_batch_vool (visualize.py:354-419) -------------------------------------------------------------------------------------------
+def test_process_batch_vool_vs_executed_reference(golden):
+    """The reference's own `process_batch_vool` EXECUTED from its source (g26, closed-form stand-in for the network): the HIP-side mirror with the
+    same stand-in behind its `feature_volumes` / `point` pair must return the same descriptions, in the same order, with bit-identical volumes
+    and the same lattice - i.e. per-description row selection, relation plumbing, ragged 2^k chunking and concatenation are the reference's."""
+    from semabs_amd.inference import process_batch_vool
+    from semabs_amd.synth import synth_vool_logits
+    g = golden("g26_process_batch_vool")
+    S, D, n_in, chunk = (int(v) for v in g["meta"])
+    seen = []
+
+    class StandIn:                                              # the network's two halves, closed form: reads what the caller selected per description
+        def feature_volumes(self, xyz, tgt, ref):
+            assert tuple(xyz.shape) == (64, 3) and tuple(tgt.shape) == (D, 64) == tuple(ref.shape)
+            return tgt[:, :1].clone(), ref[:, :1].clone()
+
+        def point(self, ft, fr, relations, q):
+            seen.append(int(q.shape[0]))
+            return torch.stack([synth_vool_logits(q.cpu().float(), float(ft[d, 0]), float(fr[d, 0]), relations[d]) for d in range(D)]).cuda()
+
+    tgt = torch.from_numpy(g["tgt"])[:, None].repeat(1, n_in)
+    ref = torch.from_numpy(g["ref"])[:, None].repeat(1, n_in)
+    batch = {"descriptions": [str(s) for s in g["descriptions"]], "spatial_relation_name": [str(s) for s in g["relations"]],
+             "input_xyz_pts": torch.zeros(n_in, 3), "input_target_saliency_pts": tgt, "input_reference_saliency_pts": ref}
+    preds, pts = process_batch_vool(StandIn(), batch, SCENE_BOUNDS, "cuda", num_input_pts=64, sampling_shape=(S, S, S), num_pts_per_pass=chunk, seed=3)
+    assert list(preds.keys()) == batch["descriptions"]
+    assert seen == [int(c) for c in g["chunks"]]                                              # same chunk sizes incl. the ragged tail
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pts.cpu().numpy().tobytes()).digest(), np.uint8), g["points_sha"])
+    got = torch.stack([preds[d] for d in batch["descriptions"]])
+    assert got.dtype == torch.float32 and tuple(got.shape) == (D, S, S, S) and not got.is_cuda
+    assert np.array_equal(got.numpy(), g["volumes"])
+
+
+def test_process_batch_vool_cached_volumes_equal_per_chunk_forward():
+    """The real SemAbsVOOL: feature volumes computed once + head per chunk == the reference's recipe (the whole `net(**batch)` per chunk and
+    description with the same sub-sample), bit for bit; and the module's forward accepts the reference's call shapes (cloud without a batch
+    dimension, saliency [1, 1, N, 1], relation [[name]]: visualize.py:387-412)."""
+    from semabs_amd.inference import get_sample_points, process_batch_vool
+    from semabs_amd.net import SemAbsVOOL
+    from semabs_amd.weights import make_semabsvool_state_dict
+    Sv, Sq, npts, chunk = 32, 24, 3000, 2 ** 12
+    net = SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cuda", decoder_concat_xyz_pts=True, voxel_shape=(Sv, Sv, Sv),
+                     scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8, unet_num_levels=6, network_inputs=["saliency"],
+                     use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1, batch_size=1)
+    net.load_state_dict(make_semabsvool_state_dict(seed=3))
+    net.eval()
+    rng = np.random.default_rng(2)
+    n_in = 5000
+    xyz = torch.from_numpy(rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.8], size=(n_in, 3)).astype(np.float32))
+    descs = [("lamp", "on", "table"), ("cushion", "behind", "chair")]
+    batch = {"descriptions": [f"the {a} {r} the {b}" for a, r, b in descs], "spatial_relation_name": [r for _, r, _ in descs], "input_xyz_pts": xyz,
+             "input_target_saliency_pts": torch.from_numpy(rng.standard_normal((2, n_in)).astype(np.float32)),
+             "input_reference_saliency_pts": torch.from_numpy(rng.standard_normal((2, n_in)).astype(np.float32))}
+    idx = rng.integers(0, n_in, size=npts)
+    preds, pts = process_batch_vool(net, batch, SCENE_BOUNDS, "cuda", npts, sampling_shape=(Sq, Sq, Sq), num_pts_per_pass=chunk, indices=idx)
+    grid = get_sample_points((Sq, Sq, Sq), SCENE_BOUNDS)
+    assert torch.equal(pts, grid)
+    for d, desc in enumerate(batch["descriptions"]):
+        parts = []
+        for j in range(0, len(grid), chunk):                                                 # the reference's loop body, its shapes
+            out = net(output_xyz_pts=grid[j:j + chunk][None, None], spatial_relation_name=[[batch["spatial_relation_name"][d]]],
+                      input_xyz_pts=xyz[idx], input_target_saliency_pts=batch["input_target_saliency_pts"][None, None, [d], idx, None],
+                      input_reference_saliency_pts=batch["input_reference_saliency_pts"][None, None, [d], idx, None])
+            parts.append(out.detach().cpu())
+        naive = torch.cat(parts, dim=-1).squeeze().view(Sq, Sq, Sq)
+        assert torch.equal(naive, preds[desc]), desc
+    assert float(torch.stack(list(preds.values())).std()) > 1e-3

@@ -242,3 +242,17 @@ def test_oracle_ovssc_post_mask_vs_executed_reference(golden):
     ref = np.unpackbits(g["packed"], axis=1)[:, : S ** 3].reshape(C, S, S, S).astype(np.float32)
     assert np.array_equal(vols.reshape(C, -1).sum(1).astype(np.int64), g["counts"])
     assert np.array_equal(vols, ref)
+
+
+def test_g26_process_batch_vool_fixture_is_the_stand_in_on_the_reference_lattice(golden):
+    """f5 glue: the reference's process_batch_vool executed from source (g26).  Without a GPU: the stored volumes are exactly the closed-form
+    stand-in evaluated on the oracle's sampling lattice with the row / relation of each description - i.e. the fixture pins what the test says."""
+    from oracle import scene as osc
+    from semabs_amd.synth import SCENE_BOUNDS, synth_vool_logits
+    g = golden("g26_process_batch_vool")
+    S, D, n_in, chunk = (int(v) for v in g["meta"])
+    pts = osc.sample_points((S, S, S), SCENE_BOUNDS)
+    assert np.array_equal(sha(pts), g["points_sha"])
+    want = np.stack([synth_vool_logits(torch.from_numpy(pts), float(g["tgt"][d]), float(g["ref"][d]), str(g["relations"][d])).numpy().reshape(S, S, S) for d in range(D)])
+    assert np.array_equal(want, g["volumes"])
+    assert [int(c) for c in g["chunks"]] == [chunk] * (S ** 3 // chunk) + ([S ** 3 % chunk] if S ** 3 % chunk else [])

@@ -28,41 +28,50 @@ H16 = lambda t: t.half().float()
 ID = lambda t: t
 
 
+OPERANDS = ("ln1", "qk", "v", "p", "o", "ln2", "act")          # the fp16 rounding points of one trunk block, by operand class
+
+
 def _block(sd, pre, x, heads, r, want=None, last=False):
-    """oracle.relevancy._block with the HIP path's rounding points: r = H16 rounds this block's GEMM operands to fp16."""
+    """oracle.relevancy._block with the HIP path's rounding points: r = H16 rounds this block's GEMM operands to fp16 (r may also be a dict
+    {operand class: rounding function} to round ONE class: ln1 = LayerNorm-1 output (A of QKV), qk = scaled q and k (operands of Q.K^T), v (B of P.V),
+    p = un-normalised probabilities (A of P.V), o = attention output (A of out-proj), ln2 = LayerNorm-2 output (A of c_fc), act = QuickGELU output
+    (A of c_proj))."""
+    rr = r if isinstance(r, dict) else {k: r for k in OPERANDS}
+    rf = lambda k: rr.get(k, ID)
     n, T, D = x.shape
     dh = D // heads
-    h = r(orl._ln(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"]))
+    h = rf("ln1")(orl._ln(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"]))
     qkv = F.linear(h, sd[pre + "attn.in_proj_weight"], sd[pre + "attn.in_proj_bias"])
     q, k, v = qkv.chunk(3, dim=-1)
     q = q * (float(dh) ** -0.5)
     if not last:
-        q, k = r(q), r(k)                                     # the last block keeps K and the CLS query in fp32 (clip/vit.py:head)
-    v = r(v)
+        q, k = rf("qk")(q), rf("qk")(k)                       # the last block keeps K and the CLS query in fp32 (clip/vit.py:head)
+    v = rf("v")(v)
     q, k, v = (t.view(n, T, heads, dh).transpose(1, 2) for t in (q, k, v))
     s = q @ k.transpose(-1, -2)
     m = s.max(dim=-1, keepdim=True).values
     e = torch.exp(s - m)
     p = e / e.sum(-1, keepdim=True)
-    pe = e if last else r(e)                                  # un-normalised probabilities are the fp16 B operand of P.V (fp32 sum, fp32 1 / sum)
-    o = r(((pe @ v) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(n, T, D))
+    pe = e if last else rf("p")(e)                            # un-normalised probabilities are the fp16 B operand of P.V (fp32 sum, fp32 1 / sum)
+    o = rf("o")(((pe @ v) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(n, T, D))
     x1 = x + F.linear(o, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"])
-    h2 = r(orl._ln(x1, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"]))
+    h2 = rf("ln2")(orl._ln(x1, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"]))
     fc = F.linear(h2, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"])
-    act = r(fc * torch.sigmoid(1.702 * fc))
+    act = rf("act")(fc * torch.sigmoid(1.702 * fc))
     x2 = x1 + F.linear(act, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
     if want is not None:
         want.update(probs=p, v=v, x1=x1, fc=fc, x2=x2)
     return x2
 
 
-def relevance(sd, tiles, w_text, trunk=(), last=False, vjp=False, heads=12, layers=12):
-    """Closed-form rollout (oracle.relevancy.gradcam_tiles) with the chosen rounding groups on."""
+def relevance(sd, tiles, w_text, trunk=(), last=False, vjp=False, heads=12, layers=12, trunk_round=None):
+    """Closed-form rollout (oracle.relevancy.gradcam_tiles) with the chosen rounding groups on.  trunk_round: what the trunk blocks in `trunk` round
+    (default everything to fp16; a dict {operand class: function} rounds one class)."""
     x = orl.vit_embed(sd, tiles)
     keep = {}
     for i in range(layers):
         is_last = i == layers - 1
-        r = H16 if ((is_last and last) or (not is_last and i in trunk)) else ID
+        r = H16 if (is_last and last) else ((trunk_round if trunk_round is not None else H16) if (not is_last and i in trunk) else ID)
         x = _block(sd, f"visual.transformer.resblocks.{i}.", x, heads, r, want=keep if is_last else None, last=is_last)
     rl, rv = (H16 if last else ID), (H16 if vjp else ID)
     pre = f"visual.transformer.resblocks.{layers - 1}."
@@ -115,3 +124,31 @@ def test_where_the_fp16_error_comes_from():
     assert e_trunk > 2.0 * max(e_last, e_vjp)
     assert e_all < 3e-3 and e_trunk < 3e-3
     assert math.sqrt(e_last ** 2 + e_vjp ** 2) < 0.6 * e_all
+
+
+def test_which_operand_carries_the_trunk_error():
+    """the budget above attributes by BLOCK; this one by OPERAND - one operand class rounded to fp16 in all 11 trunk blocks at a
+    time.  Printed; asserted: the classes add up (in quadrature, within a factor) to the all-operands figure, so nothing is unaccounted for."""
+    arch = "ViT-B/16"
+    sd = make_clip_state_dict(arch, 0, text_tower=False)
+    rng = np.random.default_rng(5)
+    tiles = torch.from_numpy(rng.standard_normal((1, 3, 224, 224)).astype(np.float32))
+    w = rng.standard_normal((512, 4)).astype(np.float32)
+    w_text = torch.from_numpy(w / np.linalg.norm(w, axis=0, keepdims=True))
+    allb = tuple(range(11))
+    with torch.no_grad():
+        ref = relevance(sd, tiles, w_text)
+        top = float(ref.abs().max())
+        err = lambda **kw: float((relevance(sd, tiles, w_text, **kw) - ref).abs().max()) / top
+        per = {k: err(trunk=allb, trunk_round={k: H16}) for k in OPERANDS}
+        e_all = err(trunk=allb)
+        # the candidates for a cheap split: P and V live in the attention kernel (MFMA mostly idle there), ln1 / ln2 / act / o are GEMM A operands
+        e_wo_pv = err(trunk=allb, trunk_round={k: H16 for k in OPERANDS if k not in ("p", "v")})
+        e_wo_ln = err(trunk=allb, trunk_round={k: H16 for k in OPERANDS if k not in ("ln1", "ln2")})
+        e_wo_act = err(trunk=allb, trunk_round={k: H16 for k in OPERANDS if k != "act"})
+    quad = math.sqrt(sum(e * e for e in per.values()))
+    print("fp16-operand error budget of the 11 trunk blocks by OPERAND CLASS (relative L-inf of the per-tile relevance):")
+    print("  " + "  ".join(f"{k} {e:.2e}" for k, e in per.items()) + f"   (in quadrature {quad:.2e}; all classes together {e_all:.2e})")
+    print(f"  everything but P and V {e_wo_pv:.2e} | everything but the LayerNorm outputs {e_wo_ln:.2e} | everything but the QuickGELU output {e_wo_act:.2e}")
+    assert 0.4 * e_all < quad < 2.5 * e_all
+    assert max(per.values()) < 1.2 * e_all

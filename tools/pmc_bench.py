@@ -11,7 +11,7 @@ vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out, ctr)
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                    sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity"],
+                    sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-stages"],
                    cwd="/tmp", env=env, capture_output=True, text=True)
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     for row in csv.DictReader(open(f)):
@@ -21,6 +21,11 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for g in glob.glob(os.path.join(d, "**", "*"), recursive=True):
         if os.path.isfile(g):
             os.remove(g)
+scenes = max(1, len(vals.get("k_aggregate", {}).get("FETCH_SIZE", [])))       # one aggregation launch per scene
+trunk = 0.0
+for k, c in vals.items():
+    if k == "k_gemm" or "k_layernorm" in k or "k_attention" in k:                # the ViT trunk: every GEMM, LayerNorm and attention launch
+        trunk += sum(c["FETCH_SIZE"]) * 1024 * 2 + sum(c["WRITE_SIZE"]) * 1024
 res = {}
 for k, c in vals.items():
     n = len(c["FETCH_SIZE"])
@@ -28,7 +33,8 @@ for k, c in vals.items():
     write = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])) * 1024
     res[k] = dict(dispatches=n, fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write)
 g = res.get("k_gemm", {})
-json.dump(dict(kernel="k_gemm8 / k_gemm_f16 (all GEMM launches)", method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity`; "
+json.dump(dict(round=4, scenes_in_run=scenes, trunk_counted_gb_per_scene=trunk / scenes / 1e9,
+               kernel="k_gemm8 / k_gemm_f16 (all GEMM launches)", method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-stages`; "
                "KB units; FETCH_SIZE doubled (gfx950 counts 128-B requests of wide reads at 64 B)", **g,
                per_kernel={k: v for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:14]}),
           open(os.path.join(out, "gemm_pmc.json"), "w"), indent=1)
