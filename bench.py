@@ -399,6 +399,36 @@ def stage_report(pipe, scenes, w_text, arch, precision):
     out["unet_config"] = f"config 3: ResidualUNet3D forward, {N_LABELS} volumes of 16 x {VOXEL}^3, channels-last, incl. the final 1x1x1 convolution"
     del u2, x
     torch.cuda.empty_cache()
+    # ---- f1 / f5 at the size the reference runs them (visualize.py:163-164, 360-361): 240^3 sampling lattice, 2^20 query points per pass ----
+    from semabs_amd.inference import process_batch_ovssc, process_batch_vool
+    from semabs_amd.net import SemAbsVOOL
+    from semabs_amd.synth import SCENE_BOUNDS as _SB
+    from semabs_amd.weights import make_semabsvool_state_dict as _mk_vool
+    rngv = np.random.default_rng(7)
+    pts = torch.from_numpy(rngv.uniform([-0.95, -0.95, -0.05], [0.95, 0.95, 1.85], size=(150000, 3)).astype(np.float32))
+    classes = [f"class {i}" for i in range(N_LABELS)]
+    ob = {"ovssc_obj_classes": classes, "input_xyz_pts": pts, "input_feature_pts": torch.from_numpy(rngv.standard_normal((N_LABELS, len(pts))).astype(np.float32)),
+          "rgb": sc["rgb"], "depth": sc["depth"], "cam_intr": sc["cam_intr"], "cam_extr": sc["cam_pose"]}
+    SQ, PASS = 240, 2 ** 20
+    chunks = -(-SQ ** 3 // PASS)
+    out["process_batch_ovssc_240_ms"] = round(timed(lambda: process_batch_ovssc(net, ob, _SB, "cuda", 80000, sampling_shape=(SQ,) * 3, num_pts_per_pass=PASS, seed=0), reps=2), 1)
+    if VOXEL == 128:
+        vool = SemAbsVOOL(pointing_method="cosine_sim", pointing_dim=64, device="cuda", decoder_concat_xyz_pts=True, voxel_shape=(VOXEL,) * 3, scene_bounds=_SB,
+                          unet_num_channels=16, unet_f_maps=16, unet_num_groups=8, unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True,
+                          pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1, batch_size=1)
+        vool.load_state_dict(_mk_vool(seed=3))
+        vool.eval()
+        ND = 4
+        vb = {"descriptions": [f"the thing {i} on the other thing" for i in range(ND)], "spatial_relation_name": ["on", "behind", "in", "on the left of"], "input_xyz_pts": pts,
+              "input_target_saliency_pts": torch.from_numpy(rngv.standard_normal((ND, len(pts))).astype(np.float32)),
+              "input_reference_saliency_pts": torch.from_numpy(rngv.standard_normal((ND, len(pts))).astype(np.float32))}
+        out["process_batch_vool_240_ms"] = round(timed(lambda: process_batch_vool(vool, vb, _SB, "cuda", 80000, sampling_shape=(SQ,) * 3, num_pts_per_pass=PASS, seed=0), reps=2), 1)
+        del vool
+    out["inference_240_config"] = (f"f1 / f5: process_batch_ovssc ({N_LABELS} classes) and process_batch_vool (4 descriptions) as visualize.py calls them: sampling_shape {SQ}^3 "
+                                   f"= {SQ ** 3} lattice points in {chunks} passes of 2^20, 80000 input points, {VOXEL}^3 feature volumes; incl. TSDF integration at {SQ}^3, frustum test, "
+                                   "post-mask and the host copy of the result.  UNet passes: the reference re-runs point MLP + scatter + UNet for every pass - "
+                                   f"{N_LABELS * chunks} (OVSSC) / {2 * 4 * chunks} (VOOL) - here the feature volumes are computed once: {N_LABELS} / {2 * 4}")
+    torch.cuda.empty_cache()
     # ---- config 5: one VOOL optimisation step ----
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from train_bench import synth_batch
@@ -426,6 +456,63 @@ def stage_report(pipe, scenes, w_text, arch, precision):
     return out
 
 
+def train_workload(args, rank, world, dist):
+    """--workload train: config 5 data-parallel.  Every rank takes one VOOL optimisation step per step on ITS OWN scene (weak scaling): forward + BCE +
+    backward, ONE flat sum all-reduce of the gradients (+ the per-relation "used" flags) over RCCL, clip, LAMB - `VOOLTrainer.step`.  value = samples / s
+    over all ranks; the all-reduce alone is timed separately on the same buffer."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from train_bench import synth_batch
+    from semabs_amd import dist as sdist
+    from semabs_amd.synth import SCENE_BOUNDS
+    from semabs_amd.train import VOOLTrainer
+    from semabs_amd.weights import make_semabsvool_state_dict
+    tr = VOOLTrainer(make_semabsvool_state_dict(seed=3), voxel_shape=(VOXEL,) * 3, scene_bounds=SCENE_BOUNDS)
+    batches = [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth_batch(VOXEL, 80000, 400000, 4, seed=1000 * rank + i).items()} for i in range(2)]
+    for i in range(args.warmup):
+        tr.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = tr.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ar_ms = None
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        sdist_t = t.cpu() if args.backend == "gloo" else t
+        dist.all_reduce(sdist_t, op=dist.ReduceOp.MAX)
+        dt = float(sdist_t.item())
+        buf = tr.flat_grad.clone()
+        sdist.allreduce_flat_gradients(buf, 0); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            sdist.allreduce_flat_gradients(buf, 0)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t1) / 3 * 1e3
+    # every rank must hold the same parameters after the step
+    import hashlib
+    dig = int.from_bytes(hashlib.sha256(torch.cat([p.detach().reshape(-1) for p in tr.params.values()]).cpu().numpy().tobytes()).digest()[:7], "big")
+    same = True
+    if dist is not None:
+        allsum = sdist.gather_results(torch.tensor([dig], dtype=torch.int64, device="cuda")).cpu().numpy()
+        same = bool((allsum == allsum[0]).all())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "VOOL optimisation steps (samples)/sec, 128^3 x 4 descriptions, 80000 / 400000 points, data-parallel (config 5)",
+            "value": args.steps * world / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 hi/lo-split MFMA operands, fp32 accumulate (fp32-equivalent)", "data": "synthetic",
+            "config": {"workload": f"SemAbsVOOL {VOXEL}^3 training step per rank: forward + BCE + backward + flat gradient all-reduce + clip + LAMB", "parallelism": f"data-parallel x{world}",
+                       "backend": args.backend if world > 1 else None},
+            "collectives": {"allreduce_bytes_per_rank_per_step": int(tr.flat_grad.numel() * 4), "allreduce_ms_alone": ar_ms, "parameters_identical_across_ranks": same},
+            "loss": float(out["loss"])}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,6 +530,15 @@ def main():
                     "hash of the launch index).  1 = every launch: free with one ViT batch per scene (~60 launches); with small batches "
                     "(--chunk 220: 660 launches per scene) it costs 1.9 %% of scenes/s - every dispatch packet then carries a completion signal - "
                     "and 5 gives the same TFLOP/s figure")
+    ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"], help="throughput (default, the driver's contract): ranks own disjoint scenes, "
+                    "weak scaling.  latency: every step is ONE scene split over all ranks (ScenePipeline.run_sharded: tile-sharded relevancy + one all-gather of "
+                    "the per-tile relevances, label-sharded voxel inference + one all-gather of the logits) - strong scaling; the JSON carries the bytes each "
+                    "rank put on the wire and a cross-rank checksum of the maps and the labels")
+    ap.add_argument("--workload", default="scene", choices=["scene", "train"], help="scene (default): the headline relevancy -> fusion -> OVSSC step.  train: config 5, "
+                    "one data-parallel VOOL optimisation step per step (every rank its own 128^3 scene, 4 descriptions, 80 000 / 400 000 points; ONE flat "
+                    "all-reduce of the gradients, /root/reference/utils.py:255-258) - samples/s over all ranks, all-reduce bytes and time in the JSON")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for --gpus > 1: nccl = RCCL over xGMI, one rank per GPU.  gloo: the "
+                    "ranks may share one device (contract tests on a 1-GPU box; device collectives are staged through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (reference goldens, outside the timed region)")
     ap.add_argument("--no-stages", action="store_true", help="skip the stage / kernel-class leg (configs 2, 3, 5 and the per-class table, outside the timed region)")
@@ -453,7 +549,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL), exactly as the driver would
         # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...), and hand back its exit code.
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and args.backend != "gloo":
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
         import socket
         import subprocess
@@ -468,14 +564,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run plainly and let bench.py spawn the ranks)")
-    if local >= torch.cuda.device_count():
+    if local >= torch.cuda.device_count() and args.backend != "gloo":
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
+    local = local % torch.cuda.device_count()                                # (gloo: ranks may share a device)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.workload == "train":
+        return train_workload(args, rank, world, dist)
 
     from semabs_amd.clip import vit as vitmod
     from semabs_amd.scene import build_default
@@ -501,9 +603,13 @@ def main():
         text_enc = TextEncoder(make_clip_state_dict(args.arch, 0, text_tower=True))
         text_tokens = torch.from_numpy(np.load(tk)["tokens"][:N_LABELS])
 
+    latency = args.mode == "latency"
+    if latency:                                          # every rank holds the SAME scenes: one scene per step, split over the ranks
+        scenes = [pipe.upload(synth_scene(IMG, IMG, seed=i)) for i in range(n_scenes)]
+
     def step(i):                                        # everything from the raw frame on is inside the timed region (incl. the colour jitter and the text tower)
         w = text_enc.zeroshot_weights(text_tokens, N_LABELS, 1) if text_enc is not None else w_text
-        return pipe.run(scenes[i], w, seed=i)
+        return pipe.run_sharded(scenes[i], w, seed=i) if latency else pipe.run(scenes[i], w, seed=i)
 
     def run_range(lo, hi):
         res = None
@@ -520,18 +626,48 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = run_range(args.warmup, n_scenes)
+    # the job's results leave the ranks through RCCL: every rank's last label volume is all-gathered (scene-shard mode has no other payload collective;
+    # in latency mode the per-step all-gathers already carried the relevances and the logits)
+    gathered = None
+    if dist is not None and res is not None and res.labels is not None:
+        from semabs_amd import dist as sdist
+        gathered = sdist.gather_results(res.labels)                           # [world, S^3] int32 on every rank
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     vitmod.GEMM_TIMER = None
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.backend == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     gs = timer.summary()
-    total_scenes = args.steps * world
+    total_scenes = args.steps * (1 if latency else world)
     value = total_scenes / dt
+    wire = None
+    if world > 1:
+        # what this rank sent per collective (payload only) and cross-rank checksums: in latency mode all ranks must end with identical maps / labels
+        import hashlib
+        from semabs_amd.clip import saliency_configs as _sc
+        from semabs_amd.clip import plan_tiles as _pt
+        ncfg = _sc["ours"](IMG)
+        n_tiles = len(_pt(IMG, IMG, ncfg["augmentations"] + 1, ncfg["cropping_augmentations"])[0])
+        g = 14 if "16" in args.arch else 7
+        per = -(-N_LABELS // world)
+        wire = {"gather_results_bytes_per_rank": int(gathered[0].numel() * gathered[0].element_size()) if gathered is not None else 0,
+                "gather_results_ranks_seen": int(gathered.shape[0]) if gathered is not None else 0}
+        if latency:
+            wire.update(tile_relevance_allgather_bytes_per_rank_per_scene=int(2 * N_LABELS * (-(-n_tiles // world)) * g * g * 4),
+                        logits_allgather_bytes_per_rank_per_scene=int(per * VOXEL ** 3 * 4))
+        digest = lambda t: int.from_bytes(hashlib.sha256(t.detach().cpu().numpy().tobytes()).digest()[:7], "big")
+        mine = torch.tensor([digest(res.relevancies), digest(res.labels)], dtype=torch.int64, device="cuda")
+        from semabs_amd import dist as sdist
+        allsum = sdist.gather_results(mine).cpu().numpy()
+        wire["maps_checksums_by_rank"] = [int(x) for x in allsum[:, 0]]
+        wire["labels_checksums_by_rank"] = [int(x) for x in allsum[:, 1]]
+        wire["identical_across_ranks"] = bool((allsum == allsum[0]).all())
+        if gathered is not None:
+            wire["gathered_label_volumes_checksum"] = digest(gathered)
     if rank == 0:
         ach = gs["flops"] / (gs["total_ms"] * 1e-3) / 1e12 if gs["total_ms"] > 0 else 0.0
         # HBM bytes per GEMM launch: PMC counters cannot be read from inside the process that is being timed (rocprofv3 owns them and
@@ -547,14 +683,15 @@ def main():
                 except Exception:
                     traffic = None
         out = {
-            "metric": "scenes/sec (relevancy+3D-UNet infer), 480x480x16-label x128^3",
+            "metric": "scenes/sec (relevancy+3D-UNet infer), 480x480x16-label x128^3" + (" - single-scene LATENCY mode: every scene tile- and label-sharded over all ranks" if latency else ""),
             "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if latency else "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "fp16" else "f16 (MFMA operands, fp32 accumulate; UNet hi/lo-split = fp32-equivalent)",
             "data": "synthetic",
             "config": {"workload": f"end-to-end relevancy->fusion->OVSSC per scene: {IMG}x{IMG} RGB-D, {N_LABELS} labels, {args.arch}, "
                                    f"'ours' saliency config (2448 tile forwards), {VOXEL}^3 voxels, 80000 input points; scene-sharded",
-                       "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": f"scene-shard x{world}"},
+                       "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": (f"tile-shard + label-shard x{world} (one scene per step)" if latency else f"scene-shard x{world}"),
+                       "mode": args.mode, "backend": args.backend if world > 1 else None},
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
             "roofline": {"kernel": "fp16 GEMM: k_gemm8 (large shapes) + k_gemm_f16 (small), all epilogues", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -582,6 +719,8 @@ def main():
                                "tokenisation of the label strings (host, the BPE table is not on the GPU box: token ids come from the committed fixture) and the "
                                "host->HBM upload of the frame (5 MB, 0.08 ms over PCIe Gen5)")
         out["text_tower_in_timed_region"] = text_enc is not None
+        if wire is not None:
+            out["collectives"] = wire
         if world == 1 and not args.no_parity:
             out["parity"] = parity_report(pipe, args.arch, args.precision)
         if world == 1 and not args.no_stages:

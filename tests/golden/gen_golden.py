@@ -1140,8 +1140,8 @@ def g27_real_scene():
     """scene_files/arkit_vn_poster.pkl (256 x 192 RGB-D of an ARKit capture: non-square, real depth, 14 OVSSC classes + 3 descriptions -> 17 relevancy
     keys) through the reference end to end: `visualize.prep_data` compiled from its source and run with the UNMODIFIED `ClipWrapper.get_clip_saliency`
     (ViT-B/32, seeded weights; "ours" with augmentations = 0 so that no random colour jitter enters - everything else of the config as shipped),
-    the reference's own get_pointcloud / filter_pts_bounds, then the reference's `SemAbs3D` (seeded weights, 64^3) on four of the classes with a
-    fixed sub-sample and fixed query points.  The scene itself (a data file of the reference) travels in the fixture; so do the token ids of the 17
+    the reference's own get_pointcloud / filter_pts_bounds, then the reference's `SemAbs3D` (seeded weights, 128^3 - the released voxel grid) on all 14 classes
+    with a fixed sub-sample and fixed query points.  The scene itself (a data file of the reference) travels in the fixture; so do the token ids of the 17
     prompts (the BPE table is not on the GPU box)."""
     import pickle
     import tempfile
@@ -1180,7 +1180,7 @@ def g27_real_scene():
     prompt = calls[-1]["prompts"][0]
     tokens = rexp.tokenize([prompt.format(k) for k in keys]).numpy().astype(np.int32)
     # ---- SemAbs3D (the reference's module, seeded weights) on four classes, fixed sub-sample / query points ----
-    S, npts, M = 64, 20000, 4096
+    S, npts, M = 128, 40000, 4096
     m = net_mod.SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8, unet_num_levels=6,
                          network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1,
                          device="cpu", decoder_concat_xyz_pts=True, batch_size=1)
@@ -1191,7 +1191,7 @@ def g27_real_scene():
     idx = rng.integers(0, n_in, size=npts)
     lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
     q = (lo + (hi - lo) * rng.random((M, 3))).astype(np.float32)
-    cls_idx = [0, 3, 6, 11]                                     # poster of vietnam, light switch, lamp, wall
+    cls_idx = list(range(len(data["ovssc_obj_classes"])))          # all 14 classes, like visualize.ovssc_inference
     logits = []
     t = time.time()
     with torch.no_grad():
@@ -1199,7 +1199,7 @@ def g27_real_scene():
             out = m(input_xyz_pts=b["input_xyz_pts"][None, idx].float(), input_feature_pts=b["input_feature_pts"][None, [c]][:, :, idx, None].float(),
                     tsdf_vol=None, output_xyz_pts=torch.from_numpy(q)[None, None])
             logits.append(out.reshape(-1).numpy())
-    print(f"    SemAbs3D 64^3 x {len(cls_idx)} classes: {time.time() - t:.1f}s", flush=True)
+    print(f"    SemAbs3D {S}^3 x {len(cls_idx)} classes: {time.time() - t:.1f}s", flush=True)
     rows = np.asarray([0, 37, 101, 128, 200, 255])
     save("g27_real_scene", rgb=data["rgb"], depth=data["depth"], cam_intr=np.asarray(data["cam_intr"]), cam_extr=np.asarray(data["cam_extr"]),
          ovssc_obj_classes=np.asarray(data["ovssc_obj_classes"]), descriptions=np.asarray([list(x) for x in data["descriptions"]]),

@@ -48,3 +48,26 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "profiles/r04_" in (rf.get("traffic_source") or "profiles/r04_"), rf.get("traffic_source")
     assert rf["mfma_probe"] is None or "imported" in rf["mfma_probe"]["source"]
     assert d.get("text_tower_in_timed_region") is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,metric_part", [(["--mode", "latency"], "LATENCY"), (["--workload", "train"], "VOOL optimisation steps")])
+def test_bench_multi_rank_modes_over_gloo_on_one_gpu(extra, metric_part):
+    """The two multi-GPU modes SURVEY 8(e) names besides scene sharding, as bench lines: two ranks sharing this box's one GPU over
+    gloo (RCCL admits one rank per device).  Latency mode: one scene tile- and label-sharded over the ranks, every rank ends with identical maps and
+    labels (checksums in the line) and the all-gather payloads are stated; train workload: the data-parallel VOOL step, identical parameters on
+    both ranks after the flat gradient all-reduce, whose bytes are stated."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-parity", "--no-stages"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and metric_part in d["metric"] and d["value"] > 0 and d["config"]["backend"] == "gloo"
+    c = d["collectives"]
+    if "--mode" in extra:
+        assert d["scaling"] == "strong" and c["identical_across_ranks"] is True and len(c["maps_checksums_by_rank"]) == 2
+        assert c["tile_relevance_allgather_bytes_per_rank_per_scene"] == 2 * 16 * 612 * 14 * 14 * 4          # 1224 tiles / 2 ranks, 16 labels, 14 x 14, two flip passes
+        assert c["logits_allgather_bytes_per_rank_per_scene"] == 8 * 128 ** 3 * 4 and c["gather_results_ranks_seen"] == 2
+    else:
+        assert d["scaling"] == "weak" and c["parameters_identical_across_ranks"] is True and c["allreduce_bytes_per_rank_per_step"] > 100e6 and c["allreduce_ms_alone"] > 0
