@@ -920,24 +920,30 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
                     }
                 }
             }
-            // Fragment double buffer over the 50 (k-step, halo row) pairs: pair i + 1 is requested right after the first MFMA of pair i, so its
-            // issue slot hides under the matrix pipe and it has the rest of the pair's MFMAs (3 .. 9) to arrive.  Inside a pair the MFMAs go
-            // product-major (wh.xh for every row served, then wl.xh, then wh.xl): dependent MFMAs are up to 3 issues apart.  The
-            // sched_barriers pin this order (left alone the compiler merges the buffers and issues the requests next to their first use).
-            f16x8 xh[2], xl[2];
+            // Fragment ring over the 50 (k-step, halo row) pairs, THREE slots, requests two pairs ahead (round 4).  A pair carries 3 x (rows it
+            // serves) MFMAs: 3 for the halo rows 0 and 9, 6 for rows 1 and 8, 9 for the rest.  With two slots the fragment of pair i + 1 was
+            // requested after the first MFMA of pair i, so behind a 3-MFMA pair it had 32 cycles to come out of LDS (~130 needed) and the matrix pipe
+            // waited - four such pairs per k-step, back to back across the k-step boundary (rows 8, 9, 0, 1): the consumers alone ran at 0.70 of their
+            // MFMA time.  Now (a) the halo rows of a k-step are walked in the order 2 0 3 1 4 9 5 8 6 7, so that a short pair always sits between
+            // two 9-MFMA pairs, and (b) pair i + 2 is requested behind the first MFMA of pair i: every fragment has at least 11 MFMAs = 176 cycles.
+            // Inside a pair the MFMAs go product-major (wh.xh for every row served, then wl.xh, then wh.xl): dependent MFMAs are up to 3 issues
+            // apart.  The sched_barriers pin this order (left alone the compiler merges the buffers and issues the requests next to their first use).
+            f16x8 xh[3], xl[3];
+            constexpr int RHO[10] = {2, 0, 3, 1, 4, 9, 5, 8, 6, 7};
             auto request = [&](int i, int slot) {
-                const int st = i / 10, rho = i % 10;
+                const int st = i / 10, rho = RHO[i % 10];
                 const int off = fbase + tapoff[st] + rho * (C16_H2 * 8);
                 xh[slot] = *reinterpret_cast<const f16x8*>(s_hi + off);
                 if (F32) xl[slot] = *reinterpret_cast<const f16x8*>(s_lo + off);
             };
             request(0, 0);
+            request(1, 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 0; st < 5; ++st) {
 #pragma unroll
-                for (int rho = 0; rho < 10; ++rho) {
-                    const int i = st * 10 + rho, slot = i & 1;
+                for (int ri = 0; ri < 10; ++ri) {
+                    const int i = st * 10 + ri, slot = i % 3, rho = RHO[ri];
                     bool first = true;
 #pragma unroll
                     for (int kind = 0; kind < (F32 ? 3 : 1); ++kind) {
@@ -948,7 +954,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
                             acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kind == 1 ? wl[dy][st] : wh[dy][st], kind == 2 ? xl[slot] : xh[slot], acc[r], 0, 0, 0);
                             if (first) {
                                 first = false;
-                                if (i + 1 < 50) request(i + 1, slot ^ 1);
+                                if (i + 2 < 50) request(i + 2, (i + 2) % 3);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }

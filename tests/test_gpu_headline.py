@@ -10,7 +10,7 @@ not needed on the GPU box).
 Both ViT batch sizes are exercised: chunk_tiles = 2448 (what bench.py times: ONE 482 256-row batch, ragged last wave of GEMM tiles, 11 GB
 workspace) and 220.  Tolerance: RELATIVE L-infinity = max|ours - ref| / max|ref| per run; measured on MI355X 6.0e-4 (aug0) and 9.0e-4 (aug5) (fp16 MFMA operands
 against the reference's fp32 CPU arithmetic; the reference's own fp16 canvases quantise at 2^-11 = 4.9e-4 relative per add), i.e. 2.9e-6 /
-2.2e-6 absolute; asserted at 3 x the larger.  Worst single label relative to its own maximum: 9.4e-4 / 1.06e-3."""
+2.2e-6 absolute; asserted at 1.3 x the measured values (the result is bit-reproducible).  Worst single label relative to its own maximum: 9.4e-4 / 1.06e-3."""
 import numpy as np
 import pytest
 import torch
@@ -20,7 +20,13 @@ from semabs_amd.synth import synth_jitter, synth_rgb
 
 pytestmark = pytest.mark.gpu
 
-REL_LINF_BOUND = 2.7e-3        # 3 x the measured relative L-infinity (see the module docstring); BASELINE bar: 1e-3 ABSOLUTE on maps whose max is 4.8e-3
+# The result is bit-reproducible (same kernels, same summation order for every batch size), so the bars sit at 1.3 x the MEASURED values (VERDICT r3
+# item 3; they were 3 x): relative L-infinity 6.0e-4 (aug0) / 9.0e-4 (aug5), worst label relative to its own maximum 9.4e-4 / 1.06e-3, absolute 2.9e-6 /
+# 2.2e-6.  BASELINE bar: 1e-3 ABSOLUTE on maps whose max is 4.8e-3.  Where the 9.0e-4 comes from: tests/test_vit_precision_budget.py (by block and by
+# operand class: the fp16 rounding of q and k, 1.5e-3 of the 2.05e-3 per tile, then the LayerNorm-1 output, 9e-4).
+REL_LINF_BOUND = {"aug0": 7.8e-4, "aug5": 1.17e-3}
+PER_LABEL_BOUND = {"aug0": 1.23e-3, "aug5": 1.38e-3}
+ABS_LINF_BOUND = {"aug0": 3.8e-6, "aug5": 2.9e-6}
 
 
 @pytest.fixture(scope="module")
@@ -66,9 +72,9 @@ def test_headline_maps_vs_reference(golden, wrapper, tag):
         sums = np.abs(m.astype(np.float64).reshape(16, -1).sum(1) - g["sums"]).max() / np.abs(g["sums"]).max()
         print(f"headline {tag} chunk {chunk}: abs L-inf {max(e_sub, e_rows):.3e}  relative L-inf {rel:.3e}  worst per-label relative {per_label:.3e}  "
               f"map-sum relative {sums:.3e}  (max|ref| {ref_max:.3e})")
-        assert rel <= REL_LINF_BOUND, rel
-        assert per_label <= 3.2e-3, per_label                              # 3 x the measured worst per-label value
-        assert max(e_sub, e_rows) <= 1e-5                                  # absolute: 3 x the measured 2.9e-6 (BASELINE.json's bar is 1e-3)
+        assert rel <= REL_LINF_BOUND[tag], rel
+        assert per_label <= PER_LABEL_BOUND[tag], per_label
+        assert max(e_sub, e_rows) <= ABS_LINF_BOUND[tag]                   # (BASELINE.json's bar is 1e-3 absolute)
         res[chunk] = m
     # the maps must not depend on the ViT batch size (same kernels, same per-row arithmetic; was tools/chunk_equiv.py)
     assert np.array_equal(res[2448], res[220]), float(np.abs(res[2448] - res[220]).max())
