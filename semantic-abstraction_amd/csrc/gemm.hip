@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ((BM / WGM) * (BN / WGN) <= 64 * 64
 //   kernel      : 0 = heuristic, 1 = the 128 x 128 ring kernel, 2 = the 256 x 256 phased kernel (when the shape allows it)
 //   ev_start/stop: optional HIP events filled by the launch's own dispatch packet (hipExtLaunchKernelGGL) - no extra barrier packets
 //                  around the kernel, unlike hipEventRecord before and after it
-struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; int v2; int pers; };
+struct GemmOpts { int kernel; hipEvent_t ev_start, ev_stop; int ring; int v2; int nopers; };
 
 #ifdef SEMABS_TUNING
 // tuning build only (libsemabs_hip_tune.so, tools/): knobs for ablations / alternative tile configurations
@@ -564,11 +564,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     *reinterpret_cast<f32x4*>(row + (((2 * kg + 1) ^ wswz) << 4)) = w[i][OUT16 ? 0 : 1];
                 }
             }
-            // ... and the stores are COMPLETE (the LDS has fetched their data registers) before anything else is issued: with the fences alone the first
-            // VALU instructions behind them (the read addresses of this pass) could still be given a store's data register - round 4's deep schedule
-            // changed the allocation of the QuickGELU instantiation and the same corruption reappeared in the last store of pass 1 (rows l15 = 3 mod 4,
-            // second dword, non-deterministic).  ~100 cycles per pass against an epilogue of several thousand.
-            __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
         };
         // coalesced layout: instruction `it` of a pass covers rows it * RPI + lane / LPR, this lane's chunk = lane % LPR
@@ -1174,6 +1169,298 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #undef GEMM8_STAMP
 }
 
+// =================================================================================================
+// k_gemm8p: the deep schedule as PERSISTENT workgroups with the next tile's prologue inside the current tile's drain (fp16-output epilogues).
+//
+// A 256 x 256 x 768 tile is ~16 us of steady-state K loop between ~8 us of fixed cost (tools/gemm_probe.py abltrace: 2 795 cycles per K tile over
+// a K = 768 tile against 2 214 in the steady state of K = 3 072; trace: 1.4 us from a tile's last store to the next workgroup's first instruction):
+// the wait for the first half-tiles of the prologue, the drain of the DMA queue, the epilogue, the acknowledgement of its stores (a workgroup is not
+// retired before that) and the dispatch of the next workgroup.  Round 4's first attempt (V3 in k_gemm8: all eight half-tiles of the next tile
+// requested between the K loop and the epilogue, vmcnt(0) at the next tile's start) lost: 128 DMA instructions in front of the epilogue's stores
+// and a wait for the acknowledgement of those stores.  Here the workgroup stays and the stage sequence simply NEVER ENDS: stage index
+// s = 4 t + j keeps counting across tiles, so the last two K tiles of a tile - which stage nothing in k_gemm8 - stage the next tile's K tiles 0 and 1
+// through the next tile's descriptors, one half-tile per phase as always, into the slots the steady-state rule frees anyway (slot of stage s - 8,
+// last read two phases ago).  Consequences:
+//   * no prologue latency, no drain, no dispatch gap after the first tile; no extra DMA issue time (the drain phases' issue slots were idle);
+//   * every wait is the steady-state vmcnt(10).  Behind the epilogue the queue also holds its 16 stores per wave, OLDER than the DMA a wait is
+//     meant to leave in flight: "at most 10 operations outstanding" then retires more than needed (some stores too), never less - the only property
+//     relied on is that LOADS retire in order among loads;
+//   * the epilogue must not touch the operand slots (they are being refilled): it transposes through 2 KB per wave BEHIND the slots (8 half
+//     passes of 32 rows x 32 columns), and loads nothing: the bias is in the accumulators from the start.  The next tile's bias row (256 fp32 =
+//     1 KB) travels by LDS-DMA as well - one more "half-tile" issued by wave 0 in front of the next tile's first stage - so the kernel issues no
+//     ordinary load at all, only LDS-DMA loads and stores.
+// Requires an even number of K tiles (buffer parity continues across tiles).  Slot map, fragment layout and MFMA order are k_gemm8's: results are
+// bit-identical to it.
+// =================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
+    static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16, "fp16-output epilogues");
+    constexpr int HT = 16384, OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
+    constexpr int OFF_SCR = 2 * BUFSZ, OFF_BIAS = OFF_SCR + 8 * 2048;      // epilogue scratch (2 KB per wave), bias row of the tile (1 KB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const bool has_bias = g.bias != nullptr;
+
+    auto tile_of = [&](int vb, long& m0, int& n0) {          // (as in k_gemm8)
+        const int b = semabs_xcd_item(vb, g.n_blocks, g.reverse != 0);
+        const int per_group = g.group_m * g.n_tiles_n, gid = b / per_group, first_m = gid * g.group_m;
+        const int gsz = (g.n_tiles_m - first_m < g.group_m) ? g.n_tiles_m - first_m : g.group_m;
+        const int r = b - gid * per_group;
+        m0 = (long)(first_m + r % gsz) * 256;
+        n0 = (r / gsz) * 256;
+    };
+    const int srow = tid >> 3, scp = tid & 7;
+    const unsigned aoff = (unsigned)(srow * (int)g.lda * 2 + (swzA8(srow, scp) - srow * 128));
+    const unsigned boff = (unsigned)(srow * g.ldb * 2 + (swzB8(srow, scp) - srow * 128));
+    const unsigned a_half = (unsigned)(128 * (int)g.lda * 2), b_half = (unsigned)(128 * g.ldb * 2);
+    const unsigned a_q = (unsigned)(64 * (int)g.lda * 2), b_q = (unsigned)(64 * g.ldb * 2);      // second 64-row piece of a half-tile: same swizzle term
+    __amdgpu_buffer_rsrc_t rA, rB, rAn, rBn;                // this tile's / the next tile's operand panels
+    const __amdgpu_buffer_rsrc_t rBias = gemm_rsrc(g.bias, has_bias ? (long)g.N * 4 : 0);
+    auto rsrc_a = [&](long m0) { const long rows = g.M - m0 < 256 ? g.M - m0 : 256; return gemm_rsrc(g.A + m0 * g.lda, ((rows - 1) * g.lda + g.K) * 2); };
+    auto rsrc_b = [&](int n0) { return gemm_rsrc(g.B + (long)n0 * g.ldb, (255L * g.ldb + g.K) * 2); };
+    // stage j (0 A0, 1 B0, 2 B1, 3 A1) of K tile kt of this (nx = false) or the next tile: two 8 KB pieces per half-tile, 1 KB per wave each
+    auto stage = [&](const int j, const int kt, const bool nx) {
+        const bool isa = j == 0 || j == 3, hi = j >= 2;
+        char* dst = smem + (kt & 1) * BUFSZ + (j == 0 ? OFF_A0 : (j == 1 ? OFF_B0 : (j == 2 ? OFF_B1 : OFF_A1))) + wid * 1024;
+        const unsigned soff = (unsigned)kt * 128 + (hi ? (isa ? a_half : b_half) : 0u);
+        const __amdgpu_buffer_rsrc_t r = isa ? (nx ? rAn : rA) : (nx ? rBn : rB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst), 16, isa ? aoff : boff, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + 8192), 16, isa ? aoff : boff, soff + (isa ? a_q : b_q), 0, 0);
+    };
+    auto stage_bias = [&](const int n0) {                    // wave 0: bias[n0 .. n0 + 255] -> LDS, 16 bytes per lane
+        if (wid == 0 && has_bias)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, (__attribute__((address_space(3))) void*)(smem + OFF_BIAS), 16, (unsigned)lane * 16u, (unsigned)n0 * 4u, 0, 0);
+    };
+    int offA[2], offB[2];                                   // fragment read offsets inside a half-tile (column tile jt = 1 of B: + 512 bytes)
+    {
+        const int rowa = wr * 64 + l15, rowb = wc * 32 + (l15 >> 2) * 8 + (l15 & 3);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { offA[kk] = swzA8(rowa, kk * 4 + kg); offB[kk] = swzB8(rowb, kk * 4 + kg); }
+    }
+    f32x4 acc[2][4][2][2];
+    f16x8 fa[4][2], fa1[4][2], fb[2][2][2], fb0n[2][2];
+    auto mma = [&](const int ha, const int hb, const f16x8 (&a)[4][2], const f16x8 (&b)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha][i][hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j][kk], a[i][kk], acc[ha][i][hb][j], 0, 0, 0);
+    };
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) f16x8* lds_frag;
+    auto pin = [&](int x) { lds_cptr p = (lds_cptr)smem + x; asm volatile("" : "+v"(p)); return p; };
+    auto rd_a = [&](f16x8 (&dst)[4][2], lds_cptr r0, lds_cptr r1, const int off) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dst[i][0] = *(lds_frag)(r0 + (off + i * 2048)); dst[i][1] = *(lds_frag)(r1 + (off + i * 2048)); }
+    };
+    auto rd_b = [&](f16x8 (&dst)[2][2], lds_cptr r0, lds_cptr r1, const int off) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { dst[j][0] = *(lds_frag)(r0 + (off + j * 512)); dst[j][1] = *(lds_frag)(r1 + (off + j * 512)); }
+    };
+#define P_INTERLEAVE(nread)                                                      \
+    do {                                                                         \
+        _Pragma("unroll") for (int q_ = 0; q_ < (nread); ++q_) {                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+        }                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - (nread), 0);            \
+    } while (0)
+    const int nk = g.K / 64;                                // even, >= 2 (checked by the launcher)
+    // One K tile = four phases; STEADY: a half-tile is staged in every phase (kts / nx say which) and the wait is vmcnt(10); else (the last two K
+    // tiles of the workgroup's LAST tile) nothing is staged and the queue drains with exact counts, as in k_gemm8.
+    // Waits behind an epilogue.  From a workgroup's second tile on, the 16 stores of the previous tile's epilogue sit in the queue between the prologue
+    // stages (0 - 7 of this tile, issued during the previous tile's last two K tiles) and the stages issued since.  vmcnt(n) is positional - everything
+    // older than the n most recently ISSUED operations has completed (in-order retirement: the property every counted wait of this kernel, and the
+    // compiler's own for mixed loads and stores on this target, rests on) - so "stages <= P + 3 landed" in global phase P of such a tile reads:
+    // 2 (4 - P) older-stage instructions + 16 stores + 2 (P + 1) newer ones = 26 may be outstanding, for P = 0 .. 4; from P = 5 on the stage wanted is
+    // younger than the stores and the count is the steady-state 10 again.  Waiting vmcnt(10) there instead forced the acknowledgement of the stores:
+    // 0.5 us per QKV tile, 1.95 us per c_fc tile (whose QuickGELU epilogue issues its stores late) - tools/gemm_probe.py v3trace.
+    auto ktile = [&](auto steady_c, const int t, const int kts, const bool nx, const int st_ph) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const int pb = (t & 1) * BUFSZ, pn = pb ^ BUFSZ;
+        const bool pen = t + 2 == nk;
+        lds_cptr r0, r1;
+#define P_SYNC(k_)                                                               \
+    do {                                                                         \
+        if (STEADY) { if ((k_) < st_ph) wait_vmcnt<26>(); else wait_vmcnt<10>(); } \
+        else if (pen) wait_vmcnt<8 - 2 * (k_)>();                                \
+        else if ((k_) == 0) wait_vmcnt<0>();                                     \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_setprio(1);                                           \
+        __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#define P_END()                                                                  \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_setprio(0);                                           \
+        __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+        if (STEADY) stage(0, kts, nx);                      // A0
+        r0 = pin(offB[0] + pb); r1 = pin(offB[1] + pb);
+        P_SYNC(0);
+        rd_b(fb[1], r0, r1, OFF_B1); mma(0, 0, fa, fb[0]);  // reads B1(t)
+        P_INTERLEAVE(4);
+        P_END();
+        if (STEADY) stage(1, kts, nx);                      // B0
+        r0 = pin(offA[0] + pb); r1 = pin(offA[1] + pb);
+        P_SYNC(1);
+        rd_a(fa1, r0, r1, OFF_A1); mma(0, 1, fa, fb[1]);    // reads A1(t)
+        P_INTERLEAVE(8);
+        P_END();
+        if (STEADY) stage(2, kts, nx);                      // B1
+        r0 = pin(offA[0] + pn); r1 = pin(offA[1] + pn);
+        P_SYNC(2);
+        rd_a(fa, r0, r1, OFF_A0); mma(1, 1, fa1, fb[1]);    // reads A0(t + 1) (= the next tile's A0(0) in the last K tile)
+        P_INTERLEAVE(8);
+        P_END();
+        if (STEADY) stage(3, kts, nx);                      // A1
+        r0 = pin(offB[0] + pn); r1 = pin(offB[1] + pn);
+        P_SYNC(3);
+        rd_b(fb0n, r0, r1, OFF_B0); mma(1, 0, fa1, fb[0]);  // reads B0(t + 1) into the spare set
+        P_INTERLEAVE(4);
+        P_END();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[0][j][kk] = fb0n[j][kk];
+    };
+    // ---- epilogue: the lane's 8 consecutive columns of a row -> 2 KB of wave-private LDS (32 rows x 64 B, 16-byte chunks XOR-swizzled) -> row-contiguous
+    // 16-byte stores (4 lanes = one 64-byte row segment), as in k_gemm8 but in half passes and with every lane-derived value recomputed from an
+    // opaque copy of the thread id, so that nothing of it is hoisted across the K loops of the persistent tile loop (the kernel has no register to spare)
+    auto epilogue = [&](const long m0, const int n0) {
+        int t_ = tid; asm volatile("" : "+v"(t_));
+        const int ln = t_ & 63, r15 = ln & 15, q4 = ln >> 4;
+        char* const ep = smem + OFF_SCR + wid * 2048;
+        const int wswz = (r15 >> 1) & 3;
+        const int crow = ln >> 2, cchunk = ln & 3;
+        const long mw = m0 + wr * 64;
+        const long rows = g.M - mw;
+        const unsigned ldcb = (unsigned)g.ldc * 2u;
+        const __amdgpu_buffer_rsrc_t rC = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * 2,
+                                                    rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * 2 : 0);
+        const unsigned voff = (unsigned)crow * ldcb + (unsigned)(cchunk * 16);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int hb = pass >> 1, ha = pass & 1;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 w[2];
+#pragma unroll
+                for (int il = 0; il < 2; ++il) {
+                    const int i = hf * 2 + il;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e]; v[4 + e] = acc[ha][i][hb][1][e]; }
+                    f16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
+                        h[e] = (f16)v[e];
+                    }
+                    w[il] = __builtin_bit_cast(f32x4, h);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int il = 0; il < 2; ++il) *reinterpret_cast<f32x4*>(ep + (il * 16 + r15) * 64 + ((q4 ^ wswz) << 4)) = w[il];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = it * 16 + crow;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + ((cchunk ^ ((row >> 1) & 3)) << 4));
+                    buf_store4<0>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v);
+                }
+                // (store-data hazard: see store_pad in k_gemm8's epilogue)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- persistent tile loop ----
+    int vb = blockIdx.x;
+    long m0; int n0;
+    tile_of(vb, m0, n0);
+    rA = rsrc_a(m0); rB = rsrc_b(n0);
+    bool first = true;
+    stage_bias(n0);
+    stage(0, 0, false); stage(1, 0, false); stage(2, 0, false); stage(3, 0, false); stage(0, 1, false); stage(1, 1, false); stage(2, 1, false); stage(3, 1, false);
+    for (;;) {
+        const int nvb = vb + (int)gridDim.x;
+        const bool has_next = nvb < g.n_blocks;
+        long m0n = 0; int n0n = 0;
+        if (has_next) { tile_of(nvb, m0n, n0n); rAn = rsrc_a(m0n); rBn = rsrc_b(n0n); } else { rAn = gemm_rsrc(g.A, 0); rBn = gemm_rsrc(g.B, 0); }
+        // stages 0 - 2 of this tile (and its bias row) have landed: 16 (wave 0: 17) prologue DMA instructions, the 10 newest may be in flight
+#ifdef SEMABS_TUNING
+        unsigned long long t_start = 0, t_main = 0, c_start = 0, c_main = 0, t_first = 0;
+        if (g.trace) { t_start = __builtin_amdgcn_s_memrealtime(); c_start = __builtin_amdgcn_s_memtime(); }
+#endif
+        if (first) wait_vmcnt<10>(); else wait_vmcnt<26>();     // (see ktile: behind an epilogue the 16 stores are inside the window)
+        __builtin_amdgcn_s_barrier();
+#ifdef SEMABS_TUNING
+        if (g.trace) t_first = __builtin_amdgcn_s_memrealtime();
+#endif
+        {
+            f32x4 b4[2][2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b4[hb][j] = has_bias ? *reinterpret_cast<const f32x4*>(smem + OFF_BIAS + (hb * 128 + wc * 32 + kg * 8 + j * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[a][i][c][j] = b4[c][j];
+        }
+        {   // B0(0), A0(0): complete in EVERY wave before the first wave enters phase 0 (their slots are re-staged in phases 0 / 1)
+            lds_cptr r0 = pin(offB[0]), r1 = pin(offB[1]);
+            rd_b(fb[0], r0, r1, OFF_B0);
+            r0 = pin(offA[0]); r1 = pin(offA[1]);
+            rd_a(fa, r0, r1, OFF_A0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // skew the second wave row by one barrier
+        // (the workgroup's LAST tile stages through zero-extent descriptors: the same instruction stream, the loads fetch nothing and write zeros into
+        //  slots nobody reads again - one body for every K tile of the kernel instead of a steady-state and a drain variant, which the register
+        //  allocator could not hold side by side: 588 spills)
+        for (int t = 0; t < nk; ++t) {
+            const bool nx = t + 2 >= nk;
+            if (has_next && t + 2 == nk) stage_bias(n0n);   // the next tile's bias row, in front of its first stage
+            ktile(std::integral_constant<bool, true>{}, t, nx ? t + 2 - nk : t + 2, nx, first ? 0 : (t == 0 ? 4 : (t == 1 ? 1 : 0)));
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // balance the skew barrier
+#ifdef SEMABS_TUNING
+        if (g.trace) { t_main = __builtin_amdgcn_s_memrealtime(); c_main = __builtin_amdgcn_s_memtime(); }
+#endif
+        epilogue(m0, n0);
+#ifdef SEMABS_TUNING
+        if (g.trace && tid == 0) {                          // {tile start, K loop end, epilogue issued, first wait passed} in 100 MHz ticks; shader-clock stamps
+            unsigned long long* tr = g.trace + (size_t)vb * 8;
+            tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = 0; tr[4] = c_start; tr[5] = c_main; tr[6] = t_first;
+        }
+#endif
+        if (!has_next) { wait_vmcnt<0>(); break; }          // nothing may be in flight towards this workgroup's LDS when it ends
+        vb = nvb; m0 = m0n; n0 = n0n; rA = rAn; rB = rBn; first = false;
+    }
+#undef P_INTERLEAVE
+#undef P_SYNC
+#undef P_END
+}
+
 // Raster group size (row panels walked fastest) by the number of 256-wide column panels.  An XCD runs 32 tiles at a time = group_m row
 // panels x 32 / group_m column panels, and an operand panel is only re-used out of its 4 MiB L2 while the panels of the resident tiles
 // fit next to the C tiles streaming through (tools/gemm_raster.py + tools/pmc_seq.py, M = 482 256; FETCH x 2 + WRITE over the algorithmic
@@ -1231,17 +1518,14 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     }
 #endif
     if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-        // fp16-output epilogues: persistent workgroups (one per CU) with cross-tile prefetch - see V3 in the kernel.  Selectable (kernel | 4096), NOT
-        // the default: measured on MI355X (tools/gemm_probe.py deep, round 4) QKV 1 626 us against 1 528 us for one workgroup per tile, c_fc 2 275
-        // against 2 245 - the 128 DMA instructions of the next tile's prologue take ~1.2 us of the CU's memory pipeline in front of the epilogue's
-        // stores, and the vmcnt(0) that opens the next tile waits for the acknowledgement of those stores; what is saved (prologue latency, the
-        // launch gap) is smaller than that.
-        if (o.v2 && o.pers) {
-            constexpr int LDS3 = 2 * 4 * 16384 + 8 * 4096;  // operand slots + 4 KB of epilogue scratch per wave = all 160 KB
-            static SemabsLdsAttr attr3;
-            semabs_ensure_lds(&k_gemm8<EPI, true, true, false, true>, LDS3, attr3);
+        // fp16-output epilogues: persistent workgroups (one per CU), the next tile's prologue inside the current tile's drain - k_gemm8p.  Needs an even
+        // number of K tiles and no super-columns; kernel | 4096 selects one workgroup per tile (A/B).
+        if (o.v2 && !o.nopers && (g.K / 64) % 2 == 0 && g.sc_w == 0) {
+            constexpr int LDSP = 2 * 4 * 16384 + 8 * 2048 + 1024;
+            static SemabsLdsAttr attr_p4;
+            semabs_ensure_lds(&k_gemm8p<EPI>, LDSP, attr_p4);
             int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
-            gemm_dispatch(k_gemm8<EPI, true, true, false, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS3, s, g, o);
+            gemm_dispatch(k_gemm8p<EPI>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDSP, s, g, o);
             SEMABS_CHECK_LAUNCH();
             return SEMABS_OK;
         }
@@ -1296,7 +1580,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((epi > 1 && epi != 5) || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
-    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 13) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order) | 512 (K = 32 ring schedule) | 2048 (round-3 PF schedule) | 4096 (persistent workgroups with cross-tile prefetch, fp16 outputs)");
+    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 13) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order) | 512 (K = 32 ring schedule) | 2048 (round-3 PF schedule) | 4096 (one workgroup per tile also for the fp16 outputs)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;
@@ -1309,9 +1593,9 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
     const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
     const int v2 = ((kernel >> 11) & 1) == 0;               // the deep schedule of the phased kernel is the default since round 4; bit 11 selects the round-3 PF schedule (A/B), bit 10 is accepted and ignored
-    const int pers = (kernel >> 12) & 1;                    // bit 12: persistent workgroups with cross-tile prefetch for the fp16-output epilogues (A/B; slower, see launch_gemm8)
+    const int nopers = (kernel >> 12) & 1;                  // bit 12: one workgroup per tile also for the fp16-output epilogues (A/B against k_gemm8p)
     kernel &= 255;
-    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring, v2, pers};
+    GemmOpts o{kernel, (hipEvent_t)start_event, (hipEvent_t)stop_event, ring, v2, nopers};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {
         case EPI_BIAS_F16: return launch<EPI_BIAS_F16>(g, s, o);

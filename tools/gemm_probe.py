@@ -97,7 +97,7 @@ if "ring" in what:
     KERNEL = 0
 if "deep" in what:
     for rep in range(3):
-        for kern, label in ((2 | 2048, "phased PF (4 half-tiles in flight)"), (2, "deep, one workgroup per tile"), (2 | 4096, "deep + persistent prefetch (fp16 outputs)")):
+        for kern, label in ((2 | 2048, "phased PF (4 half-tiles in flight)"), (2 | 4096, "deep, one workgroup per tile"), (2, "deep + persistent, prologue in the drain (fp16 out)")):
             KERNEL = kern
             log[f"deep{kern}_{rep}"] = line(f"{label} (rep {rep})")
     KERNEL = 0
@@ -175,7 +175,7 @@ if "abltrace" in what:
     tune(2, 0)
 if "v3trace" in what:
     # persistent cross-tile prefetch (V3) vs one workgroup per tile on the fp16-output shapes: per-tile timeline from the in-kernel stamps
-    for kern, label in ((2, "deep, one workgroup per tile"), (2 | 4096, "deep + persistent prefetch")):
+    for kern, label in ((2 | 4096, "deep, one workgroup per tile"), (2, "deep + persistent (k_gemm8p)")):
         for name, n, k, epi in (SHAPES[0], SHAPES[2]):
             A, B, bias, C = operands(n, k, epi)
             nb = ((M + 255) // 256) * (n // 256)
@@ -194,7 +194,7 @@ if "v3trace" in what:
             us = e0.elapsed_time(e1) / 4 * 1e3
             ghz = ((t[:, 5] - t[:, 4]) / np.maximum(1, t[:, 1] - t[:, 0])).mean() * 0.1
             print(f"{label:32s} {name:5s} {us:7.1f}us {2.0 * M * n * k / us / 1e6:6.0f}TF  tile start -> K loop end {((t[:, 1] - t[:, 0]) / 100.0).mean():6.2f}us = "
-                  f"{(t[:, 5] - t[:, 4]).mean() / (k // 64):6.0f} cycles per K tile at {ghz:.3f} GHz; -> stores acknowledged {((t[:, 2] - t[:, 1]) / 100.0).mean():6.2f}us; launch / tiles per CU {us / (nb / 256):6.2f}us", flush=True)
+                  f"{(t[:, 5] - t[:, 4]).mean() / (k // 64):6.0f} cycles per K tile at {ghz:.3f} GHz; -> epilogue done {((t[:, 2] - t[:, 1]) / 100.0).mean():6.2f}us; first wait + barrier {((t[:, 6] - t[:, 0]) / 100.0).mean() if t[:, 6].any() else float('nan'):6.2f}us; launch / tiles per CU {us / (nb / 256):6.2f}us", flush=True)
 if "tracepf" in what:
     KERNEL = 2 | 2048; what = what + ["trace"]
 if "trace" in what:
