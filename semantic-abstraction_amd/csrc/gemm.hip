@@ -1186,9 +1186,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 //     meant to leave in flight: "at most 10 operations outstanding" then retires more than needed (some stores too), never less - the only property
 //     relied on is that LOADS retire in order among loads;
 //   * the epilogue must not touch the operand slots (they are being refilled): it transposes through 2 KB per wave BEHIND the slots (8 half
-//     passes of 32 rows x 32 columns), and loads nothing: the bias is in the accumulators from the start.  The next tile's bias row (256 fp32 =
-//     1 KB) travels by LDS-DMA as well - one more "half-tile" issued by wave 0 in front of the next tile's first stage - so the kernel issues no
-//     ordinary load at all, only LDS-DMA loads and stores.
+//     passes of 32 rows x 32 columns), and loads nothing from memory: the tile's bias row (256 fp32 = 1 KB) travels by LDS-DMA as well - one more
+//     "half-tile" issued by wave 0 in front of the tile's first stage, into one of two 1 KB buffers (the next tile's row lands while this tile's
+//     epilogue reads its own) - so the kernel issues no ordinary load at all, only LDS-DMA loads and stores.  The bias is added in the epilogue,
+//     after the accumulation, as in k_gemm8 (starting the accumulators at it changed the fp32 summation order: headline L-inf 9.0e-4 -> 9.8e-4).
 // Requires an even number of K tiles (buffer parity continues across tiles).  Slot map, fragment layout and MFMA order are k_gemm8's: results are
 // bit-identical to it.
 // =================================================================================================
@@ -1196,7 +1197,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16, "fp16-output epilogues");
     constexpr int HT = 16384, OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
-    constexpr int OFF_SCR = 2 * BUFSZ, OFF_BIAS = OFF_SCR + 8 * 2048;      // epilogue scratch (2 KB per wave), bias row of the tile (1 KB)
+    constexpr int OFF_SCR = 2 * BUFSZ, OFF_BIAS = OFF_SCR + 8 * 2048;      // epilogue scratch (2 KB per wave), bias rows of this and the next tile (2 x 1 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1227,12 +1228,19 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         char* dst = smem + (kt & 1) * BUFSZ + (j == 0 ? OFF_A0 : (j == 1 ? OFF_B0 : (j == 2 ? OFF_B1 : OFF_A1))) + wid * 1024;
         const unsigned soff = (unsigned)kt * 128 + (hi ? (isa ? a_half : b_half) : 0u);
         const __amdgpu_buffer_rsrc_t r = isa ? (nx ? rAn : rA) : (nx ? rBn : rB);
+#ifdef SEMABS_TUNING
+        if ((isa && (g.ablate & 64)) || (!isa && (g.ablate & 128))) {      // cache-policy experiment: streaming (nt) operand loads
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst), 16, isa ? aoff : boff, soff, 0, 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + 8192), 16, isa ? aoff : boff, soff + (isa ? a_q : b_q), 0, 2);
+            return;
+        }
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst), 16, isa ? aoff : boff, soff, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + 8192), 16, isa ? aoff : boff, soff + (isa ? a_q : b_q), 0, 0);
     };
-    auto stage_bias = [&](const int n0) {                    // wave 0: bias[n0 .. n0 + 255] -> LDS, 16 bytes per lane
+    auto stage_bias = [&](const int n0, const int bpar) {    // wave 0: bias[n0 .. n0 + 255] -> LDS (two 1 KB buffers, by tile parity), 16 bytes per lane
         if (wid == 0 && has_bias)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, (__attribute__((address_space(3))) void*)(smem + OFF_BIAS), 16, (unsigned)lane * 16u, (unsigned)n0 * 4u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, (__attribute__((address_space(3))) void*)(smem + OFF_BIAS + bpar * 1024), 16, (unsigned)lane * 16u, (unsigned)n0 * 4u, 0, 0);
     };
     int offA[2], offB[2];                                   // fragment read offsets inside a half-tile (column tile jt = 1 of B: + 512 bytes)
     {
@@ -1336,10 +1344,18 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     // ---- epilogue: the lane's 8 consecutive columns of a row -> 2 KB of wave-private LDS (32 rows x 64 B, 16-byte chunks XOR-swizzled) -> row-contiguous
     // 16-byte stores (4 lanes = one 64-byte row segment), as in k_gemm8 but in half passes and with every lane-derived value recomputed from an
     // opaque copy of the thread id, so that nothing of it is hoisted across the K loops of the persistent tile loop (the kernel has no register to spare)
-    auto epilogue = [&](const long m0, const int n0) {
+    auto epilogue = [&](const long m0, const int n0, const int bpar) {
         int t_ = tid; asm volatile("" : "+v"(t_));
         const int ln = t_ & 63, r15 = ln & 15, q4 = ln >> 4;
         char* const ep = smem + OFF_SCR + wid * 2048;
+        // bias of the lane's 8 columns per B half, from this tile's bias buffer (the other buffer already holds the next tile's row): added here, after
+        // the accumulation, in k_gemm8's order - the results of the two kernels are bit-identical
+        f32x4 bia[2][2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bia[hb][j] = has_bias ? *reinterpret_cast<const f32x4*>(smem + OFF_BIAS + bpar * 1024 + (hb * 128 + wc * 32 + q4 * 8 + j * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         const int wswz = (r15 >> 1) & 3;
         const int crow = ln >> 2, cchunk = ln & 3;
         const long mw = m0 + wr * 64;
@@ -1359,7 +1375,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                     const int i = hf * 2 + il;
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e]; v[4 + e] = acc[ha][i][hb][1][e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[hb][0][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][1][e]; }
                     f16x8 h;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -1376,6 +1392,9 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                 for (int it = 0; it < 2; ++it) {
                     const int row = it * 16 + crow;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + ((cchunk ^ ((row >> 1) & 3)) << 4));
+#ifdef SEMABS_TUNING
+                    if (g.ablate & 32) { buf_store4<2>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }
+#endif
                     buf_store4<0>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v);
                 }
                 // (store-data hazard: see store_pad in k_gemm8's epilogue)
@@ -1392,7 +1411,8 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     tile_of(vb, m0, n0);
     rA = rsrc_a(m0); rB = rsrc_b(n0);
     bool first = true;
-    stage_bias(n0);
+    int bpar = 0;                                           // bias buffer of the current tile
+    stage_bias(n0, 0);
     stage(0, 0, false); stage(1, 0, false); stage(2, 0, false); stage(3, 0, false); stage(0, 1, false); stage(1, 1, false); stage(2, 1, false); stage(3, 1, false);
     for (;;) {
         const int nvb = vb + (int)gridDim.x;
@@ -1409,22 +1429,14 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 #ifdef SEMABS_TUNING
         if (g.trace) t_first = __builtin_amdgcn_s_memrealtime();
 #endif
-        {
-            f32x4 b4[2][2];
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    b4[hb][j] = has_bias ? *reinterpret_cast<const f32x4*>(smem + OFF_BIAS + (hb * 128 + wc * 32 + kg * 8 + j * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[a][i][c][j] = b4[c][j];
-        }
+                    for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         {   // B0(0), A0(0): complete in EVERY wave before the first wave enters phase 0 (their slots are re-staged in phases 0 / 1)
             lds_cptr r0 = pin(offB[0]), r1 = pin(offB[1]);
             rd_b(fb[0], r0, r1, OFF_B0);
@@ -1439,14 +1451,14 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         //  allocator could not hold side by side: 588 spills)
         for (int t = 0; t < nk; ++t) {
             const bool nx = t + 2 >= nk;
-            if (has_next && t + 2 == nk) stage_bias(n0n);   // the next tile's bias row, in front of its first stage
+            if (has_next && t + 2 == nk) stage_bias(n0n, bpar ^ 1);   // the next tile's bias row, in front of its first stage
             ktile(std::integral_constant<bool, true>{}, t, nx ? t + 2 - nk : t + 2, nx, first ? 0 : (t == 0 ? 4 : (t == 1 ? 1 : 0)));
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();          // balance the skew barrier
 #ifdef SEMABS_TUNING
         if (g.trace) { t_main = __builtin_amdgcn_s_memrealtime(); c_main = __builtin_amdgcn_s_memtime(); }
 #endif
-        epilogue(m0, n0);
+        epilogue(m0, n0, bpar);
 #ifdef SEMABS_TUNING
         if (g.trace && tid == 0) {                          // {tile start, K loop end, epilogue issued, first wait passed} in 100 MHz ticks; shader-clock stamps
             unsigned long long* tr = g.trace + (size_t)vb * 8;
@@ -1454,7 +1466,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         }
 #endif
         if (!has_next) { wait_vmcnt<0>(); break; }          // nothing may be in flight towards this workgroup's LDS when it ends
-        vb = nvb; m0 = m0n; n0 = n0n; rA = rAn; rB = rBn; first = false;
+        vb = nvb; m0 = m0n; n0 = n0n; rA = rAn; rB = rBn; first = false; bpar ^= 1;
     }
 #undef P_INTERLEAVE
 #undef P_SYNC
@@ -1501,13 +1513,13 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 #ifdef SEMABS_TUNING
     // compile-time ablations (no run-time branches in the loops they measure): g_ablate picks an instantiation, for the QKV / out-proj epilogues only
     if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_RESID_F32) {
-        if (g_ablate) {
+        if (g_ablate & 31) {
             auto go = [&](auto kern) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
                 gemm_dispatch(kern, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
             };
 #define GEMM8_ABL_CASE(n) case n: if (o.v2) go(k_gemm8<EPI, true, false, false, true, n>); else go(k_gemm8<EPI, true, false, false, false, n>); break;
-            switch (g_ablate) {
+            switch (g_ablate & 31) {
                 GEMM8_ABL_CASE(8) GEMM8_ABL_CASE(9) GEMM8_ABL_CASE(10) GEMM8_ABL_CASE(11) GEMM8_ABL_CASE(12) GEMM8_ABL_CASE(13) GEMM8_ABL_CASE(15)
                 default: semabs_set_error("semabs_gemm_tune: this ablation mask is not instantiated"); return SEMABS_EINVAL;
             }
@@ -1521,7 +1533,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         // fp16-output epilogues: persistent workgroups (one per CU), the next tile's prologue inside the current tile's drain - k_gemm8p.  Needs an even
         // number of K tiles and no super-columns; kernel | 4096 selects one workgroup per tile (A/B).
         if (o.v2 && !o.nopers && (g.K / 64) % 2 == 0 && g.sc_w == 0) {
-            constexpr int LDSP = 2 * 4 * 16384 + 8 * 2048 + 1024;
+            constexpr int LDSP = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024;
             static SemabsLdsAttr attr_p4;
             semabs_ensure_lds(&k_gemm8p<EPI>, LDSP, attr_p4);
             int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }

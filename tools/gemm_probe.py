@@ -173,6 +173,14 @@ if "abltrace" in what:
                 print(f"{'PF  ' if kern & 2048 else 'deep'} {label:28s} {name:5s} {us:7.1f}us {2.0 * M * n * k / us / 1e6:6.0f}TF  main loop {((t[:, 1] - t[:, 0]) / 100.0).mean():6.2f}us = "
                       f"{(t[:, 5] - t[:, 4]).mean() / (k // 64):6.0f} cycles per K tile at {ghz:.3f} GHz; tile end - start {((t[:, 2] - t[:, 0]) / 100.0).mean():6.2f}us", flush=True)
     tune(2, 0)
+if "policy" in what:
+    # cache-policy experiment on the persistent fp16-output kernel (tuning build): nt on the C stores / the A stream / the W stream
+    SH = SHAPES; SHAPES = [SH[0], SH[2]]; KERNEL = 2
+    for rep in range(2):
+        for ab, label in [(0, "default policy"), (32, "nt C stores"), (64, "nt A loads"), (128, "nt W loads"), (96, "nt C stores + nt A loads")]:
+            tune(2, ab)
+            log[f"policy{ab}_{rep}"] = line(f"k_gemm8p {label} (rep {rep})")
+    tune(2, 0); SHAPES = SH; KERNEL = 0
 if "v3trace" in what:
     # persistent cross-tile prefetch (V3) vs one workgroup per tile on the fp16-output shapes: per-tile timeline from the in-kernel stamps
     for kern, label in ((2 | 4096, "deep, one workgroup per tile"), (2, "deep + persistent (k_gemm8p)")):
