@@ -1195,7 +1195,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 // =================================================================================================
 template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
-    static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16, "fp16-output epilogues");
+    static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32, "fp16-output epilogues and the fp32 residual read-modify-write");
+    constexpr bool OUT16 = EPI != EPI_BIAS_RESID_F32;
     constexpr int HT = 16384, OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
     constexpr int OFF_SCR = 2 * BUFSZ, OFF_BIAS = OFF_SCR + 8 * 2048;      // epilogue scratch (2 KB per wave), bias rows of this and the next tile (2 x 1 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1279,6 +1280,10 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 16 - (nread), 0);            \
     } while (0)
     const int nk = g.K / 64;                                // even, >= 2 (checked by the launcher)
+    // operations that may be outstanding in the first five phases behind an epilogue: 10 + what the epilogue issued per wave (16 stores; the fp32
+    // read-modify-write issues 32 loads + 32 stores: 74 does not fit the 6-bit counter, 63 is merely a little stricter - it also retires the first
+    // residual loads, which completed long ago)
+    constexpr int VM_AFTER_EPI = OUT16 ? 26 : 63;
     // One K tile = four phases; STEADY: a half-tile is staged in every phase (kts / nx say which) and the wait is vmcnt(10); else (the last two K
     // tiles of the workgroup's LAST tile) nothing is staged and the queue drains with exact counts, as in k_gemm8.
     // Waits behind an epilogue.  From a workgroup's second tile on, the 16 stores of the previous tile's epilogue sit in the queue between the prologue
@@ -1295,7 +1300,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         lds_cptr r0, r1;
 #define P_SYNC(k_)                                                               \
     do {                                                                         \
-        if (STEADY) { if ((k_) < st_ph) wait_vmcnt<26>(); else wait_vmcnt<10>(); } \
+        if (STEADY) { if ((k_) < st_ph) wait_vmcnt<VM_AFTER_EPI>(); else wait_vmcnt<10>(); } \
         else if (pen) wait_vmcnt<8 - 2 * (k_)>();                                \
         else if ((k_) == 0) wait_vmcnt<0>();                                     \
         __builtin_amdgcn_s_waitcnt(0xc07f);                                      \
@@ -1356,10 +1361,55 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 bia[hb][j] = has_bias ? *reinterpret_cast<const f32x4*>(smem + OFF_BIAS + bpar * 1024 + (hb * 128 + wc * 32 + q4 * 8 + j * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const int wswz = (r15 >> 1) & 3;
-        const int crow = ln >> 2, cchunk = ln & 3;
         const long mw = m0 + wr * 64;
         const long rows = g.M - mw;
+        if constexpr (!OUT16) {
+            // fp32 residual read-modify-write (out-proj, c_proj): quarter passes of 16 rows x 32 columns (2 KB: a lane's two 16-byte halves of its row,
+            // chunks XOR-swizzled by the row) -> 8 lanes per 128-byte row segment; the residual rows are fetched in that coalesced layout one quarter
+            // pass ahead (ordinary loads BEHIND the next tile's LDS-DMA in the queue: the compiler's waits for them are positional like ours)
+            const int wswz8 = r15 & 7;
+            const int crow8 = ln >> 3, cchunk8 = ln & 7;
+            const unsigned ldcb = (unsigned)g.ldc * 4u;
+            const __amdgpu_buffer_rsrc_t rC = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * 4,
+                                                        rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * 4 : 0);
+            const unsigned voff = (unsigned)crow8 * ldcb + (unsigned)(cchunk8 * 16);
+            auto soff_of = [&](const int q, const int it) {      // quarter pass q = pass * 4 + i: rows ha * 128 + i * 16 + it * 8 .., columns hb * 128 ..
+                const int pass = q >> 2, i = q & 3;
+                return (unsigned)((pass & 1) * 128 + i * 16 + it * 8) * ldcb + (unsigned)((pass >> 1) * 128 * 4);
+            };
+            f32x4 res[2][2];
+            auto issue = [&](const int q) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) res[q & 1][it] = buf_load4<2>(rC, voff, soff_of(q, it));
+            };
+            issue(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pass = q >> 2, i = q & 3, hb = pass >> 1, ha = pass & 1;
+                f32x4 w0, w1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w0[e] = acc[ha][i][hb][0][e] + bia[hb][0][e]; w1[e] = acc[ha][i][hb][1][e] + bia[hb][1][e]; }
+                __builtin_amdgcn_sched_barrier(0);
+                *reinterpret_cast<f32x4*>(ep + r15 * 128 + (((2 * q4) ^ wswz8) << 4)) = w0;
+                *reinterpret_cast<f32x4*>(ep + r15 * 128 + (((2 * q4 + 1) ^ wswz8) << 4)) = w1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < 16) issue(q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = it * 8 + crow8;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 128 + ((cchunk8 ^ (row & 7)) << 4));
+                    const f32x4 o = res[q & 1][it];
+                    buf_store4<2>(rC, voff, soff_of(q, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+        const int wswz = (r15 >> 1) & 3;
+        const int crow = ln >> 2, cchunk = ln & 3;
         const unsigned ldcb = (unsigned)g.ldc * 2u;
         const __amdgpu_buffer_rsrc_t rC = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * 2,
                                                     rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * 2 : 0);
@@ -1424,7 +1474,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         unsigned long long t_start = 0, t_main = 0, c_start = 0, c_main = 0, t_first = 0;
         if (g.trace) { t_start = __builtin_amdgcn_s_memrealtime(); c_start = __builtin_amdgcn_s_memtime(); }
 #endif
-        if (first) wait_vmcnt<10>(); else wait_vmcnt<26>();     // (see ktile: behind an epilogue the 16 stores are inside the window)
+        if (first) wait_vmcnt<10>(); else wait_vmcnt<VM_AFTER_EPI>();     // (see ktile: behind an epilogue its loads / stores are inside the window)
         __builtin_amdgcn_s_barrier();
 #ifdef SEMABS_TUNING
         if (g.trace) t_first = __builtin_amdgcn_s_memrealtime();
@@ -1531,7 +1581,9 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 #endif
     if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
         // fp16-output epilogues: persistent workgroups (one per CU), the next tile's prologue inside the current tile's drain - k_gemm8p.  Needs an even
-        // number of K tiles and no super-columns; kernel | 4096 selects one workgroup per tile (A/B).
+        // number of K tiles and no super-columns; kernel | 4096 selects one workgroup per tile (A/B).  The kernel also carries the fp32 residual
+        // read-modify-write epilogue (quarter passes of 2 KB): bit-identical, but SLOWER than one workgroup per tile on the same box - out-proj 796 vs 767 us,
+        // c_proj 1 980 vs 1 925 us (16 dependent load - transpose - store rounds per tile instead of 4) - so it is not dispatched (not instantiated).
         if (o.v2 && !o.nopers && (g.K / 64) % 2 == 0 && g.sc_w == 0) {
             constexpr int LDSP = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024;
             static SemabsLdsAttr attr_p4;
