@@ -358,8 +358,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
     constexpr bool OUT16 = EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16;
     constexpr int ES = OUT16 ? 2 : 4;                       // bytes per output element
     constexpr int EAUX = OUT16 ? 0 : 2;                     // epilogue cache policy: nt for the fp32 tiles (see buf_store4)
-    // V3 = persistent workgroups with cross-tile prefetch (fp16-output epilogues, deep schedule): see the end of the tile loop
-    constexpr bool V3 = PERS && V2 && PF && OUT16 && (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,15 +507,14 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         constexpr int RPI = 64 / LPR;                       // rows per wave instruction: 16 / 8
         constexpr int NIT = 64 / RPI;                       // instructions per pass: 4 / 8
         constexpr int PASSB = 64 * ROWB;                    // 4 / 8 KB; two passes alternate inside the wave's 16 KB
-        char* const ep = V3 ? smem + 2 * BUFSZ + wid * 4096 : smem + wid * 16384;      // V3: behind the operand slots, which are being refilled
-        constexpr int PALT = V3 ? 0 : 1;                    // passes alternate between two buffers (V3: one 4 KB buffer; LDS is in order per wave)
+        char* const ep = smem + wid * 16384;
         float bia[2][8];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int ncol = n0 + hb * 128 + wc * 32 + kg * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) bia[hb][e] = 0.f;
-            if (!V3 && g.bias) {
+            if (g.bias) {
                 const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
                 bia[hb][0] = b0.x; bia[hb][1] = b0.y; bia[hb][2] = b0.z; bia[hb][3] = b0.w; bia[hb][4] = b1.x; bia[hb][5] = b1.y; bia[hb][6] = b1.z; bia[hb][7] = b1.w;
             }
@@ -533,7 +530,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         // stores' operands are only overwritten by the NEXT pass, after this pass's LDS reads have returned.
         auto lds_write = [&](int pass) {
             const int hb = pass >> 1, ha = pass & 1;
-            char* buf = ep + (pass & PALT) * PASSB;
+            char* buf = ep + (pass & 1) * PASSB;
             f32x4 w[4][OUT16 ? 1 : 2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -571,7 +568,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         auto lds_read = [&](int pass, int it) {
             const int row = it * RPI + crow;
             const int rswz = OUT16 ? ((row >> 1) & 3) : (row & 7);
-            return *reinterpret_cast<const f32x4*>(ep + (pass & PALT) * PASSB + row * ROWB + ((cchunk ^ rswz) << 4));
+            return *reinterpret_cast<const f32x4*>(ep + (pass & 1) * PASSB + row * ROWB + ((cchunk ^ rswz) << 4));
         };
         const long mw = m0 + wr * 64;                       // first row of this wave's 64-row strip of A half 0 (half 1: + 128)
         const unsigned ldcb = (unsigned)g.ldc * ES;         // output row pitch in bytes
@@ -732,40 +729,22 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #define GEMM8_STAMP(t_, ph_, pt_) do { } while (0)
 #endif
     const int nk = g.K / 64;                                // >= 2 (checked by the launcher)
-    // ---- V3 state: next tile's coordinates and bias (the accumulators start at the bias: a lane's 8 columns of a (B half, column tile pair)) ----
-    bool v3_first = true; long v3_m0 = 0; int v3_n0 = 0;
-    f32x4 v3_bias[V3 ? 2 : 1][2];
-    auto v3_load_bias = [&](const int n0_) {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int ncol = n0_ + hb * 128 + wc * 32 + kg * 8;
-            if (g.bias) {
-                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ncol), b1 = *reinterpret_cast<const float4*>(g.bias + ncol + 4);
-                v3_bias[V3 ? hb : 0][0] = f32x4{b0.x, b0.y, b0.z, b0.w}; v3_bias[V3 ? hb : 0][1] = f32x4{b1.x, b1.y, b1.z, b1.w};
-            } else { v3_bias[V3 ? hb : 0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; v3_bias[V3 ? hb : 0][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        }
-    };
     int vb = blockIdx.x;                                    // (a do-while whose condition is the constant false unless PERS: written as a for loop the compiler could not prove the single trip and
     do {                                                    //  kept every invariant of the epilogue live across the K loop - in a kernel with no register to spare)
     long m0; int n0;
-    if (!V3 || v3_first) {
-        tile_of(vb, m0, n0);
-        set_tile(m0, n0);
-        if constexpr (V3) v3_load_bias(n0);                 // (ahead of the first tile's DMA in the queue)
-    } else { m0 = v3_m0; n0 = v3_n0; }                      // V3: the descriptors already point at this tile, its first two K tiles are in flight
+    tile_of(vb, m0, n0);
+    set_tile(m0, n0);
 #ifdef SEMABS_TUNING
     const bool ptr_on = g.ptrace && vb == g.ptrace_wg && lane == 0 && (wid == 0 || wid == 4) && g.K / 64 <= 64;
 #endif
-    if constexpr (!V3) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+                for (int j = 0; j < 2; ++j) acc[a][i][c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef SEMABS_TUNING
     unsigned long long t_start = 0, t_main = 0, c_start = 0, c_main = 0;
     if (g.trace) { t_start = __builtin_amdgcn_s_memrealtime(); c_start = __builtin_amdgcn_s_memtime(); }
@@ -852,28 +831,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-    if (!V3 || v3_first) {
-        prologue();
-        if constexpr (PF) stage_b(1, 1);                    // the prefetching loop stages one phase earlier (below)
-        if constexpr (V2) { stage_a(1, 1); wait_vmcnt<10>(); }  // the deep schedule another one: K tiles 0 and 1 whole, the first three half-tiles retired
-        else wait_vmcnt<8>();                               // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
-    } else {
-        // V3, every tile but the first: the eight half-tiles were requested before the previous tile's epilogue, whose stores sit BEHIND them in the
-        // queue - counted waits are only trusted while the queue holds nothing but LDS-DMA loads, so wait for everything (the DMA landed long ago; what
-        // this waits for is the acknowledgement of the last pass's stores, partly covered by the accumulator initialisation below)
-        wait_vmcnt<0>();
-    }
-    if constexpr (V3) {
-        // accumulators start at the bias (a lane holds the same 8 columns in every row tile of a quadrant)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[a][i][c][j] = v3_bias[V3 ? c : 0][j];
-    }
+    prologue();
+    if constexpr (PF) stage_b(1, 1);                        // the prefetching loop stages one phase earlier (below)
+    if constexpr (V2) { stage_a(1, 1); wait_vmcnt<10>(); }  // the deep schedule another one: K tiles 0 and 1 whole, the first three half-tiles retired
+    else wait_vmcnt<8>();                                   // A0(0), B0(0) (PF: and B1(0)) have landed (this wave's share)
     __builtin_amdgcn_s_barrier();
     if constexpr (PF && V2) {
         // The deep schedule re-stages the slots of A0(0) / B0(0) in phases 0 / 1 of the first K tile, so their reads - which precede the loop - must
@@ -1094,27 +1055,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #ifdef SEMABS_TUNING
     if (g.trace) { t_main = __builtin_amdgcn_s_memrealtime(); c_main = __builtin_amdgcn_s_memtime(); }
 #endif
-    if constexpr (V3) {
-        // ---- persistent workgroups with cross-tile prefetch ------------------------------------------------------------------------------------------
-        // A 256 x 256 x 768 tile is ~16 us of steady-state K loop between ~8 us of fixed cost: ~2 us until the first half-tiles of its prologue arrive,
-        // the epilogue, 1 - 2 us until the stores are acknowledged (a workgroup is not retired before that) and ~1 us until the next workgroup runs
-        // (tools/gemm_probe.py abltrace / trace).  Here the workgroup stays, and the NEXT tile's first two K tiles (all eight slots = 128 KB) are
-        // requested right after the K loop, before the epilogue: they land while the epilogue runs.  The epilogue therefore transposes through the 32 KB
-        // of LDS behind the operand slots (4 KB per wave = one fp16 pass, single-buffered), and issues no load at all: the bias is in the
-        // accumulators from the start, and the NEXT tile's bias is fetched here, AHEAD of the DMA in the queue (an ordinary load behind outstanding
-        // LDS-DMA is the combination round 1 saw misbehave).  Every wave has finished its LDS reads of the last K tile (lgkmcnt(0) at the end of
-        // ktile, then the barriers above), so the slots are free.
-        const int nvb = vb + (int)gridDim.x;
-        if (nvb < g.n_blocks) {
-            tile_of(nvb, v3_m0, v3_n0);
-            v3_load_bias(v3_n0);
-            __builtin_amdgcn_sched_barrier(0);
-            set_tile(v3_m0, v3_n0);
-            stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1); stage_b(1, 1); stage_a(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        v3_first = false;
-    }
     if (!GABL(8)) epilogue(m0, n0);
     else {                                                  // ablation: keep the accumulators (and with them the whole K loop) alive
         float keep = 0.f;
@@ -1152,7 +1092,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         }
     }
 #endif
-    if (PERS && !V3) {
+    if (PERS) {
         // Persistent workgroups (one per CU): the next tile's first half-tiles are requested while this tile's stores drain - a workgroup is
         // not retired before its stores complete, and the next one cannot start before it is (the operand buffers take 128 of the 160 KB):
         // 0.9 - 5 us per tile (tools/gemm_probe.py trace).  Every wave is done with its epilogue slice of LDS before the DMA overwrites it;
@@ -1175,7 +1115,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 // A 256 x 256 x 768 tile is ~16 us of steady-state K loop between ~8 us of fixed cost (tools/gemm_probe.py abltrace: 2 795 cycles per K tile over
 // a K = 768 tile against 2 214 in the steady state of K = 3 072; trace: 1.4 us from a tile's last store to the next workgroup's first instruction):
 // the wait for the first half-tiles of the prologue, the drain of the DMA queue, the epilogue, the acknowledgement of its stores (a workgroup is not
-// retired before that) and the dispatch of the next workgroup.  Round 4's first attempt (V3 in k_gemm8: all eight half-tiles of the next tile
+// retired before that) and the dispatch of the next workgroup.  Round 4's first attempt ("V3", a variant of k_gemm8 since removed: all eight half-tiles of the next tile
 // requested between the K loop and the epilogue, vmcnt(0) at the next tile's start) lost: 128 DMA instructions in front of the epilogue's stores
 // and a wait for the acknowledgement of those stores.  Here the workgroup stays and the stage sequence simply NEVER ENDS: stage index
 // s = 4 t + j keeps counting across tiles, so the last two K tiles of a tile - which stage nothing in k_gemm8 - stage the next tile's K tiles 0 and 1
