@@ -73,21 +73,115 @@ extern "C" int semabs_resize_coeffs(int in_size, int out_size, int* xmin_out, in
 #define BAND 16
 #define MAX_IN_ROWS 64      // input rows a 16-row output band can touch: 16 * scale + 2 * support + 2  (scale <= 2.2)
 
+__device__ __forceinline__ int clamp_u8(int a) { return a < 0 ? 0 : (a > 255 ? 255 : a); }
+
+// Horizontal pass of one band: thread x owns output column x - its taps (weights, byte offsets) sit in registers and it walks the band's input rows two
+// at a time, every byte load of a row pair in flight before the first multiply (with a run-time tap loop each tap waited for its own three loads:
+// ~3 000 cycles of exposed latency per output).  KS = taps known at compile time (0: generic loop).
+template <int KS>
+__device__ __forceinline__ void tile_hpass(const unsigned char* __restrict__ src, int W, int ts, int ksize, const int* __restrict__ kx, int x0,
+                                           int r_lo, int n_rows, unsigned char (*sh)[OUT_RES][3], int x) {
+    if (KS == 0) {
+        for (int rr = 0; rr < n_rows; ++rr) {
+            const unsigned char* srow = src + (long)(r_lo + rr) * W * 3;
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+            for (int k = 0; k < ksize; ++k) {
+                int xi = x0 + k; if (xi > ts - 1) xi = ts - 1;        // taps past the edge carry weight 0
+                const int w = kx[k];
+                a0 += (int)srow[xi * 3] * w; a1 += (int)srow[xi * 3 + 1] * w; a2 += (int)srow[xi * 3 + 2] * w;
+            }
+            sh[rr][x][0] = (unsigned char)clamp_u8(a0 >> PRECISION_BITS);
+            sh[rr][x][1] = (unsigned char)clamp_u8(a1 >> PRECISION_BITS);
+            sh[rr][x][2] = (unsigned char)clamp_u8(a2 >> PRECISION_BITS);
+        }
+        return;
+    }
+    constexpr int K = KS ? KS : 1;
+    int w[K], off[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int xi = x0 + k; if (xi > ts - 1) xi = ts - 1;
+        w[k] = kx[k]; off[k] = xi * 3;
+    }
+    const long pitch = (long)W * 3;
+    const unsigned char* srow = src + (long)r_lo * pitch;
+    int rr = 0;
+    for (; rr + 2 <= n_rows; rr += 2, srow += 2 * pitch) {
+        unsigned char u[2][K][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                u[q][k][0] = srow[q * pitch + off[k]]; u[q][k][1] = srow[q * pitch + off[k] + 1]; u[q][k][2] = srow[q * pitch + off[k] + 2];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { a0 += (int)u[q][k][0] * w[k]; a1 += (int)u[q][k][1] * w[k]; a2 += (int)u[q][k][2] * w[k]; }
+            sh[rr + q][x][0] = (unsigned char)clamp_u8(a0 >> PRECISION_BITS);
+            sh[rr + q][x][1] = (unsigned char)clamp_u8(a1 >> PRECISION_BITS);
+            sh[rr + q][x][2] = (unsigned char)clamp_u8(a2 >> PRECISION_BITS);
+        }
+    }
+    if (rr < n_rows) {
+        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { a0 += (int)srow[off[k]] * w[k]; a1 += (int)srow[off[k] + 1] * w[k]; a2 += (int)srow[off[k] + 2] * w[k]; }
+        sh[rr][x][0] = (unsigned char)clamp_u8(a0 >> PRECISION_BITS);
+        sh[rr][x][1] = (unsigned char)clamp_u8(a1 >> PRECISION_BITS);
+        sh[rr][x][2] = (unsigned char)clamp_u8(a2 >> PRECISION_BITS);
+    }
+}
+
+// Vertical pass of one output row for the pixel pair (x, x + 1), x even: the pair's 6 bytes are 3 aligned 16-bit LDS reads per tap.  -> v[2][3]
+template <int KS>
+__device__ __forceinline__ void tile_vpass(const unsigned short* __restrict__ shs, const int* __restrict__ ky, int ksize, int yb, int n_rows, int x,
+                                           int (&v)[2][3]) {
+    int a[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[q][c] = 1 << (PRECISION_BITS - 1);
+    auto tap = [&](int k) {
+        int rr = yb + k; if (rr > n_rows - 1) rr = n_rows - 1;
+        const int w = ky[k];
+        const unsigned short* s = shs + ((rr * OUT_RES + x) >> 1) * 3;
+        const int s0 = s[0], s1 = s[1], s2 = s[2];                   // (R0 G0) (B0 R1) (G1 B1)
+        a[0][0] += (s0 & 255) * w; a[0][1] += (s0 >> 8) * w; a[0][2] += (s1 & 255) * w;
+        a[1][0] += (s1 >> 8) * w; a[1][1] += (s2 & 255) * w; a[1][2] += (s2 >> 8) * w;
+    };
+    if constexpr (KS == 0) {
+        for (int k = 0; k < ksize; ++k) tap(k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) tap(k);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[q][c] = clamp_u8(a[q][c] >> PRECISION_BITS);
+}
+
 __global__ __launch_bounds__(256) void k_tile_patches(const unsigned char* __restrict__ images, int H, int W,
                                                       const int* __restrict__ tiles, const int* __restrict__ coef_xmin,
                                                       const int* __restrict__ coef_kk, const int* __restrict__ coef_ksize,
                                                       const f16* __restrict__ lut, f16* __restrict__ patches, int p,
                                                       int flip, int n_tiles) {
-    __shared__ unsigned char sh[MAX_IN_ROWS][OUT_RES][3];
+    __shared__ __attribute__((aligned(16))) unsigned char sh[MAX_IN_ROWS][OUT_RES][3];
     __shared__ int s_xmin[OUT_RES];
+    __shared__ int s_ky[BAND][KMAX];
+    __shared__ f16 s_lut[3 * 256];
     const int t = blockIdx.x, band = blockIdx.y, tid = threadIdx.x;
     const int img = tiles[t * 5 + 0], row0 = tiles[t * 5 + 1], col0 = tiles[t * 5 + 2], ts = tiles[t * 5 + 3], cid = tiles[t * 5 + 4];
     const int* xmin = coef_xmin + cid * OUT_RES;
     const int* kk = coef_kk + (long)cid * OUT_RES * KMAX;
     const int ksize = coef_ksize[cid];
-    for (int i = tid; i < OUT_RES; i += 256) s_xmin[i] = xmin[i];
-    __syncthreads();
     const int y_first = band * BAND, y_last = y_first + BAND - 1;
+    for (int i = tid; i < OUT_RES; i += 256) s_xmin[i] = xmin[i];
+    for (int i = tid; i < BAND * KMAX; i += 256) s_ky[i / KMAX][i % KMAX] = kk[(y_first + i / KMAX) * KMAX + i % KMAX];
+    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = lut[i];
+    __syncthreads();
     const int r_lo = s_xmin[y_first];
     int r_hi = s_xmin[y_last] + ksize;          // exclusive
     if (r_hi > ts) r_hi = ts;
@@ -95,58 +189,65 @@ __global__ __launch_bounds__(256) void k_tile_patches(const unsigned char* __res
     const unsigned char* src = images + ((long)img * H + row0) * W * 3 + (long)col0 * 3;
     const bool identity = (ts == OUT_RES);
     // ---- phase A: horizontal pass ----
-    for (int e = tid; e < n_rows * OUT_RES; e += 256) {
-        const int rr = e / OUT_RES, x = e - rr * OUT_RES;
-        const unsigned char* srow = src + (long)(r_lo + rr) * W * 3;
-        if (identity) {
+    if (identity) {
+        for (int e = tid; e < n_rows * OUT_RES; e += 256) {
+            const int rr = e / OUT_RES, x = e - rr * OUT_RES;
+            const unsigned char* srow = src + (long)(r_lo + rr) * W * 3;
             sh[rr][x][0] = srow[x * 3]; sh[rr][x][1] = srow[x * 3 + 1]; sh[rr][x][2] = srow[x * 3 + 2];
-            continue;
         }
-        const int x0 = s_xmin[x];
-        const int* kx = kk + x * KMAX;
-        int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-        for (int k = 0; k < ksize; ++k) {
-            int xi = x0 + k; if (xi > ts - 1) xi = ts - 1;        // taps past the edge carry weight 0
-            const int w = kx[k];
-            a0 += (int)srow[xi * 3] * w; a1 += (int)srow[xi * 3 + 1] * w; a2 += (int)srow[xi * 3 + 2] * w;
+    } else if (tid < OUT_RES) {
+        const int* kx = kk + tid * KMAX;
+        const int x0 = s_xmin[tid];
+        switch (ksize) {                          // workgroup-uniform
+            case 5: tile_hpass<5>(src, W, ts, ksize, kx, x0, r_lo, n_rows, sh, tid); break;
+            case 7: tile_hpass<7>(src, W, ts, ksize, kx, x0, r_lo, n_rows, sh, tid); break;
+            case 9: tile_hpass<9>(src, W, ts, ksize, kx, x0, r_lo, n_rows, sh, tid); break;
+            case 11: tile_hpass<11>(src, W, ts, ksize, kx, x0, r_lo, n_rows, sh, tid); break;
+            default: tile_hpass<0>(src, W, ts, ksize, kx, x0, r_lo, n_rows, sh, tid); break;
         }
-        a0 >>= PRECISION_BITS; a1 >>= PRECISION_BITS; a2 >>= PRECISION_BITS;
-        sh[rr][x][0] = (unsigned char)(a0 < 0 ? 0 : (a0 > 255 ? 255 : a0));
-        sh[rr][x][1] = (unsigned char)(a1 < 0 ? 0 : (a1 > 255 ? 255 : a1));
-        sh[rr][x][2] = (unsigned char)(a2 < 0 ? 0 : (a2 > 255 ? 255 : a2));
     }
     __syncthreads();
-    // ---- phase B: vertical pass + normalise + im2col ----
+    // ---- phase B: vertical pass + normalise + im2col; thread = (row group of 8, pixel pair) ----
+    if (tid >= OUT_RES) return;
     const int g = OUT_RES / p, pp = p * p, Kp = 3 * pp;
-    for (int e = tid; e < BAND * OUT_RES; e += 256) {
-        const int yy = e / OUT_RES, x = e - yy * OUT_RES;
+    const int rg = tid / (OUT_RES / 2), x = (tid - rg * (OUT_RES / 2)) * 2;
+    const unsigned short* shs = reinterpret_cast<const unsigned short*>(&sh[0][0][0]);
+    // flip = 2: the resampled tile is written twice, as is into patches[0 .. n_tiles) and mirrored into patches[n_tiles .. 2 n_tiles)
+    const int xf = OUT_RES - 2 - x;               // mirrored pair starts here (even), pixel order swapped
+    const int px0 = x / p, ix0 = x - px0 * p, px1 = xf / p, ix1 = xf - px1 * p;
+    for (int yy = rg * (BAND / 2); yy < (rg + 1) * (BAND / 2); ++yy) {
         const int y = y_first + yy;
-        int v0, v1, v2;
+        int v[2][3];
         if (identity) {
-            const int rr = y - r_lo;
-            v0 = sh[rr][x][0]; v1 = sh[rr][x][1]; v2 = sh[rr][x][2];
+            const unsigned short* s = shs + (((y - r_lo) * OUT_RES + x) >> 1) * 3;
+            const int s0 = s[0], s1 = s[1], s2 = s[2];
+            v[0][0] = s0 & 255; v[0][1] = s0 >> 8; v[0][2] = s1 & 255; v[1][0] = s1 >> 8; v[1][1] = s2 & 255; v[1][2] = s2 >> 8;
         } else {
             const int yb = s_xmin[y] - r_lo;
-            const int* ky = kk + y * KMAX;
-            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-            for (int k = 0; k < ksize; ++k) {
-                int rr = yb + k; if (rr > n_rows - 1) rr = n_rows - 1;
-                const int w = ky[k];
-                a0 += (int)sh[rr][x][0] * w; a1 += (int)sh[rr][x][1] * w; a2 += (int)sh[rr][x][2] * w;
+            switch (ksize) {
+                case 5: tile_vpass<5>(shs, s_ky[yy], ksize, yb, n_rows, x, v); break;
+                case 7: tile_vpass<7>(shs, s_ky[yy], ksize, yb, n_rows, x, v); break;
+                case 9: tile_vpass<9>(shs, s_ky[yy], ksize, yb, n_rows, x, v); break;
+                case 11: tile_vpass<11>(shs, s_ky[yy], ksize, yb, n_rows, x, v); break;
+                default: tile_vpass<0>(shs, s_ky[yy], ksize, yb, n_rows, x, v); break;
             }
-            a0 >>= PRECISION_BITS; a1 >>= PRECISION_BITS; a2 >>= PRECISION_BITS;
-            v0 = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0); v1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1); v2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
         }
-        const f16 o0 = lut[v0], o1 = lut[256 + v1], o2 = lut[512 + v2];
-        const int py = y / p, iy = y - py * p;
-        // flip = 2: the resampled tile is written twice, as is into patches[0 .. n_tiles) and mirrored into patches[n_tiles .. 2 n_tiles)
+        f16x2 o[3], of[3];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            if (flip != 2 && f != flip) continue;
-            const int xo = f ? (OUT_RES - 1 - x) : x;
-            const int px = xo / p, ix = xo - px * p;
-            f16* dst = patches + ((long)((flip == 2 && f) ? t + n_tiles : t) * g * g + py * g + px) * Kp + iy * p + ix;
-            dst[0] = o0; dst[pp] = o1; dst[2 * pp] = o2;
+        for (int c = 0; c < 3; ++c) {
+            const f16 l = s_lut[c * 256 + v[0][c]], r = s_lut[c * 256 + v[1][c]];
+            o[c][0] = l; o[c][1] = r; of[c][0] = r; of[c][1] = l;
+        }
+        const int py = y / p, iy = y - py * p;
+        if (flip != 1) {
+            f16* dst = patches + ((long)t * g * g + py * g + px0) * Kp + iy * p + ix0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<f16x2*>(dst + c * pp) = o[c];
+        }
+        if (flip != 0) {
+            f16* dst = patches + ((long)(flip == 2 ? t + n_tiles : t) * g * g + py * g + px1) * Kp + iy * p + ix1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *reinterpret_cast<f16x2*>(dst + c * pp) = of[c];
         }
     }
 }

@@ -128,17 +128,20 @@ def _init_clip(arch, chunk=64):
     return ClipWrapper, sd
 
 
-@pytest.mark.parametrize("p", [32, 16])
-def test_tile_patches_bit_exact(p):
-    """crop -> Pillow-exact bicubic -> normalise -> im2col: equal to the oracle's fp32 tile rounded once to fp16."""
+@pytest.mark.parametrize("p,H,cfg", [
+    (32, 240, [(240, 60), (224, 8), (160, 40), (60, 90), (17, 111)]),            # 7 / identity / 5 / 5 / 5 taps
+    (16, 240, [(240, 60), (224, 8), (160, 40), (60, 90), (17, 111)]),
+    (14, 240, [(240, 60), (224, 8), (97, 70)]),                                  # ViT-L/14's patch: pixel pairs never straddle a patch
+    (16, 600, [(600, 1), (480, 60), (400, 100), (300, 150), (337, 131)]),        # 13 (generic tap loop) / 11 / 9 / 7 / 9 taps
+])
+def test_tile_patches_bit_exact(p, H, cfg):
+    """crop -> Pillow-exact bicubic -> normalise -> im2col: equal to the oracle's fp32 tile rounded once to fp16; flip = 2 writes both passes."""
     from semabs_amd import _lib
     from semabs_amd.clip import ClipWrapper, plan_tiles
     CW, _ = _init_clip("ViT-B/32" if p == 32 else "ViT-B/16")
-    H = W = 240
+    W = H
     imgs = np.stack([synth_rgb(H, W, seed=3), synth_rgb(H, W, seed=4)])
-    cfg = [{"tile_size": 240, "stride": 60}, {"tile_size": 224, "stride": 8}, {"tile_size": 160, "stride": 40},
-           {"tile_size": 60, "stride": 90}, {"tile_size": 17, "stride": 111}]
-    table, _ = plan_tiles(H, W, 2, cfg)
+    table, _ = plan_tiles(H, W, 2, [{"tile_size": a, "stride": b} for a, b in cfg])
     sel = np.unique(np.concatenate([np.arange(0, len(table), 5), np.arange(len(table) - 3, len(table))]))
     table = table[sel]
     co = CW._coeffs
@@ -147,16 +150,18 @@ def test_tile_patches_bit_exact(p):
     tiles_dev = torch.from_numpy(np.concatenate([table, ids[:, None]], 1).astype(np.int32)).cuda()
     g = 224 // p
     imgs_d = torch.from_numpy(imgs).cuda()
-    for flip in (0, 1):
-        patches = torch.zeros(len(table) * g * g, 3 * p * p, dtype=torch.float16, device="cuda")
-        _lib.call("semabs_tile_patches", _lib.ptr(imgs_d), 2, H, W, _lib.ptr(tiles_dev), len(table),
+    n = len(table)
+    ref = np.stack([op.preprocess_tile(imgs[im][x:x + ts, y:y + ts]) for im, x, y, ts in table]).astype(np.float16)
+    outs = {}
+    for flip in (0, 1, 2):
+        patches = torch.zeros((2 if flip == 2 else 1) * n * g * g, 3 * p * p, dtype=torch.float16, device="cuda")
+        _lib.call("semabs_tile_patches", _lib.ptr(imgs_d), 2, H, W, _lib.ptr(tiles_dev), n,
                   _lib.ptr(xmin_d), _lib.ptr(kk_d), _lib.ptr(ks_d), _lib.ptr(CW._lut), _lib.ptr(patches), p, flip,
                   max(co.ksize), _lib.stream())
-        got = patches.cpu().view(len(table), g, g, 3, p, p).permute(0, 3, 1, 4, 2, 5).reshape(len(table), 3, 224, 224)
-        ref = np.stack([op.preprocess_tile(imgs[im][x:x + ts, y:y + ts]) for im, x, y, ts in table])
-        if flip:
-            ref = ref[..., ::-1]
-        assert np.array_equal(got.numpy(), ref.astype(np.float16)), f"flip={flip}"
+        outs[flip] = patches.cpu().view(-1, g, g, 3, p, p).permute(0, 3, 1, 4, 2, 5).reshape(-1, 3, 224, 224).numpy()
+    assert np.array_equal(outs[0], ref)
+    assert np.array_equal(outs[1], ref[..., ::-1])
+    assert np.array_equal(outs[2][:n], ref) and np.array_equal(outs[2][n:], ref[..., ::-1])
 
 
 @pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours"), ("ours64x48", "ours")])
