@@ -98,6 +98,10 @@ int semabs_patchify(const float* x, void* patches, int n, int patch, int flip, v
 int semabs_aggregate(const float* rel, const float* rel_flip, int L, int N, int g, int H, int W, const int* scales,
                      int n_scales, int n_img, int tiles_per_img, float* out, void* stream);
 
+/* the un-flip average alone (CLIP/clip/__init__.py:196-204): out[m, h, w] = (rel[m, h, w] + rel_flip[m, h, g - 1 - w]) / 2 for n_maps = L * N maps
+ * [g, g]; aggregating `out` with rel_flip = NULL equals semabs_aggregate(rel, rel_flip) bit for bit at half the loads per covering tile. */
+int semabs_unflip_average(const float* rel, const float* rel_flip, float* out, long n_maps, int g, void* stream);
+
 /* ColorJitter(0.6, 0.6, 0.6, 0.1) family for the augmentation copies      CLIP/clip/__init__.py:55-57, 246-247
  * img uint8 [H, W, 3] in place; order4 / factors4 HOST arrays (op: 0 brightness 1 contrast 2 saturation 3 hue);
  * scratch8: 8 bytes of device memory. */

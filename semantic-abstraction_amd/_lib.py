@@ -43,6 +43,7 @@ SIGNATURES = {
     "semabs_tile_patches": [P, I, I, I, P, I, P, P, P, P, P, I, I, I, P],
     "semabs_patchify": [P, P, I, I, I, P],
     "semabs_aggregate": [P, P, I, I, I, I, I, P, I, I, I, P, P],
+    "semabs_unflip_average": [P, P, P, L, I, P],
     "semabs_color_jitter": [P, I, I, C.POINTER(I), C.POINTER(F), P, P],
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],

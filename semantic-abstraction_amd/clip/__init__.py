@@ -336,8 +336,11 @@ class ClipWrapper:
         L, N, g = int(rel[0].shape[0]), int(rel[0].shape[1]), int(rel[0].shape[2])
         out = torch.empty(L, H, W, dtype=torch.float32, device=dev)
         sc = torch.from_numpy(np.ascontiguousarray(scales, np.int32)).to(dev)
-        _lib.call("semabs_aggregate", _lib.ptr(rel[0]), _lib.ptr(rel[1]) if len(rel) > 1 else None, L, N, g, H, W,
-                  _lib.ptr(sc), len(scales), n_img, N // n_img, _lib.ptr(out), _lib.stream())
+        maps = rel[0]
+        if len(rel) > 1:                                # un-flip average once per map cell instead of once per covered pixel (bit-identical, half the loads)
+            maps = torch.empty_like(rel[0])
+            _lib.call("semabs_unflip_average", _lib.ptr(rel[0]), _lib.ptr(rel[1]), _lib.ptr(maps), L * N, g, _lib.stream())
+        _lib.call("semabs_aggregate", _lib.ptr(maps), None, L, N, g, H, W, _lib.ptr(sc), len(scales), n_img, N // n_img, _lib.ptr(out), _lib.stream())
         return out
 
 

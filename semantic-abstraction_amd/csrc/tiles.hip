@@ -371,6 +371,24 @@ extern "C" int semabs_aggregate(const float* rel, const float* rel_flip, int L, 
     return SEMABS_OK;
 }
 
+// un-flip average of the two passes (CLIP/clip/__init__.py:196-204): out[m, h, w] = (rel[m, h, w] + rel_flip[m, h, g - 1 - w]) / 2, once per map cell.
+// `semabs_aggregate` with rel_flip does the same average per covered PIXEL per covering tile (8 loads per tile instead of 4, ~500 covering tiles per
+// pixel at the headline shape): callers that have both passes average first and aggregate the result - same operation on the same operands, bit-identical.
+__global__ void k_unflip_average(const float* __restrict__ rel, const float* __restrict__ rel_flip, float* __restrict__ out, long n, int g) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int w = (int)(i % g);
+    out[i] = (rel[i] + rel_flip[i - w + (g - 1 - w)]) / 2;
+}
+extern "C" int semabs_unflip_average(const float* rel, const float* rel_flip, float* out, long n_maps, int g, void* stream) {
+    if (n_maps == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(rel && rel_flip && out && n_maps > 0 && g > 0, "semabs_unflip_average: bad args");
+    const long n = n_maps * g * g;
+    hipLaunchKernelGGL(k_unflip_average, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rel, rel_flip, out, n, g);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Colour jitter for the augmentation copies (ClipWrapper.jittering_transforms = ColorJitter(0.6, 0.6, 0.6, 0.1),
 // CLIP/clip/__init__.py:55-57, 246-247).  The reference's jitter is random (torchvision), so there is no parity

@@ -176,7 +176,17 @@ def test_aggregate_vs_golden(golden, tag, cfgname):
     rel = [torch.from_numpy(g[f"{tag}_rel"]).cuda()]
     if flip:
         rel.append(torch.from_numpy(g[f"{tag}_rel_flip"]).cuda())
-    out = CW.aggregate_device(rel, scales, aug + 1, H, W).cpu().numpy()
+    out_d = CW.aggregate_device(rel, scales, aug + 1, H, W)
+    if flip:
+        # aggregate_device averages the two passes once per map cell (semabs_unflip_average) and aggregates the result; the one-call form averages per
+        # covered pixel: the same operation on the same operands - bit-identical
+        from semabs_amd import _lib
+        one = torch.empty_like(out_d)
+        sc = torch.from_numpy(np.ascontiguousarray(scales, np.int32)).cuda()
+        N = int(rel[0].shape[1])
+        _lib.call("semabs_aggregate", _lib.ptr(rel[0]), _lib.ptr(rel[1]), L, N, gg, H, W, _lib.ptr(sc), len(scales), aug + 1, N // (aug + 1), _lib.ptr(one), _lib.stream())
+        assert torch.equal(one, out_d)
+    out = out_d.cpu().numpy()
     ref = g[f"{tag}_maps"]
     err = np.abs(out - ref)
     # same adds in the same order; an fp32 last-bit difference in the bilinear sample can flip one fp16 rounding of a
