@@ -393,7 +393,6 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
         boff[j] = (unsigned)(row * g.ldb * 2 + (swzB8(row, scp) - row * 128));
     }
     // (the swizzle terms of rows r and r + 64 are equal, so piece j = 1 is piece 0 + 64 rows: the deep schedule passes that through the scalar offset)
-    const unsigned a_q = (unsigned)(64 * (int)g.lda * 2), b_q = (unsigned)(64 * g.ldb * 2);
     const unsigned a_half = (unsigned)(128 * (int)g.lda * 2), b_half = (unsigned)(128 * g.ldb * 2);
     __amdgpu_buffer_rsrc_t rA, rB;                          // per tile: rows past M read as zeros (they only feed output rows that are never stored)
     auto set_tile = [&](long m0, int n0) {
