@@ -56,6 +56,19 @@ def line(label):
 
 what = sys.argv[1:] or ["base", "ablate", "trace"]
 log = {}
+if "datadep" in what:
+    # The PRODUCTION kernels on operands of decreasing switching activity: the same instruction stream, the same bytes moved - what changes is the power the
+    # matrix pipe draws, i.e. the clock the part holds.  (SEMABS_TUNE_LIB=0 python tools/gemm_probe.py datadep)
+    for kind in ("random (the trunk's statistics)", "constant 0.5", "zeros"):
+        for key in list(bufs):
+            del bufs[key]
+        for name, n, k, epi in SHAPES:
+            A, B, bias, C = operands(n, k, epi)
+            if kind != "random (the trunk's statistics)":
+                v = 0.5 if kind.startswith("constant") else 0.0
+                A.fill_(v); B.fill_(v * 0.1); bias.fill_(v); C.zero_()
+        log["datadep " + kind] = line("operands: " + kind)
+
 if "table" in what:
     # per-shape table of the production configuration + the vendor library's PLAIN fp16 GEMM (torch.matmul -> hipBLASLt, no bias / GELU /
     # residual) as calibration of what a large fp16 GEMM reaches on this box at these shapes
