@@ -1383,6 +1383,11 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + ((cchunk ^ ((row >> 1) & 3)) << 4));
 #ifdef SEMABS_TUNING
                     if (g.ablate & 32) { buf_store4<2>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }
+                    if (g.ablate & 256) { buf_store4<17>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }     // sc0 sc1
+                    if (g.ablate & 512) { buf_store4<18>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }     // nt sc1
+                    if (g.ablate & 1024) { buf_store4<1>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }     // sc0
+                    if (g.ablate & 2048) { buf_store4<16>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }    // sc1
+                    if (g.ablate & 4096) { buf_store4<19>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v); continue; }    // sc0 nt sc1
 #endif
                     buf_store4<0>(rC, voff, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldcb + (unsigned)(hb * 128 * 2), v);
                 }

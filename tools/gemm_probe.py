@@ -190,7 +190,8 @@ if "policy" in what:
     # cache-policy experiment on the persistent fp16-output kernel (tuning build): nt on the C stores / the A stream / the W stream
     SH = SHAPES; SHAPES = [SH[0], SH[2]]; KERNEL = 2
     for rep in range(2):
-        for ab, label in [(0, "default policy"), (32, "nt C stores"), (64, "nt A loads"), (128, "nt W loads"), (96, "nt C stores + nt A loads")]:
+        for ab, label in [(0, "default policy"), (32, "nt C stores"), (64, "nt A loads"), (128, "nt W loads"), (96, "nt C stores + nt A loads"),
+                          (256, "sc0 sc1 C stores"), (512, "nt sc1 C stores"), (1024, "sc0 C stores"), (2048, "sc1 C stores"), (4096, "sc0 nt sc1 C stores")]:
             tune(2, ab)
             log[f"policy{ab}_{rep}"] = line(f"k_gemm8p {label} (rep {rep})")
     tune(2, 0); SHAPES = SH; KERNEL = 0
