@@ -186,6 +186,42 @@ if "abltrace" in what:
                 print(f"{'PF  ' if kern & 2048 else 'deep'} {label:28s} {name:5s} {us:7.1f}us {2.0 * M * n * k / us / 1e6:6.0f}TF  main loop {((t[:, 1] - t[:, 0]) / 100.0).mean():6.2f}us = "
                       f"{(t[:, 5] - t[:, 4]).mean() / (k // 64):6.0f} cycles per K tile at {ghz:.3f} GHz; tile end - start {((t[:, 2] - t[:, 0]) / 100.0).mean():6.2f}us", flush=True)
     tune(2, 0)
+if "power" in what:
+    # ENERGY attribution (tuning build): per compile-time ablation of the deep schedule and per operand kind, the QKV GEMM launched back to back for ~4 s with rocm-smi
+    # sampled from a thread: us per launch, socket power, sclk, joules per launch.  (python tools/gemm_probe.py power)
+    import re, subprocess, threading, time
+    def smi():
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True).stdout
+        pw = re.search(r"Power \(W\): ([0-9.]+)", out); ck = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+        return (float(pw.group(1)) if pw else float("nan"), float(ck.group(1)) if ck else float("nan"))
+    name, n, k, epi = SHAPES[0]
+    for kind in ("random", "zeros"):
+        for key in list(bufs):
+            del bufs[key]
+        A, B, bias, C = operands(n, k, epi)
+        if kind == "zeros":
+            A.zero_(); B.zero_(); bias.zero_()
+        for ab, label in [(0, "full kernel"), (8, "no epilogue"), (9, "no epilogue, no DMA"), (10, "no epilogue, no LDS reads"), (15, "MFMA + barriers only")]:
+            tune(2, ab)
+            for _ in range(3):
+                gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=2 | 4096)
+            torch.cuda.synchronize()
+            samples, stop = [], threading.Event()
+            th = threading.Thread(target=lambda: [samples.append(smi()) or time.sleep(0.3) for _ in iter(lambda: stop.is_set(), True)])
+            t0 = time.time(); launches = 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            th.start(); e0.record()
+            while time.time() - t0 < 4.0:
+                for _ in range(40):
+                    gemm(A, B, C, bias, M, n, k, k, k, n, epi, kernel=2 | 4096)
+                launches += 40
+                torch.cuda.synchronize()
+            e1.record(); torch.cuda.synchronize(); stop.set(); th.join()
+            us = e0.elapsed_time(e1) / launches * 1e3
+            sm = np.array(samples[2:] or samples)
+            pw, ck = float(np.nanmean(sm[:, 0])), float(np.nanmean(sm[:, 1]))
+            print(f"{kind:7s} {label:28s} {us:7.1f} us  {2.0 * M * n * k / us / 1e6:6.0f} TF  {pw:6.0f} W  sclk {ck:5.0f} MHz  {pw * us * 1e-6:5.2f} J per launch", flush=True)
+    tune(2, 0)
 if "policy" in what:
     # cache-policy experiment on the persistent fp16-output kernel (tuning build): nt on the C stores / the A stream / the W stream
     SH = SHAPES; SHAPES = [SH[0], SH[2]]; KERNEL = 2
