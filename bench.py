@@ -198,6 +198,181 @@ def parity_report(pipe, arch, precision):
     return out
 
 
+
+class SmiSampler:
+    """Shader clock and socket power of THIS rank's GPU sampled on a side thread while the timed region runs (the power-cap
+    explanation of the GEMM fraction must be visible in the driver-run line, not only in builder-run logs).  Sources, first that works: the amdsmi
+    python binding (amdsmi_get_power_info / amdsmi_get_clock_info GFX / amdsmi_get_power_cap_info), the amdgpu hwmon files (power1_average |
+    power1_input, power1_cap, freq1_input), `rocm-smi --showpower --showclocks` (slow: ~1 sample / s).  Reads cost ~0.1-1 ms of host time each and
+    take no GPU time; the period is 50 ms."""
+
+    def __init__(self, device_index=0, period_s=0.05):
+        import threading
+        self.period = period_s
+        self.samples = []                                   # (t, sclk_mhz | None, power_w | None)
+        self.cap_w = None
+        self.source = None
+        self._stop = threading.Event()
+        self._thread = None
+        self._read = None
+        bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            bdf = None
+        for mk in (self._mk_amdsmi, self._mk_hwmon, self._mk_cli):
+            try:
+                rd = mk(device_index, bdf)
+                if rd is not None and rd() != (None, None):
+                    self._read = rd
+                    break
+            except Exception:
+                continue
+
+    # -- sources --
+    def _mk_amdsmi(self, idx, bdf):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        h = None
+        if bdf:
+            for c in hs:
+                try:
+                    if amdsmi.amdsmi_get_gpu_device_bdf(c).lower().startswith(bdf):
+                        h = c
+                        break
+                except Exception:
+                    pass
+        if h is None:
+            h = hs[idx if idx < len(hs) else 0]
+        try:
+            ci = amdsmi.amdsmi_get_power_cap_info(h)
+            cap = float(ci.get("power_cap", 0))
+            self.cap_w = cap / 1e6 if cap > 1e5 else (cap if cap > 0 else None)      # microwatts in this binding; watts in older ones
+        except Exception:
+            pass
+        num = lambda v: float(v) if isinstance(v, (int, float)) else None
+
+        def rd():
+            w = f = None
+            try:
+                pi = amdsmi.amdsmi_get_power_info(h)
+                for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                    v = num(pi.get(k))
+                    if v is not None and v > 0:
+                        w = v
+                        break
+                if self.cap_w is None and num(pi.get("power_limit")):
+                    pl = num(pi["power_limit"])
+                    self.cap_w = pl / 1e6 if pl > 1e5 else pl
+            except Exception:
+                pass
+            try:
+                ck = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                for k in ("clk", "cur_clk", "current_clk"):
+                    v = num(ck.get(k))
+                    if v is not None and v > 0:
+                        f = v
+                        break
+            except Exception:
+                pass
+            return f, w
+        self.source = "amdsmi (amdsmi_get_clock_info GFX, amdsmi_get_power_info socket power, amdsmi_get_power_cap_info)"
+        return rd
+
+    def _mk_hwmon(self, idx, bdf):
+        import glob
+        cands = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            dev = os.path.realpath(os.path.join(hw, "..", ".."))
+            if any(os.path.exists(os.path.join(hw, f)) for f in ("power1_average", "power1_input")):
+                cands.append((hw, dev))
+        if not cands:
+            return None
+        pick = next((c for c in cands if bdf and bdf in c[1].lower()), cands[idx if idx < len(cands) else 0])
+        hw = pick[0]
+        pf = next(f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f)))
+        rdnum = lambda f: float(open(os.path.join(hw, f)).read().strip())
+        try:
+            self.cap_w = rdnum("power1_cap") / 1e6
+        except Exception:
+            pass
+
+        def rd():
+            w = f = None
+            try:
+                w = rdnum(pf) / 1e6
+            except Exception:
+                pass
+            try:
+                f = rdnum("freq1_input") / 1e6
+            except Exception:
+                pass
+            return f, w
+        self.source = f"amdgpu hwmon ({pf}, freq1_input, power1_cap)"
+        return rd
+
+    def _mk_cli(self, idx, bdf):
+        import re
+        import shutil
+        import subprocess
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        if not os.path.exists(exe):
+            return None
+
+        def rd():
+            w = f = None
+            try:
+                o = subprocess.run([exe, "-d", str(idx), "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+                m = re.search(r"Socket Graphics Package Power \(W\):\s*([0-9.]+)", o) or re.search(r"Power \(W\):\s*([0-9.]+)", o)
+                w = float(m.group(1)) if m else None
+                m = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", o)
+                f = float(m.group(1)) if m else None
+                m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", o)
+                if m and self.cap_w is None:
+                    self.cap_w = float(m.group(1))
+            except Exception:
+                pass
+            return f, w
+        self.period = max(self.period, 0.5)
+        self.source = "rocm-smi --showpower --showclocks (subprocess, ~1 sample / s)"
+        return rd
+
+    # -- control --
+    def start(self):
+        import threading
+        if self._read is None:
+            return
+        self.samples = []
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                f, w = self._read()
+                self.samples.append((time.perf_counter(), f, w))
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=15)
+            self._thread = None
+
+    def summary(self):
+        """Fields merged into `roofline`: always present (None when no source answered on this box)."""
+        fs = [s[1] for s in self.samples if s[1]]
+        ws = [s[2] for s in self.samples if s[2]]
+        med = lambda v: float(np.median(v)) if v else None
+        return {"sclk_mhz_under_load": med(fs), "sclk_mhz_min_max": [float(min(fs)), float(max(fs))] if fs else None,
+                "power_w": med(ws), "power_w_max": float(max(ws)) if ws else None, "power_cap_w": self.cap_w,
+                "smi_samples": len(self.samples), "smi_source": self.source,
+                "smi_note": "medians over the timed region (side thread, 50 ms period, this rank's GPU); the whole scene runs in it, not only the GEMMs: "
+                            "the UNet / attention / LayerNorm phases draw less than the GEMM phases, so the GEMM-only figures are at or above these"}
+
+
 HBM_PEAK_TBS = 8.0                                                # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
 HBM_COPY_TBS = 6.3                                                # what a float4 copy kernel reaches on this part (same guide)
 EPI_NAMES = {0: "bias -> fp16", 1: "bias + QuickGELU -> fp16", 2: "bias + fp32 residual read-modify-write", 3: "bias -> fp32", 4: "row-remapped fp32", 5: "row-table multiply -> fp16"}
@@ -623,7 +798,10 @@ def main():
         dist.barrier()
     timer = vitmod.GemmTimer(every=args.time_every)
     vitmod.GEMM_TIMER = timer
+    smi = SmiSampler(local) if rank == 0 else None
     torch.cuda.synchronize()
+    if smi is not None:
+        smi.start()
     t0 = time.perf_counter()
     res = run_range(args.warmup, n_scenes)
     # the job's results leave the ranks through RCCL: every rank's last label volume is all-gathered (scene-shard mode has no other payload collective;
@@ -636,6 +814,8 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if smi is not None:
+        smi.stop()
     vitmod.GEMM_TIMER = None
     if dist is not None:
         t = torch.tensor([dt], device="cpu" if args.backend == "gloo" else "cuda", dtype=torch.float64)
@@ -711,6 +891,7 @@ def main():
                          # context, not the judged fraction: what back-to-back MFMAs reach on this part (imported probe results, profiles/r03_mfma_probes.txt)
                          "mfma_probe": MFMA_PROBE and dict(MFMA_PROBE, frac_of_random_operand_skeleton=ach / MFMA_PROBE["skeleton_random_operands_tflops"])},
         }
+        out["roofline"].update(smi.summary())
         out["timed_region"] = ("per scene, everything from the uint8 frame + fp32 depth resident in HBM to the label volume: " +
                                ("the text tower on the 16 labels' token ids (the reference encodes the label set on every get_clip_saliency call), " if text_enc is not None else "") +
                                "colour jitter, tiling, ViT + rollout, aggregation, unprojection + compaction + sub-sample, point MLP, scatter, UNet, decoder, TSDF, "

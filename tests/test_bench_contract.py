@@ -48,6 +48,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "profiles/r04_" in (rf.get("traffic_source") or "profiles/r04_"), rf.get("traffic_source")
     assert rf["mfma_probe"] is None or "imported" in rf["mfma_probe"]["source"]
     assert d.get("text_tower_in_timed_region") is True
+    # clock and power under load, sampled in THIS run: the keys are always there; on a box with any SMI source they carry numbers
+    for k in ("sclk_mhz_under_load", "power_w", "power_cap_w", "smi_source", "smi_samples"):
+        assert k in rf, k
+    if rf["smi_source"] is not None:
+        assert rf["smi_samples"] > 0 and (rf["sclk_mhz_under_load"] or rf["power_w"])
+        assert rf["sclk_mhz_under_load"] is None or 100 < rf["sclk_mhz_under_load"] < 3000
+        assert rf["power_w"] is None or 50 < rf["power_w"] < 2000
 
 
 @pytest.mark.gpu
