@@ -102,10 +102,14 @@ int semabs_aggregate(const float* rel, const float* rel_flip, int L, int N, int 
  * [g, g]; aggregating `out` with rel_flip = NULL equals semabs_aggregate(rel, rel_flip) bit for bit at half the loads per covering tile. */
 int semabs_unflip_average(const float* rel, const float* rel_flip, float* out, long n_maps, int g, void* stream);
 
-/* ColorJitter(0.6, 0.6, 0.6, 0.1) family for the augmentation copies      CLIP/clip/__init__.py:55-57, 246-247
- * img uint8 [H, W, 3] in place; order4 / factors4 HOST arrays (op: 0 brightness 1 contrast 2 saturation 3 hue);
- * scratch8: 8 bytes of device memory. */
+/* ColorJitter(0.6, 0.6, 0.6, 0.1) of the augmentation copies             CLIP/clip/__init__.py:55-57, 246-247
+ * (torchvision 0.13.1 ColorJitter.forward on the PIL image: functional_pil.adjust_brightness / _contrast / _saturation / _hue = Pillow
+ *  ImageEnhance blends and the uint8 HSV hue rotation; byte-exact against Pillow, tests/golden/g28_color_jitter.npz)
+ * img uint8 [H, W, 3] in place; order4 (a permutation of the op ids) / factors4 (indexed by op id) HOST arrays;
+ * op: 0 brightness 1 contrast 2 saturation 3 hue (hue factor in [-0.5, 0.5]); scratch8: 8 bytes of device memory. */
 int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, const float* factors4, void* scratch8, void* stream);
+/* One adjustment of the above, in place (torchvision functional_pil.adjust_*). */
+int semabs_color_jitter_op(unsigned char* img, int H, int W, int op, float factor, void* scratch8, void* stream);
 
 /* ============================ dense contractions (csrc/gemm.hip) ======================================== */
 

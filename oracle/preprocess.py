@@ -102,3 +102,107 @@ def preprocess_tile(crop_u8: np.ndarray) -> np.ndarray:
     """Square uint8 crop [ts, ts, 3] -> fp32 [3, 224, 224] (CenterCrop(224) of a 224x224 image is the identity)."""
     assert crop_u8.shape[0] == crop_u8.shape[1], "tiles on the path are square"
     return normalize_u8(resize_bicubic_u8(crop_u8))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Colour jitter of the augmentation copies: `ClipWrapper.jittering_transforms = ColorJitter(brightness=0.6, contrast=0.6,
+# saturation=0.6, hue=0.1)` applied to the PIL image (`CLIP/clip/__init__.py:55-57, 246-247`).  The arithmetic lives in two
+# third-party dependencies absent from /root/reference: torchvision 0.13.1 (`semabs.yml:129`: transforms.ColorJitter.forward ->
+# functional_pil.adjust_brightness / adjust_contrast / adjust_saturation / adjust_hue, applied in the order of a random permutation
+# with factors U(0.4, 1.6)^3, U(-0.1, 0.1)) and Pillow 9.2.0 (`semabs.yml:101`; this image: 12.2.0): ImageEnhance.Brightness /
+# Contrast / Color = Image.blend(degenerate, image, factor) (libImaging/Blend.c), convert("L") (Convert.c rgb2l: ITU-R 601-2 luma
+# in 16.16 fixed point), convert("HSV") / convert("RGB") (Convert.c rgb2hsv_row / hsv2rgb: uint8-quantised H, S, V).  Restated here
+# in numpy; pinned BIT-EXACT against this image's Pillow: both HSV conversions on all 2^24 colours, the blends on all 2^24 colours
+# at several factors (tests/golden/gen_golden.py g28 -> tests/test_oracle_golden.py).  The random draw itself is not part of the
+# contract (the reference's is torch's global generator): (order, factors) are arguments.
+#   op ids as in torchvision's fn_idx: 0 brightness, 1 contrast, 2 saturation, 3 hue.
+# ----------------------------------------------------------------------------------------------------------------------
+def _grey_u8(img: np.ndarray) -> np.ndarray:
+    """convert("L"): (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16."""
+    r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def _blend_u8(degenerate: np.ndarray, img: np.ndarray, factor: float) -> np.ndarray:
+    """Image.blend(degenerate, img, factor): fp32 `d + alpha * (x - d)` (alpha is a C float), truncated; clipped to [0, 255] first when
+    alpha is outside [0, 1] (for alpha inside, the value already is)."""
+    a = np.float32(factor)
+    d, x = degenerate.astype(np.float32), img.astype(np.float32)
+    t = (d + (a * (x - d)).astype(np.float32)).astype(np.float32)
+    return np.where(t <= 0, 0, np.where(t >= 255, 255, t)).astype(np.int32).astype(np.uint8)
+
+
+def jitter_brightness(img: np.ndarray, f: float) -> np.ndarray:
+    return _blend_u8(np.zeros_like(img), img, f)
+
+
+def jitter_contrast(img: np.ndarray, f: float) -> np.ndarray:
+    g = _grey_u8(img)
+    mean = int(float(g.astype(np.int64).sum()) / g.size + 0.5)           # int(ImageStat.Stat(L).mean[0] + 0.5)
+    return _blend_u8(np.full_like(img, mean), img, f)
+
+
+def jitter_saturation(img: np.ndarray, f: float) -> np.ndarray:
+    return _blend_u8(np.repeat(_grey_u8(img)[..., None], 3, axis=2), img, f)
+
+
+def rgb_to_hsv_u8(img: np.ndarray) -> np.ndarray:
+    """Pillow convert("HSV"): fp32 s, rc, gc, bc; h = 2 + rc - bc etc. in double rounded to fp32; fmod(h / 6 + 1, 1) in double; truncation to uint8."""
+    r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    maxc = np.maximum(r, np.maximum(g, b)).astype(np.int32)
+    minc = np.minimum(r, np.minimum(g, b)).astype(np.int32)
+    ok = maxc != minc
+    cr = (maxc - minc).astype(np.float32)
+    crs = np.where(ok, cr, np.float32(1))
+    s = (cr / np.where(maxc > 0, maxc, 1).astype(np.float32)).astype(np.float32)
+    rc = ((maxc - r).astype(np.float32) / crs).astype(np.float32)
+    gc = ((maxc - g).astype(np.float32) / crs).astype(np.float32)
+    bc = ((maxc - b).astype(np.float32) / crs).astype(np.float32)
+    h = np.where(r == maxc, (bc - gc).astype(np.float32),
+                 np.where(g == maxc, (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32),
+                          (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32)))
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    us = np.clip((s.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    return np.stack([np.where(ok, uh, 0), np.where(ok, us, 0), maxc], axis=-1).astype(np.uint8)
+
+
+def hsv_to_rgb_u8(hsv: np.ndarray) -> np.ndarray:
+    """Pillow HSV -> RGB: i = floor(h * 6 / 255), f (fp32) its remainder, p / q / t = round-half-away(v * (1 - ...)) in double."""
+    c_round = lambda x: np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5))
+    s, v = hsv[..., 1], hsv[..., 2]
+    hd = hsv[..., 0].astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hd).astype(np.int32)
+    f = (hd - i.astype(np.float64)).astype(np.float32).astype(np.float64)
+    fs = (s.astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    vf = v.astype(np.float64)
+    p = np.clip(c_round(vf * (1.0 - fs)), 0, 255).astype(np.int32)
+    q = np.clip(c_round(vf * (1.0 - fs * f)), 0, 255).astype(np.int32)
+    t = np.clip(c_round(vf * (1.0 - fs * (1.0 - f))), 0, 255).astype(np.int32)
+    vi = v.astype(np.int32)
+    sec = i % 6
+    out = np.stack([np.choose(sec, [vi, q, p, p, t, vi]), np.choose(sec, [t, vi, vi, q, p, p]), np.choose(sec, [p, p, t, vi, vi, q])], axis=-1)
+    return np.where((s == 0)[..., None], vi[..., None], out).astype(np.uint8)
+
+
+def hue_shift_u8(f: float) -> int:
+    """torchvision functional_pil.adjust_hue: `np_h += np.uint8(hue_factor * 255)` - truncation toward zero, then uint8 wrap-around
+    (numpy 1.22, the reference's pin, wraps a negative value; numpy 2 raises - the wrap is the contract)."""
+    return int(f * 255) % 256
+
+
+def jitter_hue(img: np.ndarray, f: float) -> np.ndarray:
+    hsv = rgb_to_hsv_u8(img)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int32) + hue_shift_u8(f)).astype(np.uint8)
+    return hsv_to_rgb_u8(hsv)
+
+
+JITTER_OPS = (jitter_brightness, jitter_contrast, jitter_saturation, jitter_hue)
+
+
+def color_jitter(img: np.ndarray, order, factors) -> np.ndarray:
+    """uint8 [H, W, 3] -> uint8 [H, W, 3]: the four adjustments in `order` (a permutation of op ids), `factors[op]` each (ColorJitter.forward)."""
+    out = np.ascontiguousarray(img)
+    for op in order:
+        out = JITTER_OPS[int(op)](out, float(factors[int(op)]))
+    return out

@@ -45,6 +45,7 @@ SIGNATURES = {
     "semabs_aggregate": [P, P, I, I, I, I, I, P, I, I, I, P, P],
     "semabs_unflip_average": [P, P, P, L, I, P],
     "semabs_color_jitter": [P, I, I, C.POINTER(I), C.POINTER(F), P, P],
+    "semabs_color_jitter_op": [P, I, I, I, F, P, P],
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
     "semabs_gemm_f16_ex": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), I, P, P, P],

@@ -390,16 +390,58 @@ extern "C" int semabs_unflip_average(const float* rel, const float* rel_flip, fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// Colour jitter for the augmentation copies (ClipWrapper.jittering_transforms = ColorJitter(0.6, 0.6, 0.6, 0.1),
-// CLIP/clip/__init__.py:55-57, 246-247).  The reference's jitter is random (torchvision), so there is no parity
-// target; this is the same family of uint8 -> uint8 point operations (brightness / contrast / saturation blends with
-// truncation, hue rotation in HSV), applied one op per launch in a caller-chosen order with caller-drawn factors.
-//   op: 0 brightness, 1 contrast (needs `mean` = rounded mean of the grey image), 2 saturation, 3 hue
+// Colour jitter for the augmentation copies (ClipWrapper.jittering_transforms = ColorJitter(0.6, 0.6, 0.6, 0.1) on the PIL image,
+// CLIP/clip/__init__.py:55-57, 246-247).  The reference's DRAW is random (torch's global generator), so (order, factors) are caller
+// arguments; the ARITHMETIC is pinned: torchvision 0.13.1's PIL path = Pillow's ImageEnhance.Brightness / Contrast / Color
+// (Image.blend(degenerate, image, factor): fp32 d + alpha (x - d), truncated, clipped when alpha is outside [0, 1]; degenerate = black /
+// the rounded mean of convert("L") / convert("L") itself, L = ITU-R 601-2 luma in 16.16 fixed point) and adjust_hue (convert("HSV") with
+// uint8-quantised H, S, V - Convert.c rgb2hsv_row / hsv2rgb, float / double steps as in the C source - and H += uint8(hue_factor * 255)
+// modulo 256).  Byte-exact against Pillow: tests/golden/g28_color_jitter.npz (all 24 op orders at 480 x 480), oracle/preprocess.py
+// color_jitter (checked on all 2^24 colours), tests/test_gpu_relevancy.py::test_color_jitter_*.  This file is built with -ffp-contract=off.
+//   op: 0 brightness, 1 contrast (needs `mean` = rounded mean of the grey image), 2 saturation, 3 hue   (torchvision's fn_idx)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int grey_u8(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
 __device__ __forceinline__ unsigned char blend_u8(float a, float b, float f) {
     float t = a + f * (b - a);
     return (unsigned char)(t <= 0.f ? 0.f : (t >= 255.f ? 255.f : t));
+}
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// Pillow rgb2hsv_row: s, rc, gc, bc in fp32 (IEEE division); h = 2 + rc - bc / 4 + gc - rc in double rounded to fp32 (bc - gc: fp32);
+// h = (float)fmod(h / 6.0 + 1.0, 1.0); H = (int)(h * 255.0), S = (int)(s * 255.0) (double products, truncation), V = max
+__device__ __forceinline__ void rgb2hsv_u8(int r, int g, int b, int& uh, int& us, int& uv) {
+    const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    uv = maxc;
+    if (minc == maxc) { uh = 0; us = 0; return; }
+    const float cr = (float)(maxc - minc);
+    const float s = __fdiv_rn(cr, (float)maxc);
+    const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+    float h;
+    if (r == maxc) h = __fsub_rn(bc, gc);
+    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    uh = clip8((int)((double)h * 255.0));
+    us = clip8((int)((double)s * 255.0));
+}
+// Pillow hsv2rgb: i = floor(h * 6 / 255) (double), f = fp32 remainder, fs = (float)(s / 255.0); p / q / t = round-half-away(v * (1 - ...)) in double
+__device__ __forceinline__ void hsv2rgb_u8(int h, int s, int v, int& r, int& g, int& b) {
+    if (s == 0) { r = g = b = v; return; }
+    const double hd = (double)(float)h * 6.0 / 255.0;
+    const int i = (int)floor(hd);
+    const double f = (double)(float)(hd - (double)(float)i);
+    const double fs = (double)(float)((double)(float)s / 255.0);
+    const double vf = (double)(float)v;
+    const int p = clip8((int)round(vf * (1.0 - fs)));
+    const int q = clip8((int)round(vf * (1.0 - fs * f)));
+    const int t = clip8((int)round(vf * (1.0 - fs * (1.0 - f))));
+    switch (i % 6) {
+        case 0: r = v; g = t; b = p; break;
+        case 1: r = q; g = v; b = p; break;
+        case 2: r = p; g = v; b = t; break;
+        case 3: r = p; g = q; b = v; break;
+        case 4: r = t; g = p; b = v; break;
+        default: r = v; g = p; b = q; break;
+    }
 }
 
 __global__ void k_grey_sum(const unsigned char* __restrict__ img, long n, unsigned long long* __restrict__ sum) {
@@ -424,49 +466,43 @@ __global__ void k_jitter_op(const unsigned char* __restrict__ src, unsigned char
         float m = (float)grey_u8(r, g, b);
         r = blend_u8(m, r, f); g = blend_u8(m, g, f); b = blend_u8(m, b, f);
     } else {
-        float fr = r / 255.f, fg = g / 255.f, fb = b / 255.f;
-        float mx = fmaxf(fr, fmaxf(fg, fb)), mn = fminf(fr, fminf(fg, fb)), d = mx - mn;
-        float h = 0.f, s = mx > 0.f ? d / mx : 0.f, v = mx;
-        if (d > 0.f) {
-            if (mx == fr) h = fmodf((fg - fb) / d, 6.f);
-            else if (mx == fg) h = (fb - fr) / d + 2.f;
-            else h = (fr - fg) / d + 4.f;
-            h /= 6.f;
-            if (h < 0.f) h += 1.f;
-        }
-        h = h + f; h -= floorf(h);
-        float hh = h * 6.f; int sector = (int)hh; float fr2 = hh - sector;
-        float p = v * (1.f - s), q = v * (1.f - s * fr2), t = v * (1.f - s * (1.f - fr2));
-        float R, G, B;
-        switch (sector % 6) {
-            case 0: R = v; G = t; B = p; break;
-            case 1: R = q; G = v; B = p; break;
-            case 2: R = p; G = v; B = t; break;
-            case 3: R = p; G = q; B = v; break;
-            case 4: R = t; G = p; B = v; break;
-            default: R = v; G = p; B = q; break;
-        }
-        r = (int)(R * 255.f + 0.5f); g = (int)(G * 255.f + 0.5f); b = (int)(B * 255.f + 0.5f);
+        // f carries the hue shift already reduced to uint8 by the host: (int)(hue_factor * 255) mod 256 (torchvision: np.uint8(hue_factor * 255))
+        int uh, us, uv;
+        rgb2hsv_u8(r, g, b, uh, us, uv);
+        uh = (uh + (int)f) & 255;
+        hsv2rgb_u8(uh, us, uv, r, g, b);
     }
     dst[i * 3] = (unsigned char)r; dst[i * 3 + 1] = (unsigned char)g; dst[i * 3 + 2] = (unsigned char)b;
 }
 
-// img uint8 [H, W, 3] jittered IN PLACE; order4 / factors4 are host arrays; scratch = 8 bytes of device memory
+// ONE adjustment, in place.  img uint8 [H, W, 3]; op as above; factor = the torchvision factor (hue: in [-0.5, 0.5]); scratch = 8 bytes of device memory
+extern "C" int semabs_color_jitter_op(unsigned char* img, int H, int W, int op, float factor, void* scratch8, void* stream) {
+    SEMABS_REQUIRE(img && scratch8 && H > 0 && W > 0, "semabs_color_jitter_op: bad args");
+    SEMABS_REQUIRE(op >= 0 && op < 4, "semabs_color_jitter_op: op must be 0..3");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)H * W;
+    float f = factor;
+    if (op == 1) {
+        semabs_fill32(scratch8, 8, 0u, s);
+        hipLaunchKernelGGL(k_grey_sum, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, n, (unsigned long long*)scratch8);
+    } else if (op == 3) {
+        SEMABS_REQUIRE(f >= -0.5f && f <= 0.5f, "semabs_color_jitter_op: hue factor must lie in [-0.5, 0.5] (torchvision adjust_hue)");
+        f = (float)(((int)((double)f * 255.0) % 256 + 256) % 256);      // np.uint8(hue_factor * 255): truncation toward zero, uint8 wrap-around
+    }
+    hipLaunchKernelGGL(k_jitter_op, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, img, n, op, f, (const unsigned long long*)scratch8);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// img uint8 [H, W, 3] jittered IN PLACE by the four adjustments in the order order4 (a permutation of 0..3), factors4[op] each (ColorJitter.forward);
+// order4 / factors4 are host arrays; scratch = 8 bytes of device memory
 extern "C" int semabs_color_jitter(unsigned char* img, int H, int W, const int* order4, const float* factors4,
                                    void* scratch8, void* stream) {
     SEMABS_REQUIRE(img && order4 && factors4 && scratch8 && H > 0 && W > 0, "semabs_color_jitter: bad args");
-    hipStream_t s = (hipStream_t)stream;
-    const long n = (long)H * W;
     for (int k = 0; k < 4; ++k) {
-        const int op = order4[k];
-        SEMABS_REQUIRE(op >= 0 && op < 4, "semabs_color_jitter: op must be 0..3");
-        if (op == 1) {
-            semabs_fill32(scratch8, 8, 0u, s);
-            hipLaunchKernelGGL(k_grey_sum, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, n, (unsigned long long*)scratch8);
-        }
-        hipLaunchKernelGGL(k_jitter_op, dim3(semabs_cdiv(n, 256)), dim3(256), 0, s, img, img, n, op, factors4[op],
-                           (const unsigned long long*)scratch8);
+        SEMABS_REQUIRE(order4[k] >= 0 && order4[k] < 4, "semabs_color_jitter: op must be 0..3");
+        const int rc = semabs_color_jitter_op(img, H, W, order4[k], factors4[order4[k]], scratch8, stream);
+        if (rc != SEMABS_OK) return rc;
     }
-    SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

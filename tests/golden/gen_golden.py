@@ -1213,3 +1213,71 @@ def g27_real_scene():
 
 if __name__ == "__main__" and "g27" in sys.argv[1:]:
     g27_real_scene()
+
+
+# ---- appended (round 5): the colour jitter of the augmentation copies (g28) ------------------------------------------------------------------
+# ClipWrapper.jittering_transforms = torchvision.transforms.ColorJitter(0.6, 0.6, 0.6, 0.1) on the PIL image (CLIP/clip/__init__.py:55-57, 246-247).
+# torchvision is not in this image; its PIL path (0.13.1 functional_pil: ImageEnhance.Brightness / Contrast / Color, and the uint8 hue rotation of
+# convert("HSV")) is four Pillow calls, executed here with this image's Pillow on FIXED (order, factors): all 24 op orders on synth_rgb(480, 480),
+# each op alone, and both HSV conversions on a 2^21-colour lattice (the generator also checks the oracle on all 2^24 colours before writing).
+def _tv_jitter_pil(img_u8, order, factors):
+    from PIL import Image, ImageEnhance
+    im = Image.fromarray(img_u8)
+    for op in order:
+        f = float(factors[op])
+        if op == 0:
+            im = ImageEnhance.Brightness(im).enhance(f)
+        elif op == 1:
+            im = ImageEnhance.Contrast(im).enhance(f)
+        elif op == 2:
+            im = ImageEnhance.Color(im).enhance(f)
+        else:                                                       # functional_pil.adjust_hue
+            h, s, v = im.convert("HSV").split()
+            np_h = np.array(h, dtype=np.uint8)
+            np_h += np.uint8(int(f * 255) % 256)                    # np.uint8(hue_factor * 255) under the reference's numpy 1.22 (wraps when negative)
+            im = Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert("RGB")
+    return np.array(im)
+
+
+def g28_color_jitter():
+    import itertools
+    from PIL import Image
+    import PIL
+    from oracle import preprocess as opre
+    print("g28 colour jitter (Pillow %s)" % PIL.__version__)
+    img = synth_rgb(480, 480, seed=0)
+    orders = np.asarray(list(itertools.permutations(range(4))), np.int32)                      # 24 x 4
+    rng = np.random.default_rng(28)
+    factors = np.stack([rng.uniform(0.4, 1.6, size=24), rng.uniform(0.4, 1.6, size=24), rng.uniform(0.4, 1.6, size=24), rng.uniform(-0.1, 0.1, size=24)], axis=1)
+    factors[0] = [0.4, 1.6, 0.4, -0.1]; factors[1] = [1.6, 0.4, 1.6, 0.1]; factors[2] = [1.0, 1.0, 1.0, 0.0]      # range ends and the identity
+    factors = factors.astype(np.float32).astype(np.float64)           # the C ABI carries fp32 factors; Pillow rounds its alpha to a C float anyway
+    outs = [_tv_jitter_pil(img, list(o), f) for o, f in zip(orders, factors)]
+    sha = np.stack([digest(o) for o in outs])
+    sub = np.stack([o[::5, ::5] for o in outs])
+    single_f = np.asarray([[0.55, 1.45], [0.62, 1.38], [0.47, 1.53], [-0.073, 0.091]])
+    single_sha = np.stack([np.stack([digest(_tv_jitter_pil(img, [op], {op: f})) for f in single_f[op]]) for op in range(4)])
+    # HSV conversions: lattice of 2^21 colours (every second value per channel) for the CPU test, all 2^24 checked against the oracle right here
+    c = np.arange(1 << 24, dtype=np.uint32)
+    allc = np.stack([(c >> 16) & 255, (c >> 8) & 255, c & 255], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)
+    hsv_all = np.array(Image.fromarray(allc).convert("HSV"))
+    rgb_all = np.array(Image.fromarray(allc, "HSV").convert("RGB"))
+    assert np.array_equal(opre.rgb_to_hsv_u8(allc), hsv_all) and np.array_equal(opre.hsv_to_rgb_u8(allc), rgb_all), "oracle != Pillow on the full colour cube"
+    for o, f, ref in zip(orders, factors, outs):
+        assert np.array_equal(opre.color_jitter(img, o, f), ref), (o, f)
+    lat = allc.reshape(256, 256, 256, 3)[::2, ::2, ::2].reshape(-1, 1, 3)
+    # every op alone on the full colour cube (4096 x 4096 image of all 2^24 colours), Pillow's bytes as sha256: the GPU test needs no CPU oracle time
+    cube_ops = np.asarray([[0, 0.55], [0, 1.45], [1, 0.62], [1, 1.38], [2, 0.47], [2, 1.53], [3, 0.0], [3, 0.1], [3, -0.073]])
+    cube_sha = []
+    for opid, f in cube_ops:
+        ref = _tv_jitter_pil(allc, [int(opid)], {int(opid): float(np.float32(f))})
+        assert np.array_equal(opre.JITTER_OPS[int(opid)](allc, float(np.float32(f))), ref), (opid, f)
+        cube_sha.append(digest(ref))
+    save("g28_color_jitter", cube_ops=cube_ops, cube_sha=np.stack(cube_sha), orders=orders, factors=factors, sha=sha, sub=sub, single_f=single_f, single_sha=single_sha,
+         lattice_hsv_sha=digest(np.array(Image.fromarray(np.ascontiguousarray(lat)).convert("HSV"))),
+         lattice_rgb_sha=digest(np.array(Image.fromarray(np.ascontiguousarray(lat), "HSV").convert("RGB"))),
+         allcolours_hsv_sha=digest(hsv_all), allcolours_rgb_sha=digest(rgb_all),
+         meta=np.asarray([480, 480, 0, 1], np.int64), pillow=np.asarray(PIL.__version__))
+
+
+if __name__ == "__main__" and "g28" in sys.argv[1:]:
+    g28_color_jitter()

@@ -164,6 +164,48 @@ def test_tile_patches_bit_exact(p, H, cfg):
     assert np.array_equal(outs[2][:n], ref) and np.array_equal(outs[2][n:], ref[..., ::-1])
 
 
+def _jitter_dev(img_u8, order, factors):
+    from semabs_amd import _lib
+    H, W = img_u8.shape[:2]
+    d = torch.from_numpy(np.ascontiguousarray(img_u8)).cuda()
+    scratch = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.call("semabs_color_jitter", d.data_ptr(), H, W, _lib.iarr([int(o) for o in order]), _lib.farr([float(f) for f in factors]), _lib.ptr(scratch), _lib.stream())
+    return d.cpu().numpy()
+
+
+def test_color_jitter_all_orders_byte_exact(golden):
+    """semabs_color_jitter against torchvision's PIL path executed with Pillow (g28): all 24 op orders at 480 x 480 with fixed factors (incl. the
+    range ends and the identity) - byte equality - and against the oracle on a second image (CLIP/clip/__init__.py:55-57, 246-247)."""
+    from conftest import sha
+    g = golden("g28_color_jitter")
+    img = synth_rgb(int(g["meta"][0]), int(g["meta"][1]), seed=int(g["meta"][2]))
+    for o, f, want, sub in zip(g["orders"], g["factors"], g["sha"], g["sub"]):
+        out = _jitter_dev(img, o, f)
+        assert np.array_equal(out[::5, ::5], sub), (o, f, int((out[::5, ::5] != sub).sum()))
+        assert np.array_equal(sha(out), want), (o, f)
+    img2 = synth_rgb(200, 312, seed=9)
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        o = rng.permutation(4)
+        f = np.asarray([rng.uniform(0.4, 1.6), rng.uniform(0.4, 1.6), rng.uniform(0.4, 1.6), rng.uniform(-0.1, 0.1)], np.float32)
+        assert np.array_equal(_jitter_dev(img2, o, f), op.color_jitter(img2, o, f.astype(np.float64))), (o, f)
+
+
+def test_color_jitter_every_op_on_the_full_colour_cube(golden):
+    """Each adjustment alone (semabs_color_jitter_op) on the 4096 x 4096 image of all 2^24 colours - both blend regimes (factor below / above 1),
+    the hue rotation at 0 / + / - : sha256 of Pillow's bytes (g28)."""
+    from conftest import sha
+    from semabs_amd import _lib
+    g = golden("g28_color_jitter")
+    c = np.arange(1 << 24, dtype=np.uint32)
+    allc = torch.from_numpy(np.stack([(c >> 16) & 255, (c >> 8) & 255, c & 255], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)).cuda()
+    scratch = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for (opid, f), want in zip(g["cube_ops"], g["cube_sha"]):
+        d = allc.clone()
+        _lib.call("semabs_color_jitter_op", d.data_ptr(), 4096, 4096, int(opid), float(np.float32(f)), _lib.ptr(scratch), _lib.stream())
+        assert np.array_equal(sha(d.cpu().numpy()), want), (opid, f)
+
+
 @pytest.mark.parametrize("tag,cfgname", [("ours120", "ours"), ("chefer96", "chefer_et_al"), ("ours56_g14", "ours"), ("ours64x48", "ours")])
 def test_aggregate_vs_golden(golden, tag, cfgname):
     from semabs_amd.clip import ClipWrapper, plan_tiles, saliency_configs

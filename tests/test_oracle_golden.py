@@ -256,3 +256,22 @@ def test_g26_process_batch_vool_fixture_is_the_stand_in_on_the_reference_lattice
     want = np.stack([synth_vool_logits(torch.from_numpy(pts), float(g["tgt"][d]), float(g["ref"][d]), str(g["relations"][d])).numpy().reshape(S, S, S) for d in range(D)])
     assert np.array_equal(want, g["volumes"])
     assert [int(c) for c in g["chunks"]] == [chunk] * (S ** 3 // chunk) + ([S ** 3 % chunk] if S ** 3 % chunk else [])
+
+
+# ---- a2: colour jitter of the augmentation copies (g28 = torchvision's PIL path executed with Pillow on fixed orders / factors) --------------
+def test_color_jitter_oracle_vs_pillow_golden(golden):
+    g = golden("g28_color_jitter")
+    img = synth_rgb(int(g["meta"][0]), int(g["meta"][1]), seed=int(g["meta"][2]))
+    for o, f, want, sub in zip(g["orders"], g["factors"], g["sha"], g["sub"]):
+        out = op.color_jitter(img, o, f)
+        assert np.array_equal(out[::5, ::5], sub), (o, f)
+        assert np.array_equal(sha(out), want), (o, f)
+    for opid in range(4):
+        for k, f in enumerate(g["single_f"][opid]):
+            assert np.array_equal(sha(op.JITTER_OPS[opid](img, float(f))), g["single_sha"][opid][k]), (opid, f)
+    # both HSV conversions on a 2^21-colour lattice (the generator checked all 2^24 against the oracle when it wrote the fixture)
+    c = np.arange(1 << 24, dtype=np.uint32)
+    lat = np.stack([(c >> 16) & 255, (c >> 8) & 255, c & 255], axis=-1).astype(np.uint8).reshape(256, 256, 256, 3)[::2, ::2, ::2].reshape(-1, 1, 3)
+    assert np.array_equal(sha(op.rgb_to_hsv_u8(lat)), g["lattice_hsv_sha"])
+    assert np.array_equal(sha(op.hsv_to_rgb_u8(lat)), g["lattice_rgb_sha"])
+    assert op.hue_shift_u8(-0.05) == 244 and op.hue_shift_u8(0.1) == 25 and op.hue_shift_u8(0.0) == 0
