@@ -776,7 +776,7 @@ def main():
         from semabs_amd.clip.vit import TextEncoder
         from semabs_amd.weights import make_clip_state_dict
         text_enc = TextEncoder(make_clip_state_dict(args.arch, 0, text_tower=True))
-        text_tokens = torch.from_numpy(np.load(tk)["tokens"][:N_LABELS])
+        text_tokens = torch.from_numpy(np.load(tk)["tokens"][:N_LABELS]).to(torch.int64).cuda()     # the label set's token ids, resident in HBM like the frame
 
     latency = args.mode == "latency"
     if latency:                                          # every rank holds the SAME scenes: one scene per step, split over the ranks

@@ -27,6 +27,14 @@ extern "C" {
 
 const char* semabs_last_error(void);
 int semabs_abi_version(void);
+
+/* Host-side buffer utilities (no reference counterpart: what torch.zeros / torch.full / Tensor.repeat / masked_fill_ did on the hot path; the
+ * product issues no ATen kernel inside a scene).  semabs_fill_u32: nbytes (a multiple of 4) of a 32-bit pattern.  semabs_replicate: dst = reps
+ * copies of src (nbytes each, a multiple of 4).  semabs_poison_empty: *n_in == 0 (no point of the depth image inside scene_bounds - an error in the
+ * reference, visualize.py:193) -> logits = NaN, labels = -1; nothing otherwise. */
+int semabs_fill_u32(void* p, long long nbytes, unsigned int value, void* stream);
+int semabs_replicate(const void* src, void* dst, long long nbytes, int reps, void* stream);
+int semabs_poison_empty(const long long* n_in, float* logits, long long n_logits, int* labels, long long n_labels, void* stream);
 int semabs_device_info(char* name /*host*/, int name_len, int* cu_count /*host*/, long long* hbm_bytes /*host*/);
 
 /* ============================ geometry (csrc/geometry.hip) =============================================== */
@@ -101,6 +109,8 @@ int semabs_aggregate(const float* rel, const float* rel_flip, int L, int N, int 
 /* the un-flip average alone (CLIP/clip/__init__.py:196-204): out[m, h, w] = (rel[m, h, w] + rel_flip[m, h, g - 1 - w]) / 2 for n_maps = L * N maps
  * [g, g]; aggregating `out` with rel_flip = NULL equals semabs_aggregate(rel, rel_flip) bit for bit at half the loads per covering tile. */
 int semabs_unflip_average(const float* rel, const float* rel_flip, float* out, long n_maps, int g, void* stream);
+/* The same for L label rows whose input maps are in_label_stride maps apart (both passes in one [L, 2 N, g, g] buffer); out [L, maps_per_label, g, g]. */
+int semabs_unflip_average_rows(const float* rel, const float* rel_flip, float* out, int L, long maps_per_label, long in_label_stride, int g, void* stream);
 
 /* ColorJitter(0.6, 0.6, 0.6, 0.1) of the augmentation copies             CLIP/clip/__init__.py:55-57, 246-247
  * (torchvision 0.13.1 ColorJitter.forward on the PIL image: functional_pil.adjust_brightness / _contrast / _saturation / _hue = Pillow
@@ -153,6 +163,9 @@ int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int
  * scores stay fp32), v fp16 [n, T, D] (it only enters averaged: o, and the rollout's V . u dots) */
 int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
 int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
+/* x[arange(B), tokens.argmax(-1)] of the text tower (the EOT rows)        CLIP/clip/model_explainability.py:480
+ * tokens int64 [B, T] (device), x fp32 [B * T, D] -> dst fp32 [B, D]. */
+int semabs_eot_rows_gather(const long long* tokens, const float* x, float* dst, int B, int T, int D, void* stream);
 int semabs_quickgelu(const float* fc, void* act, long n, void* stream);                 /* model_explainability.py:197-199 */
 /* gd = d quickgelu(x) / dx on fp32 pre-activations (fp32, n % 4 == 0): the derivative table of semabs_gemm_f16 epi 5 */
 int semabs_quickgelu_grad(const float* fc, float* gd, long n, void* stream);

@@ -28,6 +28,9 @@ D = C.c_double
 # name -> argtypes (all return int).  Kept in the order of include/semabs.h.
 SIGNATURES = {
     "semabs_abi_version": [],
+    "semabs_fill_u32": [P, C.c_longlong, C.c_uint, P],
+    "semabs_replicate": [P, P, C.c_longlong, I, P],
+    "semabs_poison_empty": [P, P, C.c_longlong, P, C.c_longlong, P],
     "semabs_device_info": [C.c_char_p, I, C.POINTER(I), C.POINTER(C.c_longlong)],
     # geometry.hip
     "semabs_pointcloud": [P, I, I, P, I, P, P, P],
@@ -44,6 +47,7 @@ SIGNATURES = {
     "semabs_patchify": [P, P, I, I, I, P],
     "semabs_aggregate": [P, P, I, I, I, I, I, P, I, I, I, P, P],
     "semabs_unflip_average": [P, P, P, L, I, P],
+    "semabs_unflip_average_rows": [P, P, P, I, L, L, I, P],
     "semabs_color_jitter": [P, I, I, C.POINTER(I), C.POINTER(F), P, P],
     "semabs_color_jitter_op": [P, I, I, I, F, P, P],
     # gemm.hip
@@ -56,6 +60,7 @@ SIGNATURES = {
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
     "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, P],
     "semabs_rows_gather": [P, P, L, I, L, L, P],
+    "semabs_eot_rows_gather": [P, P, P, I, I, I, P],
     "semabs_quickgelu": [P, P, L, P],
     "semabs_quickgelu_grad": [P, P, L, P],
     "semabs_logit_grad": [P, P, I, I, I, P, P, P, P],
@@ -181,6 +186,33 @@ def require_gpu() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("semabs_amd needs a HIP device (MI355X); there is no CPU fallback on the product path")
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def filled(shape, dtype: torch.dtype, value=0, device=None) -> torch.Tensor:
+    """torch.full(shape, value, dtype) without an ATen kernel: torch.empty + semabs_fill_u32 on the current stream (4-byte dtypes, or zero for
+    any dtype whose byte count is a multiple of 4)."""
+    t = torch.empty(shape, dtype=dtype, device=device if device is not None else require_gpu())
+    fill_(t, value)
+    return t
+
+
+def fill_(t: torch.Tensor, value=0) -> torch.Tensor:
+    import struct
+    assert t.is_contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return t
+    if value == 0:
+        pat = 0
+    elif t.dtype == torch.float32:
+        pat = struct.unpack("<I", struct.pack("<f", float(value)))[0]
+    elif t.dtype == torch.int32:
+        pat = int(value) & 0xFFFFFFFF
+    else:
+        raise TypeError(f"fill_: non-zero fill of {t.dtype}")
+    assert nbytes % 4 == 0, "fill_: byte count must be a multiple of 4"
+    call("semabs_fill_u32", t.data_ptr(), nbytes, pat, stream())
+    return t
 
 
 def farr(vals):

@@ -121,6 +121,8 @@ class ClipWrapper:
     n_streams = 1                       # HIP streams the independent tile chunks are pipelined over (when a scene is cut into several batches)
     _streams = None
     _patches = {}
+    _plans = {}                         # (H, W, n_img, cropping_augmentations) -> tile table / scale table / per-tile coefficient ids, host and device copies
+    _jitter_scratch = None              # 8 bytes of device memory for semabs_color_jitter (the grey-level sum of the contrast step)
     state_dict_provider = None          # callable(clip_model_type) -> state dict; set by tests / bench
 
     # ---- initialisation ----------------------------------------------------------------------------
@@ -139,6 +141,8 @@ class ClipWrapper:
         ClipWrapper._lut = torch.from_numpy(lut.astype(np.float32)).to(dev, torch.float16).contiguous()
         ClipWrapper.class_to_language_feature = {}
         ClipWrapper._patches = {}
+        ClipWrapper._plans = {}
+        ClipWrapper._jitter_scratch = None
 
     @staticmethod
     def _load_checkpoint(clip_model_type):
@@ -235,9 +239,16 @@ class ClipWrapper:
         if jittered_images is not None:
             assert len(jittered_images) == augmentations
             return torch.stack([base] + [torch.from_numpy(np.ascontiguousarray(j)).to(dev) for j in jittered_images])
-        out = base[None].repeat(augmentations + 1, 1, 1, 1).contiguous()
-        scratch = torch.zeros(1, dtype=torch.int64, device=dev)
         H, W = img.shape[:2]
+        base = base.contiguous()
+        out = torch.empty(augmentations + 1, H, W, 3, dtype=torch.uint8, device=dev)
+        if (H * W * 3) % 4 == 0:
+            _lib.call("semabs_replicate", _lib.ptr(base), _lib.ptr(out), H * W * 3, augmentations + 1, _lib.stream())
+        else:
+            out.copy_(base[None].expand_as(out))
+        if cls._jitter_scratch is None:
+            cls._jitter_scratch = torch.empty(1, dtype=torch.int64, device=dev)      # zeroed by the contrast step itself
+        scratch = cls._jitter_scratch
         rng = cls._rng if seed is None else np.random.default_rng(seed)
         for k in range(1, augmentations + 1):
             order = rng.permutation(4)
@@ -255,20 +266,19 @@ class ClipWrapper:
         eng = cls.engine
         dev = cls.device
         n_img, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
-        table, scales = plan_tiles(H, W, n_img, cropping_augmentations)
+        table, scales, tiles_dev, _ = cls._plan(H, W, n_img, cropping_augmentations)
         N = len(table)
         L = int(w_text.shape[0])
         g = eng.g
-        coef_ids = np.asarray([cls._coeffs.id_of(int(ts)) for ts in table[:, 3]], np.int32)
         xmin_d, kk_d, ks_d = cls._coeffs.device()
         max_ks = max(cls._coeffs.ksize) if cls._coeffs.ksize else 0
-        tiles_dev = torch.from_numpy(np.concatenate([table, coef_ids[:, None]], axis=1).astype(np.int32)).to(dev).contiguous()
         passes = 2 if horizontal_flipping else 1
         G, Kp = g * g, 3 * eng.p * eng.p
         t_lo, t_hi = (0, N) if tile_range is None else tile_range
         # relevance of every (pass, tile) forward of this call, in issue order: pass p, tile t at column p * (t_hi - t_lo) + (t - t_lo),
         # so that one ViT batch may span the flip boundary
-        rel_all = torch.zeros(L, passes * (t_hi - t_lo), g, g, dtype=torch.float32, device=dev)
+        # (every cell is written by semabs_rollout: one launch per label group covers all (pass, tile) columns of the chunk)
+        rel_all = torch.empty(L, passes * (t_hi - t_lo), g, g, dtype=torch.float32, device=dev)
         # Tile chunks are independent: alternate them over `n_streams` HIP streams (one workspace each) so one chunk's
         # memory-bound kernels and GEMM store tails overlap the other chunk's MFMA phases.
         main = torch.cuda.current_stream()
@@ -318,6 +328,9 @@ class ClipWrapper:
         for t in (images, tiles_dev, w_text, rel_all, patches_all, *w_chunks):
             for i in range(ns):
                 t.record_stream(cls._streams[i])
+        if tile_range is None and not return_tiles:
+            # both passes stay in rel_all: the un-flip average reads them in place (no slice copies) and the aggregation takes its result
+            return cls.aggregate_device([rel_all], scales, n_img, H, W, passes=passes, plan_key=(H, W, n_img, cls._aug_key(cropping_augmentations)))
         if tile_range is None:
             rel = [rel_all[:, p * N:(p + 1) * N].contiguous() if passes > 1 else rel_all for p in range(passes)]
         else:                                           # a shard: only this rank's tile slice [L, t_hi - t_lo, g, g] per pass (all-gathered by the caller)
@@ -330,14 +343,41 @@ class ClipWrapper:
     def _make_streams(cls, ns: int):
         return [torch.cuda.Stream() for _ in range(ns)]
 
+    @staticmethod
+    def _aug_key(cropping_augmentations):
+        return tuple((int(a["tile_size"]), int(a["stride"])) for a in cropping_augmentations)
+
     @classmethod
-    def aggregate_device(cls, rel, scales: np.ndarray, n_img: int, H: int, W: int) -> torch.Tensor:
+    def _plan(cls, H: int, W: int, n_img: int, cropping_augmentations):
+        """Tile table, scale table and their device copies for one (image shape, image count, crop configuration): built and uploaded ONCE - a
+        scene of a stream of equally-shaped frames issues no host -> device copy for them."""
+        key = (H, W, n_img, cls._aug_key(cropping_augmentations))
+        pl = cls._plans.get(key)
+        if pl is None or pl[4] != len(cls._coeffs.sizes):
+            table, scales = plan_tiles(H, W, n_img, cropping_augmentations)
+            coef_ids = np.asarray([cls._coeffs.id_of(int(ts)) for ts in table[:, 3]], np.int32)
+            tiles_dev = torch.from_numpy(np.concatenate([table, coef_ids[:, None]], axis=1).astype(np.int32)).to(cls.device).contiguous()
+            scales_dev = torch.from_numpy(np.ascontiguousarray(scales, np.int32)).to(cls.device)
+            if len(cls._plans) > 64:
+                cls._plans.clear()
+            pl = cls._plans[key] = (table, scales, tiles_dev, scales_dev, len(cls._coeffs.sizes))
+        return pl[0], pl[1], pl[2], pl[3]
+
+    @classmethod
+    def aggregate_device(cls, rel, scales: np.ndarray, n_img: int, H: int, W: int, passes: int | None = None, plan_key=None) -> torch.Tensor:
+        """rel: [pass-0 maps, pass-1 maps] (each [L, N, g, g]), or ONE buffer [L, passes * N, g, g] holding both passes with `passes` given."""
         dev = cls.device
-        L, N, g = int(rel[0].shape[0]), int(rel[0].shape[1]), int(rel[0].shape[2])
+        fused = passes is not None
+        L, g = int(rel[0].shape[0]), int(rel[0].shape[2])
+        N = int(rel[0].shape[1]) // (passes if fused else 1)
         out = torch.empty(L, H, W, dtype=torch.float32, device=dev)
-        sc = torch.from_numpy(np.ascontiguousarray(scales, np.int32)).to(dev)
+        pl = cls._plans.get(plan_key) if plan_key is not None else None
+        sc = pl[3] if pl is not None else torch.from_numpy(np.ascontiguousarray(scales, np.int32)).to(dev)
         maps = rel[0]
-        if len(rel) > 1:                                # un-flip average once per map cell instead of once per covered pixel (bit-identical, half the loads)
+        if fused and passes > 1:
+            maps = torch.empty(L, N, g, g, dtype=torch.float32, device=dev)
+            _lib.call("semabs_unflip_average_rows", _lib.ptr(rel[0]), rel[0].data_ptr() + N * g * g * 4, _lib.ptr(maps), L, N, passes * N, g, _lib.stream())
+        elif len(rel) > 1:                              # un-flip average once per map cell instead of once per covered pixel (bit-identical, half the loads)
             maps = torch.empty_like(rel[0])
             _lib.call("semabs_unflip_average", _lib.ptr(rel[0]), _lib.ptr(rel[1]), _lib.ptr(maps), L * N, g, _lib.stream())
         _lib.call("semabs_aggregate", _lib.ptr(maps), None, L, N, g, H, W, _lib.ptr(sc), len(scales), n_img, N // n_img, _lib.ptr(out), _lib.stream())

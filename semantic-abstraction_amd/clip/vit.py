@@ -575,7 +575,7 @@ class TextEncoder:
         dev, D, T, H, E = self.dev, self.D, self.ctx, self.H, self.E
         B = int(tokens.shape[0])
         assert tokens.shape[1] == T
-        tok = tokens.to(dev, torch.int64).contiguous()
+        tok = tokens if (tokens.is_cuda and tokens.dtype == torch.int64 and tokens.is_contiguous()) else tokens.to(dev, torch.int64).contiguous()
         M = B * T
         x = torch.empty(M, D, dtype=torch.float32, device=dev)
         h = torch.empty(M, D, dtype=torch.float16, device=dev)
@@ -593,9 +593,8 @@ class TextEncoder:
             gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
             gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
         # EOT rows (the highest token id in each sequence) -> ln_final -> text_projection
-        eot = tokens.argmax(dim=-1).to(dev)
-        rows = torch.arange(B, device=dev) * T + eot
-        xe = x.index_select(0, rows).contiguous()                       # row gather (data movement only)
+        xe = torch.empty(B, D, dtype=torch.float32, device=dev)
+        _lib.call("semabs_eot_rows_gather", _lib.ptr(tok), _lib.ptr(x), _lib.ptr(xe), B, T, D, st)
         ye = torch.empty(B, D, dtype=torch.float16, device=dev)
         layernorm(xe, *self.ln_final, ye, B, D)
         e = torch.empty(B, E, dtype=torch.float32, device=dev)

@@ -42,3 +42,66 @@ extern "C" int semabs_event_elapsed_ms(void* start, void* stop, float* ms) {
     if (hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) { semabs_set_error("hipEventElapsedTime failed"); return SEMABS_EHIP; }
     return SEMABS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Buffer utilities of the host side (round 5): the hot path issues no ATen kernel - fills, replications and the
+// empty-cloud poisoning of a scene are launches of this library on the caller's stream.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static __global__ __launch_bounds__(256) void k_fill128(u32x4* __restrict__ p, long n16, unsigned int v) {
+    const u32x4 w = u32x4{v, v, v, v};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) __builtin_nontemporal_store(w, p + i);
+}
+// nbytes % 4 == 0, p 4-byte aligned: 16-byte streaming stores over the aligned body, 4-byte stores for the ragged ends
+extern "C" int semabs_fill_u32(void* p, long long nbytes, unsigned int value, void* stream) {
+    if (nbytes == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(p && nbytes > 0 && nbytes % 4 == 0 && ((uintptr_t)p & 3) == 0, "semabs_fill_u32: pointer and byte count must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    char* c = (char*)p;
+    const long long head = ((16 - ((uintptr_t)c & 15)) & 15) < nbytes ? ((16 - ((uintptr_t)c & 15)) & 15) : nbytes;
+    if (head) semabs_fill32(c, (size_t)head, value, s);
+    const long long body = (nbytes - head) / 16 * 16;
+    if (body) {
+        const long n16 = body / 16;
+        long nb = (n16 + 255) / 256; if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(k_fill128, dim3((unsigned)nb), dim3(256), 0, s, (u32x4*)(c + head), n16, value);
+    }
+    if (nbytes - head - body) semabs_fill32(c + head + body, (size_t)(nbytes - head - body), value, s);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// dst = reps copies of src back to back (nbytes each; nbytes % 4 == 0, both 4-byte aligned): the image stack of make_images, the broadcast of one TSDF to the label volumes
+static __global__ __launch_bounds__(256) void k_replicate(const unsigned int* __restrict__ src, unsigned int* __restrict__ dst, long n, int reps) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned int v = src[i];
+        for (int r = 0; r < reps; ++r) dst[(long)r * n + i] = v;
+    }
+}
+extern "C" int semabs_replicate(const void* src, void* dst, long long nbytes, int reps, void* stream) {
+    if (nbytes == 0 || reps == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(src && dst && nbytes > 0 && reps > 0 && nbytes % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0, "semabs_replicate: bad args");
+    const long n = (long)(nbytes / 4);
+    long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_replicate, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned int*)src, (unsigned int*)dst, n, reps);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// A scene whose depth image has no point inside scene_bounds is an error in the reference (np.random.choice on an empty population, visualize.py:193).
+// The device path learns the count without a host synchronisation: when *n_in == 0 the logits become NaN and the labels -1 (one load and an early
+// exit otherwise), so the result cannot be mistaken for a valid one; SceneResult.n_in_bounds raises on first read.
+static __global__ __launch_bounds__(256) void k_poison_empty(const long long* __restrict__ n_in, float* __restrict__ logits, long n_logits,
+                                                             int* __restrict__ labels, long n_labels) {
+    if (*n_in != 0) return;
+    const float nan = __builtin_nanf("");
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_logits; i += (long)gridDim.x * 256) logits[i] = nan;
+    if (labels)
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_labels; i += (long)gridDim.x * 256) labels[i] = -1;
+}
+extern "C" int semabs_poison_empty(const long long* n_in, float* logits, long long n_logits, int* labels, long long n_labels, void* stream) {
+    SEMABS_REQUIRE(n_in && logits && n_logits >= 0 && n_labels >= 0, "semabs_poison_empty: bad args");
+    hipLaunchKernelGGL(k_poison_empty, dim3(1024), dim3(256), 0, (hipStream_t)stream, n_in, logits, (long)n_logits, labels, (long)n_labels);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}

@@ -374,17 +374,30 @@ extern "C" int semabs_aggregate(const float* rel, const float* rel_flip, int L, 
 // un-flip average of the two passes (CLIP/clip/__init__.py:196-204): out[m, h, w] = (rel[m, h, w] + rel_flip[m, h, g - 1 - w]) / 2, once per map cell.
 // `semabs_aggregate` with rel_flip does the same average per covered PIXEL per covering tile (8 loads per tile instead of 4, ~500 covering tiles per
 // pixel at the headline shape): callers that have both passes average first and aggregate the result - same operation on the same operands, bit-identical.
-__global__ void k_unflip_average(const float* __restrict__ rel, const float* __restrict__ rel_flip, float* __restrict__ out, long n, int g) {
+__global__ void k_unflip_average(const float* __restrict__ rel, const float* __restrict__ rel_flip, float* __restrict__ out, long n, int g,
+                                 long per, long in_stride) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int w = (int)(i % g);
-    out[i] = (rel[i] + rel_flip[i - w + (g - 1 - w)]) / 2;
+    const long l = i / per, src = l * in_stride + (i - l * per);      // (per == in_stride: src == i)
+    out[i] = (rel[src] + rel_flip[src - w + (g - 1 - w)]) / 2;
 }
 extern "C" int semabs_unflip_average(const float* rel, const float* rel_flip, float* out, long n_maps, int g, void* stream) {
     if (n_maps == 0) return SEMABS_OK;
     SEMABS_REQUIRE(rel && rel_flip && out && n_maps > 0 && g > 0, "semabs_unflip_average: bad args");
     const long n = n_maps * g * g;
-    hipLaunchKernelGGL(k_unflip_average, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rel, rel_flip, out, n, g);
+    hipLaunchKernelGGL(k_unflip_average, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rel, rel_flip, out, n, g, n, n);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+// The same average for L label rows of maps_per_label maps each whose INPUT rows are in_label_stride maps apart (both passes of a call live in one
+// [L, 2 N, g, g] buffer: rel = its first N maps of every label, rel_flip = rel + N maps): out [L, maps_per_label, g, g] contiguous - no slice copies.
+extern "C" int semabs_unflip_average_rows(const float* rel, const float* rel_flip, float* out, int L, long maps_per_label, long in_label_stride,
+                                          int g, void* stream) {
+    if (L == 0 || maps_per_label == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(rel && rel_flip && out && L > 0 && maps_per_label > 0 && in_label_stride >= maps_per_label && g > 0, "semabs_unflip_average_rows: bad args");
+    const long per = maps_per_label * g * g, n = (long)L * per;
+    hipLaunchKernelGGL(k_unflip_average, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rel, rel_flip, out, n, g, per, in_label_stride * g * g);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

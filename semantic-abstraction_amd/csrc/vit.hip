@@ -670,6 +670,28 @@ extern "C" int semabs_rows_gather(const float* src, float* dst, long rows, int c
     return SEMABS_OK;
 }
 
+// EOT rows of the text tower: dst[b, :] = x[b * T + argmax_t tokens[b, t], :] (`x[torch.arange(B), text.argmax(dim=-1)]`, model_explainability.py:480;
+// the end-of-text token is the largest id of a sequence; first occurrence on ties, like torch.argmax).  One wave per sequence.
+__global__ __launch_bounds__(64) void k_eot_rows_gather(const long long* __restrict__ tokens, const float* __restrict__ x, float* __restrict__ dst, int T, int D) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    long long best = -0x7fffffffffffffffLL - 1; int at = 0;
+    for (int t = lane; t < T; t += 64) { const long long v = tokens[(long)b * T + t]; if (v > best) { best = v; at = t; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long ov = __shfl_xor(best, o, 64); const int oa = __shfl_xor(at, o, 64);
+        if (ov > best || (ov == best && oa < at)) { best = ov; at = oa; }
+    }
+    const float* src = x + ((long)b * T + at) * D;
+    for (int c = lane; c < D; c += 64) dst[(long)b * D + c] = src[c];
+}
+extern "C" int semabs_eot_rows_gather(const long long* tokens, const float* x, float* dst, int B, int T, int D, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(tokens && x && dst && B > 0 && T > 0 && D > 0, "semabs_eot_rows_gather: bad args");
+    hipLaunchKernelGGL(k_eot_rows_gather, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, x, dst, T, D);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // quick-GELU forward on fp32 pre-activations -> fp16 (CLS-row MLP of the last block keeps fc for the VJP)
 __global__ void k_quickgelu(const float* __restrict__ fc, f16* __restrict__ act, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

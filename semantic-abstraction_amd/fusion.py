@@ -26,12 +26,23 @@ class TSDFVolume:
         self._vol_bnds[:, 1] = self._vol_bnds[:, 0] + self._vol_dim * self._voxel_size
         self._vol_origin = self._vol_bnds[:, 0].copy(order="C").astype(np.float32)
         dims = tuple(int(d) for d in self._vol_dim)
-        self._tsdf_vol = -torch.ones(dims, dtype=torch.float32, device=self._dev)
-        self._weight_vol = torch.zeros(dims, dtype=torch.float32, device=self._dev)
-        self._color_vol = torch.zeros(dims, dtype=torch.float32, device=self._dev)
+        self._tsdf_vol = _lib.filled(dims, torch.float32, -1.0, self._dev)
+        self._weight_vol = _lib.filled(dims, torch.float32, 0, self._dev)
+        self._color_vol = _lib.filled(dims, torch.float32, 0, self._dev)
         self.last_pix = None
 
-    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.0, keep_pix=False):
+    @staticmethod
+    def params_for(voxel_size, cam_pose, obs_weight=1.0, dev=None) -> torch.Tensor:
+        """inv(pose) rows + (voxel size, truncation margin = 5 voxels, observation weight): the 15 doubles semabs_tsdf_integrate reads from the device."""
+        T = np.linalg.inv(np.asarray(cam_pose, np.float64))
+        vs = float(voxel_size)
+        prm = np.concatenate([T[:3, :4].reshape(-1), [vs, 5 * vs, float(obs_weight)]])
+        return torch.from_numpy(prm).to(dev if dev is not None else _lib.require_gpu())
+
+    def integrate_params(self, cam_pose, obs_weight=1.0) -> torch.Tensor:
+        return TSDFVolume.params_for(self._voxel_size, cam_pose, obs_weight, self._dev)
+
+    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.0, keep_pix=False, prm=None):
         im_h, im_w = depth_im.shape[:2]
         dev = self._dev
         depth = depth_im if isinstance(depth_im, torch.Tensor) else torch.from_numpy(
@@ -42,9 +53,8 @@ class TSDFVolume:
             color = color_im if isinstance(color_im, torch.Tensor) else torch.from_numpy(
                 np.ascontiguousarray(color_im, dtype=np.uint8))
             color = color.to(dev).contiguous()
-        T = np.linalg.inv(np.asarray(cam_pose, np.float64))
-        prm = np.concatenate([T[:3, :4].reshape(-1), [self._voxel_size, self._trunc_margin, float(obs_weight)]])
-        prm = torch.from_numpy(prm).to(dev)
+        if prm is None:
+            prm = self.integrate_params(cam_pose, obs_weight)
         K = np.asarray(cam_intr).astype(np.float32)
         pix = torch.empty((self._tsdf_vol.numel(), 2), dtype=torch.int64, device=dev) if keep_pix else None
         _lib.call("semabs_tsdf_integrate", _lib.ptr(color), _lib.ptr(depth), im_h, im_w, _lib.ptr(prm),

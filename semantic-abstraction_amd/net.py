@@ -170,8 +170,8 @@ class SemAbs3D(torch.nn.Module):
         flat = self.vg.flat_idxs(xyz)
         unet = self.vol_feature_extractor
         unet._sync()
-        vol = torch.zeros(P, S0, S1, S2, self.C, dtype=unet.act_dtype, device=dev)
-        head = torch.full((nvox,), -1, dtype=torch.int32, device=dev)
+        vol = _lib.filled((P, S0, S1, S2, self.C), unet.act_dtype, 0, dev)
+        head = _lib.filled((nvox,), torch.int32, -1, dev)
         nxt = torch.empty(N, dtype=torch.int32, device=dev)
         sums = None
         if self.with_tsdf:
@@ -183,7 +183,7 @@ class SemAbs3D(torch.nn.Module):
             # generic pass over the (now dense) volume, not from the occupied-voxel shortcut of the scatter kernel
             vol[..., 0] = tsdf_vol.to(dev, unet.act_dtype).reshape(-1, S0, S1, S2)       # [S, S, S] for every volume, or one per volume [P, S, S, S]
         elif self.C == 16 and unet.in_channels == 16 and unet.enc[0][0].groups == 8:     # statistics for the first GroupNorm come out of the scatter
-            sums = torch.zeros(P, 8, 2, dtype=torch.float64, device=dev)
+            sums = _lib.filled((P, 8, 2), torch.float64, 0, dev)
             _lib.call("semabs_scatter_mean_stats", _lib.ptr(flat), _lib.ptr(pf), _lib.ptr(head), _lib.ptr(nxt), _lib.ptr(vol), P, N, self.C, nvox,
                       unet.f32, _lib.ptr(sums), st)
         else:

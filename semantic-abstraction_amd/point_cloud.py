@@ -28,13 +28,26 @@ def _params(cam_intr, cam_pose, bounds, dev):
     return torch.from_numpy(p).to(dev)
 
 
-def pointcloud_device(depth: torch.Tensor, cam_intr, cam_pose, bounds=None):
-    """depth fp32 [H, W] on the GPU -> (xyz fp32 [H*W, 3], in-bounds mask uint8 [H*W] or None), on the GPU."""
+def pointcloud_params(cam_intr, cam_pose, bounds) -> torch.Tensor:
+    return _params(cam_intr, cam_pose, bounds, _lib.require_gpu())
+
+
+def frustum_params(cam_pose, cam_intr) -> torch.Tensor:
+    """inv(pose) rows + (fx, fy, cx, cy) as 16 doubles on the device (the argument block of semabs_frustum_mask)."""
+    T = np.linalg.inv(np.asarray(cam_pose, np.float64))
+    K = np.asarray(cam_intr, np.float64)
+    return torch.from_numpy(np.concatenate([T[:3, :4].reshape(-1), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]])).to(_lib.require_gpu())
+
+
+def pointcloud_device(depth: torch.Tensor, cam_intr, cam_pose, bounds=None, prm: torch.Tensor | None = None):
+    """depth fp32 [H, W] on the GPU -> (xyz fp32 [H*W, 3], in-bounds mask uint8 [H*W] or None), on the GPU.
+    prm: the 22 camera / bounds doubles already on the device (`pointcloud_params`; ScenePipeline.upload puts them there with the frame)."""
     dev = _lib.require_gpu()
     H, W = depth.shape
     xyz = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
     mask = torch.empty(H * W, dtype=torch.uint8, device=dev) if bounds is not None else None
-    prm = _params(cam_intr, cam_pose, bounds, dev)
+    if prm is None:
+        prm = _params(cam_intr, cam_pose, bounds, dev)
     depth = depth.contiguous()
     _lib.call("semabs_pointcloud", _lib.ptr(depth), H, W, _lib.ptr(prm), int(cam_pose is not None),
               _lib.ptr(xyz), _lib.ptr(mask), _lib.stream())
@@ -64,12 +77,12 @@ def filter_pts_bounds(xyz, bounds):
     return m
 
 
-def frustum_mask_device(pts64: torch.Tensor, h: int, w: int, cam_pose, cam_intr) -> torch.Tensor:
-    """pts64 f64 [M, 3] on the GPU -> uint8 [M] on the GPU (point_cloud.py:88-110); only the 16 pose / intrinsics doubles cross PCIe."""
+def frustum_mask_device(pts64: torch.Tensor, h: int, w: int, cam_pose, cam_intr, prm: torch.Tensor | None = None) -> torch.Tensor:
+    """pts64 f64 [M, 3] on the GPU -> uint8 [M] on the GPU (point_cloud.py:88-110); only the 16 pose / intrinsics doubles cross PCIe
+    (prm: already there - `frustum_params`)."""
     dev = _lib.require_gpu()
-    T = np.linalg.inv(np.asarray(cam_pose, np.float64))
-    K = np.asarray(cam_intr, np.float64)
-    prm = torch.from_numpy(np.concatenate([T[:3, :4].reshape(-1), [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]])).to(dev)
+    if prm is None:
+        prm = frustum_params(cam_pose, cam_intr)
     pts64 = pts64.contiguous()
     mask = torch.empty(len(pts64), dtype=torch.uint8, device=dev)
     _lib.call("semabs_frustum_mask", _lib.ptr(pts64), len(pts64), _lib.ptr(prm), int(h), int(w), _lib.ptr(mask), _lib.stream())

@@ -26,7 +26,7 @@ from . import dist as sdist
 from .clip import ClipWrapper, plan_tiles, saliency_configs
 from .fusion import TSDFVolume
 from .net import SemAbs3D
-from .point_cloud import frustum_mask_device, pointcloud_device
+from .point_cloud import frustum_mask_device, frustum_params, pointcloud_device, pointcloud_params
 from .synth import SCENE_BOUNDS
 
 DEFAULT_NET_KWARGS = dict(voxel_shape=(128, 128, 128), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16,
@@ -81,7 +81,24 @@ class ScenePipeline:
         d = dict(scene)
         d["rgb_dev"] = torch.from_numpy(np.ascontiguousarray(scene["rgb"])).to(self.dev)
         d["depth_dev"] = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(self.dev)
+        # the camera of the frame travels with it: the argument blocks of the point-cloud, TSDF and frustum kernels (22 / 15 / 16 doubles) are
+        # part of the upload, so a scene issues no host -> device copy of its own
+        net = self.net
+        bounds = np.array([net.vg.lower_corner, net.vg.upper_corner], np.float64)
+        d["_pc_prm"] = pointcloud_params(scene["cam_intr"], scene["cam_pose"], bounds)
+        d["_fr_prm"] = frustum_params(scene["cam_pose"], scene["cam_intr"])
+        if self.with_tsdf:
+            d["_tsdf_prm"] = self._tsdf_volume_spec()[2](scene["cam_pose"])
         return d
+
+    def _tsdf_volume_spec(self):
+        """(bounds [3, 2], voxel size, cam_pose -> device argument block) of the scene's TSDF volume (visualize.py:217-227)."""
+        net = self.net
+        S = net.vg.grid_shape[0]
+        lo, hi = np.asarray(net.vg.lower_corner, np.float64), np.asarray(net.vg.upper_corner, np.float64)
+        vs = (hi[0] - lo[0]) / S
+
+        return np.stack([lo, hi], axis=1), vs, (lambda cam_pose, obs_weight=1.0: TSDFVolume.params_for(vs, cam_pose, obs_weight, self.dev))
 
     def run(self, scene: dict, w_text: torch.Tensor, seed: int = 0, jittered_images=None, images_dev: torch.Tensor | None = None) -> SceneResult:
         """scene: dict(rgb uint8 [H, W, 3], depth fp32 [H, W], cam_intr, cam_pose [+ rgb_dev / depth_dev]);
@@ -112,7 +129,7 @@ class ScenePipeline:
             if depth_dev is None:
                 depth_dev = torch.from_numpy(np.ascontiguousarray(scene["depth"], dtype=np.float32)).to(dev)
             bounds = np.array([net.vg.lower_corner, net.vg.upper_corner], np.float64)
-            xyz, mask = pointcloud_device(depth_dev, scene["cam_intr"], scene["cam_pose"], bounds)
+            xyz, mask = pointcloud_device(depth_dev, scene["cam_intr"], scene["cam_pose"], bounds, prm=scene.get("_pc_prm"))
             # in-bounds compaction + the seeded draw of num_input_pts points with replacement, on the device: the host never learns the point
             # count, so a scene has NO host synchronisation (several ranks sharing one host each used to block on torch.nonzero per scene)
             pix = torch.empty(H * W, dtype=torch.int64, device=dev)
@@ -152,7 +169,7 @@ class ScenePipeline:
         depth_dev, xyz, sel, maps, maps_c, n_in = state["depth_dev"], state["xyz"], state["sel"], state["maps"], state["maps_c"], state["n_in"]
         cur = torch.cuda.current_stream()
         cur.wait_event(state["geo_done"]); cur.wait_event(state["vit_done"])
-        for t in (xyz, sel, maps, maps_c, depth_dev):
+        for t in (xyz, sel, maps, maps_c, depth_dev, n_in):
             t.record_stream(cur)                                                              # produced on other streams, read here
         st = _lib.stream()
         feat = torch.empty(L, self.num_input_pts, dtype=torch.float32, device=dev)
@@ -166,7 +183,7 @@ class ScenePipeline:
         if shard_labels and world > 1:
             per = (L + world - 1) // world                                                    # equal slices (the last one padded) for all_gather
             l0, l1 = min(L, rank * per), min(L, (rank + 1) * per)
-            part = torch.zeros(per, self.grid_points.shape[0], dtype=torch.float32, device=dev)
+            part = _lib.filled((per, self.grid_points.shape[0]), torch.float32, 0, dev)
             if l1 > l0:
                 f_r = net.feature_volume(xyz_sub, feat[l0:l1].contiguous(), skip_final=self.fold_final_conv)
                 part[:l1 - l0] = net.decode(f_r, self.grid_points, shared=True, lattice=net.vg.grid_shape, pre_final=self.fold_final_conv)
@@ -178,11 +195,10 @@ class ScenePipeline:
             net.features_cl = None if self.fold_final_conv else features
         tsdf = labels = None
         if self.with_tsdf:
-            S = net.vg.grid_shape[0]
-            lo, hi = np.asarray(net.vg.lower_corner, np.float64), np.asarray(net.vg.upper_corner, np.float64)
-            tv = TSDFVolume(np.stack([lo, hi], axis=1).copy(), (hi[0] - lo[0]) / S)
+            bnds, vs, _ = self._tsdf_volume_spec()
+            tv = TSDFVolume(bnds.copy(), vs)
             rgb_dev = scene.get("rgb_dev")
-            tv.integrate(rgb_dev if rgb_dev is not None else scene["rgb"], depth_dev, scene["cam_intr"], scene["cam_pose"])
+            tv.integrate(rgb_dev if rgb_dev is not None else scene["rgb"], depth_dev, scene["cam_intr"], scene["cam_pose"], prm=scene.get("_tsdf_prm"))
             tsdf = tv._tsdf_vol
             if tuple(int(d) for d in tv._vol_dim) != tuple(net.vg.grid_shape):
                 # ceil((hi - lo) / voxel_size) can come out as S + 1 for extents that are not exactly representable / not cubic; the label kernel
@@ -196,10 +212,7 @@ class ScenePipeline:
         # An empty in-bounds cloud is an error in the reference (np.random.choice on an empty population, visualize.py:193).  The device path learns the
         # count without a host synchronisation, so it cannot raise here; it must not hand back plausible-looking output either (the sub-sample would be
         # 80 000 copies of pixel 0): the outputs are poisoned on the device - NaN logits, label -1 everywhere - and `n_in_bounds` raises on first read.
-        empty = (n_in == 0)
-        logits.masked_fill_(empty, float("nan"))
-        if labels is not None:
-            labels.masked_fill_(empty, -1)
+        _lib.call("semabs_poison_empty", _lib.ptr(n_in), _lib.ptr(logits), logits.numel(), _lib.ptr(labels), 0 if labels is None else labels.numel(), st)
         # `relevancies` = the raw relevancy maps; prep_data's x 50 / mean subtraction (visualize.py:100-112) lives in semabs_gather_point_features
         return SceneResult(relevancies=maps, logits=logits, labels=labels, tsdf=tsdf, n_in=n_in)
 
@@ -208,7 +221,7 @@ class ScenePipeline:
         per-pose cache: every scene pays for it, like in the reference's process_batch_ovssc)."""
         if self._grid_points64 is None:
             self._grid_points64 = self.grid_points.double()          # the reference hands fp32 lattice points to an f64 routine (visualize.py:231-236)
-        return frustum_mask_device(self._grid_points64, H, W, scene["cam_pose"], scene["cam_intr"])
+        return frustum_mask_device(self._grid_points64, H, W, scene["cam_pose"], scene["cam_intr"], prm=scene.get("_fr_prm"))
 
 
 def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 2448,

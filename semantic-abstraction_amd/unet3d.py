@@ -114,6 +114,7 @@ class ResidualUNet3D(torch.nn.Module):
         from .weights import make_unet_state_dict
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())            # follows torch's RNG like the reference's default init (seed_all)
         register_tree(self, make_unet_state_dict(seed, in_channels, out_channels, self.f_maps[0], len(self.f_maps)))
+        self._sums_arena = None
         self.enc: List[List[_Conv]] = []
         self.dec: List = []
         self.final = None
@@ -167,13 +168,24 @@ class ResidualUNet3D(torch.nn.Module):
         self._sig = sig
 
     # ---- kernels -----------------------------------------------------------------------------------
+    def _zero_sums(self, B: int, G: int) -> torch.Tensor:
+        """fp64 [B, G, 2] of zeros for one layer's GroupNorm statistics, cut from an arena that ONE fill zeroes per forward pass (a forward needs ~30
+        of them: one launch instead of thirty).  Outside a forward pass (no arena open) it is a plain zero-filled buffer."""
+        n = B * G * 2
+        a = self._sums_arena
+        if a is None or a[1] + n > a[0].numel():
+            return _lib.filled((B, G, 2), torch.float64, 0, self.dev)
+        t = a[0][a[1]:a[1] + n].view(B, G, 2)
+        a[1] += n
+        return t
+
     def _gn(self, x, conv: _Conv, sums=None):
         """GroupNorm scale / shift [B, C] of `conv`'s input x; `sums` = statistics already produced by the kernel that wrote x."""
         B, nvox, Cc = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], x.shape[4]
         G = conv.groups
         st = _lib.stream()
         if sums is None:
-            sums = torch.zeros(B, G, 2, dtype=torch.float64, device=self.dev)
+            sums = self._zero_sums(B, G)
             _lib.call("semabs_gn_stats", _lib.ptr(x), _lib.ptr(sums), B, nvox, Cc, G, self.f32, st)
         scale = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
         shift = torch.empty(B, Cc, dtype=torch.float32, device=self.dev)
@@ -190,7 +202,7 @@ class ResidualUNet3D(torch.nn.Module):
         args = (_lib.ptr(x), _lib.ptr(conv.w_hi), _lib.ptr(conv.w_lo), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(shift),
                 _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32 | (256 if generic else 0) | conv.packed)
         if out_groups:
-            sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
+            sums = self._zero_sums(B, out_groups)
             _lib.call("semabs_conv3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
             return y, sums
         _lib.call("semabs_conv3d", *args, _lib.stream())
@@ -217,7 +229,7 @@ class ResidualUNet3D(torch.nn.Module):
         args = (_lib.ptr(x), _lib.ptr(ct.w_hi), _lib.ptr(ct.w_lo), ct.class_off, _lib.ptr(y),
                 _lib.ptr(ct.bias), _lib.ptr(skip), B, D0, D1, D2, ct.cin, ct.cout, self.f32 | (256 if generic else 0) | ct.packed)
         if out_groups:
-            sums = torch.zeros(B, out_groups, 2, dtype=torch.float64, device=self.dev)
+            sums = self._zero_sums(B, out_groups)
             _lib.call("semabs_convtranspose3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
             return y, sums
         _lib.call("semabs_convtranspose3d", *args, _lib.stream())
@@ -230,6 +242,16 @@ class ResidualUNet3D(torch.nn.Module):
         in_sums: GroupNorm statistics of x, fp64 [B, groups, 2], when its producer already has them)."""
         self._sync()
         assert x.dtype == self.act_dtype and x.is_contiguous()
+        # statistics arena of this pass: (3 per residual block + 1 per transposed convolution) x [B, <= num_groups, 2] doubles, zeroed by one launch;
+        # a fresh allocation per pass (the caching allocator recycles it), so passes on different streams never share one
+        n_layers = 3 * (len(self.enc) + len(self.dec)) + len(self.dec) + 2
+        self._sums_arena = [_lib.filled((n_layers * int(x.shape[0]) * max(1, self.num_groups) * 2,), torch.float64, 0, self.dev), 0]
+        try:
+            return self._forward_cl(x, taps, skip_final, in_sums)
+        finally:
+            self._sums_arena = None
+
+    def _forward_cl(self, x, taps, skip_final, in_sums):
         feats = []
         for i, convs in enumerate(self.enc):
             if i > 0:
