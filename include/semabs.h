@@ -299,6 +299,9 @@ int semabs_wgrad_mfma(const float* A, const float* X, const float* gn_scale, con
  * scratch = NULL: the round-2 kernel (4 x 8 x 16 bricks transposed while staging, D1 % 8 == 0, fp32 atomics). */
 int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B, int D0,
                        int D1, int D2, int Ca, int Cx, int tap_minor, float* scratch, long scratch_floats, void* stream);
+/* Which kernel semabs_wgrad_conv3 runs for a shape with scratch_floats of scratch (0 = no scratch): *kernel = 2 transposing-read kernel, 1 brick
+ * kernel (D1 % 8 == 0), 0 unsupported (use semabs_wgrad_mfma / semabs_wgrad) - the entry point's own predicate, for host-side routing. */
+int semabs_wgrad_conv3_supported(int D0, int D1, int D2, int Ca, int Cx, long scratch_floats, int* kernel);
 
 /* out fp64 [B, C, 2] += (sum_v dY, sum_v dY * xhat) per (batch, channel); X = NULL gives plain column sums (bias gradients) */
 int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const float* rstd, double* out, int B, long nvox, int C, int G,

@@ -1476,6 +1476,13 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 // (super-columns that keep a W slice resident re-read A once per slice instead: QKV 1.61 - 1.68 at -3 .. -5 % TFLOP/s, not taken).
 static inline int gemm8_group_m(int n_tiles_n) { return n_tiles_n <= 3 ? 2 : (n_tiles_n <= 9 ? 4 : 8); }
 
+// multiprocessor count of the current device, queried once (not per launch)
+static int gemm_num_cus() {
+    static int n = 0;
+    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
+
 template <int EPI>
 static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
 #ifdef SEMABS_TUNING
@@ -1498,7 +1505,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     if (g_persist) {
         static SemabsLdsAttr attr_p;
         semabs_ensure_lds(&k_gemm8<EPI, true, true>, LDS, attr_p);
-        int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+        const int ncu = gemm_num_cus();
         gemm_dispatch(k_gemm8<EPI, true, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS, s, g, o);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
@@ -1523,6 +1530,13 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         }
     }
 #endif
+    if (o.ring) {                                           // kernel | 512: the K = 32 ring schedule (A/B relic, one workgroup per tile); overrides the schedule bits
+        static SemabsLdsAttr attr_r;
+        semabs_ensure_lds(&k_gemm8<EPI, false, false, true>, LDS, attr_r);
+        gemm_dispatch(k_gemm8<EPI, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
     if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
         // fp16-output epilogues: persistent workgroups (one per CU), the next tile's prologue inside the current tile's drain - k_gemm8p.  Needs an even
         // number of K tiles and no super-columns; kernel | 4096 selects one workgroup per tile (A/B).  The kernel also carries the fp32 residual
@@ -1532,7 +1546,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
             constexpr int LDSP = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024;
             static SemabsLdsAttr attr_p4;
             semabs_ensure_lds(&k_gemm8p<EPI>, LDSP, attr_p4);
-            int ncu = 256; { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+            const int ncu = gemm_num_cus();
             gemm_dispatch(k_gemm8p<EPI>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDSP, s, g, o);
             SEMABS_CHECK_LAUNCH();
             return SEMABS_OK;
@@ -1542,13 +1556,6 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         static SemabsLdsAttr attr_v;
         semabs_ensure_lds(&k_gemm8<EPI, true, false, false, true>, LDS, attr_v);
         gemm_dispatch(k_gemm8<EPI, true, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
-        SEMABS_CHECK_LAUNCH();
-        return SEMABS_OK;
-    }
-    if (o.ring) {
-        static SemabsLdsAttr attr_r;
-        semabs_ensure_lds(&k_gemm8<EPI, false, false, true>, LDS, attr_r);
-        gemm_dispatch(k_gemm8<EPI, false, false, true>, dim3(g.n_blocks), dim3(512), LDS, s, g, o);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
     }
@@ -1588,7 +1595,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     SEMABS_REQUIRE(M > 0 && N > 0 && K > 0, "semabs_gemm_f16: empty problem");
     SEMABS_REQUIRE(N % 128 == 0 && K % BK == 0, "semabs_gemm_f16: N must be a multiple of 128 and K of 64");
     SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ((epi > 1 && epi != 5) || ldc % 8 == 0), "semabs_gemm_f16: leading dimensions must keep 16-byte alignment");
-    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 13) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring) or 2 (phased), optionally | 256 (reversed tile order) | 512 (K = 32 ring schedule) | 2048 (round-3 PF schedule) | 4096 (one workgroup per tile also for the fp16 outputs)");
+    SEMABS_REQUIRE((kernel & 255) >= 0 && (kernel & 255) <= 2 && (kernel >> 13) == 0, "semabs_gemm_f16_ex: kernel must be 0 (heuristic), 1 (ring kernel k_gemm_f16) or 2 (phased kernel k_gemm8 / k_gemm8p: deep schedule, persistent workgroups for the fp16 outputs), optionally | 256 (reversed tile order) | 512 (phased kernel: K = 32 ring schedule, one workgroup per tile) | 2048 (phased kernel: round-3 PF schedule, one workgroup per tile) | 4096 (phased kernel: one workgroup per tile also for the fp16 outputs, i.e. NO persistent workgroups)");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ex: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = addend;

@@ -1491,6 +1491,26 @@ __global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__
 // dZ fp32 [B, D0, D1, D2, Ca], X fp32 [B, D0, D1, D2, Cx] (+ GroupNorm affine [B, Cx]); dW fp32 [Ca, 27, Cx] or (tap_minor) [Ca, Cx, 27], accumulated.
 // s2 = (s, 1 / s) device scalars of semabs_grad_scale for dZ, or null.  Needs D0 % 4 == 0, D1 % 4 == 0, D2 % 16 == 0, Ca % 16 == Cx % 16 == 0.
 // scratch (scratch_floats fp32): partial sums of the transposing-read kernel k_wgrad3_tr; NULL selects the round-2 kernel (D1 % 8 == 0, atomics).
+// Which kernel semabs_wgrad_conv3 would run for a shape: 2 = the transposing-read kernel (needs scratch), 1 = the 4 x 8 x 16 brick kernel, 0 = neither
+// (the caller must use semabs_wgrad_mfma / semabs_wgrad).  ONE predicate for the entry point and for host-side routing (semabs_wgrad_conv3_supported).
+static int wgrad_conv3_route(int D0, int D1, int D2, int Ca, int Cx, bool have_scratch, long scratch_floats, long* bmax_out) {
+    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || Ca <= 0 || Cx <= 0) return 0;
+    if (!(D0 % 4 == 0 && D1 % 4 == 0 && D2 % WG_T2 == 0 && Ca % 16 == 0 && Cx % 16 == 0)) return 0;
+    const int combos = (Ca / 16) * (Cx / 16);
+    const long vpv = (long)D0 * D1 * D2;                    // voxels per volume
+    // volumes per launch of the transposing-read kernel: its GroupNorm table holds 64 volumes and its staging offsets are 32-bit
+    long bmax = 64;
+    if ((1L << 24) / vpv < bmax) bmax = (1L << 24) / vpv;
+    if (((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4) < bmax) bmax = ((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4);
+    if (bmax_out) *bmax_out = bmax;
+    if (have_scratch && bmax >= 1 && (long)D0 * D1 < (1L << 24) / bmax && scratch_floats >= (long)combos * 6912) return 2;
+    return D1 % WG_T1 == 0 ? 1 : 0;
+}
+extern "C" int semabs_wgrad_conv3_supported(int D0, int D1, int D2, int Ca, int Cx, long scratch_floats, int* kernel) {
+    SEMABS_REQUIRE(kernel, "semabs_wgrad_conv3_supported: null pointer");
+    *kernel = wgrad_conv3_route(D0, D1, D2, Ca, Cx, scratch_floats > 0, scratch_floats, nullptr);
+    return SEMABS_OK;
+}
 extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, const float* gn_shift, const float* s2, float* dW, int B,
                                   int D0, int D1, int D2, int Ca, int Cx, int tap_minor, float* scratch, long scratch_floats, void* stream) {
     if (B == 0) return SEMABS_OK;
@@ -1500,12 +1520,10 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     SEMABS_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "semabs_wgrad_conv3: gn_scale and gn_shift go together");
     const int combos = (Ca / 16) * (Cx / 16);
     hipStream_t s = (hipStream_t)stream;
-    // volumes per launch of the transposing-read kernel: its GroupNorm table holds 64 volumes and its staging offsets are 32-bit
     const long vpv = (long)D0 * D1 * D2;                    // voxels per volume
-    long bmax = 64;
-    if ((1L << 24) / vpv < bmax) bmax = (1L << 24) / vpv;
-    if (((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4) < bmax) bmax = ((1L << 31) - 1) / (vpv * (Ca > Cx ? Ca : Cx) * 4);
-    if (scratch && bmax >= 1 && (long)D0 * D1 < (1L << 24) / bmax && scratch_floats >= (long)combos * 6912) {
+    long bmax = 0;
+    const int route = wgrad_conv3_route(D0, D1, D2, Ca, Cx, scratch != nullptr, scratch_floats, &bmax);
+    if (route == 2) {
         static SemabsLdsAttr attr3;
         semabs_ensure_lds(&k_wgrad3_tr, W3_LDS + 64 * 128, attr3);
         for (int b0 = 0; b0 < B; b0 += (int)bmax) {          // (one launch for every call of the 128^3 training step)

@@ -118,6 +118,7 @@ class UNetTrainer:
         self.mats: Dict[str, dict] = {}
         self.dev = _lib.require_gpu()
         self._wgs = None
+        self._wg_routes = {}
         self.wgrad_tr = os.environ.get("SEMABS_WGRAD_TR", "1") == "1"      # A/B: 0 = the round-2 brick kernel (transposes while staging, atomics)
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
@@ -248,6 +249,16 @@ class UNetTrainer:
         _lib.call("semabs_chan_reduce", _lib.ptr(a2d), None, None, None, _lib.ptr(red), 1, R, Cc, 1, _lib.stream())
         grad.add_(red[0, :, 0].float())
 
+    def _wgrad_conv3_route(self, D0, D1, D2, ca, cx, scratch_floats) -> int:
+        key = (D0, D1, D2, ca, cx, scratch_floats)
+        r = self._wg_routes.get(key)
+        if r is None:
+            import ctypes as C
+            k = C.c_int(0)
+            _lib.call("semabs_wgrad_conv3_supported", D0, D1, D2, ca, cx, int(scratch_floats), C.byref(k))
+            r = self._wg_routes[key] = int(k.value)
+        return r
+
     def _wg_scratch(self):
         """(pointer, capacity in floats) of the buffer semabs_wgrad_mfma parks its row chunks' partial sums in (64 MB, allocated once)."""
         if self._wgs is None:
@@ -303,10 +314,10 @@ class UNetTrainer:
         sc, sh, s2 = self._scale(dZ, B, cout)                # dynamic power-of-two scale of dZ, shared by the weight and data gradients
         inv = s2[1:]
         dW = self.g[key + "conv.weight"]                     # [cout, cin, 3, 3, 3]: the kernels accumulate in this layout directly
-        # (the transposing-read kernel takes D1 % 4 == 0; without its scratch, or above 2^24 voxels, the entry point runs the 4 x 8 x 16 brick kernel, which
-        #  needs D1 % 8 == 0 - route anything else to the row kernel below instead of into its SEMABS_REQUIRE: ADVICE round 3)
-        if D0 % 4 == 0 and D1 % (4 if (self.wgrad_tr and D0 * D1 * D2 <= (1 << 24)) else 8) == 0 and D2 % 16 == 0 and cin % 16 == 0 and self.mfma_wgrad:
-            scr = self._wg_scratch() if self.wgrad_tr else (None, 0)
+        # routing by the entry point's OWN predicate (semabs_wgrad_conv3_supported: shape, 32-bit staging offsets, scratch size), so that no shape can
+        # fall into its SEMABS_REQUIRE (ADVICE rounds 3, 4); anything it does not take goes to the row kernels below
+        scr = self._wg_scratch() if self.wgrad_tr else (None, 0)
+        if self.mfma_wgrad and self._wgrad_conv3_route(D0, D1, D2, cout, cin, scr[1]):
             _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
                       B, D0, D1, D2, cout, cin, 1, *scr, st)
         elif cin % 16 == 0 and self.mfma_wgrad:                  # 8^3 / 4^3 levels: rows through LDS, transposing reads (k_wgrad_mfma)

@@ -41,10 +41,13 @@ def _check16(got, ref, what):
 
 
 SHAPES = [(2048, 768, 768), (2381, 768, 768), (2381, 2304, 768), (2381, 3072, 768), (2381, 768, 3072), (2049, 768, 128),
-          (50432, 2304, 768), (50432, 768, 3072), (256, 768, 768), (300, 3072, 768)]
+          (50432, 2304, 768), (50432, 768, 3072), (256, 768, 768), (300, 3072, 768),
+          # K tiles per output tile nk = 2 / 3 / 5: the persistent kernel's cross-tile prologue with the shortest loop it admits (nk = 2) and the odd
+          # counts that must fall back to one workgroup per tile
+          (4100, 768, 128), (4100, 512, 192), (4100, 768, 320)]
 
 
-@pytest.mark.parametrize("kernel", [2, 1, 2 | 512, 2 | 2048, 2 | 4096])          # 2: the phased kernel (deep schedule), | 512: its K = 32 ring schedule, | 2048: its round-3 PF schedule, | 4096: persistent workgroups with cross-tile prefetch (fp16 outputs)
+@pytest.mark.parametrize("kernel", [2, 1, 2 | 512, 2 | 2048, 2 | 4096])          # 2: the phased kernel (deep schedule; persistent workgroups k_gemm8p for the fp16 outputs), | 512: its K = 32 ring schedule, | 2048: its round-3 PF schedule, | 4096: deep schedule with one workgroup per tile also for the fp16 outputs (NO persistent workgroups)
 @pytest.mark.parametrize("M,N,K", SHAPES)
 def test_gemm_kernels_all_epilogues(kernel, M, N, K):
     from semabs_amd.clip.vit import gemm
@@ -60,6 +63,9 @@ def test_gemm_kernels_all_epilogues(kernel, M, N, K):
     _check16(c16, ref, tag + " f16")
     gemm(A, B, c16, bias, M, N, K, K, K, N, EPI_GELU_F16, kernel=kernel)
     _check16(c16, ref * torch.sigmoid(1.702 * ref), tag + " gelu")
+    c16.fill_(float("nan"))
+    gemm(A, B, c16, None, M, N, K, K, K, N, EPI_F16, kernel=kernel)                    # fp16 output without a bias (the persistent kernel's bias row is optional)
+    _check16(c16, ref - bias.double(), tag + " f16 no bias")
     g = torch.Generator(device="cuda").manual_seed(1)
     res = torch.randn(M, N, device="cuda", generator=g)
     c = res.clone()
@@ -135,6 +141,26 @@ def test_gemm_quickgelu_vjp_epilogue():
         assert float((out.float() - two.float()).abs().max()) <= 2e-3 * float(ref5.abs().max())      # two fp16 roundings of nearly equal fp32 values
     with pytest.raises(RuntimeError):                                            # small M: the ring kernel has no such epilogue
         gemm(A[:300], B, out[:300], bias, 300, N, K, K, K, N, 5, addend=table, rowmap=(n_x, 1, 0))
+
+
+@pytest.mark.parametrize("epi", [EPI_F16, EPI_GELU_F16, EPI_RESID_F32])
+@pytest.mark.parametrize("M,N,K", [(2381, 2304, 768), (50432, 3072, 768), (4100, 768, 128), (20000, 768, 3072)])
+def test_gemm_schedules_bit_identical(epi, M, N, K):
+    """Every schedule of the phased kernel - round-3 PF (| 2048), deep with one workgroup per tile (| 4096), deep + persistent workgroups (the default for
+    the fp16 outputs) - runs the same fragments through the same MFMA order and the same fp32 epilogue order: the results must be EQUAL, not close
+    (tools/gemm_biteq.py as a test).  The K = 32 ring schedule (| 512) sums in a different order and is only close."""
+    from semabs_amd.clip.vit import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).half()
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    outs = []
+    for kern in (2 | 2048, 2 | 4096, 2):
+        C = (torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda") if epi != EPI_RESID_F32 else
+             torch.sin(torch.arange(M * N, device="cuda", dtype=torch.float32)).view(M, N).contiguous())
+        gemm(A, B, C, bias, M, N, K, K, K, N, epi, kernel=kern)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_gemm_kernels_agree_and_heuristic_picks_the_phased_kernel():

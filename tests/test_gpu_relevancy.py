@@ -247,8 +247,10 @@ def _tiles(n, seed):
 @pytest.mark.parametrize("arch,tag", [("ViT-B/32", "b32"), ("ViT-B/16", "b16")])
 def test_vit_gradcam(golden, arch, tag):
     """HIP ViT + analytic rollout vs the reference's autograd result (golden) and vs the oracle.
-    Tolerance: RELATIVE L-infinity (max|ours - ref| / max|ref|) <= 5.5e-3 = 3 x the largest measured value (fp16 GEMM operands over 12
-    blocks vs the fp32 CPU reference; measured on MI355X: B/32 1.65e-3 / 1.68e-3, B/16 7.5e-4 / 1.83e-3 for positive_attn_only True / False)."""
+    Tolerance: RELATIVE L-infinity (max|ours - ref| / max|ref|) <= conftest.tol(measured) = 1.3 x the value measured on MI355X for THAT case (fp16 GEMM
+    operands over 12 blocks vs the fp32 CPU reference): B/32 1.65e-3 / 1.68e-3, B/16 7.5e-4 / 1.83e-3 for positive_attn_only True / False."""
+    from conftest import tol
+    measured = {("b32", True): 1.65e-3, ("b32", False): 1.68e-3, ("b16", True): 7.5e-4, ("b16", False): 1.83e-3}
     CW, sd = _init_clip(arch)
     g = golden(f"g3g4_vit_{tag}")
     tiles = _tiles(3, 7)
@@ -258,7 +260,7 @@ def test_vit_gradcam(golden, arch, tag):
         ref = g[f"rel_pos{int(pos)}"]
         err = np.abs(rel.cpu().numpy() - ref).max()
         print(f"{arch} pos={pos}: rel Linf {err:.3e} / max|ref| {np.abs(ref).max():.3e} = {err / np.abs(ref).max():.2e} relative")
-        assert err <= 5.5e-3 * np.abs(ref).max(), (err, np.abs(ref).max())
+        assert err <= tol(measured[(tag, pos)]) * np.abs(ref).max(), (err, np.abs(ref).max())
     np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=0, atol=5e-3 * np.abs(g["feat"]).max())
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-3 * np.abs(g["logits"]).max() + 0.05)
     probs = CW.engine._workspace()["probs"][:3].cpu().numpy()
@@ -268,7 +270,9 @@ def test_vit_gradcam(golden, arch, tag):
     with torch.no_grad():
         ref_f, _ = orl.gradcam_tiles(make_clip_state_dict(arch, 0, text_tower=False), torch.flip(tiles, dims=[-1]),
                                      torch.from_numpy(g["w_text"]), True)
-    assert np.abs(rel_f.cpu().numpy() - ref_f.numpy()).max() <= 5.5e-3 * ref_f.abs().max().item()
+    e_f = np.abs(rel_f.cpu().numpy() - ref_f.numpy()).max() / ref_f.abs().max().item()
+    print(f"{arch} flipped tiles vs the oracle: {e_f:.2e} relative")
+    assert e_f <= tol(measured[(tag, True)] * 1.15)          # (the flipped pass against the ORACLE's fp32 run of the flipped tiles: same error class as pos=True)
 
 
 def test_text_tower(golden):
