@@ -144,9 +144,16 @@ class SemAbs3D(torch.nn.Module):
         self._sig = sig
 
     def _final_conv(self):
+        """Host copies of the UNet's final 1x1x1 convolution (kernel arguments of the decoder when it applies that layer itself); re-read from the
+        device only when the parameters changed - a device -> host copy per scene is a host synchronisation on the hot path."""
         u = self.vol_feature_extractor
-        return (np.ascontiguousarray(u.final_conv.weight.detach().float().cpu().numpy().reshape(-1)),
-                np.ascontiguousarray(u.final_conv.bias.detach().float().cpu().numpy().reshape(-1)))
+        w, b = u.final_conv.weight, u.final_conv.bias
+        sig = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if getattr(self, "_final_sig", None) != sig:
+            self._final_host = (np.ascontiguousarray(w.detach().float().cpu().numpy().reshape(-1)),
+                                np.ascontiguousarray(b.detach().float().cpu().numpy().reshape(-1)))
+            self._final_sig = sig
+        return self._final_host
 
     # ---- stages ------------------------------------------------------------------------------------
     @torch.no_grad()
