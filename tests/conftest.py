@@ -49,3 +49,48 @@ MEASURED_WITH_HIP = "7.0.51831"          # torch.version.hip of the image the `m
 def tol(measured: float, tight: float = 1.3, loose: float = 2.0) -> float:
     import torch
     return float(measured) * (tight if getattr(torch.version, "hip", None) == MEASURED_WITH_HIP else loose)
+
+
+# Per-case measured errors (tests/golden/measured_errors.json: pytest node id + tag -> the error measured on MI355X with MEASURED_WITH_HIP), so that
+# EVERY parametrised case of a kernel-level parity test has its own 1.3 x bar instead of one bar at several times the worst case.  Re-record with
+#   SEMABS_RECORD_ERRORS=gpurun_out/measured_errors.json python -m pytest tests -m gpu -q     (then copy the file to tests/golden/)
+_MEASURED_PATH = os.path.join(GOLDEN, "measured_errors.json")
+try:
+    import json as _json
+    _MEASURED = _json.load(open(_MEASURED_PATH))
+except Exception:
+    _MEASURED = {}
+_RECORDED = {}
+
+
+@pytest.fixture
+def bar(request):
+    """bar(tag, err, ceiling) -> bool: err <= min(ceiling, tol(measured error of this case)) - the ceiling (the old fixed bar) alone when the case has
+    no recorded value.  A recorded 0.0 demands 0.0 (bit-exact cases stay bit-exact)."""
+    def check(tag: str, err: float, ceiling: float) -> bool:
+        key = request.node.nodeid.split("tests/")[-1] + ":" + tag
+        err = float(err)
+        if os.environ.get("SEMABS_RECORD_ERRORS"):
+            _RECORDED[key] = max(err, _RECORDED.get(key, 0.0))
+        m = _MEASURED.get(key)
+        limit = float(ceiling) if m is None else min(float(ceiling), tol(m))
+        ok = err <= limit
+        if not ok:
+            print(f"[bar] {key}: error {err:.4e} > limit {limit:.4e} (measured {m}, ceiling {ceiling:.4e})")
+        return ok
+    return check
+
+
+def pytest_sessionfinish(session, exitstatus):
+    out = os.environ.get("SEMABS_RECORD_ERRORS")
+    if out and _RECORDED:
+        import json
+        os.makedirs(os.path.dirname(os.path.abspath(out)) or ".", exist_ok=True)
+        prev = {}
+        if os.path.exists(out):
+            try:
+                prev = json.load(open(out))
+            except Exception:
+                prev = {}
+        prev.update(_RECORDED)
+        json.dump(dict(sorted(prev.items())), open(out, "w"), indent=0)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("precision", ["exact", "fp16"])
-def test_scene_end_to_end(precision):
+def test_scene_end_to_end(precision, bar):
     from semabs_amd.clip import saliency_configs
     from semabs_amd.scene import build_default
     S, H, L, npts = 32, 96, 4, 4000
@@ -33,12 +33,12 @@ def test_scene_end_to_end(precision):
     r_ref = ref["relevancies"].numpy()
     e_rel = np.abs(rel - r_ref).max() / np.abs(r_ref).max()
     print(f"scene relevancies (x 50, mean-subtracted): relative L-inf {e_rel:.2e}")
-    assert e_rel <= 1e-2                                 # mean subtraction shrinks the reference's range; measured 2.7e-3
+    assert bar("relevancy_rel", e_rel, 1e-2)             # mean subtraction shrinks the reference's range; measured 3.74e-3 (tests/golden/measured_errors.json)
     lg, lg_ref = res.logits.cpu().numpy(), ref["logits"].numpy()
     err = np.abs(lg - lg_ref).max()
     print(f"{precision}: logits Linf {err:.3e} (max|ref| {np.abs(lg_ref).max():.3f})")
     # the point features inherit the fp16-GEMM relevancy error (~1e-3 relative); logits are O(0.5)
-    assert err <= (5e-3 if precision == "exact" else 2e-2)
+    assert bar("logits", err, 5e-3 if precision == "exact" else 2e-2)      # measured 5.6e-4 / 1.6e-3
     assert torch.equal(res.tsdf.cpu(), torch.from_numpy(ref["tsdf"]))                      # TSDF volume bit-exact
     lab, lab_ref = res.labels.cpu().numpy(), ref["labels"]
     assert ((lab == -1) == (lab_ref == -1)).mean() > 0.999

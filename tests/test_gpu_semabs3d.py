@@ -28,7 +28,7 @@ def _unet(precision, sd=None, levels=6):
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("cin,cout,S,B", [(16, 16, 12, 2), (16, 32, 8, 1), (32, 32, 8, 3), (64, 128, 4, 2), (512, 512, 2, 2), (32, 64, 6, 1)])
-def test_conv3d_gn_relu_resid(precision, tol, cin, cout, S, B):
+def test_conv3d_gn_relu_resid(precision, tol, cin, cout, S, B, bar):
     """GroupNorm -> Conv3d 3^3 -> (+residual) -> ReLU against torch fp32."""
     from semabs_amd import _lib
     from semabs_amd.unet3d import _Conv
@@ -48,12 +48,12 @@ def test_conv3d_gn_relu_resid(precision, tol, cin, cout, S, B):
                      + rd.float().cpu().permute(0, 4, 1, 2, 3))
     y = u._conv(xd, conv, relu=True, resid=rd)
     got = y.float().cpu().permute(0, 4, 1, 2, 3)
-    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+    assert bar("vs_torch", (got - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()))
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("dims,B,resid", [((8, 8, 16), 1, False), ((16, 24, 32), 2, True), ((8, 16, 48), 3, True)])
-def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid):
+def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid, bar):
     """The level-0 LDS-halo kernel (Cin = Cout = 16, bricks of 8 x 8 x 16) vs torch fp32 and vs the generic gather kernel."""
     from semabs_amd import _lib
     from semabs_amd.unet3d import _Conv
@@ -73,8 +73,8 @@ def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid):
     ref = F.relu(ref)
     y_lds = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
     y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
-    assert (y_lds - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (y_lds - ref).abs().max().item()
-    assert (y_lds - y_gen).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item())
+    assert bar("vs_torch", (y_lds - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()))
+    assert bar("vs_generic", (y_lds - y_gen).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item()))
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
@@ -82,7 +82,7 @@ def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid):
                                                    (32, 64, (8, 16, 32), 64, True), (64, 64, (8, 16, 32), 64, False), (16, 64, (8, 16, 32), 64, True),
                                                    (128, 128, (4, 8, 16), 1, True), (256, 256, (8, 8, 8), 2, True), (128, 256, (4, 16, 8), 3, False),
                                                    (32, 32, (4, 8, 24), 1, True)])
-def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid):
+def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid, bar):
     """k_conv_brick (64^3 .. 16^3 levels: LDS halo bricks of 4 x 8 x 16, weights software-pipelined, lane-transposed epilogue) vs torch fp32 and
     vs the generic gather kernel; the B = 64 cases have enough bricks for the four-output-block (in-place weight re-request) variants."""
     from semabs_amd.unet3d import _Conv
@@ -102,8 +102,8 @@ def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid):
     y_brick = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
     y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
     scale = max(1.0, ref.abs().max().item())
-    assert (y_brick - ref).abs().max().item() <= tol * scale, (y_brick - ref).abs().max().item()
-    assert (y_brick - y_gen).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale
+    assert bar("vs_torch", (y_brick - ref).abs().max().item(), tol * scale)
+    assert bar("vs_generic", (y_brick - y_gen).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * scale)
 
 
 @pytest.mark.parametrize("precision", ["exact", "fp16"])
@@ -140,7 +140,7 @@ def test_packed_weights_equal_rowmajor(precision, cin, cout, dims):
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("cin,cout,S,B", [(32, 16, 6, 2), (64, 32, 4, 1), (512, 256, 2, 2), (128, 64, 3, 1)])
-def test_convtranspose3d_skip(precision, tol, cin, cout, S, B):
+def test_convtranspose3d_skip(precision, tol, cin, cout, S, B, bar):
     from semabs_amd.unet3d import _ConvT
     rng = np.random.default_rng(cin)
     x = torch.from_numpy(rng.standard_normal((B, cin, S, S + 1, S + 2)).astype(np.float32))
@@ -153,7 +153,7 @@ def test_convtranspose3d_skip(precision, tol, cin, cout, S, B):
                                                                                  padding=1, output_padding=1)
     y = u._up(xd, sd_, _ConvT(w, b, u.dev))
     got = y.float().cpu().permute(0, 4, 1, 2, 3)
-    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+    assert bar("vs_torch", (got - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()))
 
 
 @pytest.mark.parametrize("precision", ["exact", "fp16"])
@@ -194,7 +194,7 @@ def _model(S, precision):
 
 
 @pytest.mark.parametrize("precision,tol_feat,tol_out", [("exact", 2e-4, 2e-4), ("fp16", 2e-2, 1e-2)])
-def test_semabs3d_forward_vs_golden(golden, precision, tol_feat, tol_out):
+def test_semabs3d_forward_vs_golden(golden, precision, tol_feat, tol_out, bar):
     """SemAbs3D.forward at 32^3 (point MLP -> scatter-mean -> 6-level UNet -> decoder) vs the reference's outputs."""
     g = golden("g9_semabs3d")
     S, N, M, P, seed, wseed = (int(v) for v in g["meta"])
@@ -210,11 +210,11 @@ def test_semabs3d_forward_vs_golden(golden, precision, tol_feat, tol_out):
     ref = g["unet_sub"]
     err = np.abs(feats[:, :, ::3, ::3, ::3] - ref).max()
     print(f"{precision}: UNet feature Linf {err:.3e} (max|ref| {np.abs(ref).max():.3f})")
-    assert err <= tol_feat * np.abs(ref).max()
+    assert bar("unet_feature", err, tol_feat * np.abs(ref).max())
     out = m.forward(torch.from_numpy(xyz), torch.from_numpy(feat), None, torch.from_numpy(q)).cpu().numpy()
     err = np.abs(out - g["out"]).max()
     print(f"{precision}: logit Linf {err:.3e} (max|ref| {np.abs(g['out']).max():.3f})")
-    assert err <= tol_out * max(1.0, np.abs(g["out"]).max())
+    assert bar("logits", err, tol_out * max(1.0, np.abs(g["out"]).max()))
     vvf = m.visual_volumetric_features
     assert tuple(vvf.shape) == (P, 16, S, S, S)
 
@@ -271,7 +271,7 @@ def test_point_mlp():
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 3e-4), ("fp16", 3e-2)])
-def test_unet128_vs_golden(golden, precision, tol):
+def test_unet128_vs_golden(golden, precision, tol, bar):
     """One 128^3 ResidualUNet3D forward (config 3 shape) against sampled voxels of the reference's output."""
     g = golden("g10_unet128")
     u = _unet(precision, make_semabs3d_state_dict(seed=int(g["meta"][1])))
@@ -282,7 +282,7 @@ def test_unet128_vs_golden(golden, precision, tol):
     y = u.forward(torch.from_numpy(x)).cpu().numpy()
     err = np.abs(y.reshape(-1)[g["si"]] - g["y_s"]).max()
     print(f"{precision}: unet128 Linf {err:.3e} (max|ref| {np.abs(g['y_s']).max():.3f})")
-    assert err <= tol * np.abs(g["y_s"]).max()
+    assert bar("unet128", err, tol * np.abs(g["y_s"]).max())
 
 
 def test_decoder_lattice_walk_is_bit_identical():
@@ -305,7 +305,7 @@ def test_decoder_lattice_walk_is_bit_identical():
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
 @pytest.mark.parametrize("cin,cout,dims,B", [(32, 16, (4, 8, 16), 2), (64, 32, (8, 8, 16), 1), (128, 64, (4, 16, 32), 1)])
-def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B):
+def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B, bar):
     """Input dims that tile into 4 x 8 x 16 bricks take the two-launch LDS-halo kernel: against torch and against the parity-class gather
     launches (same arithmetic, different summation order across taps)."""
     from semabs_amd import _lib
@@ -324,8 +324,8 @@ def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B):
     y_brick = u._up(xd, sd_, ct).float().cpu().permute(0, 4, 1, 2, 3)
     y_gather = u._up(xd, sd_, ct, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
     scale = max(1.0, ref.abs().max().item())
-    assert (y_brick - ref).abs().max().item() <= tol * scale
-    assert (y_brick - y_gather).abs().max().item() <= (1e-5 if precision == "exact" else 2e-3) * scale
+    assert bar("vs_torch", (y_brick - ref).abs().max().item(), tol * scale)
+    assert bar("vs_generic", (y_brick - y_gather).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * scale)
 
 
 def test_decoder_folded_final_conv_matches_materialised():
