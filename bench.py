@@ -408,6 +408,10 @@ def gemm_roof_ms(fl, by):
 
 def _classify(name, a):
     """C-ABI entry point + its arguments -> (kernel class, algorithmic flops, algorithmic bytes) of that launch; None = small / host-side."""
+    if name == "semabs_gemm_f16_ln":
+        M, N, K, epi = a[4], a[5], a[6], a[10]
+        return ("fp16 GEMM: " + gemm_shape_name(N, K, epi, M) + (" + LayerNorm producer (fp16 x*gamma copy, row partials)" if a[11] else " + LayerNorm consumer"),
+                2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else 8) + (M * N * 2 if a[11] else 0))
     if name.startswith("semabs_gemm_f16"):
         M, N, K, epi = a[5], a[6], a[7], a[11]
         return "fp16 GEMM: " + gemm_shape_name(N, K, epi, M), 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4))

@@ -142,6 +142,16 @@ int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias,
                        long lda, int ldb, long ldc, int epi, const int* rowmap3, int kernel, void* start_event, void* stop_event,
                        void* stream);
 
+/* LayerNorm folded into the GEMMs on either side of it (auxiliary.py:129,340 / model_explainability.py:232-255: ln_1 -> in_proj, ln_2 -> c_fc): large
+ * shapes (M >= 2048, N % 256 == 0, K >= 128).  epi 2 with (ln_xg, ln_gamma, ln_part): x += A W^T + b AND xg = fp16(x_new * gamma) [M, N], row partials
+ * (sum, sum of squares) [M, N / 256, 2]; epi 0 / 1 with (ln_rowac, ln_colsum): C = rstd_row * (A W^T) - mean_row * rstd_row * colsum[n] + bias[n]
+ * (A = such an xg, K % 128 == 0; colsum[n] = sum_k gamma_k W[n, k]; bias must already contain sum_k beta_k W[n, k]).  reverse: tile order (zigzag).
+ * semabs_ln_rowstats: partials -> (rstd, -mean * rstd) [M, 2]. */
+int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
+                       void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum, int reverse,
+                       void* start_event, void* stop_event, void* stream);
+int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, void* stream);
+
 /* ============================ transformer pieces (csrc/vit.hip) ========================================= */
 
 /* LayerNorm (fp32 statistics)                                        model_explainability.py:188-194 */

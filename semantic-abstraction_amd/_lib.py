@@ -53,6 +53,8 @@ SIGNATURES = {
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
     "semabs_gemm_f16_ex": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), I, P, P, P],
+    "semabs_gemm_f16_ln": [P, P, P, P, L, I, I, L, I, L, I, P, P, P, P, P, I, P, P, P],
+    "semabs_ln_rowstats": [P, L, I, I, F, P, P],
     # vit.hip
     "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
     "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],

@@ -99,6 +99,26 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, k
 _gemm = gemm
 
 
+def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, part=None, rowac=None, colsum=None, reverse=0):
+    """A GEMM with the LayerNorm that precedes (consumer: rowac, colsum) or follows (producer: xg, gamma, part) it folded in - see
+    `semabs_gemm_f16_ln` (csrc/gemm.hip, LNP / LNC).  Timed by GEMM_TIMER like every other GEMM launch; the producer's algorithmic bytes include
+    the fp16 copy it writes."""
+    t = GEMM_TIMER
+    e0 = e1 = None
+    if t is not None:
+        t.seen += 1
+        if t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0:
+            e0, e1 = t._pair()
+            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else 8) + (M * N * 2 if xg is not None else 0),
+                              (int(N), int(K), int(epi))))
+    _lib.call("semabs_gemm_f16_ln", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), int(M), int(N), int(K), int(lda), int(ldb), int(ldc), int(epi),
+              _lib.ptr(xg), _lib.ptr(gamma), _lib.ptr(part), _lib.ptr(rowac), _lib.ptr(colsum), int(reverse), e0, e1, _lib.stream())
+
+
+def ln_rowstats(part, M, ntile, D, rowac, eps=1e-5):
+    _lib.call("semabs_ln_rowstats", _lib.ptr(part), int(M), int(ntile), int(D), float(eps), _lib.ptr(rowac), _lib.stream())
+
+
 def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5, order=0):
     """order: 0 = rows in dispatch order, 1 / 2 = XCD-contiguous runs of rows walked forwards / backwards (the zigzag schedule of the trunk)."""
     _lib.call("semabs_layernorm", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out), int(M), int(D), float(eps),
@@ -138,6 +158,14 @@ class _BlockWeights:
         self.ln2_w, self.ln2_b = f(sd[pre + "ln_2.weight"]), f(sd[pre + "ln_2.bias"])
         self.w_fc, self.b_fc = h(sd[pre + "mlp.c_fc.weight"]), f(sd[pre + "mlp.c_fc.bias"])
         self.w_pr, self.b_pr = h(sd[pre + "mlp.c_proj.weight"]), f(sd[pre + "mlp.c_proj.bias"])
+        # LayerNorm folded into the GEMM that consumes it (gemm.hip LNC): with xg = fp16(x * gamma) as the A operand,
+        #   LN(x) W^T + b = rstd * (xg W^T) - mean * rstd * colsum + (b + W beta),   colsum[n] = sum_k gamma_k W[n, k]
+        # (sums in fp64 over the fp16-exact weights the kernels read)
+        wi, wf = self.w_in.double().cpu(), self.w_fc.double().cpu()
+        g1, be1 = sd[pre + "ln_1.weight"].double().cpu(), sd[pre + "ln_1.bias"].double().cpu()
+        g2, be2 = sd[pre + "ln_2.weight"].double().cpu(), sd[pre + "ln_2.bias"].double().cpu()
+        self.cs_in, self.b_in_f = f(wi @ g1), f(b_in.double().cpu() + wi @ be1)
+        self.cs_fc, self.b_fc_f = f(wf @ g2), f(sd[pre + "mlp.c_fc.bias"].double().cpu() + wf @ be2)
         if last or bwd:  # transposed copies: B operands ([N, K]) of the VJP GEMMs
             self.w_o_t = h(sd[pre + "attn.out_proj.weight"].float().t())
             self.w_fc_t = h(sd[pre + "mlp.c_fc.weight"].float().t())
@@ -200,6 +228,10 @@ class VisionRollout:
         # Zigzag schedule of the trunk: consecutive kernels walk the token rows in opposite directions (per XCD run), so each starts with the
         # rows its producer wrote last - still in the 256 MiB Infinity Cache - instead of the ones written first (semabs_common.h)
         self.zigzag = os.environ.get("SEMABS_ZIGZAG", "1") == "1"
+        # LayerNorm fold (trunk, large batches): ln_2 into out-proj -> c_fc and ln_1 into c_proj -> in_proj (csrc/gemm.hip LNP / LNC).  21 of the 26
+        # LayerNorm passes of a scene disappear (each a 1.48 GB fp32 read + 0.74 GB fp16 write at the benchmark batch); the residual GEMMs write the
+        # fp16 (x * gamma) copy from their epilogue instead.  SEMABS_LN_FOLD=0 runs the LayerNorm kernels (A/B).
+        self.ln_fold = os.environ.get("SEMABS_LN_FOLD", "1") == "1"
         self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
@@ -219,6 +251,7 @@ class VisionRollout:
             R = Lm * n
             self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), delta=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
+                ln_part=e32(n * T, max(1, D // 256), 2), ln_rowac=e32(n * T, 2),
                 k32=e32(n * T, D), v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
                 h2c=e16(n, D), fc=e32(n, 4 * D), actc=e16(n, 4 * D), x2c=e32(n, D), yc=e16(n, D), feat=e32(n, E),
                 logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, D),
@@ -252,6 +285,27 @@ class VisionRollout:
             def step():                                      # direction of the next launch: 0 = forwards, 1 = backwards
                 c[0] ^= 1
                 return c[0] ^ 1
+            if self.ln_fold and M >= 2048 and D % 256 == 0 and D % 128 == 0:
+                # h doubles as xg = fp16(x * gamma_next): written by the residual GEMMs' epilogues, read as the next GEMM's A operand
+                part, rowac, nt = ws["ln_part"], ws["ln_rowac"], D // 256
+                trunk_blocks = self.blocks[:-1]
+                d = (lambda: step()) if zz else (lambda: 0)
+                for bi, b in enumerate(trunk_blocks):
+                    if bi == 0:                              # ln_1 of the first block follows ln_pre, not a GEMM
+                        layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=(1 + d()) if zz else 0)
+                        gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, kernel=2 | (d() << 8))
+                    else:
+                        gemm_ln(h, b.w_in, qkv, b.b_in_f, M, 3 * D, D, D, D, 3 * D, EPI_F16, rowac=rowac, colsum=b.cs_in, reverse=d())
+                    _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, ((1 + d()) << 3) if zz else 0, _lib.stream())
+                    gemm_ln(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32, xg=h, gamma=b.ln2_w, part=part, reverse=d())
+                    ln_rowstats(part, M, nt, D, rowac)
+                    gemm_ln(h, b.w_fc, hid, b.b_fc_f, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16, rowac=rowac, colsum=b.cs_fc, reverse=d())
+                    if bi + 1 < len(trunk_blocks):
+                        gemm_ln(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32, xg=h, gamma=trunk_blocks[bi + 1].ln1_w, part=part, reverse=d())
+                        ln_rowstats(part, M, nt, D, rowac)
+                    else:                                    # the last block's ln_1 feeds K | V | the CLS query: stays a LayerNorm pass (head)
+                        gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32, kernel=2 | (d() << 8))
+                return
             for b in self.blocks[:-1]:
                 if not zz:
                     layernorm(x, b.ln1_w, b.ln1_b, h, M, D)

@@ -32,6 +32,9 @@ struct GemmArgs {
     int n_tiles_n; int n_tiles_m; int group_m; int n_blocks;
     int sc_w;                   // column panels per super-column of the raster (see tile_of in k_gemm8); 0 = all of them
     int reverse;                // k_gemm8: every XCD walks its run of tiles backwards (zigzag with the producer of A, semabs_common.h)
+    // LayerNorm folded into the GEMMs on either side of it (semabs_gemm_f16_ln; k_gemm8's LNP / k_gemm8p's LNC template parameters):
+    f16* ln_xg; const float* ln_gamma; float* ln_part;      // producer (fp32 residual epilogue): fp16 (x_new * gamma) [M, N], gamma [N], row partials [M, N / 256, 2]
+    const float* ln_rowac; const float* ln_colsum;          // consumer (fp16 outputs): per row (rstd, -mean * rstd) [M, 2], per column sum_k gamma_k W[n, k] [N]
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only (k_gemm_f16; k_gemm8 takes its ablations as the template parameter ABL): bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
@@ -349,9 +352,16 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, AUX);
 }
 
-template <int EPI, bool PF, bool PERS = false, bool RING = false, bool V2 = false, int ABL = 0>      // ABL: compile-time ablation bits (tuning build only; 0 in the product)
+// LNP (LayerNorm fold, PRODUCER side; EPI_BIAS_RESID_F32 only): besides x += acc + bias the epilogue writes xg = fp16(x_new * gamma) - the A operand of
+// the GEMM behind the LayerNorm that follows - with 16-byte stores (two rows' 8-byte halves exchanged between neighbouring lanes by DPP), and per row the
+// partial sums (sum x_new, sum x_new^2) over this tile's 256 columns into ln_part[row][tile column]: reduced over the 8 lanes of a row by DPP, then over
+// the 4 wave columns x 2 B halves through 16 KB of LDS behind the operand buffers in a FIXED order (no atomics: bit-reproducible, batch-size independent).
+// semabs_ln_rowstats turns the partials into (rstd, -mean * rstd) per row; k_gemm8p<EPI, true> (the consumer) applies them:
+//   sum_k ((x_k - mu) rstd gamma_k + beta_k) W[n,k] = rstd * sum_k xg_k W[n,k] - mu rstd * sum_k gamma_k W[n,k] + sum_k beta_k W[n,k].
+template <int EPI, bool PF, bool PERS = false, bool RING = false, bool V2 = false, int ABL = 0, bool LNP = false>      // ABL: compile-time ablation bits (tuning build only; 0 in the product)
 //       // PERS: persistent workgroups (see the end of the kernel); RING: the K = 32 ring schedule (see `ring`); V2: the deep schedule (see `v2`)
 __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
+    static_assert(!LNP || EPI == EPI_BIAS_RESID_F32, "the LayerNorm producer lives in the fp32 residual epilogue");
 #define GABL(bit) ((ABL & (bit)) != 0)      /* 1 no in-loop DMA, 2 no in-loop LDS reads, 4 no DMA waits, 8 no epilogue, 16 no B staging */
     constexpr int HT = 16384;                               // one half-tile: 128 rows x 64 fp16
     constexpr int OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
@@ -649,19 +659,85 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) res[pass & 1][it] = buf_load4<EAUX>(rC, voff, soff_of(pass, it));
                 };
+                // LNP: the fp16 (x_new * gamma) copy and the row partials of the LayerNorm that follows (see the template comment).  Coalesced layout
+                // here: 8 lanes per row (cchunk = lane % 8 holds 4 consecutive columns), 8 rows per instruction.  xg: instructions it and it + 1
+                // of a pass are paired - the even lane of a pair collects row `it`'s 8 columns, the odd lane row `it + 1`'s - one 16-byte store per pair.
+                [[maybe_unused]] __amdgpu_buffer_rsrc_t rG = rC;
+                [[maybe_unused]] f32x4 gam[2];
+                [[maybe_unused]] float* const sred = reinterpret_cast<float*>(smem + 2 * BUFSZ);        // [256 rows][4 wave columns][2 B halves][2]
+                [[maybe_unused]] const unsigned ldgb = (unsigned)g.N * 2u;
+                [[maybe_unused]] const bool odd = (cchunk & 1) != 0;
+                [[maybe_unused]] unsigned gvoff = 0;
+                if constexpr (LNP) {
+                    rG = gemm_rsrc(reinterpret_cast<const char*>(g.ln_xg) + (mw * (long)g.N + n0 + wc * 32) * 2,
+                                   rows > 0 ? (rows - 1) * (long)ldgb + (long)(g.N - n0 - wc * 32) * 2 : 0);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const float4 t = *reinterpret_cast<const float4*>(g.ln_gamma + n0 + hb * 128 + wc * 32 + cchunk * 4);
+                        gam[hb] = f32x4{t.x, t.y, t.z, t.w};
+                    }
+                    gvoff = (unsigned)(crow + (odd ? RPI : 0)) * ldgb + (unsigned)((cchunk & ~1) * 8);
+                }
+                auto dpp = [](float x, auto ctrl) {            // x of the lane selected by the DPP control word (all rows / banks, no bound control)
+                    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+                };
+                using XOR1 = std::integral_constant<int, 0xB1>;  // quad_perm [1, 0, 3, 2]
+                using XOR2 = std::integral_constant<int, 0x4E>;  // quad_perm [2, 3, 0, 1]
+                using HMIR = std::integral_constant<int, 0x141>; // row_half_mirror: lane i <-> 7 - i of each 8
                 issue(0);
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     lds_write(pass);
                     if (pass + 1 < 4) issue(pass + 1);
                     __builtin_amdgcn_sched_barrier(0);
+                    [[maybe_unused]] unsigned keep0 = 0, keep1 = 0;        // the even instruction's fp16 pairs, until its partner instruction arrives
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const f32x4 v = lds_read(pass, it);
                         const f32x4 o = res[pass & 1][it];
-                        buf_store4<EAUX>(rC, voff, soff_of(pass, it), f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]});
+                        const f32x4 nw = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
+                        buf_store4<EAUX>(rC, voff, soff_of(pass, it), nw);
+                        if constexpr (LNP) {
+                            const int hb = pass >> 1;
+                            typedef f16 f16x2v __attribute__((ext_vector_type(2)));
+                            const f16x2v h01 = f16x2v{(f16)(nw[0] * gam[hb][0]), (f16)(nw[1] * gam[hb][1])};
+                            const f16x2v h23 = f16x2v{(f16)(nw[2] * gam[hb][2]), (f16)(nw[3] * gam[hb][3])};
+                            const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+                            if ((it & 1) == 0) { keep0 = u01; keep1 = u23; }
+                            else {
+                                // even lanes send this (odd) instruction's values and receive the partner's even-instruction values; odd lanes the reverse
+                                const unsigned snd0 = odd ? keep0 : u01, snd1 = odd ? keep1 : u23;
+                                const unsigned rcv0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd0, 0xB1, 0xf, 0xf, false);
+                                const unsigned rcv1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd1, 0xB1, 0xf, 0xf, false);
+                                const u32x4 w = odd ? u32x4{rcv0, rcv1, u01, u23} : u32x4{keep0, keep1, rcv0, rcv1};
+                                __builtin_amdgcn_raw_buffer_store_b128(w, rG, gvoff, (unsigned)((pass & 1) * 128 + (it - 1) * RPI) * ldgb + (unsigned)(hb * 128 * 2), 0);
+                                __builtin_amdgcn_sched_barrier(0);      // (store-data hazard, see store_pad: no VALU write to w right behind the store)
+                                asm volatile("s_nop 7" ::: "memory");
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            float s1 = (nw[0] + nw[1]) + (nw[2] + nw[3]);
+                            float s2 = (nw[0] * nw[0] + nw[1] * nw[1]) + (nw[2] * nw[2] + nw[3] * nw[3]);
+                            s1 += dpp(s1, XOR1{}); s2 += dpp(s2, XOR1{});
+                            s1 += dpp(s1, XOR2{}); s2 += dpp(s2, XOR2{});
+                            s1 += dpp(s1, HMIR{}); s2 += dpp(s2, HMIR{});
+                            if (cchunk == 0) {
+                                const int row = (pass & 1) * 128 + wr * 64 + it * RPI + crow;
+                                *reinterpret_cast<float2*>(sred + ((row * 4 + wc) * 2 + hb) * 2) = make_float2(s1, s2);
+                            }
+                        }
                     }
                     store_pad();
+                }
+                if constexpr (LNP) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                    if (tid < 256 && m0 + tid < g.M) {
+                        const float* pr = sred + tid * 16;
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { s1 += pr[q * 2]; s2 += pr[q * 2 + 1]; }
+                        *reinterpret_cast<float2*>(g.ln_part + ((m0 + tid) * g.n_tiles_n + n0 / 256) * 2) = make_float2(s1, s2);
+                    }
                 }
             } else {
 #pragma unroll
@@ -1132,12 +1208,18 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 // Requires an even number of K tiles (buffer parity continues across tiles).  Slot map, fragment layout and MFMA order are k_gemm8's: results are
 // bit-identical to it.
 // =================================================================================================
-template <int EPI>
+// LNC (LayerNorm fold, CONSUMER side; fp16 outputs): C = a_row * acc + (c_row * colsum[n] + bias'[n]) with (a, c) = (rstd, -mean * rstd) of the row
+// (semabs_ln_rowstats) - LN(x) W^T + b without materialising LN(x); A is the producer's xg = fp16(x * gamma), bias' = b + W beta.  The tile's colsum row
+// (1 KB) and its 256 (a, c) pairs (2 KB) travel by LDS-DMA like the bias row - waves 1, 2, 3 issue one more 16-byte-per-lane load each in front of the
+// tile's first stage, exactly where wave 0 issues the bias row - so the kernel still issues no ordinary load and every counted wait keeps its meaning.
+template <int EPI, bool LNC = false>
 __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32, "fp16-output epilogues and the fp32 residual read-modify-write");
+    static_assert(!LNC || EPI != EPI_BIAS_RESID_F32, "the LayerNorm consumer has fp16 outputs");
     constexpr bool OUT16 = EPI != EPI_BIAS_RESID_F32;
     constexpr int HT = 16384, OFF_A0 = 0, OFF_B0 = HT, OFF_B1 = 2 * HT, OFF_A1 = 3 * HT, BUFSZ = 4 * HT;
     constexpr int OFF_SCR = 2 * BUFSZ, OFF_BIAS = OFF_SCR + 8 * 2048;      // epilogue scratch (2 KB per wave), bias rows of this and the next tile (2 x 1 KB)
+    constexpr int OFF_CS = OFF_BIAS + 2 * 1024, OFF_RA = OFF_CS + 2 * 1024; // LNC: colsum rows (2 x 1 KB) and (rstd, -mean rstd) pairs of the tile's 256 rows (2 x 2 KB), by tile parity
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1160,6 +1242,8 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     const unsigned a_q = (unsigned)(64 * (int)g.lda * 2), b_q = (unsigned)(64 * g.ldb * 2);      // second 64-row piece of a half-tile: same swizzle term
     __amdgpu_buffer_rsrc_t rA, rB, rAn, rBn;                // this tile's / the next tile's operand panels
     const __amdgpu_buffer_rsrc_t rBias = gemm_rsrc(g.bias, has_bias ? (long)g.N * 4 : 0);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rCs = gemm_rsrc(g.ln_colsum, LNC ? (long)g.N * 4 : 0);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rRa = gemm_rsrc(g.ln_rowac, LNC ? (g.M * 8 > 0x7fffffffL ? 0x7fffffffL : g.M * 8) : 0);
     auto rsrc_a = [&](long m0) { const long rows = g.M - m0 < 256 ? g.M - m0 : 256; return gemm_rsrc(g.A + m0 * g.lda, ((rows - 1) * g.lda + g.K) * 2); };
     auto rsrc_b = [&](int n0) { return gemm_rsrc(g.B + (long)n0 * g.ldb, (255L * g.ldb + g.K) * 2); };
     // stage j (0 A0, 1 B0, 2 B1, 3 A1) of K tile kt of this (nx = false) or the next tile: two 8 KB pieces per half-tile, 1 KB per wave each
@@ -1178,9 +1262,16 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst), 16, isa ? aoff : boff, soff, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + 8192), 16, isa ? aoff : boff, soff + (isa ? a_q : b_q), 0, 0);
     };
-    auto stage_bias = [&](const int n0, const int bpar) {    // wave 0: bias[n0 .. n0 + 255] -> LDS (two 1 KB buffers, by tile parity), 16 bytes per lane
+    auto stage_bias = [&](const long m0, const int n0, const int bpar) {    // wave 0: bias[n0 .. n0 + 255] -> LDS (two 1 KB buffers, by tile parity), 16 bytes per lane
         if (wid == 0 && has_bias)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, (__attribute__((address_space(3))) void*)(smem + OFF_BIAS + bpar * 1024), 16, (unsigned)lane * 16u, (unsigned)n0 * 4u, 0, 0);
+        if constexpr (LNC) {                                 // wave 1: colsum[n0 .. n0 + 255]; waves 2, 3: (a, c) of rows m0 .. m0 + 127 / m0 + 128 .. m0 + 255 (8 bytes per row)
+            if (wid == 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rCs, (__attribute__((address_space(3))) void*)(smem + OFF_CS + bpar * 1024), 16, (unsigned)lane * 16u, (unsigned)n0 * 4u, 0, 0);
+            if (wid == 2 || wid == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rRa, (__attribute__((address_space(3))) void*)(smem + OFF_RA + bpar * 2048 + (wid - 2) * 1024), 16,
+                                                         (unsigned)lane * 16u, (unsigned)(m0 * 8 + (wid - 2) * 1024), 0, 0);
+        }
     };
     int offA[2], offB[2];                                   // fragment read offsets inside a half-tile (column tile jt = 1 of B: + 512 bytes)
     {
@@ -1300,6 +1391,14 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 bia[hb][j] = has_bias ? *reinterpret_cast<const f32x4*>(smem + OFF_BIAS + bpar * 1024 + (hb * 128 + wc * 32 + q4 * 8 + j * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] f32x4 csm[LNC ? 2 : 1][2];
+        if constexpr (LNC) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    csm[hb][j] = *reinterpret_cast<const f32x4*>(smem + OFF_CS + bpar * 1024 + (hb * 128 + wc * 32 + q4 * 8 + j * 4) * 4);
+        }
         const long mw = m0 + wr * 64;
         const long rows = g.M - mw;
         if constexpr (!OUT16) {
@@ -1363,8 +1462,17 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                 for (int il = 0; il < 2; ++il) {
                     const int i = hf * 2 + il;
                     float v[8];
+                    if constexpr (LNC) {
+                        const float2 ra = *reinterpret_cast<const float2*>(smem + OFF_RA + bpar * 2048 + (ha * 128 + wr * 64 + i * 16 + r15) * 8);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[hb][0][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][1][e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[ha][i][hb][0][e] * ra.x + (ra.y * csm[hb][0][e] + bia[hb][0][e]);
+                            v[4 + e] = acc[ha][i][hb][1][e] * ra.x + (ra.y * csm[hb][1][e] + bia[hb][1][e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[hb][0][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][1][e]; }
+                    }
                     f16x8 h;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -1406,7 +1514,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     rA = rsrc_a(m0); rB = rsrc_b(n0);
     bool first = true;
     int bpar = 0;                                           // bias buffer of the current tile
-    stage_bias(n0, 0);
+    stage_bias(m0, n0, 0);
     stage(0, 0, false); stage(1, 0, false); stage(2, 0, false); stage(3, 0, false); stage(0, 1, false); stage(1, 1, false); stage(2, 1, false); stage(3, 1, false);
     for (;;) {
         const int nvb = vb + (int)gridDim.x;
@@ -1445,7 +1553,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         //  allocator could not hold side by side: 588 spills)
         for (int t = 0; t < nk; ++t) {
             const bool nx = t + 2 >= nk;
-            if (has_next && t + 2 == nk) stage_bias(n0n, bpar ^ 1);   // the next tile's bias row, in front of its first stage
+            if (has_next && t + 2 == nk) stage_bias(m0n, n0n, bpar ^ 1);   // the next tile's bias row (LNC: + colsum row and row pairs), in front of its first stage
             ktile(std::integral_constant<bool, true>{}, t, nx ? t + 2 - nk : t + 2, nx, first ? 0 : (t == 0 ? 4 : (t == 1 ? 1 : 0)));
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();          // balance the skew barrier
@@ -1530,6 +1638,27 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         }
     }
 #endif
+    if constexpr (EPI == EPI_BIAS_RESID_F32) {
+        if (g.ln_xg) {                                       // LayerNorm producer (deep schedule): + 16 KB of LDS behind the operand buffers for the row partials
+            static SemabsLdsAttr attr_lp;
+            semabs_ensure_lds(&k_gemm8<EPI, true, false, false, true, 0, true>, LDS + 16384, attr_lp);
+            gemm_dispatch(k_gemm8<EPI, true, false, false, true, 0, true>, dim3(g.n_blocks), dim3(512), LDS + 16384, s, g, o);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
+    }
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
+        if (g.ln_rowac) {                                    // LayerNorm consumer (persistent workgroups): + 2 x 1 KB colsum rows + 2 x 2 KB row pairs
+            if ((g.K / 64) % 2 != 0) { semabs_set_error("semabs_gemm_f16_ln: the consumer kernel needs an even number of 64-wide K tiles"); return SEMABS_EINVAL; }
+            constexpr int LDSC = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024 + 2 * 1024 + 2 * 2048;
+            static SemabsLdsAttr attr_lc;
+            semabs_ensure_lds(&k_gemm8p<EPI, true>, LDSC, attr_lc);
+            const int ncu = gemm_num_cus();
+            gemm_dispatch(k_gemm8p<EPI, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDSC, s, g, o);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
+    }
     if (o.ring) {                                           // kernel | 512: the K = 32 ring schedule (A/B relic, one workgroup per tile); overrides the schedule bits
         static SemabsLdsAttr attr_r;
         semabs_ensure_lds(&k_gemm8<EPI, false, false, true>, LDS, attr_r);
@@ -1606,6 +1735,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
+    g.ln_xg = nullptr; g.ln_gamma = nullptr; g.ln_part = nullptr; g.ln_rowac = nullptr; g.ln_colsum = nullptr;
     const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
     const int v2 = ((kernel >> 11) & 1) == 0;               // the deep schedule of the phased kernel is the default since round 4; bit 11 selects the round-3 PF schedule (A/B), bit 10 is accepted and ignored
     const int nopers = (kernel >> 12) & 1;                  // bit 12: one workgroup per tile also for the fp16-output epilogues (A/B against k_gemm8p)
@@ -1626,6 +1756,37 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     }
     semabs_set_error("semabs_gemm_f16: unknown epilogue");
     return SEMABS_EINVAL;
+}
+
+// LayerNorm folded into the GEMMs on either side of it (large shapes only: M >= 2048, N % 256 == 0, K >= 128; k_gemm8's LNP / k_gemm8p's LNC).
+//   epi 2 (x += A W^T + b, fp32) with ln_xg / ln_gamma / ln_part: also xg = fp16(x_new * gamma) [M, N] and the row partials [M, N / 256, 2];
+//   epi 0 / 1 (fp16 outputs) with ln_rowac / ln_colsum: C = rstd_row * (A W^T) - mean_row rstd_row * colsum + bias, A being such an xg (K % 128 == 0).
+// reverse: walk the tiles backwards per XCD (the zigzag schedule of the trunk, like kernel | 256 of semabs_gemm_f16_ex).
+extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
+                                  void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum, int reverse,
+                                  void* start_event, void* stop_event, void* stream) {
+    SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16_ln: null operand");
+    SEMABS_REQUIRE(M >= 2048 && N % 256 == 0 && K >= 128 && K % BK == 0, "semabs_gemm_f16_ln: needs M >= 2048, N % 256 == 0, K >= 128 (the phased kernel)");
+    SEMABS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (epi > 1 || ldc % 8 == 0) && lda < (1L << 20) && ldb < (1 << 20) && ldc < (1L << 20),
+                   "semabs_gemm_f16_ln: leading dimensions");
+    const bool producer = epi == EPI_BIAS_RESID_F32 && ln_xg && ln_gamma && ln_part && !ln_rowac && !ln_colsum;
+    const bool consumer = (epi == EPI_BIAS_F16 || epi == EPI_BIAS_GELU_F16) && ln_rowac && ln_colsum && !ln_xg && !ln_gamma && !ln_part;
+    SEMABS_REQUIRE(producer || consumer, "semabs_gemm_f16_ln: epi 2 with (xg, gamma, partials) or epi 0 / 1 with (rowac, colsum)");
+    SEMABS_REQUIRE(!consumer || K % 128 == 0, "semabs_gemm_f16_ln: the consumer needs K % 128 == 0");
+    SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ln: start and stop events go together");
+    GemmArgs g;
+    g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.g_in = 1; g.g_out = 1; g.g_off = 0;
+    g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = reverse ? 1 : 0;
+    g.ln_xg = (f16*)ln_xg; g.ln_gamma = ln_gamma; g.ln_part = ln_part; g.ln_rowac = ln_rowac; g.ln_colsum = ln_colsum;
+    GemmOpts o{2, (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, 1, 0};
+    hipStream_t s = (hipStream_t)stream;
+    switch (epi) {
+        case EPI_BIAS_F16: return launch_gemm8<EPI_BIAS_F16>(g, s, o);
+        case EPI_BIAS_GELU_F16: return launch_gemm8<EPI_BIAS_GELU_F16>(g, s, o);
+        default: return launch_gemm8<EPI_BIAS_RESID_F32>(g, s, o);
+    }
 }
 
 extern "C" int semabs_gemm_f16(const void* A, const void* B, void* C, const float* bias, const float* addend,

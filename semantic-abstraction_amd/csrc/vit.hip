@@ -139,6 +139,31 @@ extern "C" int semabs_layernorm(const float* x, const float* gamma, const float*
 }
 
 // =================================================================================================
+// LayerNorm folded into the GEMMs (gemm.hip, LNP / LNC): the producer GEMM leaves per-row partial sums (sum x, sum x^2) per 256-column tile;
+// this turns them into the two per-row numbers the consumer GEMM's epilogue applies: (rstd, -mean * rstd).   model_explainability.py:188-194
+// The tiles' fp32 sums are combined in fp64 (the variance is a difference of two large numbers when |mean| >> sigma).
+// =================================================================================================
+__global__ void k_ln_rowstats(const float* __restrict__ part, long M, int ntile, int D, float eps, float* __restrict__ rowac) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < ntile; ++t) { s1 += (double)part[(r * ntile + t) * 2]; s2 += (double)part[(r * ntile + t) * 2 + 1]; }
+    const double mean = s1 / D;
+    double var = s2 / D - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    rowac[r * 2] = rstd;
+    rowac[r * 2 + 1] = (float)(-mean) * rstd;
+}
+extern "C" int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(part && rowac && ntile > 0 && D > 0, "semabs_ln_rowstats: bad args");
+    hipLaunchKernelGGL(k_ln_rowstats, dim3(semabs_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, part, M, ntile, D, eps, rowac);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
 // CLS rows of the token matrix: x[n, 0, :] = class_embedding + pos[0, :]   (patch rows come from the GEMM epilogue)
 // =================================================================================================
 __global__ void k_embed_cls(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos0,

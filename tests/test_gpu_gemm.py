@@ -188,3 +188,100 @@ def test_gemm_ex_rejects_bad_options():
     ev = torch.cuda.Event(enable_timing=True)
     rc = h.semabs_gemm_f16_ex(a.data_ptr(), a.data_ptr(), c.data_ptr(), None, None, 256, 128, 128, 128, 128, 128, 3, None, 0, 1, None, None)
     assert rc == -1 and b"go together" in h.semabs_last_error()
+
+
+# ---- LayerNorm folded into the GEMMs on either side of it (gemm.hip LNP / LNC, semabs_gemm_f16_ln, semabs_ln_rowstats) -------------------------------
+@pytest.mark.parametrize("M,K", [(2048, 768), (2381, 768), (2381, 3072), (50432, 768)])
+def test_gemm_layernorm_producer_epilogue(M, K):
+    """LNP: the residual GEMM's epilogue also emits xg = fp16(x_new * gamma) (16-byte stores assembled from lane pairs) and per-row partial sums per
+    256-column tile.  x_new must be BIT-identical to the plain residual epilogue's, xg bit-identical to fp16(x_new * gamma), the partials exact to fp32
+    summation order, rows past M untouched, a second launch bit-identical (fixed reduction order, no atomics)."""
+    from semabs_amd.clip.vit import gemm, gemm_ln
+    N = 768
+    A, B, bias, ref = _operands(M, N, K, K, K, seed=M + K)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    res = torch.randn(M, N, device="cuda", generator=g) * 3 + 0.5
+    gamma = torch.randn(N, device="cuda", generator=g)
+    x0 = res.clone()
+    gemm(A, B, x0, bias, M, N, K, K, K, N, EPI_RESID_F32, kernel=2)
+    for reverse in (0, 1):
+        x1 = torch.full((M + 256, N), 7.0, dtype=torch.float32, device="cuda")
+        x1[:M] = res
+        xg = torch.full((M + 256, N), 7.0, dtype=torch.float16, device="cuda")
+        part = torch.full((M + 256, N // 256, 2), 7.0, dtype=torch.float32, device="cuda")
+        gemm_ln(A, B, x1, bias, M, N, K, K, K, N, EPI_RESID_F32, xg=xg, gamma=gamma, part=part, reverse=reverse)
+        assert torch.equal(x1[:M], x0)
+        assert torch.equal(xg[:M], (x0 * gamma).half())
+        assert bool((x1[M:] == 7.0).all()) and bool((xg[M:] == 7.0).all()) and bool((part[M:] == 7.0).all())
+        t = x0.double().view(M, N // 256, 256)
+        ref_p = torch.stack([t.sum(-1), (t * t).sum(-1)], dim=-1)
+        assert float((part[:M].double() - ref_p).abs().max()) <= 2e-6 * float(ref_p.abs().max())
+        x2 = res.clone()
+        part2 = torch.empty(M, N // 256, 2, dtype=torch.float32, device="cuda")
+        gemm_ln(A, B, x2, bias, M, N, K, K, K, N, EPI_RESID_F32, xg=xg[:M], gamma=gamma, part=part2, reverse=reverse)
+        assert torch.equal(part2, part[:M])
+
+
+@pytest.mark.parametrize("M,N,epi", [(2048, 2304, EPI_F16), (2381, 2304, EPI_F16), (2381, 3072, EPI_GELU_F16), (50432, 3072, EPI_GELU_F16), (50432, 2304, EPI_F16)])
+def test_gemm_layernorm_consumer_epilogue_equals_layernorm_then_gemm(M, N, epi):
+    """LNC + semabs_ln_rowstats: rstd * (xg W^T) - mean rstd colsum + (b + W beta) against LayerNorm (fp64) followed by the product, and against the
+    unfused kernels (LayerNorm kernel -> fp16 -> GEMM): same result to the fp16 rounding of the two different A operands."""
+    from semabs_amd.clip.vit import gemm, gemm_ln, layernorm, ln_rowstats
+    K = D = 768
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, D, device="cuda", generator=g) * torch.linspace(0.3, 3.0, D, device="cuda") + 0.4       # channel-dependent spread, non-zero mean
+    gamma = 1.0 + 0.2 * torch.randn(D, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(D, device="cuda", generator=g)
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
+    b = torch.randn(N, device="cuda", generator=g)
+    xg = (x * gamma).half()
+    t = x.view(M, D // 256, 256)
+    part = torch.stack([t.sum(-1), (t * t).sum(-1)], dim=-1).contiguous()
+    rowac = torch.empty(M, 2, dtype=torch.float32, device="cuda")
+    ln_rowstats(part, M, D // 256, D, rowac)
+    mean, var = x.double().mean(-1), x.double().var(-1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    assert float((rowac[:, 0].double() - rstd).abs().max()) <= 1e-5 * float(rstd.max())
+    assert float((rowac[:, 1].double() + mean * rstd).abs().max()) <= 1e-5 * float((mean * rstd).abs().max())
+    colsum = (W.double() @ gamma.double()).float()
+    bias_f = (b.double() + W.double() @ beta.double()).float()
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-5)
+    ref = ln @ W.double().T + b.double()
+    if epi == EPI_GELU_F16:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    scale = float(ref.abs().max())
+    h = torch.empty(M, D, dtype=torch.float16, device="cuda")
+    layernorm(x, gamma, beta, h, M, D)
+    out_u = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    gemm(h, W, out_u, b, M, N, K, K, K, N, epi, kernel=2)
+    err_u = float((out_u.double() - ref).abs().max())
+    outs = []
+    for reverse in (0, 1):
+        out = torch.full((M + 256, N), 7.0, dtype=torch.float16, device="cuda")
+        gemm_ln(xg, W, out, bias_f, M, N, K, K, K, N, epi, rowac=rowac, colsum=colsum, reverse=reverse)
+        err = float((out[:M].double() - ref).abs().max())
+        print(f"LN-folded GEMM {M}x{N} epi {epi} reverse {reverse}: L-inf {err:.3e} vs LayerNorm-then-GEMM kernels {err_u:.3e} (max|ref| {scale:.2f})")
+        assert err <= 2.5e-3 * scale and err <= 2.0 * err_u + 5e-4 * scale          # as accurate as the unfused path (both round one A operand to fp16)
+        assert bool((out[M:] == 7.0).all())
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])                                            # the tile order does not enter the result
+
+
+def test_trunk_with_and_without_layernorm_fold():
+    """VisionRollout.trunk with the fold on (default) against the unfused launch sequence on the same weights and input: the residual stream after
+    11 blocks agrees to the accumulated fp16-operand noise of either path."""
+    from semabs_amd.clip.vit import VisionRollout
+    from semabs_amd.weights import make_clip_state_dict
+    eng = VisionRollout(make_clip_state_dict("ViT-B/32", 0, text_tower=False), chunk_tiles=48, max_labels=4)
+    n = 48                                                   # 48 x 50 tokens = 2 400 rows >= 2 048: the phased kernel and the fold are active
+    g = torch.Generator(device="cuda").manual_seed(0)
+    patches = torch.randn(n * 49, 3 * 32 * 32, device="cuda", generator=g).half()
+    outs = []
+    for fold in (True, False):
+        eng.ln_fold = fold
+        eng.embed(patches, n)
+        eng.trunk(n)
+        outs.append(eng._workspace()["x"][: n * 50].clone())
+    d = float((outs[0] - outs[1]).abs().max()) / float(outs[1].abs().max())
+    print(f"trunk, LayerNorm fold on vs off: relative L-inf {d:.2e} of the residual stream")
+    assert d <= 3e-3 and bool(torch.isfinite(outs[0]).all())
