@@ -652,6 +652,7 @@ def train_workload(args, rank, world, dist):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    sdist.reset_stats()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = tr.step(batches[i % 2])
@@ -660,7 +661,10 @@ def train_workload(args, rank, world, dist):
         dist.barrier()
     dt = time.perf_counter() - t0
     ar_ms = None
+    per_rank = None
     if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "steps": args.steps, "collectives": sdist.stats_snapshot()})
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         sdist_t = t.cpu() if args.backend == "gloo" else t
         dist.all_reduce(sdist_t, op=dist.ReduceOp.MAX)
@@ -686,7 +690,12 @@ def train_workload(args, rank, world, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 hi/lo-split MFMA operands, fp32 accumulate (fp32-equivalent)", "data": "synthetic",
             "config": {"workload": f"SemAbsVOOL {VOXEL}^3 training step per rank: forward + BCE + backward + flat gradient all-reduce + clip + LAMB", "parallelism": f"data-parallel x{world}",
                        "backend": args.backend if world > 1 else None},
-            "collectives": {"allreduce_bytes_per_rank_per_step": int(tr.flat_grad.numel() * 4), "allreduce_ms_alone": ar_ms, "parameters_identical_across_ranks": same},
+            "collectives": {"allreduce_bytes_per_rank_per_step": int(tr.flat_grad.numel() * 4), "allreduce_ms_alone": ar_ms, "parameters_identical_across_ranks": same,
+                            "overlapped_with_backward": bool(tr.overlap_allreduce), "buckets_bytes": [int((b - a) * 4) for a, b in tr.buckets.ranges],
+                            "per_rank": per_rank,
+                            "per_rank_note": "payload bytes and HOST-side milliseconds of every collective each rank issued inside the timed region, by kind: "
+                                             "all_reduce_bucket = the asynchronous bucket launches (host time = launch cost), all_reduce_wait = making the compute "
+                                             "stream wait for them (host time; the device-side exposed time is ms_per_step minus the single-rank step)"},
             "loss": float(out["loss"])}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -802,6 +811,9 @@ def main():
         dist.barrier()
     timer = vitmod.GemmTimer(every=args.time_every)
     vitmod.GEMM_TIMER = timer
+    if dist is not None:
+        from semabs_amd import dist as _sdist
+        _sdist.reset_stats()
     smi = SmiSampler(local) if rank == 0 else None
     torch.cuda.synchronize()
     if smi is not None:
@@ -830,6 +842,9 @@ def main():
     value = total_scenes / dt
     wire = None
     if world > 1:
+        from semabs_amd import dist as sdist
+        per_rank = [None] * world                            # (snapshot first: the checksum exchange below is not part of the timed region)
+        dist.all_gather_object(per_rank, {"rank": rank, "scenes": args.steps, "collectives": sdist.stats_snapshot()})
         # what this rank sent per collective (payload only) and cross-rank checksums: in latency mode all ranks must end with identical maps / labels
         import hashlib
         from semabs_amd.clip import saliency_configs as _sc
@@ -847,6 +862,8 @@ def main():
         mine = torch.tensor([digest(res.relevancies), digest(res.labels)], dtype=torch.int64, device="cuda")
         from semabs_amd import dist as sdist
         allsum = sdist.gather_results(mine).cpu().numpy()
+        wire["per_rank"] = per_rank
+        wire["per_rank_note"] = "payload bytes this rank contributed and host-side milliseconds of every collective it issued inside the timed region, by kind"
         wire["maps_checksums_by_rank"] = [int(x) for x in allsum[:, 0]]
         wire["labels_checksums_by_rank"] = [int(x) for x in allsum[:, 1]]
         wire["identical_across_ranks"] = bool((allsum == allsum[0]).all())

@@ -1455,6 +1455,13 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int hb = pass >> 1, ha = pass & 1;
+            // LNC: the (rstd, -mean rstd) pairs of this lane's four rows of the pass, all four LDS reads in flight together (one per use cost
+            // ~0.9 us per tile in dependent LDS round trips)
+            [[maybe_unused]] float2 rap[LNC ? 4 : 1];
+            if constexpr (LNC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rap[i] = *reinterpret_cast<const float2*>(smem + OFF_RA + bpar * 2048 + (ha * 128 + wr * 64 + i * 16 + r15) * 8);
+            }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 f32x4 w[2];
@@ -1463,7 +1470,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                     const int i = hf * 2 + il;
                     float v[8];
                     if constexpr (LNC) {
-                        const float2 ra = *reinterpret_cast<const float2*>(smem + OFF_RA + bpar * 2048 + (ha * 128 + wr * 64 + i * 16 + r15) * 8);
+                        const float2 ra = rap[i];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v[e] = acc[ha][i][hb][0][e] * ra.x + (ra.y * csm[hb][0][e] + bia[hb][0][e]);

@@ -18,6 +18,26 @@ import torch
 import torch.distributed as dist
 
 
+# Per-process collective accounting: payload bytes this rank contributed and host-side wall time of every collective issued through
+# this module, by kind - bench.py prints it per rank in every N > 1 line, so the first real multi-GPU run explains itself.
+STATS: dict = {}
+
+
+def _account(kind: str, nbytes: int, seconds: float, calls: int = 1) -> None:
+    d = STATS.setdefault(kind, {"calls": 0, "bytes": 0, "host_ms": 0.0})
+    d["calls"] += calls
+    d["bytes"] += int(nbytes)
+    d["host_ms"] += seconds * 1e3
+
+
+def reset_stats() -> None:
+    STATS.clear()
+
+
+def stats_snapshot() -> dict:
+    return {k: dict(v, host_ms=round(v["host_ms"], 3)) for k, v in STATS.items()}
+
+
 def rank_world() -> Tuple[int, int]:
     """(rank, world size) of the default process group; (0, 1) when torch.distributed is not initialised."""
     if dist.is_available() and dist.is_initialized():
@@ -40,15 +60,19 @@ def shard_list(items: Sequence, rank: int, world: int) -> List:
 def _all_gather_list(local: torch.Tensor) -> List[torch.Tensor]:
     """dist.all_gather of equally shaped tensors; gloo has no device collectives, so CUDA tensors are staged through the host there
     (the CPU / single-GPU tests); with "nccl" (= RCCL) the device buffers go over xGMI directly."""
+    import time
     world = dist.get_world_size()
+    t0 = time.perf_counter()
     if local.is_cuda and dist.get_backend() == "gloo":
         host = local.detach().cpu().contiguous()
         out = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(out, host)
-        return [o.to(local.device) for o in out]
-    out = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(out, local.contiguous())
-    return out
+        res = [o.to(local.device) for o in out]
+    else:
+        res = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(res, local.contiguous())
+    _account("all_gather", local.numel() * local.element_size(), time.perf_counter() - t0)
+    return res
 
 
 def allgather_tile_relevance(rel_local: List[torch.Tensor], n_tiles: int) -> List[torch.Tensor]:
@@ -85,15 +109,79 @@ def allreduce_flat_gradients(flat: torch.Tensor, n_flags: int = 0) -> Tuple[floa
     collective suits xGMI's per-link-bound rings better than 100+ per-tensor ones.  The last `n_flags` entries of `flat` are per-
     parameter "used on this rank" flags travelling in the same message; -> (scale = 1 / world to apply to the gradients, host bool
     tensor "used on any rank" or None when n_flags == 0).  World size 1 / no process group: nothing is sent."""
+    import time
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world > 1:
-        if flat.is_cuda and dist.get_backend() == "gloo":              # gloo (CPU / single-GPU tests): stage through the host; RCCL reduces in place
-            host = flat.detach().cpu()
-            dist.all_reduce(host)
-            flat.copy_(host)
-        else:
-            dist.all_reduce(flat)
+        t0 = time.perf_counter()
+        _allreduce_sum(flat)
+        _account("all_reduce", flat.numel() * flat.element_size(), time.perf_counter() - t0)
     flags = None
     if n_flags:
         flags = flat[flat.numel() - n_flags:].detach().cpu() > 0
     return 1.0 / world, flags
+
+
+def _allreduce_sum(t: torch.Tensor, async_op: bool = False):
+    """Sum all-reduce of a contiguous tensor in place.  RCCL ("nccl"): device buffers over xGMI, optionally asynchronous (the work object is returned;
+    the collective runs on the process group's own stream behind everything queued on the current stream).  gloo (CPU / single-GPU tests): staged
+    through the host, always synchronous."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()
+        dist.all_reduce(host)
+        t.copy_(host)
+        return None
+    return dist.all_reduce(t, async_op=True) if async_op else dist.all_reduce(t)
+
+
+class BucketedAllReduce:
+    """Data-parallel gradient exchange overlapped with the backward pass (what the reference gets from DistributedDataParallel's bucketed all-reduce,
+    utils.py:255-258): the flat gradient buffer is cut into a few CONTIGUOUS buckets in the order the backward pass completes them; `ready(i)` starts
+    bucket i's sum all-reduce asynchronously (RCCL: on the process group's stream, behind the kernels already queued on the compute stream), `finish()`
+    reduces whatever was not started and makes the compute stream wait for all of them.  Summing disjoint slices separately or the whole buffer at once
+    gives the same numbers (element-wise sums; bit-identical for two ranks, where the order of the two addends cannot matter).
+    World size 1 / no process group: every call is a no-op."""
+
+    def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]]):
+        self.flat = flat
+        self.ranges = [(int(a), int(b)) for a, b in ranges]
+        assert all(a < b for a, b in self.ranges)
+        cover = sorted(self.ranges)
+        assert cover[0][0] == 0 and cover[-1][1] == flat.numel() and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1)), \
+            "buckets must tile the flat buffer"
+        self.started = [False] * len(self.ranges)
+        self.works = []
+        self.exposed_ms = 0.0
+
+    @property
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin_step(self) -> None:
+        self.started = [False] * len(self.ranges)
+        self.works = []
+
+    def ready(self, i: int) -> None:
+        import time
+        if not self.active or self.started[i]:
+            return
+        a, b = self.ranges[i]
+        t0 = time.perf_counter()
+        w = _allreduce_sum(self.flat[a:b], async_op=True)
+        _account("all_reduce_bucket", (b - a) * self.flat.element_size(), time.perf_counter() - t0)
+        self.started[i] = True
+        if w is not None:
+            self.works.append(w)
+
+    def finish(self) -> float:
+        """Start the buckets nobody announced, wait for all; -> 1 / world (the scale the caller applies to the summed gradients)."""
+        import time
+        if not self.active:
+            return 1.0
+        for i in range(len(self.ranges)):
+            self.ready(i)
+        t0 = time.perf_counter()
+        for w in self.works:
+            w.wait()                                         # (RCCL: the compute stream waits for the collective's stream; the host does not block)
+        self.works = []
+        _account("all_reduce_wait", 0, time.perf_counter() - t0)
+        return 1.0 / dist.get_world_size()

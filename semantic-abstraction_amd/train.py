@@ -369,8 +369,10 @@ class UNetTrainer:
                   B, 2 * D0, 2 * D1, 2 * D2, D0, D1, D2, 2, cout, cin, 27, TAPS_CONV3, 1 | m["bwd"][2], st)
         return dx, s2[1:]                                    # still scaled: the block that consumes it multiplies by 1 / s in its first pass
 
-    def backward(self, tape, dy: torch.Tensor) -> torch.Tensor:
-        """dy fp32 [B, S, S, S, Cout] -> gradient w.r.t. the UNet input; parameter gradients are accumulated into `grads`."""
+    def backward(self, tape, dy: torch.Tensor, on_done=None) -> torch.Tensor:
+        """dy fp32 [B, S, S, S, Cout] -> gradient w.r.t. the UNet input; parameter gradients are accumulated into `grads`.
+        on_done(name): called when every parameter gradient of "decoders.<i>" / "encoders.<i>" has been issued (in that order: finest decoder first,
+        encoder 0 last) - the data-parallel trainer starts that part's all-reduce behind it while the rest of the backward pass runs."""
         st = _lib.stream()
         L = len(self.f_maps)
         d_skip: Dict[int, torch.Tensor] = {}
@@ -397,11 +399,15 @@ class UNetTrainer:
             elif kind == "block":
                 g = self._block_bwd(item[1:], g, in_scale=g_scale)
                 g_scale = None
+                if on_done is not None and item[1].name.startswith("encoders."):
+                    on_done(".".join(item[1].name.split(".")[:2]))
             elif kind == "up":
                 _, pre, xin, level = item
                 assert g_scale is None
                 d_skip[level] = g                                   # y = skip + convT(x) + bias: the skip gets the same gradient
                 g, g_scale = self._up_bwd(pre, xin, g)
+                if on_done is not None:
+                    on_done(".".join(pre.split(".")[:2]))
             elif kind == "pool":
                 _, x, level = item                                  # x = output of encoder `level`, also used as a skip
                 assert g_scale is None
@@ -464,6 +470,8 @@ class VOOLTrainer:
         # VOOL graph never reaches keep grad = None and are skipped by step() - so `optimizer.state_dict()` is interchangeable with the reference's
         self.opt = Lamb([self.params[k] for k in names], lr=lr, weight_decay=weight_decay) if module is None else None
         self.steps = 0
+        # data-parallel gradient exchange: bucketed and overlapped with the backward pass (default) or ONE blocking all-reduce after it (A/B, tests)
+        self.overlap_allreduce = os.environ.get("SEMABS_DP_OVERLAP", "1") == "1"
         self._sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.last = {}
 
@@ -472,12 +480,32 @@ class VOOLTrainer:
         self.flat_grad = flat
         self.rel_flags = flat[self.total:]
         off = 0
+        starts = {}
         for k in self.trainable:
             n = self.params[k].numel()
             self.grads[k] = flat[off: off + n].view_as(self.params[k])
             if attach:
                 self.params[k].grad = self.grads[k]
+            starts[k] = off
             off += n
+        # Data-parallel buckets, in the order the backward pass completes them (state-dict order = point MLP, encoders 0 .. L-1, decoders 0 .. L-2,
+        # final conv, samplers, relation embeddings, flags; the backward pass runs it roughly backwards): [decoder 0 .. end of the buffer] is complete
+        # when decoder 0 (the coarsest, processed last of the decoders) is, then the two deepest encoders - 96 % of the bytes - each on its own, and
+        # the small head of the buffer [point MLP, encoders 0 .. L-3] at the very end.  Their all-reduces run behind the fine levels' backward kernels.
+        up = "completion_net.vol_feature_extractor."
+        first = lambda pre: min((o for k, o in starts.items() if k.startswith(up + pre)), default=None)
+        L = len(self.unet.f_maps)
+        cuts = {"decoders.0": first("decoders.0."), f"encoders.{L - 1}": first(f"encoders.{L - 1}."), f"encoders.{L - 2}": first(f"encoders.{L - 2}.")}
+        self.bucket_of = {}
+        ranges = []
+        if all(v is not None for v in cuts.values()) and 0 < cuts[f"encoders.{L - 2}"] < cuts[f"encoders.{L - 1}"] < cuts["decoders.0"] < flat.numel():
+            ranges = [(cuts["decoders.0"], flat.numel()), (cuts[f"encoders.{L - 1}"], cuts["decoders.0"]),
+                      (cuts[f"encoders.{L - 2}"], cuts[f"encoders.{L - 1}"]), (0, cuts[f"encoders.{L - 2}"])]
+            self.bucket_of = {"decoders.0": 0, f"encoders.{L - 1}": 1, f"encoders.{L - 2}": 2}
+        else:
+            ranges = [(0, flat.numel())]
+        from .dist import BucketedAllReduce
+        self.buckets = BucketedAllReduce(flat, ranges)
 
     # ---- helpers -----------------------------------------------------------------------------------------------------------------
     def _linear(self, x, w, b, act):
@@ -597,7 +625,7 @@ class VOOLTrainer:
         cell_next = torch.empty(D * M, dtype=torch.int32, device=dev)
         _lib.call("semabs_vool_sample_bwd", _lib.ptr(df), _lib.ptr(query), off3, sc3, shp, D, M, _lib.ptr(cell_head), _lib.ptr(cell_next),
                   _lib.ptr(dvol[:D]), _lib.ptr(dvol[D:]), st)
-        dscat = u.backward(c["tape"], dvol)
+        dscat = u.backward(c["tape"], dvol, on_done=c.get("on_done"))
         count = torch.zeros(nvox, dtype=torch.int32, device=dev)
         dpf = torch.empty(P * N, self.C, dtype=torch.float32, device=dev)
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
@@ -612,9 +640,12 @@ class VOOLTrainer:
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
 
-    def _scene(self, xyz, sal_t, sal_r, query, label, weight, rel_names, n_total, loss_acc, logits_out):
-        """Fused form (VOOLTrainer.step): the BCE-with-logits loss and its gradient come out of the pointer-head kernel."""
+    def _scene(self, xyz, sal_t, sal_r, query, label, weight, rel_names, n_total, loss_acc, logits_out, last=False):
+        """Fused form (VOOLTrainer.step): the BCE-with-logits loss and its gradient come out of the pointer-head kernel.
+        last: this is the step's last scene - its backward pass announces the finished gradient buckets to the data-parallel all-reduce."""
         c = self._scene_fwd(xyz, sal_t, sal_r, query, rel_names)
+        if last and self.overlap_allreduce and self.buckets.active:
+            c["on_done"] = lambda name: self.buckets.ready(self.bucket_of[name]) if name in self.bucket_of else None
         dO = torch.empty_like(c["o"])
         drel = torch.zeros(c["D"], self.E, dtype=torch.float32, device=self.dev)
         _lib.call("semabs_cos_bce", _lib.ptr(c["o"]), _lib.ptr(c["rel"]), _lib.ptr(label), _lib.ptr(weight), c["D"], c["M"], self.temperature, n_total,
@@ -702,16 +733,22 @@ class VOOLTrainer:
         for n in RELATIONS:                                                  # local view; optimizer_step() widens it to "any rank"
             if "relation_embeddings." + n in self.grads:
                 self.params["relation_embeddings." + n].grad = self.grads["relation_embeddings." + n] if n in used else None
+        self.buckets.begin_step()
         for b in range(B):
             self._scene(xyz[b].contiguous(), st_[b].contiguous(), sr_[b].contiguous(), q[b].reshape(D, M, 3).contiguous(), label[b],
-                        None if weight is None else weight[b], list(names[b]), B * D * M, loss, logits[b])
+                        None if weight is None else weight[b], list(names[b]), B * D * M, loss, logits[b], last=(b == B - 1))
         return {"loss": loss[0], "logits": logits}
 
     @torch.no_grad()
     def optimizer_step(self) -> torch.Tensor:
         """(all-reduce ->) clip_grad_norm_ -> Lamb.step; returns the pre-clip global gradient norm (device scalar)."""
-        from .dist import allreduce_flat_gradients
-        scale, used = allreduce_flat_gradients(self.flat_grad, len(RELATIONS))
+        if self.overlap_allreduce:
+            # the buckets the backward pass announced are already in flight (RCCL); the rest start now; the compute stream then waits for all of them
+            scale = self.buckets.finish()
+            used = self.flat_grad[self.flat_grad.numel() - len(RELATIONS):].detach().cpu() > 0
+        else:
+            from .dist import allreduce_flat_gradients
+            scale, used = allreduce_flat_gradients(self.flat_grad, len(RELATIONS))
         for n, u_ in zip(RELATIONS, used.tolist()):
             k = "relation_embeddings." + n
             if k in self.grads:

@@ -72,9 +72,15 @@ def test_bench_multi_rank_modes_over_gloo_on_one_gpu(extra, metric_part):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and metric_part in d["metric"] and d["value"] > 0 and d["config"]["backend"] == "gloo"
     c = d["collectives"]
+    # every N > 1 line says what each rank put on the wire and how long its host spent issuing it
+    assert len(c["per_rank"]) == 2 and sorted(r["rank"] for r in c["per_rank"]) == [0, 1]
+    assert all(sum(k["bytes"] for k in r["collectives"].values()) > 0 for r in c["per_rank"])
     if "--mode" in extra:
         assert d["scaling"] == "strong" and c["identical_across_ranks"] is True and len(c["maps_checksums_by_rank"]) == 2
         assert c["tile_relevance_allgather_bytes_per_rank_per_scene"] == 2 * 16 * 612 * 14 * 14 * 4          # 1224 tiles / 2 ranks, 16 labels, 14 x 14, two flip passes
         assert c["logits_allgather_bytes_per_rank_per_scene"] == 8 * 128 ** 3 * 4 and c["gather_results_ranks_seen"] == 2
     else:
         assert d["scaling"] == "weak" and c["parameters_identical_across_ranks"] is True and c["allreduce_bytes_per_rank_per_step"] > 100e6 and c["allreduce_ms_alone"] > 0
+        # the gradient exchange runs in >= 4 buckets announced by the backward pass; together they are the whole flat buffer
+        assert c["overlapped_with_backward"] is True and len(c["buckets_bytes"]) >= 4 and sum(c["buckets_bytes"]) == c["allreduce_bytes_per_rank_per_step"]
+        assert all(r["collectives"]["all_reduce_bucket"]["calls"] == 4 * r["steps"] for r in c["per_rank"])

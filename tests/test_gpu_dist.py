@@ -36,6 +36,20 @@ scale, used = sd.allreduce_flat_gradients(flat, 3)
 tot = sum(r + 1 for r in range(world))
 assert scale == 1.0 / world and torch.equal(flat[:6].cpu(), torch.arange(6, dtype=torch.float32) * tot)
 assert used.tolist() == ([True, False, True] if world > 1 else [True, False, False])
+# the bucketed, asynchronous gradient exchange of the training step (RCCL works on the process group's stream): bit-identical to the single call
+gen = torch.Generator().manual_seed(7 + rank)
+base = torch.randn(1 << 20, generator=gen).cuda()
+want = base.clone(); sd.allreduce_flat_gradients(want, 0)
+for announce in ((), (0, 2), (0, 1, 2, 3)):
+    buf = base.clone()
+    br = sd.BucketedAllReduce(buf, [(600000, 1 << 20), (250000, 600000), (100000, 250000), (0, 100000)])
+    br.begin_step()
+    for i in announce:
+        br.ready(i)
+        buf2 = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")      # compute queued behind the announcement
+    assert br.finish() == 1.0 / world
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want), announce
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL_OK", rank, world, flush=True)
@@ -81,6 +95,24 @@ def test_bench_world_size_mismatch_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("extra,key", [(["--mode", "latency"], "identical_across_ranks"), (["--workload", "train"], "parameters_identical_across_ranks")])
+def test_bench_two_ranks_over_rccl_agree(extra, key):
+    """With two devices the RCCL paths MUST work: one scene tile- / label-sharded over two ranks ends with identical maps and labels on both, and the
+    data-parallel training step (bucketed all-reduce overlapped with the backward pass) with identical parameters.  Fails - does not skip - on any
+    box that has the devices; a one-GPU box cannot form a two-rank RCCL group (one rank per device) and runs the same code over
+    gloo instead (tests/test_bench_contract.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("ONE HIP device: RCCL admits one rank per device (the same modes run over gloo in tests/test_bench_contract.py)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
+                        "--no-stages"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["backend"] == "nccl" and d["collectives"][key] is True
+    assert len(d["collectives"]["per_rank"]) == 2 and all(v for v in d["collectives"]["per_rank"])
 
 
 def test_bench_spawns_its_own_ranks():

@@ -129,7 +129,25 @@ def _gloo_worker(rank, world, port, q):
     flat = torch.cat([torch.arange(6, dtype=torch.float32) * (rank + 1), torch.tensor([1.0, 0.0, 0.0] if rank == 0 else [0.0, 0.0, 1.0])])
     scale, used = allreduce_flat_gradients(flat, 3)
     ok3 = scale == 0.5 and torch.equal(flat[:6] * scale, torch.arange(6, dtype=torch.float32) * 1.5) and used.tolist() == [True, False, True]
-    q.put((rank, bool(ok1), bool(ok2 and ok3)))
+    # the same exchange in buckets announced in backward-completion order (tail of the buffer first, head last) and started asynchronously where the
+    # backend can: bit-identical to the single call, for any announcement pattern (none / some / all before finish); per-process accounting filled
+    from semabs_amd import dist as sdist
+    from semabs_amd.dist import BucketedAllReduce
+    gen = torch.Generator().manual_seed(7 + rank)
+    base = torch.randn(1000, generator=gen)
+    want = base.clone()
+    allreduce_flat_gradients(want, 0)
+    ok4 = True
+    for announce in ((), (0, 2), (0, 1, 2, 3), (3, 1)):
+        buf = base.clone()
+        br = BucketedAllReduce(buf, [(600, 1000), (250, 600), (100, 250), (0, 100)])
+        br.begin_step()
+        for i in announce:
+            br.ready(i)
+        ok4 = ok4 and br.finish() == 0.5 and torch.equal(buf, want)
+    st = sdist.stats_snapshot()
+    ok4 = ok4 and st["all_reduce_bucket"]["bytes"] == 4 * 4000 and st["all_reduce"]["calls"] >= 2 and st["all_gather"]["bytes"] > 0
+    q.put((rank, bool(ok1), bool(ok2 and ok3 and ok4)))
     dist.destroy_process_group()
 
 
