@@ -4,6 +4,8 @@ The experiment runs on the CPU oracle: the level-0 convolutions of the UNet get 
 activations rounded to fp16 - which is exactly what dropping the `a_hi * w_lo` or the `a_lo * w_hi` MFMA product does - and the voxel logits
 are compared with the unrounded run.  Measured at 64^3: 1.9e-3 (weights) / 1.5e-3 (activations) of a 0.81 logit maximum; BASELINE.json's bar
 on the logits is 1e-3.  If this test starts failing because the errors became SMALLER than the bar, a two-product level 0 is worth building."""
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -52,3 +54,64 @@ def test_level0_needs_both_low_order_products(monkeypatch):
         err = float((out[what] - ref).abs().max())
         assert err > 1e-3, (what, err)                              # over the bar: that product cannot be dropped
         assert err < 1e-2, (what, err)                              # and the experiment is not broken
+
+
+# ---- every level: which MFMA products could be dropped where --------------------------------------------------------
+# Measured with this file's experiment at 64^3 / 32^3 (logit L-inf for rounding the WEIGHTS | the ACTIVATIONS | both, of all 3^3 convolutions at one
+# resolution = the encoder's and the decoder's residual blocks of that level; "->" rows: the transposed convolution that produces that level):
+#   level 0 (S)     1.9e-3 | 1.6e-3 | 2.8e-3        3.2e-3 at 32^3     -> over the 1e-3 bar on its own: three products
+#   level 1 (S/2)   1.4e-3 | 1.2e-3 | 2.1e-3        1.8e-3             -> over the bar: three products
+#   level 2 (S/4)   8.2e-4 | 9.4e-4 | 1.4e-3        1.2e-3             -> at the bar: three products
+#   level 3 (S/8)   5.2e-4 | 5.4e-4 | 6.8e-4        6.0e-4             -> half the bar for 8 % of the issued flops: kept
+#   level 4 (S/16)  3.7e-4 | 3.1e-4 | 5.5e-4        3.2e-4             -> a third of the bar for 4 % of the issued flops: kept
+#   level 5 (S/32)  9.6e-5 | 8.9e-5 | 1.3e-4        2.9e-5             -> droppable (< 2e-4) - but the 4^3 level is launch-latency-bound (0.019 of its roof)
+#   -> level k      1.3e-4 .. 1.6e-4 per product, 1.7e-4 .. 2.0e-4 both, for each of the five transposed convolutions
+# The droppable set (level 5 + the five transposed convolutions) adds up to 4.0e-4 in quadrature - 40 % of the bar, where the exact path measures
+# 6e-5 against the reference (g9 / g10) - and none of those kernels is bound by its MFMAs (k_convT_brick: matrix pipe busy 0.14; the 4^3 level:
+# 0.019 of its roof): the products stay everywhere; this test pins the measurement so that the decision can be revisited when a kernel changes.
+def test_every_level_precision_budget(monkeypatch):
+    S32 = 32
+    sd = {k: torch.as_tensor(np.asarray(v)).float() for k, v in make_semabs3d_state_dict(seed=0).items()}
+    rng = np.random.default_rng(0)
+    n = 20000
+    xyz = rng.uniform(-1.0, 1.0, (1, n, 3)).astype(np.float32)
+    xyz[..., 2] = (rng.integers(0, 4, (1, n)) * 0.3 - 0.5 + rng.normal(0, 0.01, (1, n))).astype(np.float32)
+    feat = (rng.standard_normal((1, 2, n, 1)) * 0.5).astype(np.float32)
+    q = rng.uniform(-1.0, 1.0, (1, 2, n, 3)).astype(np.float32)
+    xyz, feat, q = (torch.from_numpy(a) for a in (xyz, feat, q))
+    bounds = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    mode = {"lvl": None, "t": False}
+    conv3d, convT = F.conv3d, F.conv_transpose3d
+
+    def rc(x, w, b=None, **kw):
+        if not mode["t"] and mode["lvl"] is not None and w.shape[-1] == 3 and x.shape[-1] == S32 >> mode["lvl"]:
+            x, w = x.half().float(), w.half().float()
+        return conv3d(x, w, b, **kw)
+
+    def rct(x, w, b=None, **kw):
+        if mode["t"] and x.shape[-1] * 2 == S32 >> mode["lvl"]:
+            x, w = x.half().float(), w.half().float()
+        return convT(x, w, b, **kw)
+
+    monkeypatch.setattr(F, "conv3d", rc)
+    monkeypatch.setattr(F, "conv_transpose3d", rct)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.semabs3d_forward(sd, xyz, feat, q, bounds, (S32,) * 3)
+        err = {}
+        for lvl in range(6):
+            for t in (False, True):
+                if t and lvl == 5:
+                    continue
+                mode.update(lvl=lvl, t=t)
+                err[(lvl, t)] = float((O.semabs3d_forward(sd, xyz, feat, q, bounds, (S32,) * 3) - ref).abs().max())
+    print("single-product logit error by level (3^3 convolutions | transposed convolution into the level): " +
+          "  ".join(f"L{l}{'->' if t else ''} {e:.1e}" for (l, t), e in sorted(err.items())))
+    assert float(ref.abs().max()) > 0.3
+    for lvl in (0, 1, 2):
+        assert err[(lvl, False)] > 1e-3, (lvl, err[(lvl, False)])          # one MFMA product at the fine levels: over the bar on its own
+    for lvl in (3, 4):
+        assert 1.5e-4 < err[(lvl, False)] < 1e-3, (lvl, err[(lvl, False)])  # a sizeable share of the bar each
+    droppable = [err[(5, False)]] + [err[(l, True)] for l in range(5)]
+    assert all(e < 3e-4 for e in droppable), droppable
+    assert 2e-4 < math.sqrt(sum(e * e for e in droppable)) < 1e-3            # ... but together they would spend a large part of the budget
