@@ -65,15 +65,18 @@ _RECORDED = {}
 
 @pytest.fixture
 def bar(request):
-    """bar(tag, err, ceiling) -> bool: err <= min(ceiling, tol(measured error of this case)) - the ceiling (the old fixed bar) alone when the case has
-    no recorded value.  A recorded 0.0 demands 0.0 (bit-exact cases stay bit-exact)."""
-    def check(tag: str, err: float, ceiling: float) -> bool:
+    """bar(tag, err, ceiling) -> bool: err <= min(ceiling, max(tol(measured error of this case), floor)) - the ceiling (the old fixed bar) alone when
+    the case has no recorded value.  floor (default 5 % of the ceiling): errors of a few fp32 ulps can double when one rounding flips (the fp64
+    GroupNorm statistics are accumulated with atomics, i.e. in a run-dependent order), so no bar is ever tighter than that.  A recorded 0.0 with
+    floor = 0 demands 0.0 (bit-exact cases stay bit-exact)."""
+    def check(tag: str, err: float, ceiling: float, floor: float | None = None) -> bool:
         key = request.node.nodeid.split("tests/")[-1] + ":" + tag
         err = float(err)
         if os.environ.get("SEMABS_RECORD_ERRORS"):
             _RECORDED[key] = max(err, _RECORDED.get(key, 0.0))
         m = _MEASURED.get(key)
-        limit = float(ceiling) if m is None else min(float(ceiling), tol(m))
+        fl = 0.05 * float(ceiling) if floor is None else float(floor)
+        limit = float(ceiling) if m is None else min(float(ceiling), max(tol(m), fl))
         ok = err <= limit
         if not ok:
             print(f"[bar] {key}: error {err:.4e} > limit {limit:.4e} (measured {m}, ceiling {ceiling:.4e})")
