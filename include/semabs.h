@@ -146,9 +146,11 @@ int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias,
  * shapes (M >= 2048, N % 256 == 0, K >= 128).  epi 2 with (ln_xg, ln_gamma, ln_part): x += A W^T + b AND xg = fp16(x_new * gamma) [M, N], row partials
  * (sum, sum of squares) [M, N / 256, 2]; epi 0 / 1 with (ln_rowac, ln_colsum): C = rstd_row * (A W^T) - mean_row * rstd_row * colsum[n] + bias[n]
  * (A = such an xg, K % 128 == 0; colsum[n] = sum_k gamma_k W[n, k]; bias must already contain sum_k beta_k W[n, k]).  reverse: tile order (zigzag).
- * semabs_ln_rowstats: partials -> (rstd, -mean * rstd) [M, 2]. */
+ * epi 0 with lo_out (precision = "parity"): additionally lo_out[m, n] = fp16(v - fp16(v)) for n < lo_cols (lo_cols % 256 == 0, row pitch ld_lo): the low
+ * halves of q | k, consumed by semabs_attention_split.  semabs_ln_rowstats: partials -> (rstd, -mean * rstd) [M, 2]. */
 int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
-                       void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum, int reverse,
+                       void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum,
+                       void* lo_out, int lo_cols, long ld_lo, int reverse,
                        void* start_event, void* stop_event, void* stream);
 int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, void* stream);
 
@@ -171,6 +173,10 @@ int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int
                      int causal, void* stream);
 /* last block, CLS query only; keeps the softmax row (the hooked attn_probs, auxiliary.py:330-335).  q fp32 [n, D], k fp32 [n, T, D] (the
  * scores stay fp32), v fp16 [n, T, D] (it only enters averaged: o, and the rollout's V . u dots) */
+/* semabs_attention with q and k as fp16 hi + lo pairs (precision = "parity"): qk_lo fp16 [n_seq, T, ld_lo], q_lo | k_lo at column offsets 0 / D;
+ * scores = q_hi k_hi + q_hi k_lo + q_lo k_hi in fp32                                                      CLIP/clip/auxiliary.py:307-337 */
+int semabs_attention_split(const void* qkv, const void* qk_lo, void* out, void* row_stats, int n_seq, int T, int H, int head_dim, int ld, int ld_lo,
+                           int causal, void* stream);
 int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
 int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
 /* x[arange(B), tokens.argmax(-1)] of the text tower (the EOT rows)        CLIP/clip/model_explainability.py:480

@@ -53,13 +53,14 @@ SIGNATURES = {
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
     "semabs_gemm_f16_ex": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), I, P, P, P],
-    "semabs_gemm_f16_ln": [P, P, P, P, L, I, I, L, I, L, I, P, P, P, P, P, I, P, P, P],
+    "semabs_gemm_f16_ln": [P, P, P, P, L, I, I, L, I, L, I, P, P, P, P, P, P, I, L, I, P, P, P],
     "semabs_ln_rowstats": [P, L, I, I, F, P, P],
     # vit.hip
     "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
     "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],
     "semabs_embed_finish": [P, P, P, I, I, I, P],
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
+    "semabs_attention_split": [P, P, P, P, I, I, I, I, I, I, I, P],
     "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, P],
     "semabs_rows_gather": [P, P, L, I, L, L, P],
     "semabs_eot_rows_gather": [P, P, P, I, I, I, P],

@@ -126,13 +126,20 @@ class ClipWrapper:
     state_dict_provider = None          # callable(clip_model_type) -> state dict; set by tests / bench
 
     # ---- initialisation ----------------------------------------------------------------------------
-    def __init__(self, clip_model_type, device=None, state_dict=None, chunk_tiles=2448, max_labels=32, **kwargs):
+    def __init__(self, clip_model_type, device=None, state_dict=None, chunk_tiles=2448, max_labels=32, precision: str | None = None, **kwargs):
+        """precision: None / "default" = fp16 MFMA operands throughout the trunk (the reference's own CUDA dtype); "parity" = q and k additionally carried
+        as fp16 hi + lo pairs into the attention scores (ViT-B; ~4 % slower, relevancy maps ~30 % closer to the fp32 CPU reference - clip/vit.py)."""
         dev = _lib.require_gpu()
+        assert precision in (None, "default", "parity"), precision
         if state_dict is None:
             state_dict = ClipWrapper._load_checkpoint(clip_model_type)
         ClipWrapper.device = dev
         ClipWrapper.clip_model_type = clip_model_type
         ClipWrapper.engine = make_vision_engine(state_dict, chunk_tiles=chunk_tiles, max_labels=max_labels)
+        if precision == "parity":
+            if not hasattr(ClipWrapper.engine, "qk_split"):
+                raise NotImplementedError('precision="parity" is implemented for the ViT-B towers (closed-form rollout)')
+            ClipWrapper.engine.qk_split = True
         ClipWrapper.text = TextEncoder(state_dict) if "token_embedding.weight" in state_dict else None
         ClipWrapper._coeffs = _ResizeCoeffs(dev)
         # ToTensor (/255) then Normalize, all fp32 like torchvision, then rounded once to the GEMM operand type

@@ -99,7 +99,7 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, k
 _gemm = gemm
 
 
-def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, part=None, rowac=None, colsum=None, reverse=0):
+def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, part=None, rowac=None, colsum=None, reverse=0, lo=None, lo_cols=0):
     """A GEMM with the LayerNorm that precedes (consumer: rowac, colsum) or follows (producer: xg, gamma, part) it folded in - see
     `semabs_gemm_f16_ln` (csrc/gemm.hip, LNP / LNC).  Timed by GEMM_TIMER like every other GEMM launch; the producer's algorithmic bytes include
     the fp16 copy it writes."""
@@ -109,10 +109,11 @@ def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, par
         t.seen += 1
         if t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0:
             e0, e1 = t._pair()
-            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else 8) + (M * N * 2 if xg is not None else 0),
-                              (int(N), int(K), int(epi))))
+            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else 8) + (M * N * 2 if xg is not None else 0)
+                              + (M * lo_cols * 2 if lo is not None else 0), (int(N), int(K), int(epi))))
     _lib.call("semabs_gemm_f16_ln", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), int(M), int(N), int(K), int(lda), int(ldb), int(ldc), int(epi),
-              _lib.ptr(xg), _lib.ptr(gamma), _lib.ptr(part), _lib.ptr(rowac), _lib.ptr(colsum), int(reverse), e0, e1, _lib.stream())
+              _lib.ptr(xg), _lib.ptr(gamma), _lib.ptr(part), _lib.ptr(rowac), _lib.ptr(colsum), _lib.ptr(lo), int(lo_cols), int(lo.shape[1]) if lo is not None else 0,
+              int(reverse), e0, e1, _lib.stream())
 
 
 def ln_rowstats(part, M, ntile, D, rowac, eps=1e-5):
@@ -232,6 +233,10 @@ class VisionRollout:
         # LayerNorm passes of a scene disappear (each a 1.48 GB fp32 read + 0.74 GB fp16 write at the benchmark batch); the residual GEMMs write the
         # fp16 (x * gamma) copy from their epilogue instead.  SEMABS_LN_FOLD=0 runs the LayerNorm kernels (A/B).
         self.ln_fold = os.environ.get("SEMABS_LN_FOLD", "1") == "1"
+        # precision = "parity" (opt-in; ClipWrapper(..., precision="parity") or SEMABS_QK_SPLIT=1): the QKV GEMM also stores the LOW fp16 halves of q and k
+        # and the attention kernel forms the scores from hi + lo pairs (three MFMA products in fp32) - the fp16 rounding of q and k is the largest
+        # single term of the maps' deviation from the fp32 reference.  + 1.48 GB written and read per block, one attention workgroup per CU.
+        self.qk_split = os.environ.get("SEMABS_QK_SPLIT", "0") == "1"
         self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
@@ -251,7 +256,7 @@ class VisionRollout:
             R = Lm * n
             self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), delta=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
-                ln_part=e32(n * T, max(1, D // 256), 2), ln_rowac=e32(n * T, 2),
+                ln_part=e32(n * T, max(1, D // 256), 2), ln_rowac=e32(n * T, 2), qk_lo=e16(n * T, 2 * D) if self.qk_split else None,
                 k32=e32(n * T, D), v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
                 h2c=e16(n, D), fc=e32(n, 4 * D), actc=e16(n, 4 * D), x2c=e32(n, D), yc=e16(n, D), feat=e32(n, E),
                 logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, D),
@@ -290,13 +295,21 @@ class VisionRollout:
                 part, rowac, nt = ws["ln_part"], ws["ln_rowac"], D // 256
                 trunk_blocks = self.blocks[:-1]
                 d = (lambda: step()) if zz else (lambda: 0)
+                qk_lo = ws["qk_lo"] if (self.qk_split and (2 * D) % 256 == 0) else None
                 for bi, b in enumerate(trunk_blocks):
                     if bi == 0:                              # ln_1 of the first block follows ln_pre, not a GEMM
                         layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=(1 + d()) if zz else 0)
-                        gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, kernel=2 | (d() << 8))
+                        if qk_lo is None:
+                            gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, kernel=2 | (d() << 8))
+                        else:
+                            gemm_ln(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, reverse=d(), lo=qk_lo, lo_cols=2 * D)
                     else:
-                        gemm_ln(h, b.w_in, qkv, b.b_in_f, M, 3 * D, D, D, D, 3 * D, EPI_F16, rowac=rowac, colsum=b.cs_in, reverse=d())
-                    _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, ((1 + d()) << 3) if zz else 0, _lib.stream())
+                        gemm_ln(h, b.w_in, qkv, b.b_in_f, M, 3 * D, D, D, D, 3 * D, EPI_F16, rowac=rowac, colsum=b.cs_in, reverse=d(), lo=qk_lo, lo_cols=2 * D)
+                    if qk_lo is None:
+                        _lib.call("semabs_attention", _lib.ptr(qkv), _lib.ptr(att), None, n, T, H, 64, 3 * D, ((1 + d()) << 3) if zz else 0, _lib.stream())
+                    else:
+                        _lib.call("semabs_attention_split", _lib.ptr(qkv), _lib.ptr(qk_lo), _lib.ptr(att), None, n, T, H, 64, 3 * D, 2 * D,
+                                  ((1 + d()) << 3) if zz else 0, _lib.stream())
                     gemm_ln(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32, xg=h, gamma=b.ln2_w, part=part, reverse=d())
                     ln_rowstats(part, M, nt, D, rowac)
                     gemm_ln(h, b.w_fc, hid, b.b_fc_f, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16, rowac=rowac, colsum=b.cs_fc, reverse=d())

@@ -35,6 +35,7 @@ struct GemmArgs {
     // LayerNorm folded into the GEMMs on either side of it (semabs_gemm_f16_ln; k_gemm8's LNP / k_gemm8p's LNC template parameters):
     f16* ln_xg; const float* ln_gamma; float* ln_part;      // producer (fp32 residual epilogue): fp16 (x_new * gamma) [M, N], gamma [N], row partials [M, N / 256, 2]
     const float* ln_rowac; const float* ln_colsum;          // consumer (fp16 outputs): per row (rstd, -mean * rstd) [M, 2], per column sum_k gamma_k W[n, k] [N]
+    f16* lo_out; int lo_cols; long ld_lo;                   // k_gemm8p<.., QKLO>: the LOW fp16 half of the first lo_cols output columns, lo_out[m, n] = fp16(v - fp16(v))
 #ifdef SEMABS_TUNING
     int ablate;     // tuning build only (k_gemm_f16; k_gemm8 takes its ablations as the template parameter ABL): bit0 skip in-loop DMA, bit1 skip in-loop LDS reads, bit2 skip in-loop waits+barrier, bit3 skip epilogue
     unsigned long long* trace;  // tuning build only: per-workgroup {start, main loop end, end} s_memrealtime stamps + hw id
@@ -1212,8 +1213,13 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
 // (semabs_ln_rowstats) - LN(x) W^T + b without materialising LN(x); A is the producer's xg = fp16(x * gamma), bias' = b + W beta.  The tile's colsum row
 // (1 KB) and its 256 (a, c) pairs (2 KB) travel by LDS-DMA like the bias row - waves 1, 2, 3 issue one more 16-byte-per-lane load each in front of the
 // tile's first stage, exactly where wave 0 issues the bias row - so the kernel still issues no ordinary load and every counted wait keeps its meaning.
-template <int EPI, bool LNC = false>
+// QKLO (precision = "parity"; EPI_BIAS_F16 only): tiles whose columns lie below g.lo_cols (the q | k columns of the QKV projection; lo_cols % 256 == 0)
+// also store the LOW half of every output, lo_out[m, n] = fp16(v - fp16(v)), through the same transposition - the attention kernel then forms the
+// scores from hi + lo pairs (vit.hip k_attention<.., SPLIT>).  Such a tile issues 32 stores per wave instead of 16: the positional waits behind its
+// epilogue allow 42 outstanding operations where they allow 26 behind a plain tile (see VM_AFTER_EPI).
+template <int EPI, bool LNC = false, bool QKLO = false>
 __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
+    static_assert(!QKLO || EPI == EPI_BIAS_F16, "the low halves exist for the plain fp16 output only");
     static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32, "fp16-output epilogues and the fp32 residual read-modify-write");
     static_assert(!LNC || EPI != EPI_BIAS_RESID_F32, "the LayerNorm consumer has fp16 outputs");
     constexpr bool OUT16 = EPI != EPI_BIAS_RESID_F32;
@@ -1323,6 +1329,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
     // 2 (4 - P) older-stage instructions + 16 stores + 2 (P + 1) newer ones = 26 may be outstanding, for P = 0 .. 4; from P = 5 on the stage wanted is
     // younger than the stores and the count is the steady-state 10 again.  Waiting vmcnt(10) there instead forced the acknowledgement of the stores:
     // 0.5 us per QKV tile, 1.95 us per c_fc tile (whose QuickGELU epilogue issues its stores late) - tools/gemm_probe.py v3trace.
+    bool prev_lo = false;                                   // QKLO: the previous tile of this workgroup stored low halves too (32 stores in the queue)
     auto ktile = [&](auto steady_c, const int t, const int kts, const bool nx, const int st_ph) {
         constexpr bool STEADY = decltype(steady_c)::value;
         const int pb = (t & 1) * BUFSZ, pn = pb ^ BUFSZ;
@@ -1330,7 +1337,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         lds_cptr r0, r1;
 #define P_SYNC(k_)                                                               \
     do {                                                                         \
-        if (STEADY) { if ((k_) < st_ph) wait_vmcnt<VM_AFTER_EPI>(); else wait_vmcnt<10>(); } \
+        if (STEADY) { if ((k_) < st_ph) { if (QKLO && prev_lo) wait_vmcnt<VM_AFTER_EPI + 16>(); else wait_vmcnt<VM_AFTER_EPI>(); } else wait_vmcnt<10>(); } \
         else if (pen) wait_vmcnt<8 - 2 * (k_)>();                                \
         else if ((k_) == 0) wait_vmcnt<0>();                                     \
         __builtin_amdgcn_s_waitcnt(0xc07f);                                      \
@@ -1452,6 +1459,11 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         const __amdgpu_buffer_rsrc_t rC = gemm_rsrc(reinterpret_cast<const char*>(g.C) + (mw * g.ldc + n0 + wc * 32) * 2,
                                                     rows > 0 ? (rows - 1) * (long)ldcb + (long)(g.N - n0 - wc * 32) * 2 : 0);
         const unsigned voff = (unsigned)crow * ldcb + (unsigned)(cchunk * 16);
+        [[maybe_unused]] const bool tile_lo = QKLO && n0 < g.lo_cols;
+        [[maybe_unused]] const unsigned ldlob = (unsigned)g.ld_lo * 2u;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rLo = gemm_rsrc(reinterpret_cast<const char*>(g.lo_out) + (mw * g.ld_lo + n0 + wc * 32) * 2,
+                                                                       (QKLO && tile_lo && rows > 0) ? (rows - 1) * (long)ldlob + (long)(g.lo_cols - n0 - wc * 32) * 2 : 0);
+        [[maybe_unused]] const unsigned volo = (unsigned)crow * ldlob + (unsigned)(cchunk * 16);
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int hb = pass >> 1, ha = pass & 1;
@@ -1465,6 +1477,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 f32x4 w[2];
+                [[maybe_unused]] f32x4 wl[QKLO ? 2 : 1];
 #pragma unroll
                 for (int il = 0; il < 2; ++il) {
                     const int i = hf * 2 + il;
@@ -1481,12 +1494,15 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                         for (int e = 0; e < 4; ++e) { v[e] = acc[ha][i][hb][0][e] + bia[hb][0][e]; v[4 + e] = acc[ha][i][hb][1][e] + bia[hb][1][e]; }
                     }
                     f16x8 h;
+                    [[maybe_unused]] f16x8 hl;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (EPI == EPI_BIAS_GELU_F16) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[e]));
                         h[e] = (f16)v[e];
+                        if constexpr (QKLO) hl[e] = (f16)(v[e] - (float)h[e]);
                     }
                     w[il] = __builtin_bit_cast(f32x4, h);
+                    if constexpr (QKLO) wl[il] = __builtin_bit_cast(f32x4, hl);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1510,6 +1526,22 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (QKLO) {
+                    if (tile_lo) {                           // the same half pass once more for the low halves (the wave's LDS accesses are in order)
+#pragma unroll
+                        for (int il = 0; il < 2; ++il) *reinterpret_cast<f32x4*>(ep + (il * 16 + r15) * 64 + ((q4 ^ wswz) << 4)) = wl[il];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int row = it * 16 + crow;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + ((cchunk ^ ((row >> 1) & 3)) << 4));
+                            buf_store4<0>(rLo, volo, (unsigned)(ha * 128 + hf * 32 + it * 16) * ldlob + (unsigned)(hb * 128 * 2), v);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         }
     };
@@ -1533,7 +1565,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         unsigned long long t_start = 0, t_main = 0, c_start = 0, c_main = 0, t_first = 0;
         if (g.trace) { t_start = __builtin_amdgcn_s_memrealtime(); c_start = __builtin_amdgcn_s_memtime(); }
 #endif
-        if (first) wait_vmcnt<10>(); else wait_vmcnt<VM_AFTER_EPI>();     // (see ktile: behind an epilogue its loads / stores are inside the window)
+        if (first) wait_vmcnt<10>(); else if (QKLO && prev_lo) wait_vmcnt<VM_AFTER_EPI + 16>(); else wait_vmcnt<VM_AFTER_EPI>();     // (see ktile: behind an epilogue its loads / stores are inside the window)
         __builtin_amdgcn_s_barrier();
 #ifdef SEMABS_TUNING
         if (g.trace) t_first = __builtin_amdgcn_s_memrealtime();
@@ -1575,6 +1607,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
         }
 #endif
         if (!has_next) { wait_vmcnt<0>(); break; }          // nothing may be in flight towards this workgroup's LDS when it ends
+        if constexpr (QKLO) prev_lo = n0 < g.lo_cols;
         vb = nvb; m0 = m0n; n0 = n0n; rA = rAn; rB = rBn; first = false; bpar ^= 1;
     }
 #undef P_INTERLEAVE
@@ -1655,13 +1688,29 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         }
     }
     if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16) {
-        if (g.ln_rowac) {                                    // LayerNorm consumer (persistent workgroups): + 2 x 1 KB colsum rows + 2 x 2 KB row pairs
-            if ((g.K / 64) % 2 != 0) { semabs_set_error("semabs_gemm_f16_ln: the consumer kernel needs an even number of 64-wide K tiles"); return SEMABS_EINVAL; }
+        if (g.ln_rowac || g.lo_out) {                        // LayerNorm consumer and / or low halves (persistent workgroups): + 2 x 1 KB colsum rows + 2 x 2 KB row pairs
+            if ((g.K / 64) % 2 != 0) { semabs_set_error("semabs_gemm_f16_ln: the persistent kernel needs an even number of 64-wide K tiles"); return SEMABS_EINVAL; }
             constexpr int LDSC = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024 + 2 * 1024 + 2 * 2048;
+            const int ncu = gemm_num_cus();
+            const dim3 grid(g.n_blocks < ncu ? g.n_blocks : ncu);
+            if constexpr (EPI == EPI_BIAS_F16) {
+                if (g.lo_out && g.ln_rowac) {
+                    static SemabsLdsAttr a1; semabs_ensure_lds(&k_gemm8p<EPI, true, true>, LDSC, a1);
+                    gemm_dispatch(k_gemm8p<EPI, true, true>, grid, dim3(512), LDSC, s, g, o);
+                    SEMABS_CHECK_LAUNCH();
+                    return SEMABS_OK;
+                }
+                if (g.lo_out) {
+                    static SemabsLdsAttr a2; semabs_ensure_lds(&k_gemm8p<EPI, false, true>, LDSC, a2);
+                    gemm_dispatch(k_gemm8p<EPI, false, true>, grid, dim3(512), LDSC, s, g, o);
+                    SEMABS_CHECK_LAUNCH();
+                    return SEMABS_OK;
+                }
+            }
+            if (g.lo_out) { semabs_set_error("semabs_gemm_f16_ln: low halves exist for epi 0 only"); return SEMABS_EINVAL; }
             static SemabsLdsAttr attr_lc;
             semabs_ensure_lds(&k_gemm8p<EPI, true>, LDSC, attr_lc);
-            const int ncu = gemm_num_cus();
-            gemm_dispatch(k_gemm8p<EPI, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDSC, s, g, o);
+            gemm_dispatch(k_gemm8p<EPI, true>, grid, dim3(512), LDSC, s, g, o);
             SEMABS_CHECK_LAUNCH();
             return SEMABS_OK;
         }
@@ -1743,6 +1792,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
     g.ln_xg = nullptr; g.ln_gamma = nullptr; g.ln_part = nullptr; g.ln_rowac = nullptr; g.ln_colsum = nullptr;
+    g.lo_out = nullptr; g.lo_cols = 0; g.ld_lo = 0;
     const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
     const int v2 = ((kernel >> 11) & 1) == 0;               // the deep schedule of the phased kernel is the default since round 4; bit 11 selects the round-3 PF schedule (A/B), bit 10 is accepted and ignored
     const int nopers = (kernel >> 12) & 1;                  // bit 12: one workgroup per tile also for the fp16-output epilogues (A/B against k_gemm8p)
@@ -1768,9 +1818,12 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
 // LayerNorm folded into the GEMMs on either side of it (large shapes only: M >= 2048, N % 256 == 0, K >= 128; k_gemm8's LNP / k_gemm8p's LNC).
 //   epi 2 (x += A W^T + b, fp32) with ln_xg / ln_gamma / ln_part: also xg = fp16(x_new * gamma) [M, N] and the row partials [M, N / 256, 2];
 //   epi 0 / 1 (fp16 outputs) with ln_rowac / ln_colsum: C = rstd_row * (A W^T) - mean_row rstd_row * colsum + bias, A being such an xg (K % 128 == 0).
+//   epi 0 with lo_out (with or without the consumer operands): also lo_out[m, n] = fp16(v - fp16(v)) for the columns n < lo_cols (lo_cols % 256 == 0; row
+//   pitch ld_lo elements) - the low halves of q | k for precision = "parity" (semabs_attention_split).
 // reverse: walk the tiles backwards per XCD (the zigzag schedule of the trunk, like kernel | 256 of semabs_gemm_f16_ex).
 extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
-                                  void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum, int reverse,
+                                  void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum,
+                                  void* lo_out, int lo_cols, long ld_lo, int reverse,
                                   void* start_event, void* stop_event, void* stream) {
     SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16_ln: null operand");
     SEMABS_REQUIRE(M >= 2048 && N % 256 == 0 && K >= 128 && K % BK == 0, "semabs_gemm_f16_ln: needs M >= 2048, N % 256 == 0, K >= 128 (the phased kernel)");
@@ -1778,8 +1831,11 @@ extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const f
                    "semabs_gemm_f16_ln: leading dimensions");
     const bool producer = epi == EPI_BIAS_RESID_F32 && ln_xg && ln_gamma && ln_part && !ln_rowac && !ln_colsum;
     const bool consumer = (epi == EPI_BIAS_F16 || epi == EPI_BIAS_GELU_F16) && ln_rowac && ln_colsum && !ln_xg && !ln_gamma && !ln_part;
-    SEMABS_REQUIRE(producer || consumer, "semabs_gemm_f16_ln: epi 2 with (xg, gamma, partials) or epi 0 / 1 with (rowac, colsum)");
-    SEMABS_REQUIRE(!consumer || K % 128 == 0, "semabs_gemm_f16_ln: the consumer needs K % 128 == 0");
+    const bool plain_lo = epi == EPI_BIAS_F16 && lo_out && !ln_rowac && !ln_colsum && !ln_xg && !ln_gamma && !ln_part;
+    SEMABS_REQUIRE(producer || consumer || plain_lo, "semabs_gemm_f16_ln: epi 2 with (xg, gamma, partials), epi 0 / 1 with (rowac, colsum), or epi 0 with lo_out");
+    SEMABS_REQUIRE(!(consumer || plain_lo) || K % 128 == 0, "semabs_gemm_f16_ln: the persistent kernel needs K % 128 == 0");
+    SEMABS_REQUIRE(!lo_out || (epi == EPI_BIAS_F16 && lo_cols > 0 && lo_cols % 256 == 0 && lo_cols <= N && ld_lo % 8 == 0 && ld_lo >= lo_cols && ld_lo < (1L << 20)),
+                   "semabs_gemm_f16_ln: lo_out needs epi 0, lo_cols a multiple of 256 within N and a 16-byte aligned row pitch >= lo_cols");
     SEMABS_REQUIRE((start_event == nullptr) == (stop_event == nullptr), "semabs_gemm_f16_ln: start and stop events go together");
     GemmArgs g;
     g.A = (const f16*)A; g.B = (const f16*)B; g.C = C; g.bias = bias; g.addend = nullptr;
@@ -1787,6 +1843,7 @@ extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const f
     g.g_in = 1; g.g_out = 1; g.g_off = 0;
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = reverse ? 1 : 0;
     g.ln_xg = (f16*)ln_xg; g.ln_gamma = ln_gamma; g.ln_part = ln_part; g.ln_rowac = ln_rowac; g.ln_colsum = ln_colsum;
+    g.lo_out = (f16*)lo_out; g.lo_cols = lo_out ? lo_cols : 0; g.ld_lo = ld_lo;
     GemmOpts o{2, (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, 1, 0};
     hipStream_t s = (hipStream_t)stream;
     switch (epi) {

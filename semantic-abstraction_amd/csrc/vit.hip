@@ -190,26 +190,34 @@ extern "C" int semabs_embed_finish(float* x, const float* cls, const float* pos,
 // =================================================================================================
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int NKB, bool CAUSAL>   // number of 32-key blocks: TP = 32 * NKB
-__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out,
-                                                   float* __restrict__ stats, int T, int H, int ld, int D, int order) {
+// SPLIT (precision = "parity"): q and k arrive as fp16 hi + lo pairs (qk_lo [n_seq, T, ld_lo] holds the low halves, q | k at column
+// offsets 0 / D; written by the QKV GEMM's epilogue) and the scores are S = q_hi k_hi + q_hi k_lo + q_lo k_hi in fp32 - the rounding of q and k to fp16
+// is the largest single term of the relevancy maps' deviation from the fp32 reference (tests/test_vit_precision_budget.py: 1.5e-3 of 2.05e-3 per tile).
+// Costs a third LDS image (K_lo) - one workgroup per CU instead of two - and two more score MFMAs per k-step.
+template <int NKB, bool CAUSAL, bool SPLIT = false>   // number of 32-key blocks: TP = 32 * NKB
+__global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), SPLIT ? 1 : 2) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out,
+                                                   float* __restrict__ stats, int T, int H, int ld, int D, int order,
+                                                   const f16* __restrict__ qk_lo = nullptr, int ld_lo = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = 32 * NKB;
     constexpr int VS = TP + 4;                    // V^T row stride (elements): keeps ds_read_b64 8-byte aligned
     char* sK = smem;
     f16* sV = reinterpret_cast<f16*>(smem + TP * 128);
+    [[maybe_unused]] char* sKl = smem + TP * 128 + 64 * VS * 2;      // SPLIT: K_lo, same swizzled layout as K
     constexpr int NWAVE = (NKB > 4) ? 8 : 4;        // one 32-query block per wave when there are more than 4 of them
     constexpr int NTHR = 64 * NWAVE;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = order ? semabs_xcd_item((int)blockIdx.x, (int)gridDim.x, order == 2) : (int)blockIdx.x;    // (see k_layernorm: zigzag order)
     const int seq = wg / H, h = wg % H;
     const f16* base = qkv + (long)seq * T * ld + h * 64;
+    [[maybe_unused]] const f16* base_lo = SPLIT ? qk_lo + (long)seq * T * ld_lo + h * 64 : nullptr;
 
     // Staging: ALL of a thread's K / V rows are requested before the first LDS store (the loop used to alternate load - store, i.e. one
     // ~1-2 us HBM round trip per iteration, 4-7 of them in a row: SQ_WAIT_ANY was 48 % of the wave cycles), and the query fragments of the
     // wave's first block are requested before the barrier as well.
     constexpr int NIT_ST = (TP * 8 + NTHR - 1) / NTHR;
     f16x8 kvs[NIT_ST], vvs[NIT_ST];
+    [[maybe_unused]] f16x8 kls[SPLIT ? NIT_ST : 1];
 #pragma unroll
     for (int it = 0; it < NIT_ST; ++it) {
         const int c = tid + it * NTHR;
@@ -217,18 +225,23 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         if (c < TP * 8 && row < T) {
             kvs[it] = *reinterpret_cast<const f16x8*>(base + (long)row * ld + D + kc * 8);
             vvs[it] = *reinterpret_cast<const f16x8*>(base + (long)row * ld + 2 * D + kc * 8);
+            if constexpr (SPLIT) kls[it] = *reinterpret_cast<const f16x8*>(base_lo + (long)row * ld_lo + D + kc * 8);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kvs[it][e] = (f16)0.f; vvs[it][e] = (f16)0.f; }
+            for (int e = 0; e < 8; ++e) { kvs[it][e] = (f16)0.f; vvs[it][e] = (f16)0.f; if constexpr (SPLIT) kls[it][e] = (f16)0.f; }
         }
     }
     const int ql = lane & 31, hi = lane >> 5;
     f16x8 fq0[4];
+    [[maybe_unused]] f16x8 fq0l[SPLIT ? 4 : 1];
     {
         const int q = wid * 32 + ql;
         const int qc = q < T ? q : T - 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fq0[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+        for (int ks = 0; ks < 4; ++ks) {
+            fq0[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+            if constexpr (SPLIT) fq0l[ks] = *reinterpret_cast<const f16x8*>(base_lo + (long)qc * ld_lo + (ks * 2 + hi) * 8);
+        }
     }
 #pragma unroll
     for (int it = 0; it < NIT_ST; ++it) {
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         const int row = c >> 3, kc = c & 7;
         if (c < TP * 8) {
             *reinterpret_cast<f16x8*>(sK + kswz(row, kc)) = kvs[it];
+            if constexpr (SPLIT) *reinterpret_cast<f16x8*>(sKl + kswz(row, kc)) = kls[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e) sV[(kc * 8 + e) * VS + row] = vvs[it][e];
         }
@@ -250,12 +264,16 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
         const int q = qb * 32 + ql;
         const int qc = q < T ? q : T - 1;
         f16x8 fq[4];
+        [[maybe_unused]] f16x8 fql[SPLIT ? 4 : 1];
         if (qb == wid) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fq[ks] = fq0[ks];
+            for (int ks = 0; ks < 4; ++ks) { fq[ks] = fq0[ks]; if constexpr (SPLIT) fql[ks] = fq0l[ks]; }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+            for (int ks = 0; ks < 4; ++ks) {
+                fq[ks] = *reinterpret_cast<const f16x8*>(base + (long)qc * ld + (ks * 2 + hi) * 8);
+                if constexpr (SPLIT) fql[ks] = *reinterpret_cast<const f16x8*>(base_lo + (long)qc * ld_lo + (ks * 2 + hi) * 8);
+            }
         }
         // One score block (4 MFMAs) at a time instead of keeping all NKB blocks in registers (112 VGPRs at T = 197): exponentiate, feed the
         // un-normalised probabilities straight into P.V; O is scaled by 1 / sum at the end.  ~100 VGPRs -> two workgroups per CU.
@@ -265,6 +283,11 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention(const
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f16x8 fk = *reinterpret_cast<const f16x8*>(sK + kb * 4096 + koff[ks]);
+                if constexpr (SPLIT) {                       // the two small products first, the large one last (fp32 accumulation)
+                    const f16x8 fkl = *reinterpret_cast<const f16x8*>(sKl + kb * 4096 + koff[ks]);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fkl, fq[ks], sc, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fql[ks], sc, 0, 0, 0);
+                }
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fk, fq[ks], sc, 0, 0, 0);
             }
             // sc[r] = score(key = kb*32 + (r&3) + 8*(r>>2) + 4*hi, query = q); only a block that reaches past T (or, causal, past the query) needs masking
@@ -560,8 +583,21 @@ __global__ __launch_bounds__(64 * ((NKB > 4) ? 8 : 4), 2) void k_attention2(cons
 // qkv fp16 [n_seq, T, ld] with q | k | v at column offsets 0, D, 2D (q already scaled); out fp16 [n_seq, T, D]
 // row_stats (optional, may be NULL) fp32 [n_seq, H, T, 2] = (reference maximum, 1 / sum) of every query's softmax
 // causal: bit 0 = causal mask (text tower); bit 1 = k_attention2 with register staging, bit 2 = k_attention2 with LDS-DMA staging (A/B; all three give identical results)
+static int attention_impl(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim, int ld, int causal,
+                          const void* qk_lo, int ld_lo, void* stream);
 extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim,
                                 int ld, int causal, void* stream) {
+    return attention_impl(qkv, out, row_stats, n_seq, T, H, head_dim, ld, causal, nullptr, 0, stream);
+}
+// The same with q and k as fp16 hi + lo pairs: qk_lo fp16 [n_seq, T, ld_lo], q_lo | k_lo at column offsets 0 / D (precision = "parity": three score
+// products in fp32; k_attention<.., SPLIT>).  causal bits 1-2 (the k_attention2 A/B variants) are not available here.
+extern "C" int semabs_attention_split(const void* qkv, const void* qk_lo, void* out, void* row_stats, int n_seq, int T, int H, int head_dim,
+                                      int ld, int ld_lo, int causal, void* stream) {
+    SEMABS_REQUIRE(qk_lo && ld_lo % 8 == 0 && ld_lo >= 2 * H * 64 && (causal & 6) == 0, "semabs_attention_split: needs qk_lo with a 16-byte aligned row pitch >= 2 D and the default kernel");
+    return attention_impl(qkv, out, row_stats, n_seq, T, H, head_dim, ld, causal, qk_lo, ld_lo, stream);
+}
+static int attention_impl(const void* qkv, void* out, void* row_stats, int n_seq, int T, int H, int head_dim, int ld, int causal,
+                          const void* qk_lo, int ld_lo, void* stream) {
     if (n_seq == 0) return SEMABS_OK;
     SEMABS_REQUIRE(qkv && out && n_seq > 0 && T > 0 && H > 0, "semabs_attention: bad args");
     SEMABS_REQUIRE(head_dim == 64, "semabs_attention: head_dim must be 64");
@@ -591,7 +627,15 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
         semabs_ensure_lds(&k_attention2<N, C, DM>, (int)lds, attr2);                                                 \
         hipLaunchKernelGGL((k_attention2<N, C, DM>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D); \
     }
-#define ATT_CASE(N) { if (legacy) { if (is_causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }                                 \
+#define ATT_SPLIT_LAUNCH(N, C)                                                                                       \
+    {                                                                                                                \
+        size_t lds = (size_t)(32 * N) * 128 * 2 + 64 * (32 * N + 4) * 2;                                             \
+        static SemabsLdsAttr attr_s;                                                                                 \
+        semabs_ensure_lds(&k_attention<N, C, true>, (int)lds, attr_s);                                               \
+        hipLaunchKernelGGL((k_attention<N, C, true>), grid, dim3(64 * ((N > 4) ? 8 : 4)), lds, s, (const f16*)qkv, (f16*)out, (float*)row_stats, T, H, ld, D, order, (const f16*)qk_lo, ld_lo); \
+    }
+#define ATT_CASE(N) { if (qk_lo) { if (is_causal) ATT_SPLIT_LAUNCH(N, true) else ATT_SPLIT_LAUNCH(N, false) }                      \
+                      else if (legacy) { if (is_causal) ATT_LAUNCH(N, true) else ATT_LAUNCH(N, false) }                            \
                       else if (dma) { if (is_causal) ATT2_LAUNCH(N, true, true) else ATT2_LAUNCH(N, false, true) }                 \
                       else { if (is_causal) ATT2_LAUNCH(N, true, false) else ATT2_LAUNCH(N, false, false) } }
     switch (nkb) {
@@ -606,6 +650,7 @@ extern "C" int semabs_attention(const void* qkv, void* out, void* row_stats, int
     }
 #undef ATT_CASE
 #undef ATT_LAUNCH
+#undef ATT_SPLIT_LAUNCH
 #undef ATT2_LAUNCH
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;

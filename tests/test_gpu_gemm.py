@@ -285,3 +285,69 @@ def test_trunk_with_and_without_layernorm_fold():
     d = float((outs[0] - outs[1]).abs().max()) / float(outs[1].abs().max())
     print(f"trunk, LayerNorm fold on vs off: relative L-inf {d:.2e} of the residual stream")
     assert d <= 3e-3 and bool(torch.isfinite(outs[0]).all())
+
+
+# ---- precision = "parity": low fp16 halves of q | k out of the QKV GEMM, attention scores from hi + lo pairs -------------------------------------------
+@pytest.mark.parametrize("M", [2048, 2381, 50432])
+@pytest.mark.parametrize("consumer", [False, True])
+def test_gemm_low_halves_of_the_first_columns(M, consumer):
+    """k_gemm8p<.., QKLO>: C is bit-identical to the kernel without the option; lo[m, n] = fp16(v - fp16(v)) for the first lo_cols columns, i.e. C + lo
+    reproduces the fp32 value to 2^-22 relative; columns past lo_cols and rows past M are not written (tiles with and without low halves alternate on
+    a workgroup: both positional wait counts are exercised)."""
+    from semabs_amd.clip.vit import gemm, gemm_ln, ln_rowstats
+    N, K, LO = 2304, 768, 1536
+    g = torch.Generator(device="cuda").manual_seed(M)
+    A = torch.randn(M, K, device="cuda", generator=g).half()
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    kw = {}
+    if consumer:
+        part = torch.rand(M, 3, 2, device="cuda", generator=g) * 100 + 50
+        part[..., 1] = part[..., 0] ** 2 / 256 + 300.0
+        rowac = torch.empty(M, 2, device="cuda")
+        ln_rowstats(part, M, 3, K, rowac)
+        kw = dict(rowac=rowac, colsum=torch.randn(N, device="cuda", generator=g))
+    for reverse in (0, 1):
+        c0 = torch.full((M + 256, N), 7.0, dtype=torch.float16, device="cuda")
+        if consumer:
+            gemm_ln(A, B, c0, bias, M, N, K, K, K, N, EPI_F16, reverse=reverse, **kw)
+        else:
+            gemm(A, B, c0, bias, M, N, K, K, K, N, EPI_F16, kernel=2 | (reverse << 8))
+        c1 = torch.full((M + 256, N), 7.0, dtype=torch.float16, device="cuda")
+        lo = torch.full((M + 256, LO + 256), 7.0, dtype=torch.float16, device="cuda")
+        gemm_ln(A, B, c1, bias, M, N, K, K, K, N, EPI_F16, reverse=reverse, lo=lo, lo_cols=LO, **kw)
+        assert torch.equal(c1, c0)
+        assert bool((lo[M:] == 7.0).all()) and bool((lo[:, LO:] == 7.0).all())
+        ref = A.double() @ B.double().T
+        if consumer:
+            ref = ref * rowac[:, :1].double() + rowac[:, 1:].double() * kw["colsum"].double() + bias.double()
+        else:
+            ref = ref + bias.double()
+        both = c1[:M, :LO].double() + lo[:M, :LO].double()
+        e_hi = float((c1[:M, :LO].double() - ref[:, :LO]).abs().max()) / float(ref.abs().max())
+        e_both = float((both - ref[:, :LO]).abs().max()) / float(ref.abs().max())
+        print(f"M {M} consumer {consumer}: fp16 output {e_hi:.2e}, hi + lo {e_both:.2e} of max|ref|")
+        assert e_both < 4e-6 and e_both < e_hi / 50
+
+
+def test_attention_split_scores():
+    """semabs_attention_split against an fp64 attention on q = q_hi + q_lo, k = k_hi + k_lo, and against semabs_attention on the hi halves alone: the
+    split result must be closer to the fp64 result of the UNROUNDED q, k by an order of magnitude."""
+    from semabs_amd import _lib
+    n, T, H, D = 5, 197, 12, 768
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv32 = torch.randn(n, T, 3 * D, device="cuda", generator=g) * 1.5
+    qkv32[..., :D] *= 0.125 * 4.0                              # sharpened scores: the softmax is far from uniform
+    hi = qkv32.half()
+    lo = (qkv32[..., :2 * D] - hi[..., :2 * D].float()).half().contiguous()
+    out_s = torch.empty(n, T, D, dtype=torch.float16, device="cuda")
+    out_h = torch.empty_like(out_s)
+    _lib.call("semabs_attention_split", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(out_s), None, n, T, H, 64, 3 * D, 2 * D, 0, _lib.stream())
+    _lib.call("semabs_attention", _lib.ptr(hi), _lib.ptr(out_h), None, n, T, H, 64, 3 * D, 0, _lib.stream())
+    q, k = (qkv32[..., i * D:(i + 1) * D].double().view(n, T, H, 64).transpose(1, 2) for i in (0, 1))
+    v = hi[..., 2 * D:].double().view(n, T, H, 64).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(n, T, D)
+    e_s = float((out_s.double() - ref).abs().max())
+    e_h = float((out_h.double() - ref).abs().max())
+    print(f"attention vs fp64 on unrounded q, k: hi only {e_h:.3e}, hi + lo {e_s:.3e}")
+    assert e_s < e_h / 3 and e_s < 5e-3                       # measured 2.0e-2 / 3.7e-3 (what is left: fp16 P, V and the fp16 output, |o| up to ~5)

@@ -24,9 +24,19 @@ pytestmark = pytest.mark.gpu
 # item 3; they were 3 x): relative L-infinity 6.0e-4 (aug0) / 9.0e-4 (aug5), worst label relative to its own maximum 9.4e-4 / 1.06e-3, absolute 2.9e-6 /
 # 2.2e-6.  BASELINE bar: 1e-3 ABSOLUTE on maps whose max is 4.8e-3.  Where the 9.0e-4 comes from: tests/test_vit_precision_budget.py (by block and by
 # operand class: the fp16 rounding of q and k, 1.5e-3 of the 2.05e-3 per tile, then the LayerNorm-1 output, 9e-4).
-REL_LINF_BOUND = {"aug0": 7.8e-4, "aug5": 1.17e-3}
-PER_LABEL_BOUND = {"aug0": 1.23e-3, "aug5": 1.38e-3}
-ABS_LINF_BOUND = {"aug0": 3.8e-6, "aug5": 2.9e-6}
+# Round 5 (LayerNorm folded into the GEMMs): measured 7.52e-4 / 1.026e-3 relative, 9.50e-4 / 1.148e-3 per label, 3.58e-6 / 2.54e-6 absolute; bars = 1.3 x.
+# Why the default path's aug5 bar is NOT <= 1.0e-3 relative: with fp16 MFMA operands in the trunk the per-tile deviation is
+# 1.7 - 2.1e-3 and the headline maps land at (0.9 - 1.03)e-3 of their maximum depending on which equally accurate rounding points the kernels use; the
+# opt-in precision = "parity" brings both shapes under 1e-3 (below) at +10 ms per scene.  north_star's own bar (1e-3 ABSOLUTE) is met 390 x over.
+REL_LINF_BOUND = {"aug0": 7.52e-4 * 1.3, "aug5": 1.026e-3 * 1.3}
+PER_LABEL_BOUND = {"aug0": 9.50e-4 * 1.3, "aug5": 1.148e-3 * 1.3}
+ABS_LINF_BOUND = {"aug0": 3.58e-6 * 1.3, "aug5": 2.55e-6 * 1.3}
+# precision = "parity" (q, k as fp16 hi + lo pairs in the scores; +10 ms per scene): measured 6.01e-4 / 9.40e-4 relative, 7.74e-4 / 9.76e-4 per label - under
+# 1e-3 on both shapes, but by far less than the single-tile budget predicted (tests/test_vit_precision_budget.py: -30 %): the L-infinity over 3.7 M map
+# cells is an extreme-value statistic of ~2 448 averaged tile errors and moves by +-15 % between equally accurate roundings (the LayerNorm fold alone
+# moved it from 8.98e-4 to 1.026e-3 on aug5 and from 9.3e-4 to 8.1e-4 on the 96-pixel ours case, with the same per-GEMM accuracy).
+PARITY_REL_BOUND = {"aug0": 6.014e-4 * 1.3, "aug5": 1.0e-3}
+PARITY_PER_LABEL_BOUND = {"aug0": 7.74e-4 * 1.3, "aug5": 9.76e-4 * 1.3}
 
 
 @pytest.fixture(scope="module")
@@ -35,9 +45,9 @@ def wrapper():
     from semabs_amd.weights import make_clip_state_dict
     sd = make_clip_state_dict("ViT-B/16", 0, text_tower=False)
 
-    def make(chunk):
+    def make(chunk, precision=None):
         ClipWrapper.engine = None
-        ClipWrapper("ViT-B/16", state_dict=sd, chunk_tiles=chunk, max_labels=16)
+        ClipWrapper("ViT-B/16", state_dict=sd, chunk_tiles=chunk, max_labels=16, precision=precision)
         return ClipWrapper
 
     return make
@@ -78,3 +88,16 @@ def test_headline_maps_vs_reference(golden, wrapper, tag):
         res[chunk] = m
     # the maps must not depend on the ViT batch size (same kernels, same per-row arithmetic; was tools/chunk_equiv.py)
     assert np.array_equal(res[2448], res[220]), float(np.abs(res[2448] - res[220]).max())
+
+
+@pytest.mark.parametrize("tag", ["aug0", "aug5"])
+def test_headline_maps_parity_precision(golden, wrapper, tag):
+    """precision = "parity" (q and k as fp16 hi + lo pairs in the attention scores) on the headline shape: closer to the fp32
+    reference than the default path, printed next to it."""
+    g = golden(f"g16_headline_{tag}")
+    m = _run(wrapper(2448, "parity"), g, tag)
+    ref_max = float(g["absmax"].max())
+    rel = float(max(np.abs(m[:, ::4, ::4] - g["sub"]).max(), np.abs(m[:, g["rows_idx"], :] - g["rows"]).max())) / ref_max
+    per_label = (np.abs(m[:, ::4, ::4] - g["sub"]).reshape(16, -1).max(1) / g["absmax"]).max()
+    print(f"headline {tag} precision=parity: relative L-inf {rel:.3e}  worst per-label relative {per_label:.3e}")
+    assert rel <= PARITY_REL_BOUND[tag] and per_label <= PARITY_PER_LABEL_BOUND[tag], (rel, per_label)
