@@ -66,8 +66,9 @@ _RECORDED = {}
 @pytest.fixture
 def bar(request):
     """bar(tag, err, ceiling) -> bool: err <= min(ceiling, max(tol(measured error of this case), floor)) - the ceiling (the old fixed bar) alone when
-    the case has no recorded value.  floor (default 5 % of the ceiling): errors of a few fp32 ulps can double when one rounding flips (the fp64
-    GroupNorm statistics are accumulated with atomics, i.e. in a run-dependent order), so no bar is ever tighter than that.  A recorded 0.0 with
+    the case has no recorded value.  floor (default 10 % of the ceiling): errors of a few fp32 ulps can double when one rounding flips (the fp64
+    GroupNorm statistics are accumulated with atomics, i.e. in a run-dependent order: measured 3 ulps in one run, 4 in the next), so no bar is ever
+    tighter than that.  A recorded 0.0 with
     floor = 0 demands 0.0 (bit-exact cases stay bit-exact)."""
     def check(tag: str, err: float, ceiling: float, floor: float | None = None) -> bool:
         key = request.node.nodeid.split("tests/")[-1] + ":" + tag
@@ -75,7 +76,7 @@ def bar(request):
         if os.environ.get("SEMABS_RECORD_ERRORS"):
             _RECORDED[key] = max(err, _RECORDED.get(key, 0.0))
         m = _MEASURED.get(key)
-        fl = 0.05 * float(ceiling) if floor is None else float(floor)
+        fl = 0.10 * float(ceiling) if floor is None else float(floor)
         limit = float(ceiling) if m is None else min(float(ceiling), max(tol(m), fl))
         ok = err <= limit
         if not ok:
