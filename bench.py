@@ -383,7 +383,7 @@ def _load_probe():
     pth = os.path.join(ROOT, "profiles", "r04_mfma_probes.json")
     try:
         d = json.load(open(pth))
-        d["source"] = "profiles/r04_mfma_probes.json (tools/mfma_skeleton.cpp + tools/gemm_probe.py abltrace, this round; imported, not measured in this run)"
+        d["source"] = "profiles/r04_mfma_probes.json (tools/mfma_skeleton.cpp + tools/gemm_probe.py abltrace, round 4; imported, not measured in this run)"
         return d
     except Exception:
         return None
@@ -544,7 +544,7 @@ def stage_report(pipe, scenes, w_text, arch, precision):
     if trunk:
         fl = sum(v.get("algorithmic_tflop") or 0.0 for v in trunk); gb = sum(v.get("algorithmic_gb") or 0.0 for v in trunk); ms = sum(v["ms_per_scene"] for v in trunk)
         counted = None
-        for name in ("r04_gemm_pmc.json",):
+        for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json"):
             pth = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pth):
                 try:
@@ -874,7 +874,7 @@ def main():
         # HBM bytes per GEMM launch: PMC counters cannot be read from inside the process that is being timed (rocprofv3 owns them and
         # serialises the kernels), so this figure is IMPORTED from the committed counter run of this same command and labelled as such
         traffic, traffic_src = None, None
-        for name in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
+        for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:

@@ -45,7 +45,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for name, row in rf.get("per_shape", {}).items():
         assert row["frac_of_roof"] <= 1.0, (name, row)
     # imported counter / probe figures must come from THIS round's profiles and say that they are imported
-    assert "profiles/r04_" in (rf.get("traffic_source") or "profiles/r04_"), rf.get("traffic_source")
+    assert "profiles/r05_" in (rf.get("traffic_source") or "profiles/r05_"), rf.get("traffic_source")
     assert rf["mfma_probe"] is None or "imported" in rf["mfma_probe"]["source"]
     assert d.get("text_tower_in_timed_region") is True
     # clock and power under load, sampled in THIS run: the keys are always there; on a box with any SMI source they carry numbers
