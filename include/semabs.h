@@ -351,6 +351,11 @@ int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, 
 /* Y[R, Co] = act(X[R, Ci] . W[Co, Ci]^T + bias), act 0 none / 1 LeakyReLU(slope): the point MLP and sampler MLP layers and, with W
  * transposed by the caller, their data gradients                                                         net.py:358-367, 300-309 */
 int semabs_linear_f32(const float* X, const float* W, const float* bias, float* Y, long R, int Ci, int Co, int act, float slope, void* stream);
+/* The same layer on the matrix cores with fp32-like accuracy (operands split into fp16 hi + lo, three products): Y = act((s X) W^T + b), W addressed as
+ * W[n * w_sn + k * w_sk] (plain: Ci, 1; transposed: 1, Co), in_scale = optional device scalar s (the power-of-two scale of a gradient input; the output
+ * stays scaled unless out_scale - a device scalar the accumulator is multiplied by, e.g. 1 / s - is given).  Ci % 4 == 0, Co <= 128, act 0 none / 1 LeakyReLU(slope).                                  net.py:358-367, 215-256 (and their backward) */
+int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
+                       int act, float slope, const float* in_scale, const float* out_scale, void* stream);
 
 /* scatter-mean backward: dpf[b, p] = dvol[b, flat[p]] / count[flat[p]]; count int32 [nvox] zero-filled by the caller   net.py:185-201 */
 int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol, float* dpf, int P, long N, int C, long nvox, void* stream);

@@ -800,6 +800,111 @@ extern "C" int semabs_linear_f32(const float* X, const float* W, const float* bi
 }
 
 // =================================================================================================
+// Tall-and-skinny linear layers of the training step (point MLP 4 -> 128 -> 128 -> 16 on P * N rows, sampler MLP 36 -> 32 -> 64 on D * M rows, and
+// their data gradients) on the matrix cores with fp32-like accuracy: Y[R, Co] = act((s X)[R, Ci] . W^T + b), X / Y fp32 row-major, W fp32 addressed as
+// W[n * w_sn + k * w_sk] (so the transpose needs no copy), operands split into fp16 hi + lo on the fly (three MFMA products, fp32 accumulation - the
+// scheme of the convolutions).  Round 5: these layers ran as 1 x 1 x 1 "convolutions" on the generic gather kernel (0.7 - 0.9 ms each at 640 k - 1.6 M rows,
+// 0.02 of their roof) or on the fp32 FMA kernel k_linear (0.73 ms): ~5.5 ms of the 62.8 ms step.
+// A workgroup (4 waves) stages W once as fp16 hi / lo planes in LDS ([Co16][Kp + 8]: the 16-byte pad puts the 16 rows of a fragment read on distinct bank
+// groups), then each wave walks 16-row tiles: per k-step of 32 a lane loads its row's 8 fp32 (2 x 16 B), scales and splits them, and multiplies them
+// against the Co16 / 16 column tiles.  s (optional, a device scalar) is the dynamic power-of-two scale of a gradient input - REQUIRED for one: values of
+// 1e-7 are fp16 subnormals before the split; the accumulator is multiplied by out_scale (optional device scalar, e.g. 1 / s) in front of the bias.
+// =================================================================================================
+template <int NT>                                            // column tiles of 16 kept in registers per pass (Co16 / 16 <= NT)
+__global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X, long ldx, const float* __restrict__ W, long w_sn, long w_sk,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, long R, int Ci, int Co, int act, float slope,
+                                                     const float* __restrict__ in_scale, const float* __restrict__ out_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Kp = (Ci + 31) / 32 * 32, KS = Kp + 8;         // padded K and LDS row stride (fp16 elements)
+    const int Co16 = (Co + 15) / 16 * 16;
+    f16* s_hi = reinterpret_cast<f16*>(smem);
+    f16* s_lo = s_hi + (long)Co16 * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < Co16 * Kp; i += 256) {
+        const int n = i / Kp, k = i - n * Kp;
+        const float w = (n < Co && k < Ci) ? W[n * w_sn + k * w_sk] : 0.f;
+        const f16 h = (f16)w;
+        s_hi[n * KS + k] = h; s_lo[n * KS + k] = (f16)(w - (float)h);
+    }
+    __syncthreads();
+    const float sx = in_scale ? in_scale[0] : 1.f, so = out_scale ? out_scale[0] : 1.f;
+    const int vl = lane & 15, kg = lane >> 4;
+    const int nt = Co16 / 16;
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = (bias && j < nt && j * 16 + vl < Co) ? bias[j * 16 + vl] : 0.f;
+    const long ntiles = (R + 15) / 16;
+    for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
+        const long row = t * 16 + vl;
+        const float* xr = X + (row < R ? row : R - 1) * ldx;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < Kp; ks += 32) {
+            const int k0 = ks + kg * 8;
+            float v[8];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int k = k0 + hf * 4;
+                if (k + 4 <= Ci) { const float4 q = *reinterpret_cast<const float4*>(xr + k); v[hf * 4] = q.x; v[hf * 4 + 1] = q.y; v[hf * 4 + 2] = q.z; v[hf * 4 + 3] = q.w; }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[hf * 4 + e] = (k + e < Ci) ? xr[k + e] : 0.f;
+                }
+            }
+            f16x8 xh, xl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float q = v[e] * sx; xh[e] = (f16)q; xl[e] = (f16)(q - (float)xh[e]); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j < nt) {
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(s_hi + (j * 16 + vl) * KS + k0);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(s_lo + (j * 16 + vl) * KS + k0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        // acc[j][i] = Y[t * 16 + 4 * kg + i][j * 16 + vl]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j < nt && j * 16 + vl < Co) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long r = t * 16 + 4 * kg + i;
+                    float o = acc[j][i] * so + bv[j];
+                    if (act == 1) o = o > 0.f ? o : slope * o;
+                    if (r < R) Y[r * Co + j * 16 + vl] = o;
+                }
+            }
+        }
+    }
+}
+extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
+                                  int act, float slope, const float* in_scale, const float* out_scale, void* stream) {
+    if (R == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(X && W && Y && R > 0 && Ci > 0 && Co > 0, "semabs_linear_rows: bad args");
+    SEMABS_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0 && Ci <= 512 && Co <= 128 && (act == 0 || act == 1), "semabs_linear_rows: Ci % 4 == 0, Ci <= 512, Co <= 128, act 0 / 1");
+    const int Kp = (Ci + 31) / 32 * 32, Co16 = (Co + 15) / 16 * 16;
+    const size_t lds = (size_t)Co16 * (Kp + 8) * 2 * 2;
+    SEMABS_REQUIRE(lds <= 160 * 1024, "semabs_linear_rows: the weight matrix does not fit LDS");
+    const long ntiles = (R + 15) / 16;
+    long nb = (ntiles + 3) / 4; const long cap = 2048; if (nb > cap) nb = cap;
+    hipStream_t s = (hipStream_t)stream;
+#define LR_LAUNCH(NT)                                                                                                           \
+    {                                                                                                                           \
+        static SemabsLdsAttr attr;                                                                                              \
+        semabs_ensure_lds(&k_linear_rows<NT>, 160 * 1024, attr);                                                                \
+        hipLaunchKernelGGL(k_linear_rows<NT>, dim3((unsigned)nb), dim3(256), lds, s, X, ldx, W, w_sn, w_sk, bias, Y, R, Ci, Co, act, slope, in_scale, out_scale); \
+    }
+    if (Co16 <= 32) LR_LAUNCH(2) else if (Co16 <= 64) LR_LAUNCH(4) else LR_LAUNCH(8)
+#undef LR_LAUNCH
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
 // Scatter-mean backward: dpf[b, p, :] = dvol[b, flat[p], :] / count[flat[p]]   (count via an integer histogram)
 // =================================================================================================
 __global__ void k_voxel_count(const long long* __restrict__ flat, long N, int* __restrict__ count) {

@@ -472,6 +472,7 @@ class VOOLTrainer:
         self.steps = 0
         # data-parallel gradient exchange: bucketed and overlapped with the backward pass (default) or ONE blocking all-reduce after it (A/B, tests)
         self.overlap_allreduce = os.environ.get("SEMABS_DP_OVERLAP", "1") == "1"
+        self.rows_linear = os.environ.get("SEMABS_ROWS_LINEAR", "1") == "1"      # the MLP layers on semabs_linear_rows (A/B: 0 = k_linear / 1x1x1 convolutions)
         self._sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.last = {}
 
@@ -508,10 +509,18 @@ class VOOLTrainer:
         self.buckets = BucketedAllReduce(flat, ranges)
 
     # ---- helpers -----------------------------------------------------------------------------------------------------------------
-    def _linear(self, x, w, b, act):
+    def _linear(self, x, w, b, act, grad_in=False):
+        """grad_in: x is a gradient (values of 1e-7 and below): the matrix-core kernel then scales it by a power of two on the way in and the
+        accumulator back on the way out - unscaled, such values are fp16 subnormals before the hi / lo split (the fp32 FMA kernel does not care)."""
         R, Ci = x.shape
         Co = w.shape[0]
         y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
+        if self.rows_linear and Ci % 4 == 0 and Co <= 128 and w.is_contiguous():
+            # (round 5) the matrix-core row kernel: the fp32 FMA kernel below took 0.73 ms per layer at 640 k - 1.6 M rows
+            s2 = self.unet._scale(x, 1, Ci)[2] if grad_in else None
+            _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), Ci, 1, _lib.ptr(b), _lib.ptr(y), R, Ci, Co, int(act), SLOPE,
+                      _lib.ptr(s2), None if s2 is None else s2[1:].data_ptr(), _lib.stream())
+            return y
         _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
         return y
 
@@ -522,6 +531,15 @@ class VOOLTrainer:
         R, Ci = x.shape
         w = self.params[wkey]
         Co = w.shape[1] if transposed else w.shape[0]
+        if self.rows_linear and Ci % 4 == 0 and Co <= 128:
+            # (round 5) the matrix-core row kernel reads W (or its transpose, through strides) straight from the fp32 parameter and splits it while
+            # staging: no per-step operand gather, and 0.05 - 0.1 ms per layer where the 1 x 1 x 1 "convolution" on the gather kernel took 0.7 - 0.9 ms
+            y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
+            s2 = self.unet._scale(x, 1, Ci)[2] if grad_in else None
+            wd = w.detach()
+            _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(wd), 1 if transposed else wd.shape[1], wd.shape[1] if transposed else 1,
+                      _lib.ptr(b), _lib.ptr(y), R, Ci, Co, 1 if act else 0, SLOPE, _lib.ptr(s2), None, _lib.stream())
+            return (y, s2[1:]) if grad_in else y
         hi, lo, pk = self.unet.layouts.get(f"lin:{wkey}:{int(transposed)}", w, (lambda t: _flat_packed(_pad32(t.t().contiguous()))) if transposed else
                                            (lambda t: _flat_packed(_pad32(t.contiguous()))))
         y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
@@ -619,7 +637,7 @@ class VOOLTrainer:
         dh = u._ew(y_, h, 1, want_max=True, in_scale=inv_)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
-        df = self._linear(dh, w1p.t().contiguous(), None, 0)                             # [D*M, 36]
+        df = self._linear(dh, w1p.t().contiguous(), None, 0, grad_in=True)               # [D*M, 36]
         dvol = torch.empty(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
         cell_head = torch.empty(D * nvox, dtype=torch.int32, device=dev)
         cell_next = torch.empty(D * M, dtype=torch.int32, device=dev)
