@@ -119,6 +119,7 @@ class UNetTrainer:
         self.dev = _lib.require_gpu()
         self._wgs = None
         self._wg_routes = {}
+        self.rows_linear = os.environ.get("SEMABS_ROWS_LINEAR", "1") == "1"      # 1 x 1 x 1 convolutions / MLP layers on semabs_linear_rows
         self.wgrad_tr = os.environ.get("SEMABS_WGRAD_TR", "1") == "1"      # A/B: 0 = the round-2 brick kernel (transposes while staging, atomics)
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
@@ -237,8 +238,14 @@ class UNetTrainer:
         m = self.mats["final_conv."]
         B, D0, D1, D2, _ = x.shape
         y = torch.empty(B, D0, D1, D2, m["cout"], dtype=torch.float32, device=self.dev)
-        _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(y), None, None,
-                  _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1 | m["fwd"][2], st)
+        wf = self.p[self.prefix + "final_conv.weight"].detach()
+        if self.rows_linear and m["cin"] % 4 == 0 and m["cout"] <= 128 and wf.is_contiguous():
+            # the 1 x 1 x 1 convolution IS a row-linear layer over the voxels: semabs_linear_rows streams it at HBM speed (the gather kernel: 1.28 ms at 8 x 128^3)
+            _lib.call("semabs_linear_rows", _lib.ptr(x), m["cin"], _lib.ptr(wf), m["cin"], 1, _lib.ptr(self.p[self.prefix + "final_conv.bias"]), _lib.ptr(y),
+                      B * D0 * D1 * D2, m["cin"], m["cout"], 0, 0.0, None, None, st)
+        else:
+            _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(y), None, None,
+                      _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1 | m["fwd"][2], st)
         tape.append(("final", x))
         return y, tape
 
@@ -393,8 +400,12 @@ class UNetTrainer:
                 self._colsum(g.view(R, cout), self.g[self.prefix + "final_conv.bias"])
                 dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
                 sc, sh, s2 = self._scale(g, B, cout)
-                _lib.call("semabs_conv3d", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh), None, None,
-                          B, D0, D1, D2, cout, cin, 1, 0, 1 | m["bwd"][2], st)
+                wf = self.p[self.prefix + "final_conv.weight"].detach()
+                if self.rows_linear and cout % 4 == 0 and cin <= 128 and wf.is_contiguous():      # dx = (s g) W: the transposed row-linear layer (see forward)
+                    _lib.call("semabs_linear_rows", _lib.ptr(g), cout, _lib.ptr(wf), 1, cin, None, _lib.ptr(dx), R, cout, cin, 0, 0.0, _lib.ptr(s2), None, st)
+                else:
+                    _lib.call("semabs_conv3d", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh), None, None,
+                              B, D0, D1, D2, cout, cin, 1, 0, 1 | m["bwd"][2], st)
                 g, g_scale = dx, s2[1:]
             elif kind == "block":
                 g = self._block_bwd(item[1:], g, in_scale=g_scale)
