@@ -48,7 +48,9 @@ def test_conv3d_gn_relu_resid(precision, tol, cin, cout, S, B, bar):
                      + rd.float().cpu().permute(0, 4, 1, 2, 3))
     y = u._conv(xd, conv, relu=True, resid=rd)
     got = y.float().cpu().permute(0, 4, 1, 2, 3)
-    assert bar("vs_torch", (got - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()))
+    # (fp16 mode: the error of a single layer is one or two fp16 ulps of the output and moves by an ulp from run to run - the GroupNorm statistics are
+    #  accumulated with atomics - so its bar stays at the fixed value; the exact mode's bars are per case, conftest.bar)
+    assert bar("vs_torch", (got - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()), floor=None if precision == "exact" else tol * max(1.0, ref.abs().max().item()))
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
@@ -73,8 +75,8 @@ def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid, bar):
     ref = F.relu(ref)
     y_lds = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
     y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
-    assert bar("vs_torch", (y_lds - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()))
-    assert bar("vs_generic", (y_lds - y_gen).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item()))
+    assert bar("vs_torch", (y_lds - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()), floor=None if precision == "exact" else tol * max(1.0, ref.abs().max().item()))
+    assert bar("vs_generic", (y_lds - y_gen).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item()), floor=None if precision == "exact" else (1e-5 if precision == "exact" else 2e-3) * max(1.0, ref.abs().max().item()))
 
 
 @pytest.mark.parametrize("precision,tol", [("exact", 2e-5), ("fp16", 4e-3)])
@@ -102,8 +104,8 @@ def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid, bar):
     y_brick = u._conv(xd, conv, relu=True, resid=rd if resid else None).float().cpu().permute(0, 4, 1, 2, 3)
     y_gen = u._conv(xd, conv, relu=True, resid=rd if resid else None, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
     scale = max(1.0, ref.abs().max().item())
-    assert bar("vs_torch", (y_brick - ref).abs().max().item(), tol * scale)
-    assert bar("vs_generic", (y_brick - y_gen).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * scale)
+    assert bar("vs_torch", (y_brick - ref).abs().max().item(), tol * scale, floor=None if precision == "exact" else tol * scale)
+    assert bar("vs_generic", (y_brick - y_gen).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * scale, floor=None if precision == "exact" else (1e-5 if precision == "exact" else 2e-3) * scale)
 
 
 @pytest.mark.parametrize("precision", ["exact", "fp16"])
@@ -153,7 +155,7 @@ def test_convtranspose3d_skip(precision, tol, cin, cout, S, B, bar):
                                                                                  padding=1, output_padding=1)
     y = u._up(xd, sd_, _ConvT(w, b, u.dev))
     got = y.float().cpu().permute(0, 4, 1, 2, 3)
-    assert bar("vs_torch", (got - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()))
+    assert bar("vs_torch", (got - ref).abs().max().item(), tol * max(1.0, ref.abs().max().item()), floor=None if precision == "exact" else tol * max(1.0, ref.abs().max().item()))
 
 
 @pytest.mark.parametrize("precision", ["exact", "fp16"])
@@ -324,8 +326,8 @@ def test_convtranspose3d_brick_kernel(precision, tol, cin, cout, dims, B, bar):
     y_brick = u._up(xd, sd_, ct).float().cpu().permute(0, 4, 1, 2, 3)
     y_gather = u._up(xd, sd_, ct, generic=True).float().cpu().permute(0, 4, 1, 2, 3)
     scale = max(1.0, ref.abs().max().item())
-    assert bar("vs_torch", (y_brick - ref).abs().max().item(), tol * scale)
-    assert bar("vs_generic", (y_brick - y_gather).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * scale)
+    assert bar("vs_torch", (y_brick - ref).abs().max().item(), tol * scale, floor=None if precision == "exact" else tol * scale)
+    assert bar("vs_generic", (y_brick - y_gather).abs().max().item(), (1e-5 if precision == "exact" else 2e-3) * scale, floor=None if precision == "exact" else (1e-5 if precision == "exact" else 2e-3) * scale)
 
 
 def test_decoder_folded_final_conv_matches_materialised():
