@@ -260,3 +260,51 @@ def test_two_ranks_through_the_module_equal_the_fused_single_rank_step():
         med = worst_param_deviation(sd, ref_sd, before, ref_gu, quantile=0.5)
         assert med <= 1e-2 and worst <= 0.5, (rank, med, worst)
     assert all(np.array_equal(got[0][3][k], got[1][3][k]) for k in ref_sd)
+
+
+def test_reference_amp_branch_runs_through_the_module():
+    """`--use_amp` (utils.py:292-293, 405-411, 522): the loop runs under `torch.cuda.amp.autocast` with a `GradScaler` - scale(loss).backward(),
+    unscale_(optimizer), clip_grad_norm_, scaler.step(optimizer), scaler.update().  The HIP forward ignores autocast (its arithmetic is the
+    fp32-equivalent split-fp16 MFMA path either way), the loss-scaled gradient enters the hand-written backward as an fp32 tensor (whose dynamic
+    power-of-two scale absorbs the 65 536 x), `unscale_` divides the p.grad the backward left and finds them finite - so the AMP branch takes the
+    SAME step as the plain branch, to the noise of two runs of the same backward."""
+    from semabs_amd.optim import Lamb
+    S, N, M, D, L = 16, 1500, 700, 3, 4
+    if True:
+        rng = np.random.default_rng(21)
+        lo, hi = np.array(SCENE_BOUNDS[0]), np.array(SCENE_BOUNDS[1])
+        batch = dict(input_xyz_pts=torch.from_numpy((lo + (hi - lo) * rng.random((2, N, 3))).astype(np.float32)),
+                     input_target_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                     input_reference_saliency_pts=torch.from_numpy(rng.random((2, D, N, 1)).astype(np.float32)),
+                     output_xyz_pts=torch.from_numpy((lo - 0.05 + (hi - lo + 0.1) * rng.random((2, D, M, 3))).astype(np.float32)),
+                     output_label_pts=torch.from_numpy((rng.random((2, D, M)) < 0.25).astype(np.float32)),
+                     spatial_relation_name=[["on", "behind"], ["in", "[pad]"], ["on the left of", "on"]])
+    sd = make_semabsvool_state_dict(seed=9, unet_num_levels=L)
+    plain = _net(S, sd, levels=L)
+    opt_p = Lamb(plain.parameters(), lr=1e-3, weight_decay=1e-5)
+    _, loss_p, total_p = _loop_step(plain, opt_p, batch)
+    amp = _net(S, sd, levels=L)
+    opt_a = Lamb(amp.parameters(), lr=1e-3, weight_decay=1e-5)
+    scaler = torch.cuda.amp.grad_scaler.GradScaler()
+    b = {k: (v.to("cuda") if type(v) == torch.Tensor else v) for k, v in batch.items()}
+    with torch.cuda.amp.autocast(enabled=True):
+        outputs = amp(**b)
+        loss_a = F.binary_cross_entropy_with_logits(outputs.float(), b["output_label_pts"], weight=torch.ones_like(b["output_label_pts"]))
+        opt_a.zero_grad()
+        scaler.scale(loss_a).backward()
+        scaler.unscale_(opt_a)
+        total_a = torch.nn.utils.clip_grad_norm_(amp.parameters(), 2.0)
+        scaler.step(opt_a)
+        scaler.update()
+    amp.steps += 1                                                            # utils.py:416-417
+    assert outputs.dtype == torch.float32 and bool(torch.isfinite(total_a))
+    assert float(scaler.get_scale()) == 65536.0                                # no inf / nan found: the step was taken, the scale kept
+    assert abs(float(loss_a.detach()) - float(loss_p.detach())) <= 1e-5 * float(loss_p.detach())
+    assert abs(float(total_a) - float(total_p)) <= 2e-3 * float(total_p)
+    npy = lambda d: {k: v.detach().cpu().numpy() for k, v in d.items()}
+    ref_g = {k: p.grad.detach().cpu().numpy() for k, p in plain.named_parameters() if p.grad is not None}
+    base = {k: v.numpy() for k, v in sd.items()}
+    med = worst_param_deviation(npy(amp.state_dict()), npy(plain.state_dict()), base, ref_g, quantile=0.5)
+    worst = worst_param_deviation(npy(amp.state_dict()), npy(plain.state_dict()), base, ref_g)
+    print(f"AMP branch vs plain branch: per-tensor median parameter deviation {med:.3e}, worst {worst:.3e} of the tensor's own step")
+    assert med <= 1e-2 and worst <= 0.5
