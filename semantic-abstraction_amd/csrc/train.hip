@@ -1404,85 +1404,100 @@ __global__ __launch_bounds__(WG_NTHR) void k_wgrad16_lds(Wgrad16Args a) {
 // and the voxel-major fragments produced by the transposing LDS read (ds_read_b64_tr_b16, as in k_wgrad_mfma): staging is an 8-byte store per
 // (voxel, 4 channels) instead of sixteen 4-byte scatter stores per voxel pair, a fragment read of 16 consecutive x is one contiguous 512 B
 // (conflict-free at any dx shift, so the three dx taps are plain address offsets - no v_alignbit), and 4 x 4 x 16 bricks (58 KB) leave room for
-// the accumulators.  A workgroup = 8 waves, one per CU: wave w multiplies k-steps 2 (w & 3), 2 (w & 3) + 1 of a brick (k-step = two x rows =
-// 32 voxels) against taps 13 (w >> 2) .. + 13 (14 accumulators; the dZ fragment is read once per k-step and tap half); the next brick's global
-// loads are issued before the MFMAs of the current one and land in registers meanwhile.  The workgroup's 27 x 16 x 16 sums meet in LDS and go to a partial-sum buffer,
-// one row per workgroup; k_wgrad3_reduce adds the rows into dW (no atomics: deterministic, and 16 G atomics / s was a third of the old kernel).
+// the accumulators.
+//
+// Round 5: a workgroup = 16 waves, one per CU, in two roles (the round-4 kernel did both jobs in every wave, one after the other, and was bound by VALU
+// issue - ~700 VALU instructions per thread and brick for addresses, the fp16 hi / lo split and operand assembly, beside 84 MFMAs - at 0.28 matrix-pipe busy):
+//  * waves 8 .. 15 LOAD: brick i + 2's global loads are in flight in registers while brick i + 1 is split into fp16 hi / lo planes in the LDS buffer the
+//    multiplying waves are not reading (two 58 KB buffers); one barrier per brick.  A slot's address is a per-thread constant plus a per-brick scalar
+//    (see `relx` below), whether a slot is outside the volume comes from six per-thread bit sets: ~25 VALU instructions per 16-byte slot, all of them the
+//    GroupNorm affine and the split.
+//  * waves 0 .. 7 MULTIPLY: wave w takes z slab w & 3 of the brick and half of the 27 taps.  A k-step is the pair of x rows (kk, kk + 2) of the slab
+//    (kk = 0, 1), so that tap dy of k-step kk needs the halo rows (j, j + 2) with j = dy + 1 + kk: the SAME fragment serves (kk = 0, dy) and (kk = 1, dy - 1),
+//    and for one tap group g = (dz, dx) the four fragments j = 0 .. 3 feed all six (kk, dy) products (with rows (kk, kk + 1) a product needed its own).
+//    A slab's nine groups are split 5 + 4 between the two waves that share its SIMD (the slabs alternate which of the two gets five: 81 MFMAs per brick and
+//    SIMD pair, no tap computed twice); a group's six products run kk-major - hi.hi for all six, then lo.hi, then hi.lo - so that MFMAs on one accumulator
+//    are three apart.
+// The workgroup's 27 x 16 x 16 sums meet in LDS and go to a partial-sum buffer, one row per workgroup; k_wgrad3_reduce adds the rows into dW (no atomics:
+// deterministic up to the order of four LDS float adds per element, and 16 G atomics / s was a third of the round-2 kernel).
+// Measured (tools/wgrad_time.py, [8, 128^3, 16 x 16], random operands, 1 500 launches back to back): 740 us at 1 869 MHz and 1 391 W of the 1 400 W cap,
+// against 955 us at 2 365 MHz and 1 374 W before - BOTH versions run at the socket's power cap, so the time is the energy a launch takes (1.03 J vs 1.31 J);
+// the multiplying waves alone (no loads, no split) take 494 us at 1 199 W.  In the training step (post-ReLU gradients: half the operands are zeros) the six
+// level-0 launches take 700 - 800 us each (1 000 - 1 230 before), the step's weight gradients 8.7 ms (12.4).
 // =================================================================================================
+__device__ __forceinline__ constexpr int w3_frag_off(int g, int j) { return (((g / 3) * 6 + j) * 18 + g % 3) * 32; }   // bytes from the slab's first halo voxel
 struct Wgrad3Args {
     const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* s2; float* part;
     int B, D0, D1, D2, Ca, Cx;
 };
 #define W3_HV (6 * 6 * 18)
 #define W3_LDS (2 * W3_HV * 32 + 2 * 256 * 32)
+#ifndef W3_NLD
+#define W3_NLD 512                                          // loader threads (8 waves) beside the 512 multiplying ones
+#endif
+#define W3_NTHR (512 + W3_NLD)
+#define W3_NX ((W3_HV * 4 + W3_NLD - 1) / W3_NLD)
+#define W3_NA (1024 / W3_NLD)
 
-__global__ __launch_bounds__(512) void k_wgrad3_tr(Wgrad3Args a) {
+__global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sXh = smem; char* const sXl = sXh + W3_HV * 32; char* const sAh = sXl + W3_HV * 32; char* const sAl = sAh + 256 * 32;
-    float* const sG = reinterpret_cast<float*>(smem + W3_LDS);      // [B][scale 16 | shift 16] of this channel slice (no global loads per brick)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kp = w & 3, half = w >> 2;                    // k-steps 2 kp, 2 kp + 1; taps 13 half .. 13 half + 13
+    float* const sG = reinterpret_cast<float*>(smem + 2 * W3_LDS);  // [B][scale 16 | shift 16] of this channel slice (no global loads per brick)
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = w >= 8;                             // waves 8 .. 15 stage bricks, waves 0 .. 7 multiply them (see the header comment)
+    const int tid = loader ? (int)threadIdx.x - 512 : (int)threadIdx.x;   // index within the role
+    const int kp = w & 3, half = (w >> 2) & 1;              // k-steps 2 kp, 2 kp + 1; taps 13 half .. 13 half + 13
     const int ca0 = blockIdx.y * 16, cx0 = blockIdx.z * 16;
     const int n0 = a.D0 / 4, n1 = a.D1 / 4, n2 = a.D2 / 16;
     const int nbricks = a.B * n0 * n1 * n2;
     const float s_in = a.s2 ? a.s2[0] : 1.f;
     const int q = tid & 3;                                  // this thread's 4-channel quarter in every staging slot
-    f32x4 acc[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int e = tid; e < a.B * 32; e += 512) {
+    for (int e = threadIdx.x; e < a.B * 32; e += W3_NTHR) {
         const int b = e >> 5, c = e & 15;
         sG[e] = a.gn_scale ? ((e & 16) ? a.gn_shift[(long)b * a.Cx + cx0 + c] : a.gn_scale[(long)b * a.Cx + cx0 + c]) : ((e & 16) ? 0.f : 1.f);
     }
-    float4 px[6], pa[2];
+    float4 px[W3_NX], pa[W3_NA];
     unsigned okmask = 0;
-    // Staging addresses: the slot -> (hz, hy, hx) split is the same for every brick, so it is done once; per brick a slot costs three
-    // add + clamp (v_med3) pairs, the in-volume test and three 24-bit multiplies for a 32-bit byte offset into a buffer descriptor (the
-    // launcher guarantees B D0 D1 < 2^24 and < 4 GB per tensor).  With 64-bit pointer arithmetic and the divisions inside the loop the
-    // fetch alone was 2 us of VALU work per brick - as long as the brick's MFMAs.
-    int hpos[6], apos[2];
+    // Staging addresses.  A slot's voxel differs from the brick's first halo voxel by a fixed (hz, hy, hx), so its byte offset is a per-thread constant
+    // `rel` plus a per-brick UNIFORM base (scalar arithmetic): one v_add per load.  Nothing is clamped: the arithmetic wraps modulo 2^32, the buffer
+    // descriptors carry the tensors' exact sizes (< 2^31 bytes, the launcher's guarantee), so a slot outside the volume either lands outside the
+    // descriptor (the load returns 0) or on some other voxel of the tensor - and store() zeroes every such slot: whether slot i is outside depends
+    // only on which faces of the volume the brick touches (uniform, 6 bits) and on which faces of the halo the slot lies on (six per-thread bit sets
+    // `face[k]` over i).  Before, three clamps, three compares and three 24-bit multiplies per slot made the fetch ~250 VALU instructions per brick
+    // and thread - and VALU issue, not the matrix pipe or the LDS, was what bounded this kernel.
+    unsigned relx[W3_NX], rela[W3_NA], face[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    const unsigned xq = (unsigned)(cx0 + q * 4) * 4u, aq = (unsigned)(ca0 + q * 4) * 4u, xvb = (unsigned)a.Cx * 4u, avb = (unsigned)a.Ca * 4u;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        int hv = (i * 512 + tid) >> 2; hv = hv < W3_HV ? hv : W3_HV - 1;
-        hpos[i] = (hv / 108) | (((hv / 18) % 6) << 8) | ((hv % 18) << 16);
+    for (int i = 0; i < W3_NX; ++i) {
+        int hv = (i * W3_NLD + tid) >> 2; hv = hv < W3_HV ? hv : W3_HV - 1;
+        const int hz = hv / 108, hy = (hv / 18) % 6, hx = hv % 18;
+        relx[i] = (unsigned)((hz * a.D1 + hy) * a.D2 + hx) * xvb + xq;
+        face[0] |= (hz == 0 ? 1u : 0u) << i; face[1] |= (hz == 5 ? 1u : 0u) << i;
+        face[2] |= (hy == 0 ? 1u : 0u) << i; face[3] |= (hy == 5 ? 1u : 0u) << i;
+        face[4] |= (hx == 0 ? 1u : 0u) << i; face[5] |= (hx == 17 ? 1u : 0u) << i;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int av = (i * 512 + tid) >> 2; apos[i] = (av >> 6) | (((av >> 4) & 3) << 8) | ((av & 15) << 16); }
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7fffffff, 0x00020000);
-    const unsigned xq = (unsigned)(cx0 + q * 4) * 4u, aq = (unsigned)(ca0 + q * 4) * 4u, xvb = (unsigned)a.Cx * 4u, avb = (unsigned)a.Ca * 4u;
+    for (int i = 0; i < W3_NA; ++i) {
+        const int av = (i * W3_NLD + tid) >> 2;
+        rela[i] = (unsigned)(((av >> 6) * a.D1 + ((av >> 4) & 3)) * a.D2 + (av & 15)) * avb + aq;
+    }
+    const unsigned vox_all = (unsigned)a.B * (unsigned)(a.D0 * a.D1) * (unsigned)a.D2;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)(vox_all * xvb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(vox_all * avb), 0x00020000);
     auto fetch = [&](int brick) {
-        int t = brick;
+        int t = brick;                                     // (uniform: scalar arithmetic)
         const int t2 = t % n2; t /= n2;
         const int t1 = t % n1; t /= n1;
         const int t0 = t % n0; const int b = t / n0;
-        const int z0 = t0 * 4, y0 = t1 * 4, x0 = t2 * 16, bz = b * a.D0;
-        unsigned m = 0, xo[6], ao[2];
+        const int z0 = t0 * 4, y0 = t1 * 4, x0 = t2 * 16;
+        const unsigned bx = (unsigned)(((b * a.D0 + z0 - 1) * a.D1 + (y0 - 1)) * a.D2 + (x0 - 1)) * xvb;
+        const unsigned ba = (unsigned)(((b * a.D0 + z0) * a.D1 + y0) * a.D2 + x0) * avb;
+        okmask = ~((z0 == 0 ? face[0] : 0u) | (z0 + 4 == a.D0 ? face[1] : 0u) | (y0 == 0 ? face[2] : 0u) | (y0 + 4 == a.D1 ? face[3] : 0u) |
+                   (x0 == 0 ? face[4] : 0u) | (x0 + 16 == a.D2 ? face[5] : 0u));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {                      // branch-free: out-of-volume slots read a clamped address and are zeroed in store()
-            const int gz = z0 - 1 + (hpos[i] & 0xff), gy = y0 - 1 + ((hpos[i] >> 8) & 0xff), gx = x0 - 1 + (hpos[i] >> 16);
-            const int cz = min(max(gz, 0), a.D0 - 1), cy = min(max(gy, 0), a.D1 - 1), cxx = min(max(gx, 0), a.D2 - 1);      // v_med3_i32
-            m |= ((cz == gz && cy == gy && cxx == gx) ? 1u : 0u) << i;
-            const unsigned vox = __umul24(__umul24((unsigned)(bz + cz), (unsigned)a.D1) + (unsigned)cy, (unsigned)a.D2) + (unsigned)cxx;
-            xo[i] = __umul24(vox, xvb) + xq;
-        }
+        for (int i = 0; i < W3_NX; ++i) { const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, relx[i] + bx, 0, 0)); px[i] = make_float4(v[0], v[1], v[2], v[3]); }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int z = z0 + (apos[i] & 0xff), y = y0 + ((apos[i] >> 8) & 0xff), x = x0 + (apos[i] >> 16);
-            const unsigned vox = __umul24(__umul24((unsigned)(bz + z), (unsigned)a.D1) + (unsigned)y, (unsigned)a.D2) + (unsigned)x;
-            ao[i] = __umul24(vox, avb) + aq;
-        }
-        okmask = m;
-        // all addresses and the mask FIRST, then nothing but loads (otherwise the register allocator parks mask arithmetic in a load's
-        // destination registers and waits for that load - the full memory latency - before the MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, xo[i], 0, 0)); px[i] = make_float4(v[0], v[1], v[2], v[3]); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, ao[i], 0, 0)); pa[i] = make_float4(v[0], v[1], v[2], v[3]); }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < W3_NA; ++i) { const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, rela[i] + ba, 0, 0)); pa[i] = make_float4(v[0], v[1], v[2], v[3]); }
     };
     auto split_store = [&](const float f[4], char* hi, char* lo) {
         f16x4 h, l;
@@ -1490,12 +1505,13 @@ __global__ __launch_bounds__(512) void k_wgrad3_tr(Wgrad3Args a) {
         for (int e = 0; e < 4; ++e) { h[e] = (f16)f[e]; l[e] = (f16)(f[e] - (float)h[e]); }
         *reinterpret_cast<f16x4*>(hi) = h; *reinterpret_cast<f16x4*>(lo) = l;
     };
-    auto store = [&](int brick) {
+    auto store = [&](int brick, char* buf) {
+        char* const sXh = buf; char* const sXl = sXh + W3_HV * 32; char* const sAh = sXl + W3_HV * 32; char* const sAl = sAh + 256 * 32;
         const int b = brick / (n0 * n1 * n2);
         const float4 gsc = *reinterpret_cast<const float4*>(sG + b * 32 + q * 4), gsh = *reinterpret_cast<const float4*>(sG + b * 32 + 16 + q * 4);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int hv = (i * 512 + tid) >> 2;
+        for (int i = 0; i < W3_NX; ++i) {
+            const int hv = (i * W3_NLD + tid) >> 2;
             if (hv < W3_HV) {
                 const bool ok = (okmask >> i) & 1u;          // the affine applies to voxels inside the volume only: the padding is zero AFTER GroupNorm
                 const float f[4] = {ok ? px[i].x * gsc.x + gsh.x : 0.f, ok ? px[i].y * gsc.y + gsh.y : 0.f, ok ? px[i].z * gsc.z + gsh.z : 0.f,
@@ -1504,8 +1520,8 @@ __global__ __launch_bounds__(512) void k_wgrad3_tr(Wgrad3Args a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int av = (i * 512 + tid) >> 2;
+        for (int i = 0; i < W3_NA; ++i) {
+            const int av = (i * W3_NLD + tid) >> 2;
             const float f[4] = {pa[i].x * s_in, pa[i].y * s_in, pa[i].z * s_in, pa[i].w * s_in};
             split_store(f, sAh + av * 32 + q * 8, sAl + av * 32 + q * 8);
         }
@@ -1521,62 +1537,105 @@ __global__ __launch_bounds__(512) void k_wgrad3_tr(Wgrad3Args a) {
         return r;
     };
 
-    int brick = blockIdx.x;
-    if (brick < nbricks) fetch(brick);
-    for (; brick < nbricks; brick += gridDim.x) {
-        __syncthreads();                                    // the previous brick's fragments are no longer being read
-        store(brick);
+    const int G = (int)gridDim.x;
+    const int brick0 = blockIdx.x;
+    float* const sOut = reinterpret_cast<float*>(smem);
+    __syncthreads();                                        // sG
+    // The two roles run SEPARATE loops with the same number of barriers (a wave's role never changes, but in one shared loop the register allocator
+    // keeps the loaders' staging registers alive through the multiplying code and spills the accumulators).
+    if (loader) {
+        if (brick0 < nbricks) {
+            fetch(brick0);
+            store(brick0, smem);
+            // unconditional (past the end it re-reads the last brick): a conditional fetch makes the staging registers a merge of old and new
+            // values, and the copies the compiler inserts for it wait for the loads at the merge
+            fetch(brick0 + G < nbricks ? brick0 + G : brick0);
+        }
         __syncthreads();
-        // unconditional (the last iteration re-reads its own brick): a conditional fetch makes the staging registers a merge of old and new
-        // values, and the copies the compiler inserts for it wait for the loads right here
-        fetch(brick + (int)gridDim.x < nbricks ? brick + (int)gridDim.x : brick);
-        __builtin_amdgcn_sched_barrier(0);                  // the loads are ISSUED here, before the MFMAs (left alone, the scheduler sinks them to their first use)
+        int it = 0;
+        for (int brick = brick0; brick < nbricks; brick += G, ++it) {
+            // brick + G arrived in registers while the multiplying waves worked on the brick before this one: split it into the OTHER buffer (its
+            // last readers passed the barrier that ended the previous iteration), then start brick + 2 G on its way
+            if (brick + G < nbricks) {
+                store(brick + G, smem + ((it + 1) & 1) * W3_LDS);
+                fetch(brick + 2 * G < nbricks ? brick + 2 * G : brick + G);
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                    // (the multiplying waves zero sOut between these two)
+        __syncthreads();
+    } else {
+        f32x4 acc[15];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ks = kp * 2 + kk, z = ks >> 1, y0 = (ks & 1) * 2;
-            const int ab = ((z * 4 + y0) * 16) * 32 + fo;
-            const f16x8 ah = frag(sAh + ab, 512), al = frag(sAl + ab, 512);
-            const int xb = ((z * 6 + y0) * 18) * 32 + fo;  // halo voxel (z, y0, 0); a tap adds ((dz + 1) 6 + dy + 1) 18 + dx + 1 voxels
-            // taps in pairs: the fragments of pair p + 1 are requested before the MFMAs of pair p, and the two taps' accumulators alternate so
-            // that no MFMA waits for the result of the one before it.  tap = 13 half + tt (wave-uniform); tap 13 is computed by both halves
-            // (branch-free loop), half 1 drops it at the end
-            auto xoff = [&](int tt) { const int tap = half * 13 + tt; return xb + (((tap / 9) * 6 + (tap / 3) % 3) * 18 + tap % 3) * 32; };
-            f16x8 xh[2][2], xl[2][2];
+        for (int i = 0; i < 15; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                    // buffer 0 is complete
+        // The loop exists once per tap half, with `half` a compile-time constant: every tap's fragment address is then the wave's base register plus
+        // an immediate (with a run-time `half` the 28 offsets are loop-invariant VGPRs, and at 128 registers they spill).
+        auto multiply = [&](auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        int it = 0;
+        for (int brick = brick0; brick < nbricks; brick += G, ++it) {
+            const char* const sXh = smem + (it & 1) * W3_LDS + (kp * 6 * 18) * 32 + fo;          // slab kp's first halo voxel, this lane's part of a fragment
+            const char* const sAh = smem + (it & 1) * W3_LDS + 2 * W3_HV * 32 + (kp * 4 * 16) * 32 + fo;
+            auto rows2 = [&](const char* p, const char* p2) -> f16x8 {                           // the x rows at p and p2 -> one 32-voxel fragment
+                const wg_s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3)))*)(p));
+                const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s16x4 __attribute__((address_space(3)))*)(p2));
+                const f16x4 fu = __builtin_bit_cast(f16x4, u), fv = __builtin_bit_cast(f16x4, v);
+                f16x8 r;
+                r[0] = fu[0]; r[1] = fu[1]; r[2] = fu[2]; r[3] = fu[3]; r[4] = fv[0]; r[5] = fv[1]; r[6] = fv[2]; r[7] = fv[3];
+                return r;
+            };
+            f16x8 ah[2], al[2], xh[2][4], xl[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int bb = xoff(u); xh[0][u] = frag(sXh + bb, 576); xl[0][u] = frag(sXl + bb, 576); }
+            for (int kk = 0; kk < 2; ++kk) { ah[kk] = rows2(sAh + kk * 512, sAh + kk * 512 + 1024); al[kk] = rows2(sAh + 256 * 32 + kk * 512, sAh + 256 * 32 + kk * 512 + 1024); }
+            // Halo rows 2 and 3 are the second row of one fragment and the first of another.  Left to itself the compiler reads them once and assembles the
+            // MFMA operands with v_mov - VALU issue this kernel does not have.  The second rows are read through a base the optimiser cannot relate to the first.
+            int second = 2 * 18 * 32;
+            asm volatile("" : "+v"(second));
+            const char* const sXh2 = sXh + second;
 #pragma unroll
-            for (int p = 0; p < 7; ++p) {
-                const int cur = p & 1, nxt = cur ^ 1;
-                if (p + 1 < 7) {
+            for (int j = 0; j < 4; ++j) xh[0][j] = rows2(sXh + w3_frag_off(LO, j), sXh2 + w3_frag_off(LO, j));
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { const int bb = xoff(2 * p + 2 + u); xh[nxt][u] = frag(sXh + bb, 576); xl[nxt][u] = frag(sXl + bb, 576); }
+            for (int g = LO; g < HI; ++g) {
+                const int cur = (g - LO) & 1, a0 = 3 * (g - LO);
+                // product e = 3 kk + (dy + 1): fragment j = kk + dy + 1, accumulator a0 + dy + 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xl[j] = rows2(sXh + W3_HV * 32 + w3_frag_off(g, j), sXh2 + W3_HV * 32 + w3_frag_off(g, j));
+#pragma unroll
+                for (int e = 0; e < 6; ++e) acc[a0 + e % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[e / 3], xh[cur][e / 3 + e % 3], acc[a0 + e % 3], 0, 0, 0);
+                if (g + 1 < HI) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xh[cur ^ 1][j] = rows2(sXh + w3_frag_off(g + 1, j), sXh2 + w3_frag_off(g + 1, j));
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[2 * p + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[cur][u], acc[2 * p + u], 0, 0, 0);
+                for (int e = 0; e < 6; ++e) acc[a0 + e % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[e / 3], xh[cur][e / 3 + e % 3], acc[a0 + e % 3], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[2 * p + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[cur][u], acc[2 * p + u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[2 * p + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[cur][u], acc[2 * p + u], 0, 0, 0);
+                for (int e = 0; e < 6; ++e) acc[a0 + e % 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[e / 3], xl[e / 3 + e % 3], acc[a0 + e % 3], 0, 0, 0);
             }
+            __syncthreads();                                // this buffer is free again, the other one is complete
         }
-    }
-    // acc[tt][r] = this wave's share of dW[ca = 4 g16 + r][tap][cx = li]: the four k-step waves of a tap half meet in LDS, ordered [ca][cx][tap]
-    const float inv = a.s2 ? a.s2[1] : 1.f;
-    float* sOut = reinterpret_cast<float*>(smem);
-    __syncthreads();
-    for (int e = tid; e < 6912; e += 512) sOut[e] = 0.f;
-    __syncthreads();
+        };
+        using I0 = std::integral_constant<int, 0>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I9 = std::integral_constant<int, 9>;
+        const int glo = half ? 5 - (kp & 1) : 0, ghi = half ? 9 : 5 - (kp & 1);
+        if (half == 0) { if (kp & 1) multiply(I0{}, I4{}); else multiply(I0{}, I5{}); }
+        else           { if (kp & 1) multiply(I4{}, I9{}); else multiply(I5{}, I9{}); }
+        // acc[tt][r] = this wave's share of dW[ca = 4 g16 + r][tap][cx = li]: the four k-step waves of a tap half meet in LDS, ordered [ca][cx][tap]
+        const float inv = a.s2 ? a.s2[1] : 1.f;
+        __syncthreads();
+        for (int e = tid; e < 6912; e += 512) sOut[e] = 0.f;
+        __syncthreads();
 #pragma unroll
-    for (int tt = 0; tt < 14; ++tt) {
-        const int tap = half * 13 + tt;
-        if (tt > 0 || half == 0) {
+        for (int tt = 0; tt < 15; ++tt) {
+            const int g = glo + tt / 3, tap = ((g / 3) * 3 + tt % 3) * 3 + g % 3;       // group (dz, dx) = (g / 3, g % 3), dy + 1 = tt % 3
+            if (g < ghi) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&sOut[((4 * g16 + r) * 16 + li) * 27 + tap], acc[tt][r] * inv);
+                for (int r = 0; r < 4; ++r) atomicAdd(&sOut[((4 * g16 + r) * 16 + li) * 27 + tap], acc[tt][r] * inv);
+            }
         }
     }
     __syncthreads();
     float* dst = a.part + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 6912;
-    for (int e = tid; e < 6912; e += 512) dst[e] = sOut[e];
+    for (int e = threadIdx.x; e < 6912; e += W3_NTHR) dst[e] = sOut[e];
 }
 // part [nx][Ca / 16][Cx / 16][16 ca][16 cx][27] -> dW += sum over nx
 __global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__ part, float* __restrict__ dW, int nx, int ny, int nz, int Cx, int tap_minor) {
@@ -1630,7 +1689,7 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     const int route = wgrad_conv3_route(D0, D1, D2, Ca, Cx, scratch != nullptr, scratch_floats, &bmax);
     if (route == 2) {
         static SemabsLdsAttr attr3;
-        semabs_ensure_lds(&k_wgrad3_tr, W3_LDS + 64 * 128, attr3);
+        semabs_ensure_lds(&k_wgrad3_tr, 2 * W3_LDS + 64 * 128, attr3);
         for (int b0 = 0; b0 < B; b0 += (int)bmax) {          // (one launch for every call of the 128^3 training step)
             const int Bc = B - b0 < bmax ? B - b0 : (int)bmax;
             // one persistent workgroup per CU in all, every workgroup leaves one 27 x 16 x 16 partial sum in scratch
@@ -1641,7 +1700,7 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
             a.A = dZ + (long)b0 * vpv * Ca; a.X = X + (long)b0 * vpv * Cx;
             a.gn_scale = gn_scale ? gn_scale + (long)b0 * Cx : nullptr; a.gn_shift = gn_shift ? gn_shift + (long)b0 * Cx : nullptr;
             a.s2 = s2; a.part = scratch; a.B = Bc; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
-            hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(512), W3_LDS + (size_t)Bc * 128, s, a);
+            hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(W3_NTHR), 2 * W3_LDS + (size_t)Bc * 128, s, a);
             hipLaunchKernelGGL(k_wgrad3_reduce, dim3(semabs_cdiv((long)combos * 6912, 256)), dim3(256), 0, s, scratch, dW, bx, Ca / 16, Cx / 16, Cx, tap_minor);
         }
         SEMABS_CHECK_LAUNCH();
