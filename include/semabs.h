@@ -318,6 +318,17 @@ int semabs_wgrad_conv3(const float* dZ, const float* X, const float* gn_scale, c
 /* Which kernel semabs_wgrad_conv3 runs for a shape with scratch_floats of scratch (0 = no scratch): *kernel = 2 transposing-read kernel, 1 brick
  * kernel (D1 % 8 == 0), 0 unsupported (use semabs_wgrad_mfma / semabs_wgrad) - the entry point's own predicate, for host-side routing. */
 int semabs_wgrad_conv3_supported(int D0, int D1, int D2, int Ca, int Cx, long scratch_floats, int* kernel);
+/* Weight gradient AND the GroupNorm-backward reductions of a GroupNorm -> Conv3d 3x3x3 layer from ONE pass over (dZ, X): X [B, D0, D1, D2, Cx] is the
+ * layer's GroupNorm INPUT with its statistics mean / rstd [B, G] and affine gamma / beta [Cx], W [Ca, Cx, 27] the layer's weights.
+ *   dW [Ca, Cx, 27] += d loss / d W;   red fp64 [B, Cx, 2] = (sum_v dXn, sum_v dXn * xhat) with dXn = conv^T(dZ), in dZ's dynamic scale -
+ * exactly what semabs_chan_reduce(dXn, X, mean, rstd) returns, without reading dXn or X again (csrc/train.hip has the algebra).  Shapes as
+ * semabs_wgrad_conv3 plus B <= 64 and scratch for 256 / ((Ca / 16) (Cx / 16)) rows of 7344 floats; ask semabs_wgrad_conv3_gn_supported first.
+ * Replaces, for these layers, the weight-gradient and GroupNorm-statistics halves of loss.backward() (reference: train_vool.py / utils.py loop -> torch
+ * autograd of unet3d.py:63-118). */
+int semabs_wgrad_conv3_gn_supported(int B, int D0, int D1, int D2, int Ca, int Cx, long scratch_floats, int* ok);
+int semabs_wgrad_conv3_gn(const float* dZ, const float* X, const float* mean, const float* rstd, int G, const float* gamma, const float* beta,
+                          const float* W, const float* s2, float* dW, double* red, int B, int D0, int D1, int D2, int Ca, int Cx, float* scratch,
+                          long scratch_floats, void* stream);
 
 /* out fp64 [B, C, 2] += (sum_v dY, sum_v dY * xhat) per (batch, channel); X = NULL gives plain column sums (bias gradients) */
 int semabs_chan_reduce(const float* dY, const float* X, const float* mean, const float* rstd, double* out, int B, long nvox, int C, int G,

@@ -1429,7 +1429,12 @@ __device__ __forceinline__ constexpr int w3_frag_off(int g, int j) { return (((g
 struct Wgrad3Args {
     const float* A; const float* X; const float* gn_scale; const float* gn_shift; const float* s2; float* part;
     int B, D0, D1, D2, Ca, Cx;
+    // per-volume mode (semabs_wgrad_conv3_gn): X is staged as xhat = (x - mean) rstd of its GroupNorm (no affine), every workgroup stays inside ONE volume
+    // (blockIdx.x % B) and its partial row also carries Q = the 27 boundary-restricted sums of dZ (W3_ROW_PV floats per row); rows keep the gradient scale.
+    const float* gn_mean; const float* gn_rstd; int G, per_vol;
 };
+#define W3_ROW 6912
+#define W3_ROW_PV (6912 + 16)
 #define W3_HV (6 * 6 * 18)
 #define W3_LDS (2 * W3_HV * 32 + 2 * 256 * 32)
 #ifndef W3_NLD
@@ -1449,13 +1454,19 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
     const int kp = w & 3, half = (w >> 2) & 1;              // k-steps 2 kp, 2 kp + 1; taps 13 half .. 13 half + 13
     const int ca0 = blockIdx.y * 16, cx0 = blockIdx.z * 16;
     const int n0 = a.D0 / 4, n1 = a.D1 / 4, n2 = a.D2 / 16;
-    const int nbricks = a.B * n0 * n1 * n2;
     const float s_in = a.s2 ? a.s2[0] : 1.f;
     const int q = tid & 3;                                  // this thread's 4-channel quarter in every staging slot
+    float* const sQ = sG + a.B * 32;                        // [16 ca]: per-volume mode's sum of dZ over the workgroup's bricks
     for (int e = threadIdx.x; e < a.B * 32; e += W3_NTHR) {
         const int b = e >> 5, c = e & 15;
-        sG[e] = a.gn_scale ? ((e & 16) ? a.gn_shift[(long)b * a.Cx + cx0 + c] : a.gn_scale[(long)b * a.Cx + cx0 + c]) : ((e & 16) ? 0.f : 1.f);
+        if (a.gn_mean) {
+            const int g = (cx0 + c) / (a.Cx / a.G);
+            const float rs = a.gn_rstd[b * a.G + g];
+            sG[e] = (e & 16) ? -a.gn_mean[b * a.G + g] * rs : rs;
+        } else
+            sG[e] = a.gn_scale ? ((e & 16) ? a.gn_shift[(long)b * a.Cx + cx0 + c] : a.gn_scale[(long)b * a.Cx + cx0 + c]) : ((e & 16) ? 0.f : 1.f);
     }
+    if (threadIdx.x < 16) sQ[threadIdx.x] = 0.f;
     float4 px[W3_NX], pa[W3_NA];
     unsigned okmask = 0;
     // Staging addresses.  A slot's voxel differs from the brick's first halo voxel by a fixed (hz, hy, hx), so its byte offset is a per-thread constant
@@ -1481,6 +1492,7 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
         const int av = (i * W3_NLD + tid) >> 2;
         rela[i] = (unsigned)(((av >> 6) * a.D1 + ((av >> 4) & 3)) * a.D2 + (av & 15)) * avb + aq;
     }
+    float tsum[4] = {0.f, 0.f, 0.f, 0.f};                   // per-volume mode: this thread's running sum of its four dZ channels over all its slots
     const unsigned vox_all = (unsigned)a.B * (unsigned)(a.D0 * a.D1) * (unsigned)a.D2;
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)(vox_all * xvb), 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)(vox_all * avb), 0x00020000);
@@ -1524,6 +1536,10 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
             const int av = (i * W3_NLD + tid) >> 2;
             const float f[4] = {pa[i].x * s_in, pa[i].y * s_in, pa[i].z * s_in, pa[i].w * s_in};
             split_store(f, sAh + av * 32 + q * 8, sAl + av * 32 + q * 8);
+            if (a.per_vol) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tsum[j] += f[j];
+            }
         }
     };
     const int g16 = lane >> 4, li = lane & 15;
@@ -1537,8 +1553,11 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
         return r;
     };
 
-    const int G = (int)gridDim.x;
-    const int brick0 = blockIdx.x;
+    // this workgroup's bricks: brick0, brick0 + G, .. < nbricks (per-volume mode: the bricks of volume blockIdx.x % B only)
+    const int nbv = n0 * n1 * n2;
+    const int G = a.per_vol ? (int)gridDim.x / a.B : (int)gridDim.x;
+    const int brick0 = a.per_vol ? ((int)blockIdx.x % a.B) * nbv + (int)blockIdx.x / a.B : (int)blockIdx.x;
+    const int nbricks = a.per_vol ? ((int)blockIdx.x % a.B + 1) * nbv : a.B * nbv;
     float* const sOut = reinterpret_cast<float*>(smem);
     __syncthreads();                                        // sG
     // The two roles run SEPARATE loops with the same number of barriers (a wave's role never changes, but in one shared loop the register allocator
@@ -1561,6 +1580,10 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
                 fetch(brick + 2 * G < nbricks ? brick + 2 * G : brick + G);
             }
             __syncthreads();
+        }
+        if (a.per_vol) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(sQ + q * 4 + j, tsum[j]);
         }
         __syncthreads();                                    // (the multiplying waves zero sOut between these two)
         __syncthreads();
@@ -1620,7 +1643,7 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
         if (half == 0) { if (kp & 1) multiply(I0{}, I4{}); else multiply(I0{}, I5{}); }
         else           { if (kp & 1) multiply(I4{}, I9{}); else multiply(I5{}, I9{}); }
         // acc[tt][r] = this wave's share of dW[ca = 4 g16 + r][tap][cx = li]: the four k-step waves of a tap half meet in LDS, ordered [ca][cx][tap]
-        const float inv = a.s2 ? a.s2[1] : 1.f;
+        const float inv = a.s2 && !a.per_vol ? a.s2[1] : 1.f;
         __syncthreads();
         for (int e = tid; e < 6912; e += 512) sOut[e] = 0.f;
         __syncthreads();
@@ -1634,8 +1657,9 @@ __global__ __launch_bounds__(W3_NTHR) void k_wgrad3_tr(Wgrad3Args a) {
         }
     }
     __syncthreads();
-    float* dst = a.part + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * 6912;
+    float* dst = a.part + (((long)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (a.per_vol ? W3_ROW_PV : W3_ROW);
     for (int e = threadIdx.x; e < 6912; e += W3_NTHR) dst[e] = sOut[e];
+    if (a.per_vol && threadIdx.x < 16) dst[6912 + threadIdx.x] = sQ[threadIdx.x];
 }
 // part [nx][Ca / 16][Cx / 16][16 ca][16 cx][27] -> dW += sum over nx
 __global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__ part, float* __restrict__ dW, int nx, int ny, int nz, int Cx, int tap_minor) {
@@ -1689,7 +1713,7 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     const int route = wgrad_conv3_route(D0, D1, D2, Ca, Cx, scratch != nullptr, scratch_floats, &bmax);
     if (route == 2) {
         static SemabsLdsAttr attr3;
-        semabs_ensure_lds(&k_wgrad3_tr, 2 * W3_LDS + 64 * 128, attr3);
+        semabs_ensure_lds(&k_wgrad3_tr, 2 * W3_LDS + 64 * 128 + 64, attr3);
         for (int b0 = 0; b0 < B; b0 += (int)bmax) {          // (one launch for every call of the 128^3 training step)
             const int Bc = B - b0 < bmax ? B - b0 : (int)bmax;
             // one persistent workgroup per CU in all, every workgroup leaves one 27 x 16 x 16 partial sum in scratch
@@ -1700,7 +1724,8 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
             a.A = dZ + (long)b0 * vpv * Ca; a.X = X + (long)b0 * vpv * Cx;
             a.gn_scale = gn_scale ? gn_scale + (long)b0 * Cx : nullptr; a.gn_shift = gn_shift ? gn_shift + (long)b0 * Cx : nullptr;
             a.s2 = s2; a.part = scratch; a.B = Bc; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
-            hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(W3_NTHR), 2 * W3_LDS + (size_t)Bc * 128, s, a);
+            a.gn_mean = nullptr; a.gn_rstd = nullptr; a.G = 1; a.per_vol = 0;
+            hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, Ca / 16, Cx / 16), dim3(W3_NTHR), 2 * W3_LDS + (size_t)Bc * 128 + 64, s, a);
             hipLaunchKernelGGL(k_wgrad3_reduce, dim3(semabs_cdiv((long)combos * 6912, 256)), dim3(256), 0, s, scratch, dW, bx, Ca / 16, Cx / 16, Cx, tap_minor);
         }
         SEMABS_CHECK_LAUNCH();
@@ -1715,6 +1740,184 @@ extern "C" int semabs_wgrad_conv3(const float* dZ, const float* X, const float* 
     const int nbricks = B * (D0 / WG_T0) * (D1 / WG_T1) * (D2 / WG_T2);
     int bx = 768 / combos; if (bx < 8) bx = 8; if (bx > nbricks) bx = nbricks;
     hipLaunchKernelGGL(k_wgrad16_lds, dim3(bx, Ca / 16, Cx / 16), dim3(WG_NTHR), lds, s, a);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Weight gradient AND the GroupNorm-backward reductions of a 3^3 convolution layer from ONE pass over (dZ, x)  (round 5).
+// The layer is y = conv(xn), xn = gamma xhat + beta inside the volume and 0 in the padding, xhat = (x - mean) rstd.  With the per-volume correlations
+//     Chat[b, ca, tap, cx] = sum_u dZ[b, u, ca] xhat[b, u + tap, cx]            (u + tap inside the volume; k_wgrad3_tr with xhat staged instead of xn)
+//     Z[b, ca, tap]        = sum_u dZ[b, u, ca] [u + tap inside]
+// everything the backward pass needs besides the data gradient follows WITHOUT reading the data gradient dXn = conv^T(dZ) or x again:
+//     dW[ca, cx, tap]                 = sum_b gamma[cx] Chat[b, ca, tap, cx] + beta[cx] Z[b, ca, tap]
+//     Sa[b, c] = sum_v dXn[b, v, c]          = sum_{ca, tap} W[ca, c, tap] Z[b, ca, tap]
+//     Sb[b, c] = sum_v dXn[b, v, c] xhat[..] = sum_{ca, tap} W[ca, c, tap] Chat[b, ca, tap, c]
+// (Sa, Sb) are what semabs_chan_reduce computed from dXn and x - a pass over two activation-sized tensors per layer (2.1 GB at 8 x 128^3 x 16, 4.0 ms of the
+// training step).  Z comes from 27 restricted sums of dZ, Q[sz, sy, sx] with s = 0 (all), 1 (first slab only), 2 (last slab only) per axis: the total
+// Q[0, 0, 0] is accumulated by the loader waves of k_wgrad3_tr from the dZ values they stage anyway, the other 26 (faces, edges, corners: 5 % of the
+// voxels at 128^3) by k_dz_boundary_sums.  Tap offset d = -1 excludes the first slab of its axis, d = +1 the last, so
+//     Z[b, ca, (dz, dy, dx)] = sum over the subsets S of {axes with d != 0} of (-1)^|S| Q[the excluded slab on the axes in S, all on the others].
+// Rows of `part`: [bx][Ca / 16][Cx / 16][W3_ROW_PV = 6912 + 16 totals], row x belongs to volume x % B and keeps dZ's dynamic gradient scale.
+// (Accumulating the 26 boundary sums in the loader waves too - LDS float atomics from the boundary bricks - cost 2 ms per step: 16-way address conflicts.)
+// =================================================================================================
+__device__ __forceinline__ float w3_z_from_q(const float* __restrict__ q, int ca_stride, int tap) {     // q -> Q[0][ca], entries ca_stride apart
+    const int ex[3] = {tap / 9 == 0 ? 1 : tap / 9 == 2 ? 2 : 0, (tap / 3) % 3 == 0 ? 1 : (tap / 3) % 3 == 2 ? 2 : 0, tap % 3 == 0 ? 1 : tap % 3 == 2 ? 2 : 0};
+    float z = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (((m & 1) && !ex[0]) || ((m & 2) && !ex[1]) || ((m & 4) && !ex[2])) continue;
+        const int idx = (((m & 1) ? ex[0] : 0) * 3 + ((m & 2) ? ex[1] : 0)) * 3 + ((m & 4) ? ex[2] : 0);
+        const float v = q[(long)idx * ca_stride];
+        z += (__popc(m) & 1) ? -v : v;
+    }
+    return z;
+}
+// qb fp32 [B][27][Ca] (zeroed by the caller; entry 0 stays 0): sums of s dZ over the voxels whose coordinate on every axis with s != 0 is the first (1) /
+// last (2) index.  grid = (26 regions, B, chunks); thread = (voxel of the chunk, 4 channels).
+__global__ __launch_bounds__(256) void k_dz_boundary_sums(const float* __restrict__ dZ, const float* __restrict__ s2, float* __restrict__ qb, int D0, int D1, int D2, int Ca) {
+    const int idx = (int)blockIdx.x + 1, b = blockIdx.y;
+    const int sel[3] = {idx / 9, (idx / 3) % 3, idx % 3}, D[3] = {D0, D1, D2};
+    int n[3], lo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { n[k] = sel[k] ? 1 : D[k]; lo[k] = sel[k] == 2 ? D[k] - 1 : 0; }
+    const long nv = (long)n[0] * n[1] * n[2];
+    const int cq = Ca / 4, tq = threadIdx.x % cq;            // Ca / 4 divides 256 for Ca = 16 .. 128
+    const int vpb = 256 / cq;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long v = (long)blockIdx.z * vpb + threadIdx.x / cq; v < nv; v += (long)gridDim.z * vpb) {
+        const int x = lo[2] + (int)(v % n[2]), y = lo[1] + (int)((v / n[2]) % n[1]), z = lo[0] + (int)(v / n[2] / n[1]);
+        const float4 t = *reinterpret_cast<const float4*>(dZ + ((((long)b * D0 + z) * D1 + y) * D2 + x) * Ca + tq * 4);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    __shared__ float4 sm[256];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < cq) {
+        float4 t = sm[threadIdx.x];
+        for (int k = threadIdx.x + cq; k < 256; k += cq) { const float4 u = sm[k]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float sc = s2 ? s2[0] : 1.f;
+        float* dst = qb + ((long)b * 27 + idx) * Ca + tq * 4;
+        atomicAdd(dst, t.x * sc); atomicAdd(dst + 1, t.y * sc); atomicAdd(dst + 2, t.z * sc); atomicAdd(dst + 3, t.w * sc);
+    }
+}
+// rows -> chat [B][ny][nz][6912] (sum over the volume's rows) and qv [B][ny][432] (totals from the cx block 0 rows, the rest from qb)
+__global__ __launch_bounds__(256) void k_wgrad3_pv_reduce(const float* __restrict__ part, const float* __restrict__ qb, float* __restrict__ chat,
+                                                           float* __restrict__ qv, int bx, int B, int ny, int nz) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nchat = (long)B * ny * nz * 6912, nq = (long)B * ny * 432;
+    if (i >= nchat + nq) return;
+    int b, y, z, e;
+    if (i < nchat) { e = (int)(i % 6912); long t = i / 6912; z = (int)(t % nz); t /= nz; y = (int)(t % ny); b = (int)(t / ny); }
+    else {
+        const long k = i - nchat;
+        const int idx = (int)(k % 432) / 16, c16 = (int)(k % 16);
+        y = (int)((k / 432) % ny); b = (int)(k / 432 / ny);
+        if (idx) { qv[k] = qb[((long)b * 27 + idx) * (ny * 16) + y * 16 + c16]; return; }
+        e = 6912 + c16; z = 0;
+    }
+    float s0 = 0.f, s1 = 0.f;
+    const long rstride = (long)B * ny * nz * W3_ROW_PV;     // from row x to row x + B (the same volume's next workgroup)
+    const float* p0 = part + (((long)b * ny + y) * nz + z) * W3_ROW_PV + e;
+    int x = 0;
+    for (; x + 2 * B <= bx; x += 2 * B) { s0 += p0[0]; s1 += p0[rstride]; p0 += 2 * rstride; }
+    if (x < bx) s0 += p0[0];
+    if (i < nchat) chat[i] = s0 + s1; else qv[i - nchat] = s0 + s1;
+}
+// blocks [0, nw): dW[ca][cx][tap] += inv sum_b (gamma[cx] Chat + beta[cx] Z);  blocks [nw, ..): red[b][c] = (Sa, Sb) in dZ's scale (fp64, like semabs_chan_reduce)
+__global__ __launch_bounds__(256) void k_wgrad3_pv_finish(const float* __restrict__ chat, const float* __restrict__ qv, const float* __restrict__ W,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ s2,
+                                                           float* __restrict__ dW, double* __restrict__ red, int B, int Ca, int Cx, int nw) {
+    const int ny = Ca / 16, nz = Cx / 16;
+    if ((int)blockIdx.x < nw) {
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;            // = (ca Cx + cx) 27 + tap, the layout of dW
+        if (i >= (long)Ca * Cx * 27) return;
+        const int tap = (int)(i % 27), cx = (int)((i / 27) % Cx), ca = (int)(i / 27 / Cx);
+        const float g = gamma[cx], bt = beta[cx];
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float ch = chat[((((long)b * ny + ca / 16) * nz + cx / 16) * 6912) + ((ca % 16) * 16 + cx % 16) * 27 + tap];
+            const float z = w3_z_from_q(qv + ((long)b * ny + ca / 16) * 432 + ca % 16, 16, tap);
+            acc += g * ch + bt * z;
+        }
+        dW[i] += acc * (s2 ? s2[1] : 1.f);
+        return;
+    }
+    // one block per (volume b, 16-channel slice of c): thread = (c % 16, one of 16 ca classes); Z of the block's volume goes through LDS once
+    __shared__ float sz[128 * 27];
+    __shared__ double sred[16][16][2];
+    const int blk = (int)blockIdx.x - nw, b = blk / nz, cz = blk % nz;
+    for (int e = threadIdx.x; e < Ca * 27; e += 256) { const int ca = e / 27; sz[e] = w3_z_from_q(qv + ((long)b * ny + ca / 16) * 432 + ca % 16, 16, e % 27); }
+    __syncthreads();
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4, c = cz * 16 + cl;
+    double sa = 0.0, sb = 0.0;
+    for (int ca = part; ca < Ca; ca += 16) {
+        const float* wrow = W + ((long)ca * Cx + c) * 27;
+        const float* crow = chat + ((((long)b * ny + ca / 16) * nz + cz) * 6912) + ((ca % 16) * 16 + cl) * 27;
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) { pa += wrow[tap] * sz[ca * 27 + tap]; pb += wrow[tap] * crow[tap]; }
+        sa += (double)pa; sb += (double)pb;
+    }
+    sred[part][cl][0] = sa; sred[part][cl][1] = sb;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x & 1, cc = threadIdx.x >> 1;
+        double t = 0.0;
+        for (int p2 = 0; p2 < 16; ++p2) t += sred[p2][cc][k];
+        red[((long)b * Cx + cz * 16 + cc) * 2 + k] = t;
+    }
+}
+// bx (workgroups along x, a multiple of B) for the per-volume launch, or 0 if the shape / scratch does not allow it
+static int wgrad_conv3_gn_bx(int B, int D0, int D1, int D2, int Ca, int Cx, long scratch_floats) {
+    long bmax = 0;
+    if (B <= 0 || Ca > 128 || wgrad_conv3_route(D0, D1, D2, Ca, Cx, true, scratch_floats, &bmax) != 2 || B > bmax || B > 64) return 0;
+    const int combos = (Ca / 16) * (Cx / 16);
+    const int nbv = (D0 / 4) * (D1 / 4) * (D2 / 16);
+    int per = 256 / combos / B;                             // workgroups per volume
+    if (per > nbv) per = nbv;
+    const long fixed = (long)B * combos * 6912 + (long)B * (Ca / 16) * 432 + (long)B * 27 * Ca;      // chat + qv + qb behind the rows
+    while (per >= 1 && (long)per * B * combos * W3_ROW_PV + fixed > scratch_floats) --per;
+    return per >= 1 ? per * B : 0;
+}
+extern "C" int semabs_wgrad_conv3_gn_supported(int B, int D0, int D1, int D2, int Ca, int Cx, long scratch_floats, int* ok) {
+    SEMABS_REQUIRE(ok, "semabs_wgrad_conv3_gn_supported: null pointer");
+    *ok = wgrad_conv3_gn_bx(B, D0, D1, D2, Ca, Cx, scratch_floats) > 0 ? 1 : 0;
+    return SEMABS_OK;
+}
+// dZ fp32 [B, D0, D1, D2, Ca] (scaled by s2[0] on the way in, s2 = semabs_grad_scale's (s, 1 / s) or null), X fp32 [B, D0, D1, D2, Cx] = the layer's
+// GroupNorm INPUT with its statistics mean / rstd [B, G] and affine gamma / beta [Cx]; W = the layer's weights fp32 [Ca, Cx, 27].
+// dW fp32 [Ca, Cx, 27] += the weight gradient; red fp64 [B, Cx, 2] = (sum dXn, sum dXn xhat) in dZ's scale - the output of semabs_chan_reduce(dXn, X, ..).
+extern "C" int semabs_wgrad_conv3_gn(const float* dZ, const float* X, const float* mean, const float* rstd, int G, const float* gamma, const float* beta,
+                                     const float* W, const float* s2, float* dW, double* red, int B, int D0, int D1, int D2, int Ca, int Cx,
+                                     float* scratch, long scratch_floats, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(dZ && X && mean && rstd && gamma && beta && W && dW && red && scratch, "semabs_wgrad_conv3_gn: null pointer");
+    SEMABS_REQUIRE(G > 0 && Cx % G == 0, "semabs_wgrad_conv3_gn: the group count must divide the input channels");
+    SEMABS_REQUIRE(Ca <= 128, "semabs_wgrad_conv3_gn: at most 128 output channels");
+    const int bx = wgrad_conv3_gn_bx(B, D0, D1, D2, Ca, Cx, scratch_floats);
+    SEMABS_REQUIRE(bx > 0, "semabs_wgrad_conv3_gn: shape / scratch not supported (ask semabs_wgrad_conv3_gn_supported first)");
+    hipStream_t s = (hipStream_t)stream;
+    const int ny = Ca / 16, nz = Cx / 16, combos = ny * nz;
+    static SemabsLdsAttr attr3;
+    semabs_ensure_lds(&k_wgrad3_tr, 2 * W3_LDS + 64 * 128 + 64, attr3);
+    Wgrad3Args a;
+    a.A = dZ; a.X = X; a.gn_scale = nullptr; a.gn_shift = nullptr; a.s2 = s2; a.part = scratch; a.B = B; a.D0 = D0; a.D1 = D1; a.D2 = D2; a.Ca = Ca; a.Cx = Cx;
+    a.gn_mean = mean; a.gn_rstd = rstd; a.G = G; a.per_vol = 1;
+    hipLaunchKernelGGL(k_wgrad3_tr, dim3(bx, ny, nz), dim3(W3_NTHR), 2 * W3_LDS + (size_t)B * 128 + 64, s, a);
+    float* chat = scratch + (long)bx * combos * W3_ROW_PV;
+    float* qv = chat + (long)B * combos * 6912;
+    float* qb = qv + (long)B * ny * 432;                    // [B][27][Ca]
+    (void)hipMemsetAsync(qb, 0, (size_t)B * 27 * Ca * 4, s);
+    {
+        const long face = (long)(D0 > D1 ? D0 : D1) * (D1 > D2 ? D1 : D2);       // voxels of the largest face
+        const int vpb = 256 / (Ca / 4);
+        int chunks = (int)semabs_cdiv(face, (long)vpb * 8); if (chunks > 64) chunks = 64; if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(k_dz_boundary_sums, dim3(26, B, chunks), dim3(256), 0, s, dZ, s2, qb, D0, D1, D2, Ca);
+    }
+    hipLaunchKernelGGL(k_wgrad3_pv_reduce, dim3(semabs_cdiv((long)B * combos * 6912 + (long)B * ny * 432, 256)), dim3(256), 0, s, scratch, qb, chat, qv, bx, B, ny, nz);
+    const int nw = (int)semabs_cdiv((long)Ca * Cx * 27, 256);
+    hipLaunchKernelGGL(k_wgrad3_pv_finish, dim3(nw + B * nz), dim3(256), 0, s, chat, qv, W, gamma, beta, s2, dW, red, B, Ca, Cx, nw);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

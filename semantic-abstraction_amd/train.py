@@ -121,6 +121,9 @@ class UNetTrainer:
         self._wg_routes = {}
         self.rows_linear = os.environ.get("SEMABS_ROWS_LINEAR", "1") == "1"      # 1 x 1 x 1 convolutions / MLP layers on semabs_linear_rows
         self.wgrad_tr = os.environ.get("SEMABS_WGRAD_TR", "1") == "1"      # A/B: 0 = the round-2 brick kernel (transposes while staging, atomics)
+        # GroupNorm-backward reductions (sum dXn, sum dXn xhat) from the weight-gradient pass instead of a pass over (dXn, x): semabs_wgrad_conv3_gn.
+        self.wgrad_gn = os.environ.get("SEMABS_WGRAD_GN", "1") == "1"      # A/B: 0 = semabs_wgrad_conv3 + semabs_chan_reduce
+        self._wg_gn_ok = {}
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
         self.arena = _ZeroArena(self.dev)
@@ -266,6 +269,16 @@ class UNetTrainer:
             r = self._wg_routes[key] = int(k.value)
         return r
 
+    def _wgrad_conv3_gn_ok(self, B, D0, D1, D2, ca, cx, scratch_floats) -> bool:
+        key = (B, D0, D1, D2, ca, cx, scratch_floats)
+        r = self._wg_gn_ok.get(key)
+        if r is None:
+            import ctypes as C
+            k = C.c_int(0)
+            _lib.call("semabs_wgrad_conv3_gn_supported", B, D0, D1, D2, ca, cx, int(scratch_floats), C.byref(k))
+            r = self._wg_gn_ok[key] = bool(k.value)
+        return r
+
     def _wg_scratch(self):
         """(pointer, capacity in floats) of the buffer semabs_wgrad_mfma parks its row chunks' partial sums in (64 MB, allocated once)."""
         if self._wgs is None:
@@ -324,7 +337,15 @@ class UNetTrainer:
         # routing by the entry point's OWN predicate (semabs_wgrad_conv3_supported: shape, 32-bit staging offsets, scratch size), so that no shape can
         # fall into its SEMABS_REQUIRE (ADVICE rounds 3, 4); anything it does not take goes to the row kernels below
         scr = self._wg_scratch() if self.wgrad_tr else (None, 0)
-        if self.mfma_wgrad and self._wgrad_conv3_route(D0, D1, D2, cout, cin, scr[1]):
+        red = self.arena.zeros((B, cin, 2), torch.float64)
+        have_red = False
+        if self.mfma_wgrad and self.wgrad_tr and self.wgrad_gn and self._wgrad_conv3_gn_ok(B, D0, D1, D2, cout, cin, scr[1]):
+            # one pass over (dZ, x): the weight gradient AND the (sum dXn, sum dXn xhat) the GroupNorm backward needs (csrc/train.hip has the algebra)
+            _lib.call("semabs_wgrad_conv3_gn", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), G, _lib.ptr(self.p[key + "groupnorm.weight"]),
+                      _lib.ptr(self.p[key + "groupnorm.bias"]), _lib.ptr(self.p[key + "conv.weight"]), _lib.ptr(s2), _lib.ptr(dW), _lib.ptr(red),
+                      B, D0, D1, D2, cout, cin, *scr, st)
+            have_red = True
+        elif self.mfma_wgrad and self._wgrad_conv3_route(D0, D1, D2, cout, cin, scr[1]):
             _lib.call("semabs_wgrad_conv3", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(s2), _lib.ptr(dW),
                       B, D0, D1, D2, cout, cin, 1, *scr, st)
         elif cin % 16 == 0 and self.mfma_wgrad:                  # 8^3 / 4^3 levels: rows through LDS, transposing reads (k_wgrad_mfma)
@@ -336,8 +357,8 @@ class UNetTrainer:
         dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
         _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
                   B, D0, D1, D2, cout, cin, 3, 0, 1 | m["bwd"][2], st)
-        red = self.arena.zeros((B, cin, 2), torch.float64)
-        _lib.call("semabs_chan_reduce", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(red), B, nvox, cin, G, st)
+        if not have_red:
+            _lib.call("semabs_chan_reduce", _lib.ptr(dXn), _lib.ptr(r.x), _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(red), B, nvox, cin, G, st)
         coef = torch.empty(B, cin, 3, dtype=torch.float32, device=self.dev)
         _lib.call("semabs_gn_bwd_coef", _lib.ptr(red), _lib.ptr(self.p[key + "groupnorm.weight"]), _lib.ptr(r.rstd), _lib.ptr(inv), _lib.ptr(coef),
                   _lib.ptr(self.g[key + "groupnorm.weight"]), _lib.ptr(self.g[key + "groupnorm.bias"]), B, cin, G, nvox, st)

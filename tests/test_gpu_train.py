@@ -46,12 +46,14 @@ def _uncl(x):
     return x.permute(0, 4, 1, 2, 3).cpu().numpy()
 
 
+@pytest.mark.parametrize("wgrad_gn", [True, False])
 @pytest.mark.parametrize("gscale", [1.0, 1e-7])
-def test_gn_conv_layer_backward_strict(gscale):
+def test_gn_conv_layer_backward_strict(gscale, wgrad_gn):
     """One GroupNorm + Conv3d (no ReLU, so nothing can flip): data, weight and affine gradients to fp32 accuracy - also for gradients
     of magnitude 1e-7, which the split-fp16 MFMA operands only survive through the dynamic power-of-two scale."""
     import torch.nn.functional as F
     sd, params, grads, u, pre = _unet_setup(3, 5)
+    u.wgrad_gn = wgrad_gn                                    # False: semabs_wgrad_conv3 + semabs_chan_reduce (the path of shapes semabs_wgrad_conv3_gn does not take)
     rng = np.random.default_rng(2)
     # 16^3 volumes take the MFMA brick kernel for the weight gradient (semabs_wgrad_conv3, incl. channel slicing), the others the fp32 one
     for name, cin, cout, s in [("encoders.0.basic_module.conv1.", 16, 16, 16), ("encoders.1.basic_module.conv1.", 16, 32, 8),
@@ -74,6 +76,53 @@ def test_gn_conv_layer_backward_strict(gscale):
         assert _rel(grads[key + "conv.weight"].cpu().numpy(), w.grad.numpy()) < 1e-5, name
         assert _rel(grads[key + "groupnorm.weight"].cpu().numpy(), ga.grad.numpy()) < 1e-5, name
         assert _rel(grads[key + "groupnorm.bias"].cpu().numpy(), be.grad.numpy()) < 1e-5, name
+
+
+@pytest.mark.parametrize("B,D,Ca,Cx,G,gscale", [(2, (8, 12, 32), 16, 16, 8, 1.0), (3, (4, 4, 16), 32, 16, 8, 1.0), (8, (16, 16, 16), 32, 32, 8, 1e-7),
+                                                (1, (8, 8, 16), 16, 32, 4, 1.0), (4, (16, 8, 32), 64, 64, 8, 1.0)])
+def test_wgrad_conv3_gn_vs_fp64(B, D, Ca, Cx, G, gscale):
+    """semabs_wgrad_conv3_gn: the weight gradient and the GroupNorm-backward sums (sum dXn, sum dXn xhat) of a GroupNorm -> Conv3d layer from ONE pass over
+    (dZ, x), against torch fp64 autograd / fp64 sums over the materialised dXn - non-cubic volumes (every face of the restricted sums differs), batch sizes
+    that do and do not divide the workgroup count, channel slicing, gradients of magnitude 1e-7 through the dynamic scale, a non-zero-mean input."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from semabs_amd import _lib
+    g = torch.Generator().manual_seed(B * 1000 + Ca + Cx + D[0])
+    x = (torch.randn(B, Cx, *D, generator=g) * 0.8 + 0.4).double()
+    dz = (torch.randn(B, Ca, *D, generator=g) * gscale).double()
+    w = (torch.randn(Ca, Cx, 3, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+    ga = (torch.rand(Cx, generator=g) + 0.5).double().requires_grad_(True)
+    be = (torch.randn(Cx, generator=g) * 0.3).double().requires_grad_(True)
+    xn_in = x.clone().requires_grad_(True)
+    xn = F.group_norm(xn_in, G, ga, be, 1e-5)
+    xn.retain_grad()
+    F.conv3d(xn, w, None, padding=1).backward(dz)
+    xg = x.reshape(B, G, -1)
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    xhat = ((xg - mean[..., None]) * rstd[..., None]).reshape(x.shape)
+    dxn = xn.grad                                            # = conv^T(dz)
+    sa, sb = dxn.sum(dim=(2, 3, 4)), (dxn * xhat).sum(dim=(2, 3, 4))         # [B, Cx]
+    scratch = torch.empty(16 << 20, device="cuda")
+    ok = C.c_int(0)
+    _lib.call("semabs_wgrad_conv3_gn_supported", B, D[0], D[1], D[2], Ca, Cx, scratch.numel(), C.byref(ok))
+    assert ok.value == 1
+    cl = lambda t: t.float().cuda().permute(0, 2, 3, 4, 1).contiguous()
+    dzc, xc = cl(dz), cl(x)
+    s = 2.0 ** 20 if gscale < 1e-3 else 1.0
+    s2 = torch.tensor([s, 1.0 / s], device="cuda")
+    base = 0.5 * gscale
+    dW = torch.full((Ca, Cx, 27), base, device="cuda")       # accumulated into
+    red = torch.zeros(B, Cx, 2, dtype=torch.float64, device="cuda")
+    dev = [t.detach().float().cuda().contiguous() for t in (mean, rstd, ga, be, w)]      # (kept alive across the call)
+    _lib.call("semabs_wgrad_conv3_gn", _lib.ptr(dzc), _lib.ptr(xc), _lib.ptr(dev[0]), _lib.ptr(dev[1]), G, _lib.ptr(dev[2]), _lib.ptr(dev[3]), _lib.ptr(dev[4]),
+              _lib.ptr(s2), _lib.ptr(dW), _lib.ptr(red), B, D[0], D[1], D[2], Ca, Cx, _lib.ptr(scratch), scratch.numel(), _lib.stream())
+    torch.cuda.synchronize()
+    ref_w = w.grad.reshape(Ca, Cx, 27)
+    assert float(((dW.cpu().double() - float(np.float32(base))) - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
+    got = red.cpu() / s
+    assert float((got[..., 0] - sa).abs().max()) < 1e-5 * float(sa.abs().max())
+    assert float((got[..., 1] - sb).abs().max()) < 1e-5 * float(sb.abs().max())
 
 
 @pytest.mark.parametrize("R,Ci,Co,act,transposed,scaled", [(100003, 4, 128, 1, False, False), (100003, 128, 128, 1, False, False), (50001, 128, 16, 0, False, False),
