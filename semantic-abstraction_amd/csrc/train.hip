@@ -173,6 +173,50 @@ __global__ __launch_bounds__(256) void k_wgrad_rows16(const float* __restrict__ 
     atomicAdd(&dW[threadIdx.x], (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]));
 }
 
+// Linear layers with a NARROW input (the point MLP's first layer, 4 inputs; the sampler MLP's, 36): dW[co][ci] += sum_r A[r][co] X[r][ci].  k_wgrad walks
+// 32-row batches through LDS with two barriers each - one memory round trip per 32 rows: 0.7 - 1.0 TB/s on these shapes.  Here a thread owns a 4 x 4 block
+// of dW (one quad of outputs, one quad of inputs: two 16-byte loads feed 16 FMAs), a row group = (Ca / 4) (Cx / 4) threads, the block's row groups take
+// every n-th row, four rows in flight per thread.  Block sums meet in LDS, then one atomic per (co, ci) and block.
+__global__ __launch_bounds__(256) void k_wgrad_rows_narrow(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ dW, long R, int Ca, int Cx) {
+    extern __shared__ float sred[];                         // [row groups][Ca][Cx]
+    const int nqi = Cx / 4, tpg = (Ca / 4) * nqi, nrg = 256 / tpg;
+    const int rg = threadIdx.x / tpg, tg = threadIdx.x % tpg, qo = tg / nqi, qi = tg % nqi;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+    if (rg < nrg) {
+        const long step = (long)gridDim.x * nrg;
+        long r = (long)blockIdx.x * nrg + rg;
+        auto fma16 = [&](const float4& d, const float4& x) {
+            const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i][0] += dv[i] * x.x; acc[i][1] += dv[i] * x.y; acc[i][2] += dv[i] * x.z; acc[i][3] += dv[i] * x.w; }
+        };
+        for (; r + 3 * step < R; r += 4 * step) {
+            float4 d[4], x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d[u] = *reinterpret_cast<const float4*>(A + (r + u * step) * Ca + qo * 4);
+                x[u] = *reinterpret_cast<const float4*>(X + (r + u * step) * Cx + qi * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fma16(d[u], x[u]);
+        }
+        for (; r < R; r += step) fma16(*reinterpret_cast<const float4*>(A + r * Ca + qo * 4), *reinterpret_cast<const float4*>(X + r * Cx + qi * 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sred[((long)rg * Ca + qo * 4 + i) * Cx + qi * 4 + k] = acc[i][k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Ca * Cx; e += 256) {
+        float t = 0.f;
+        for (int g = 0; g < nrg; ++g) t += sred[(long)g * Ca * Cx + e];
+        atomicAdd(&dW[e], t);
+    }
+}
 extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scale, const float* gn_shift, float* dW, int B, int M0,
                             int M1, int M2, int I0, int I1, int I2, int in_stride, int Ca, int Cx, int ntaps, const signed char* taps,
                             int tap_minor, void* stream) {
@@ -189,6 +233,14 @@ extern "C" int semabs_wgrad(const float* A, const float* X, const float* gn_scal
         I2 == M2 && R >= (1L << 18)) {
         int nb = semabs_cdiv(R, 128 * 64); if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(k_wgrad_rows16, dim3(nb), dim3(256), 0, (hipStream_t)stream, A, X, dW, R);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
+    if (ntaps == 1 && !gn_scale && in_stride == 1 && taps[0] == 0 && taps[1] == 0 && taps[2] == 0 && I0 == M0 && I1 == M1 && I2 == M2 && Cx <= 36 &&
+        (Ca / 4) * (Cx / 4) <= 256 && R >= (1L << 16)) {
+        const int nrg = 256 / ((Ca / 4) * (Cx / 4));
+        int nb = (int)semabs_cdiv(R, (long)nrg * 64); if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_wgrad_rows_narrow, dim3(nb), dim3(256), (size_t)nrg * Ca * Cx * 4, (hipStream_t)stream, A, X, dW, R, Ca, Cx);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
     }

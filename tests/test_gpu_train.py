@@ -207,7 +207,8 @@ def test_linear_wgrad_colsum_vs_torch():
     from semabs_amd import _lib
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(3)
-    for R, Ci, Co in [(1000, 4, 128), (777, 128, 16), (2050, 36, 32), (64, 32, 64)]:
+    # (the last three shapes: k_wgrad_rows_narrow - at least 2^16 rows, at most 36 inputs; ragged row counts)
+    for R, Ci, Co in [(1000, 4, 128), (777, 128, 16), (2050, 36, 32), (64, 32, 64), (70001, 4, 128), (100003, 36, 32), (65536, 4, 128)]:
         x = torch.from_numpy(rng.standard_normal((R, Ci)).astype(np.float32))
         w = torch.from_numpy(rng.standard_normal((Co, Ci)).astype(np.float32))
         b = torch.from_numpy(rng.standard_normal(Co).astype(np.float32))
