@@ -1,6 +1,7 @@
 """Per-kernel utilisation table from a tools/pmc_run.py summary:  python tools/pmc_table.py <pmc_summary.json> [rows]
 cycles = GRBM_GUI_ACTIVE / 8 XCDs; matrix pipe = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles; VALU = SQ_INSTS_VALU x 4 cycles / 1024 / cycles (an
-estimate: one issue slot per wave instruction); LDS = SQ_LDS_IDX_ACTIVE / 256 CUs / cycles; HBM = FETCH_SIZE (KiB) + WRITE_SIZE (KiB) per dispatch."""
+estimate: one issue slot per wave instruction); LDS = SQ_LDS_IDX_ACTIVE / 256 CUs / cycles; HBM = FETCH_SIZE + WRITE_SIZE per dispatch as the counters
+report them (KiB; the guide's gfx950 corrections are applied by tools/pmc_bench.py for the figures bench.py prints, not here: read this column as relative)."""
 import json, sys
 d = json.load(open(sys.argv[1]))
 rows = []
