@@ -83,10 +83,11 @@ def test_conv16_lds_brick_kernel(precision, tol, dims, B, resid, bar):
 @pytest.mark.parametrize("cin,cout,dims,B,resid", [(16, 32, (4, 8, 16), 2, False), (32, 32, (8, 16, 32), 3, True), (64, 64, (4, 16, 16), 2, True),
                                                    (32, 64, (8, 16, 32), 64, True), (64, 64, (8, 16, 32), 64, False), (16, 64, (8, 16, 32), 64, True),
                                                    (128, 128, (4, 8, 16), 1, True), (256, 256, (8, 8, 8), 2, True), (128, 256, (4, 16, 8), 3, False),
-                                                   (32, 32, (4, 8, 24), 1, True)])
+                                                   (32, 32, (4, 8, 24), 1, True), (32, 16, (8, 16, 32), 3, True), (64, 16, (4, 8, 16), 2, False)])
 def test_conv_brick_kernel(precision, tol, cin, cout, dims, B, resid, bar):
     """k_conv_brick (64^3 .. 16^3 levels: LDS halo bricks of 4 x 8 x 16, weights software-pipelined, lane-transposed epilogue) vs torch fp32 and
-    vs the generic gather kernel; the B = 64 cases have enough bricks for the four-output-block (in-place weight re-request) variants."""
+    vs the generic gather kernel; the B = 64 cases have enough bricks for the four-output-block (in-place weight re-request) variants, the Cout = 16
+    cases take the one-output-block variant (the data gradient of the network's 16 -> 32 convolution)."""
     from semabs_amd.unet3d import _Conv
     rng = np.random.default_rng(cin * 7 + cout + B)
     x = torch.from_numpy(rng.standard_normal((B, cin, *dims)).astype(np.float32)) * 1.5 + 0.3
