@@ -1107,45 +1107,63 @@ extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const
     return SEMABS_OK;
 }
 
-// cosine pointer + BCE: logit = cos(o, rel_d) / T;  loss += w * BCEwithlogits(logit, y) / n_total
-// one wave per point (E = 64 = one element per lane); writes logits, dO [R, 64], accumulates drel [P, 64] and the loss
-__global__ __launch_bounds__(256) void k_cos_bce(const float* __restrict__ o, const float* __restrict__ rel, const float* __restrict__ label,
-                                                 const float* __restrict__ weight, int P, long M, float inv_temp, float inv_n,
-                                                 float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel, double* __restrict__ loss) {
+// cosine pointer (+ BCE): logit = cos(o, rel_d) / T;  BCE mode (label != null): loss += w * BCEwithlogits(logit, y) / n_total and dz = d loss / d logit is
+// formed here; head mode: dz = dz_in (null = logits only).  16 lanes per point (E = 64 = one float4 per lane), four points per wave, row reductions by DPP:
+// ~25 instructions per point (one wave per point with two 64-lane reductions and the transcendentals in every lane: ~120, 760 us for 1.6 M points - VALU-bound
+// at 0.6 GB of traffic).  Writes logits, dO [R, 64]; accumulates drel [P, 64] and the loss.
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));     // quad_perm [1, 0, 3, 2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));     // quad_perm [2, 3, 0, 1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));    // row_mirror
+    return v;
+}
+__global__ __launch_bounds__(256) void k_cos_rows(const float* __restrict__ o, const float* __restrict__ rel, const float* __restrict__ label,
+                                                  const float* __restrict__ weight, const float* __restrict__ dz_in, int P, long M, float inv_temp, float inv_n,
+                                                  float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel, double* __restrict__ loss) {
     __shared__ float s_drel[64];
     __shared__ float s_loss;
     if (threadIdx.x < 64) s_drel[threadIdx.x] = 0.f;
     if (threadIdx.x == 0) s_loss = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    // blocks are aligned to descriptions: blockIdx.y = description, blockIdx.x strides over its M points (4 per iteration)
+    const int q = threadIdx.x & 15;
+    // blocks are aligned to descriptions: blockIdx.y = description, blockIdx.x strides over its M points (16 per iteration)
     const int d = blockIdx.y;
-    const float rv = rel[d * 64 + lane];
-    const float nr = fmaxf(sqrtf(wave_sum(rv * rv)), 1e-8f);
-    const float rh = rv / nr;
-    float acc_drel = 0.f, acc_loss = 0.f;
-    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
+    const float4 rv = *reinterpret_cast<const float4*>(rel + d * 64 + q * 4);
+    const float nr = fmaxf(sqrtf(row16_sum((rv.x * rv.x + rv.y * rv.y) + (rv.z * rv.z + rv.w * rv.w))), 1e-8f);
+    const float inr = 1.f / nr;
+    const float rh[4] = {rv.x / nr, rv.y / nr, rv.z / nr, rv.w / nr};
+    const bool grad = label || dz_in;
+    float acc_drel[4] = {0.f, 0.f, 0.f, 0.f}, acc_loss = 0.f;
+    for (long m = (long)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (long)gridDim.x * 16) {
         const long pt = (long)d * M + m;
-        const float ov = o[pt * 64 + lane];
-        const float no = fmaxf(sqrtf(wave_sum(ov * ov)), 1e-8f);
-        const float oh = ov / no;
-        const float cs = wave_sum(oh * rh);
+        const float4 ov = *reinterpret_cast<const float4*>(o + pt * 64 + q * 4);
+        const float no = fmaxf(sqrtf(row16_sum((ov.x * ov.x + ov.y * ov.y) + (ov.z * ov.z + ov.w * ov.w))), 1e-8f);
+        const float oh[4] = {ov.x / no, ov.y / no, ov.z / no, ov.w / no};
+        const float cs = row16_sum((oh[0] * rh[0] + oh[1] * rh[1]) + (oh[2] * rh[2] + oh[3] * rh[3]));
         const float z = cs * inv_temp;
-        const float y = label[pt], wgt = weight ? weight[pt] : 1.f;
-        // numerically stable BCE with logits: max(z, 0) - z y + log(1 + exp(-|z|))
-        const float l = fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
-        const float dz = (1.f / (1.f + __expf(-z)) - y) * wgt * inv_n;
-        const float dc = dz * inv_temp;
-        if (logits && lane == 0) logits[pt] = z;
-        dO[pt * 64 + lane] = (rh - oh * cs) / no * dc;
-        acc_drel += (oh - rh * cs) / nr * dc;
-        if (lane == 0) acc_loss += l * wgt * inv_n;
+        if (logits && q == 0) logits[pt] = z;
+        if (!grad) continue;
+        float dz;
+        if (label) {
+            const float y = label[pt], wgt = weight ? weight[pt] : 1.f;
+            // numerically stable BCE with logits: max(z, 0) - z y + log(1 + exp(-|z|))
+            const float l = fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+            dz = (1.f / (1.f + __expf(-z)) - y) * wgt * inv_n;
+            if (q == 0) acc_loss += l * wgt * inv_n;
+        } else dz = dz_in[pt];
+        const float dc = dz * inv_temp, ino = dc / no, dcr = dc * inr;
+        *reinterpret_cast<float4*>(dO + pt * 64 + q * 4) = make_float4((rh[0] - oh[0] * cs) * ino, (rh[1] - oh[1] * cs) * ino, (rh[2] - oh[2] * cs) * ino, (rh[3] - oh[3] * cs) * ino);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_drel[j] += (oh[j] - rh[j] * cs) * dcr;
     }
-    atomicAdd(&s_drel[lane], acc_drel);
-    if (lane == 0) atomicAdd(&s_loss, acc_loss);
+    if (!grad) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(&s_drel[q * 4 + j], acc_drel[j]);
+    if (label && q == 0) atomicAdd(&s_loss, acc_loss);
     __syncthreads();
     if (threadIdx.x < 64) atomicAdd(&drel[d * 64 + threadIdx.x], s_drel[threadIdx.x]);
-    if (threadIdx.x == 0) atomicAdd(loss, (double)s_loss);
+    if (label && threadIdx.x == 0) atomicAdd(loss, (double)s_loss);
 }
 // o fp32 [P*M, 64]; rel fp32 [P, 64]; label / weight fp32 [P*M] (weight optional); outputs: logits [P*M] (optional), dO [P*M, 64],
 // drel fp32 [P, 64] and loss fp64 [1] ACCUMULATED (zero them first).  n_total = element count of the mean reduction.
@@ -1153,9 +1171,9 @@ extern "C" int semabs_cos_bce(const float* o, const float* rel, const float* lab
                               long n_total, float* logits, float* dO, float* drel, double* loss, void* stream) {
     if (P == 0 || M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(o && rel && label && dO && drel && loss && temperature > 0.f && n_total > 0, "semabs_cos_bce: bad args");
-    int bx = semabs_cdiv(M, 4 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_cos_bce, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, label, weight, P, M, 1.0f / temperature, 1.0f / (float)n_total,
-                       logits, dO, drel, loss);
+    int bx = semabs_cdiv(M, 16 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_cos_rows, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, label, weight, (const float*)nullptr, P, M, 1.0f / temperature,
+                       1.0f / (float)n_total, logits, dO, drel, loss);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -1163,41 +1181,13 @@ extern "C" int semabs_cos_bce(const float* o, const float* rel, const float* lab
 // The same pointer head with the loss left to the CALLER (the reference's own loop: `loss = BCE(net(**batch), label); loss.backward()`,
 // train_vool.py:171-178, utils.py:404-417 - semabs_amd.net.SemAbsVOOL under autograd): dz == NULL -> logits only (forward);
 // dz = d loss / d logits [P*M] -> dO = d loss / d o and drel (accumulated) = d loss / d rel.
-__global__ __launch_bounds__(256) void k_cos_head(const float* __restrict__ o, const float* __restrict__ rel, const float* __restrict__ dz_in, int P, long M,
-                                                  float inv_temp, float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel) {
-    __shared__ float s_drel[64];
-    if (threadIdx.x < 64) s_drel[threadIdx.x] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int d = blockIdx.y;
-    const float rv = rel[d * 64 + lane];
-    const float nr = fmaxf(sqrtf(wave_sum(rv * rv)), 1e-8f);
-    const float rh = rv / nr;
-    float acc_drel = 0.f;
-    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
-        const long pt = (long)d * M + m;
-        const float ov = o[pt * 64 + lane];
-        const float no = fmaxf(sqrtf(wave_sum(ov * ov)), 1e-8f);
-        const float oh = ov / no;
-        const float cs = wave_sum(oh * rh);
-        if (logits && lane == 0) logits[pt] = cs * inv_temp;
-        if (dz_in) {
-            const float dc = dz_in[pt] * inv_temp;
-            dO[pt * 64 + lane] = (rh - oh * cs) / no * dc;
-            acc_drel += (oh - rh * cs) / nr * dc;
-        }
-    }
-    if (!dz_in) return;
-    atomicAdd(&s_drel[lane], acc_drel);
-    __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(&drel[d * 64 + threadIdx.x], s_drel[threadIdx.x]);
-}
 extern "C" int semabs_cos_head(const float* o, const float* rel, const float* dlogits, int P, long M, float temperature, float* logits, float* dO,
                                float* drel, void* stream) {
     if (P == 0 || M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(o && rel && temperature > 0.f && (dlogits ? (dO && drel) : (logits != nullptr)), "semabs_cos_head: bad args");
-    int bx = semabs_cdiv(M, 4 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_cos_head, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, dlogits, P, M, 1.0f / temperature, logits, dO, drel);
+    int bx = semabs_cdiv(M, 16 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_cos_rows, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, (const float*)nullptr, (const float*)nullptr, dlogits, P, M,
+                       1.0f / temperature, 0.f, logits, dO, drel, (double*)nullptr);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -156,6 +156,44 @@ def test_linear_rows_vs_fp64(R, Ci, Co, act, transposed, scaled):
     assert bool((y[R:] == 7.0).all())
 
 
+@pytest.mark.parametrize("P,M", [(3, 1001), (1, 16), (4, 40000)])
+def test_cos_bce_and_cos_head_vs_torch_fp64(P, M):
+    """semabs_cos_bce / semabs_cos_head (net.py:571-579 cosine pointer at temperature 0.07 + utils.py's weighted BCE-with-logits mean): logits, loss, d loss / d o
+    and d loss / d relation embedding against torch fp64 autograd; ragged point counts (16 points per block iteration)."""
+    from semabs_amd import _lib
+    g = torch.Generator().manual_seed(P * 7 + M)
+    o = torch.randn(P * M, 64, generator=g)
+    rel = torch.randn(P, 64, generator=g)
+    label = (torch.rand(P * M, generator=g) < 0.3).float()
+    weight = torch.rand(P * M, generator=g) + 0.5
+    od, rd = o.double().requires_grad_(True), rel.double().requires_grad_(True)
+    z = torch.nn.functional.cosine_similarity(od.reshape(P, M, 64), rd[:, None, :], dim=-1).reshape(-1) / 0.07
+    loss = (torch.nn.functional.binary_cross_entropy_with_logits(z, label.double(), reduction="none") * weight.double()).sum() / (P * M)
+    loss.backward()
+    dev = [t.cuda().contiguous() for t in (o, rel, label, weight)]
+    logits = torch.empty(P * M, device="cuda"); dO = torch.empty(P * M, 64, device="cuda")
+    drel = torch.zeros(P, 64, device="cuda"); lossd = torch.zeros(1, dtype=torch.float64, device="cuda")
+    _lib.call("semabs_cos_bce", _lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), P, M, 0.07, P * M, _lib.ptr(logits), _lib.ptr(dO),
+              _lib.ptr(drel), _lib.ptr(lossd), _lib.stream())
+    assert _rel(logits.cpu().numpy(), z.detach().numpy()) < 2e-6
+    assert abs(float(lossd) - float(loss)) < 1e-6 * float(loss)
+    assert _rel(dO.cpu().numpy(), od.grad.numpy()) < 1e-5
+    assert _rel(drel.cpu().numpy(), rd.grad.numpy()) < 1e-5
+    # the head with the loss left to the caller: logits only, then the gradients for a given d loss / d logits
+    logits2 = torch.empty(P * M, device="cuda")
+    _lib.call("semabs_cos_head", _lib.ptr(dev[0]), _lib.ptr(dev[1]), None, P, M, 0.07, _lib.ptr(logits2), None, None, _lib.stream())
+    assert bool((logits2 == logits).all())
+    dz = torch.randn(P * M, generator=g)
+    od.grad = None; rd.grad = None
+    z2 = torch.nn.functional.cosine_similarity(od.reshape(P, M, 64), rd[:, None, :], dim=-1).reshape(-1) / 0.07
+    z2.backward(dz.double())
+    dzd = dz.cuda()
+    dO2 = torch.empty(P * M, 64, device="cuda"); drel2 = torch.zeros(P, 64, device="cuda")
+    _lib.call("semabs_cos_head", _lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dzd), P, M, 0.07, None, _lib.ptr(dO2), _lib.ptr(drel2), _lib.stream())
+    assert _rel(dO2.cpu().numpy(), od.grad.numpy()) < 1e-5
+    assert _rel(drel2.cpu().numpy(), rd.grad.numpy()) < 1e-5
+
+
 def test_convtranspose_backward_strict():
     import torch.nn.functional as F
     sd, params, grads, u, pre = _unet_setup(3, 5)
