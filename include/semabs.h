@@ -375,8 +375,9 @@ int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol
  * gradient volumes (gather over per-cell point lists; head int32 [P * S^3], next int32 [P * M] scratch)                                                            net.py:215-256, 556-565 */
 int semabs_vool_sample(const float* vol_t, const float* vol_r, const float* query, const float* off3, const float* sc3, const int* shape3,
                        int P, long M, float* f, void* stream);
+/* absmax_bits (optional, uint32 [1], zeroed by the caller): receives the bit pattern of max |dvol| (what semabs_grad_scale(.., have_max = 1) takes) */
 int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
-                           int* head, int* next, float* dvol_t, float* dvol_r, void* stream);
+                           int* head, int* next, float* dvol_t, float* dvol_r, unsigned int* absmax_bits, void* stream);
 
 /* logits = cos(o, rel) / T; loss += sum w BCEwithlogits(logit, label) / n_total; dO and drel (accumulated) = d loss / d o, d rel
  *                                                                                                        net.py:566-579, train_vool.py:171-178 */

@@ -112,7 +112,7 @@ SIGNATURES = {
     "semabs_linear_rows": [P, L, P, L, L, P, P, L, I, I, I, F, P, P, P],
     "semabs_scatter_mean_bwd": [P, P, P, P, I, L, I, L, P],
     "semabs_vool_sample": [P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P],
-    "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P, P, P],
+    "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P, P, P, P],
     "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P],
     "semabs_cos_head": [P, P, P, I, L, F, P, P, P, P],
     "semabs_gather_split16": [P, P, L, P, P, P],

@@ -1047,7 +1047,7 @@ __global__ void k_vool_cells(const float* __restrict__ query, SampArgs a, int P,
 // thread = (description, voxel, volume selector): 16 channels in registers
 __global__ __launch_bounds__(256) void k_vool_sample_bwd(const float* __restrict__ df, const float* __restrict__ query, SampArgs a, int P, long M,
                                                          const int* __restrict__ head, const int* __restrict__ next,
-                                                         float* __restrict__ dvol_t, float* __restrict__ dvol_r) {
+                                                         float* __restrict__ dvol_t, float* __restrict__ dvol_r, unsigned int* __restrict__ bits) {
     const long nvox = (long)a.S0 * a.S1 * a.S2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)P * nvox * 2) return;
@@ -1076,6 +1076,12 @@ __global__ __launch_bounds__(256) void k_vool_sample_bwd(const float* __restrict
     float4* o = reinterpret_cast<float4*>((sel ? dvol_r : dvol_t) + dv * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (bits) {                                             // max |dvol| for the dynamic gradient scale of the first backward layer (saves its pass over dvol)
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) m = fmaxf(m, fabsf(acc[c]));
+        absmax_commit(bits, m);
+    }
 }
 static void fill_samp(SampArgs& a, const float* off3, const float* sc3, const int* shape3) {
     for (int k = 0; k < 3; ++k) { a.off[k] = off3[k]; a.sc[k] = sc3[k]; }
@@ -1093,7 +1099,7 @@ extern "C" int semabs_vool_sample(const float* vol_t, const float* vol_r, const 
 }
 // df fp32 [P*M, 36] -> dvol_t / dvol_r fp32 [P, S, S, S, 16] (fully written).  head int32 [P * S^3] and next int32 [P * M] are scratch.
 extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
-                                      int* head, int* next, float* dvol_t, float* dvol_r, void* stream) {
+                                      int* head, int* next, float* dvol_t, float* dvol_r, unsigned int* absmax_bits, void* stream) {
     if (P == 0) return SEMABS_OK;
     SEMABS_REQUIRE(df && query && off3 && sc3 && shape3 && head && next && dvol_t && dvol_r, "semabs_vool_sample_bwd: null pointer");
     SEMABS_REQUIRE(M < (1L << 31), "semabs_vool_sample_bwd: at most 2^31 - 1 query points per description");
@@ -1102,7 +1108,7 @@ extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const
     const long nvox = (long)a.S0 * a.S1 * a.S2;
     semabs_fill32(head, sizeof(int) * P * nvox, 0xffffffffu, s);
     if (M > 0) hipLaunchKernelGGL(k_vool_cells, dim3(semabs_cdiv((long)P * M, 256)), dim3(256), 0, s, query, a, P, M, head, next);
-    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * nvox * 2, 256)), dim3(256), 0, s, df, query, a, P, M, head, next, dvol_t, dvol_r);
+    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * nvox * 2, 256)), dim3(256), 0, s, df, query, a, P, M, head, next, dvol_t, dvol_r, absmax_bits);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

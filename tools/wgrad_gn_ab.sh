@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r5n
-python -m pytest tests/test_gpu_train.py tests/test_gpu_autograd_boundary.py -q -x 2>&1 | tail -3 | cut -c1-220
+python -m pytest tests/test_gpu_train.py tests/test_gpu_autograd_boundary.py tests/test_gpu_train_dp.py -q 2>&1 | grep -E "passed|failed|^E  " | head -6 | cut -c1-220
 for i in 1 2; do
   echo "--- step"; python tools/train_bench.py --steps 6 --warmup 2 2>/dev/null | tail -1 | cut -c1-120
 done
-python tools/train_calls.py "semabs_cos" 6 2>/dev/null | head -5
+python tools/train_calls.py "semabs_grad_scale" 16 2>/dev/null | head -12
