@@ -1044,42 +1044,49 @@ __global__ void k_vool_cells(const float* __restrict__ query, SampArgs a, int P,
     const long cell = (((long)d * a.S0 + z0) * a.S1 + y0) * a.S2 + x0;
     next[pt] = atomicExch(&head[cell], (int)(pt - (long)d * M));            // list entries are point indices within the description
 }
-// thread = (description, voxel, volume selector): 16 channels in registers
+// thread = (description, voxel): the 16 + 16 channels of BOTH gradient volumes in registers.  (One thread per (voxel, volume) walked every cell list twice and
+// set up every visited point twice; with 0.2 points per cell almost every wave has some lane with a non-empty list at every corner, so the list walk - not
+// the 64 B stores - is what the kernel costs: VALU issue 0.68 at 1.1 ms.)
 __global__ __launch_bounds__(256) void k_vool_sample_bwd(const float* __restrict__ df, const float* __restrict__ query, SampArgs a, int P, long M,
                                                          const int* __restrict__ head, const int* __restrict__ next,
                                                          float* __restrict__ dvol_t, float* __restrict__ dvol_r, unsigned int* __restrict__ bits) {
     const long nvox = (long)a.S0 * a.S1 * a.S2;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)P * nvox * 2) return;
-    const int sel = (int)(i & 1); const long dv = i >> 1;
+    const long dv = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dv >= (long)P * nvox) return;
     const int d = (int)(dv / nvox); long v = dv - (long)d * nvox;
     const int vx = (int)(v % a.S2); v /= a.S2;
     const int vy = (int)(v % a.S1); const int vz = (int)(v / a.S1);
-    float acc[16];
+    float acc[32];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    int hp[8];                                              // the eight list heads first: independent loads, one memory latency instead of eight
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int cz = vz - (k >> 2), cy = vy - ((k >> 1) & 1), cx = vx - (k & 1);          // this voxel is corner k of cell (cz, cy, cx)
-        if (cz < 0 || cy < 0 || cx < 0) continue;
-        int p = head[(((long)d * a.S0 + cz) * a.S1 + cy) * a.S2 + cx];
+        hp[k] = (cz < 0 || cy < 0 || cx < 0) ? -1 : head[(((long)d * a.S0 + cz) * a.S1 + cy) * a.S2 + cx];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int p = hp[k];
         while (p >= 0) {
             const long pt = (long)d * M + p;
             float qn[3], w[6]; int x0, y0, z0;
             samp_setup(query + pt * 3, a, qn, x0, y0, z0, w);
             const float wt = w[k & 1] * w[2 + ((k >> 1) & 1)] * w[4 + (k >> 2)];
-            const float4* g = reinterpret_cast<const float4*>(df + pt * 36 + sel * 16);
+            const float4* g = reinterpret_cast<const float4*>(df + pt * 36);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const float4 gv = g[q]; acc[4 * q] += gv.x * wt; acc[4 * q + 1] += gv.y * wt; acc[4 * q + 2] += gv.z * wt; acc[4 * q + 3] += gv.w * wt; }
+            for (int q = 0; q < 8; ++q) { const float4 gv = g[q]; acc[4 * q] += gv.x * wt; acc[4 * q + 1] += gv.y * wt; acc[4 * q + 2] += gv.z * wt; acc[4 * q + 3] += gv.w * wt; }
             p = next[pt];
         }
     }
-    float4* o = reinterpret_cast<float4*>((sel ? dvol_r : dvol_t) + dv * 16);
+    float4* ot = reinterpret_cast<float4*>(dvol_t + dv * 16);
+    float4* orf = reinterpret_cast<float4*>(dvol_r + dv * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    for (int q = 0; q < 4; ++q) { ot[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]); orf[q] = make_float4(acc[16 + 4 * q], acc[17 + 4 * q], acc[18 + 4 * q], acc[19 + 4 * q]); }
     if (bits) {                                             // max |dvol| for the dynamic gradient scale of the first backward layer (saves its pass over dvol)
         float m = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) m = fmaxf(m, fabsf(acc[c]));
+        for (int c = 0; c < 32; ++c) m = fmaxf(m, fabsf(acc[c]));
         absmax_commit(bits, m);
     }
 }
@@ -1108,7 +1115,7 @@ extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const
     const long nvox = (long)a.S0 * a.S1 * a.S2;
     semabs_fill32(head, sizeof(int) * P * nvox, 0xffffffffu, s);
     if (M > 0) hipLaunchKernelGGL(k_vool_cells, dim3(semabs_cdiv((long)P * M, 256)), dim3(256), 0, s, query, a, P, M, head, next);
-    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * nvox * 2, 256)), dim3(256), 0, s, df, query, a, P, M, head, next, dvol_t, dvol_r, absmax_bits);
+    hipLaunchKernelGGL(k_vool_sample_bwd, dim3(semabs_cdiv((long)P * nvox, 256)), dim3(256), 0, s, df, query, a, P, M, head, next, dvol_t, dvol_r, absmax_bits);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
