@@ -355,18 +355,21 @@ int semabs_grad_scale(const float* x, long n, float* scale_arr, float* shift_arr
                       void* stream);
 /* MaxPool3d(2) backward: first maximal element of each window takes dY                                   unet3d.py:298-317 */
 int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, int B, int D0, int D1, int D2, int C, void* stream);
-/* + `add` (like dX: the skip connection's gradient) added on the way out, max |dX| -> absmax_bits (optional, zero it first): one pass less per level */
-int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, float* dX, unsigned int* absmax_bits, int B, int D0, int D1, int D2,
-                             int C, void* stream);
+/* + `add` (like dX: the skip connection's gradient) added on the way out, max |dX| -> absmax_bits (optional, zero it first): one pass less per level.
+ * relu_mask != 0: X is a post-ReLU activation and dX is wanted in front of that ReLU (dX = 0 where X <= 0): the residual block's mask pass folded in. */
+int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, float* dX, unsigned int* absmax_bits, int relu_mask, int B, int D0, int D1,
+                             int D2, int C, void* stream);
 
 /* Y[R, Co] = act(X[R, Ci] . W[Co, Ci]^T + bias), act 0 none / 1 LeakyReLU(slope): the point MLP and sampler MLP layers and, with W
  * transposed by the caller, their data gradients                                                         net.py:358-367, 300-309 */
 int semabs_linear_f32(const float* X, const float* W, const float* bias, float* Y, long R, int Ci, int Co, int act, float slope, void* stream);
 /* The same layer on the matrix cores with fp32-like accuracy (operands split into fp16 hi + lo, three products): Y = act((s X) W^T + b), W addressed as
  * W[n * w_sn + k * w_sk] (plain: Ci, 1; transposed: 1, Co), in_scale = optional device scalar s (the power-of-two scale of a gradient input; the output
- * stays scaled unless out_scale - a device scalar the accumulator is multiplied by, e.g. 1 / s - is given).  Ci % 4 == 0, Co <= 128, act 0 none / 1 LeakyReLU(slope).                                  net.py:358-367, 215-256 (and their backward) */
+ * stays scaled unless out_scale - a device scalar the accumulator is multiplied by, e.g. 1 / s - is given).  Ci % 4 == 0, Co <= 128, act 0 none / 1 LeakyReLU(slope).                                  net.py:358-367, 215-256 (and their backward)
+ * relu_mask (optional, like Y): Y = 0 where relu_mask <= 0 (Y is a gradient in front of the ReLU that produced relu_mask); absmax_bits (optional, uint32 [1],
+ * zeroed by the caller): bit pattern of max |Y|. */
 int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
-                       int act, float slope, const float* in_scale, const float* out_scale, void* stream);
+                       int act, float slope, const float* in_scale, const float* out_scale, const float* relu_mask, unsigned int* absmax_bits, void* stream);
 
 /* scatter-mean backward: dpf[b, p] = dvol[b, flat[p]] / count[flat[p]]; count int32 [nvox] zero-filled by the caller   net.py:185-201 */
 int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol, float* dpf, int P, long N, int C, long nvox, void* stream);

@@ -770,6 +770,7 @@ extern "C" int semabs_ew_scaled(const float* a, const float* b, const float* in_
 }
 
 // MaxPool3d(2) backward, channels-last fp32: the FIRST maximal element of each 2x2x2 window (scan order d, h, w) gets dY
+template <bool RELU_MASK>                                   // RELU_MASK: X is a post-ReLU activation and the caller wants the gradient in FRONT of that ReLU
 __global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dX, int B, int O0, int O1, int O2, int C,
                               const float* __restrict__ add, unsigned int* __restrict__ bits) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -781,11 +782,13 @@ __global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restri
     const int o0 = (int)(v % O0); const int b = (int)(v / O0);
     const int I1 = 2 * O1, I2 = 2 * O2;
     float best = -INFINITY; int arg = 0; long idx[8];
+    unsigned pos = 0;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         idx[d] = ((((long)b * 2 * O0 + 2 * o0 + (d >> 2)) * I1 + 2 * o1 + ((d >> 1) & 1)) * I2 + 2 * o2 + (d & 1)) * C + c;
         const float x = X[idx[d]];
         if (x > best) { best = x; arg = d; }
+        pos |= (x > 0.f ? 1u : 0u) << d;
     }
     const float g = dY[i];
     float m = 0.f;
@@ -793,6 +796,7 @@ __global__ void k_maxpool_bwd(const float* __restrict__ X, const float* __restri
     for (int d = 0; d < 8; ++d) {
         float o = (d == arg) ? g : 0.f;
         if (add) o += add[idx[d]];                           // the skip connection's gradient (the pooled tensor is also a decoder input): one pass less
+        if (RELU_MASK && !((pos >> d) & 1u)) o = 0.f;        // ... and the ReLU that produced X: the block's own mask pass (read dX, read X, write) is gone
         dX[idx[d]] = o;
         m = fmaxf(m, fabsf(o));
     }
@@ -802,18 +806,19 @@ extern "C" int semabs_maxpool3d_bwd(const float* X, const float* dY, float* dX, 
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && dY && dX && D0 % 2 == 0 && D1 % 2 == 0 && D2 % 2 == 0, "semabs_maxpool3d_bwd: bad args");
     const long tot = (long)B * (D0 / 2) * (D1 / 2) * (D2 / 2) * C;
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C,
+    hipLaunchKernelGGL(k_maxpool_bwd<false>, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C,
                        (const float*)nullptr, (unsigned int*)nullptr);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
 // the same + `add` (like dX, e.g. the skip connection's gradient) added on the way out, and (optional) max |dX| -> absmax_bits (zero it first)
-extern "C" int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, float* dX, unsigned int* absmax_bits, int B, int D0, int D1,
-                                        int D2, int C, void* stream) {
+extern "C" int semabs_maxpool3d_bwd_add(const float* X, const float* dY, const float* add, float* dX, unsigned int* absmax_bits, int relu_mask, int B, int D0,
+                                        int D1, int D2, int C, void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && dY && add && dX && D0 % 2 == 0 && D1 % 2 == 0 && D2 % 2 == 0, "semabs_maxpool3d_bwd_add: bad args");
     const long tot = (long)B * (D0 / 2) * (D1 / 2) * (D2 / 2) * C;
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C, add, absmax_bits);
+    if (relu_mask) hipLaunchKernelGGL(k_maxpool_bwd<true>, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C, add, absmax_bits);
+    else hipLaunchKernelGGL(k_maxpool_bwd<false>, dim3(semabs_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, X, dY, dX, B, D0 / 2, D1 / 2, D2 / 2, C, add, absmax_bits);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -865,7 +870,8 @@ extern "C" int semabs_linear_f32(const float* X, const float* W, const float* bi
 template <int NT>                                            // column tiles of 16 kept in registers per pass (Co16 / 16 <= NT)
 __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X, long ldx, const float* __restrict__ W, long w_sn, long w_sk,
                                                      const float* __restrict__ bias, float* __restrict__ Y, long R, int Ci, int Co, int act, float slope,
-                                                     const float* __restrict__ in_scale, const float* __restrict__ out_scale) {
+                                                     const float* __restrict__ in_scale, const float* __restrict__ out_scale,
+                                                     const float* __restrict__ relu_mask, unsigned int* __restrict__ bits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Kp = (Ci + 31) / 32 * 32, KS = Kp + 8;         // padded K and LDS row stride (fp16 elements)
     const int Co16 = (Co + 15) / 16 * 16;
@@ -886,6 +892,7 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
 #pragma unroll
     for (int j = 0; j < NT; ++j) bv[j] = (bias && j < nt && j * 16 + vl < Co) ? bias[j * 16 + vl] : 0.f;
     const long ntiles = (R + 15) / 16;
+    float amax = 0.f;
     for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
         const long row = t * 16 + vl;
         const float* xr = X + (row < R ? row : R - 1) * ldx;
@@ -927,14 +934,20 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
                     const long r = t * 16 + 4 * kg + i;
                     float o = acc[j][i] * so + bv[j];
                     if (act == 1) o = o > 0.f ? o : slope * o;
-                    if (r < R) Y[r * Co + j * 16 + vl] = o;
+                    if (r < R) {
+                        if (relu_mask && !(relu_mask[r * Co + j * 16 + vl] > 0.f)) o = 0.f;     // Y is a gradient in front of the ReLU that produced relu_mask
+                        Y[r * Co + j * 16 + vl] = o;
+                        amax = fmaxf(amax, fabsf(o));
+                    }
                 }
             }
         }
     }
+    if (bits) absmax_commit(bits, amax);
 }
 extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
-                                  int act, float slope, const float* in_scale, const float* out_scale, void* stream) {
+                                  int act, float slope, const float* in_scale, const float* out_scale, const float* relu_mask, unsigned int* absmax_bits,
+                                  void* stream) {
     if (R == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && W && Y && R > 0 && Ci > 0 && Co > 0, "semabs_linear_rows: bad args");
     SEMABS_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0 && Ci <= 512 && Co <= 128 && (act == 0 || act == 1), "semabs_linear_rows: Ci % 4 == 0, Ci <= 512, Co <= 128, act 0 / 1");
@@ -948,7 +961,7 @@ extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long
     {                                                                                                                           \
         static SemabsLdsAttr attr;                                                                                              \
         semabs_ensure_lds(&k_linear_rows<NT>, 160 * 1024, attr);                                                                \
-        hipLaunchKernelGGL(k_linear_rows<NT>, dim3((unsigned)nb), dim3(256), lds, s, X, ldx, W, w_sn, w_sk, bias, Y, R, Ci, Co, act, slope, in_scale, out_scale); \
+        hipLaunchKernelGGL(k_linear_rows<NT>, dim3((unsigned)nb), dim3(256), lds, s, X, ldx, W, w_sn, w_sk, bias, Y, R, Ci, Co, act, slope, in_scale, out_scale, relu_mask, absmax_bits); \
     }
     if (Co16 <= 32) LR_LAUNCH(2) else if (Co16 <= 64) LR_LAUNCH(4) else LR_LAUNCH(8)
 #undef LR_LAUNCH

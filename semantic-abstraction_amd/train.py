@@ -245,7 +245,7 @@ class UNetTrainer:
         if self.rows_linear and m["cin"] % 4 == 0 and m["cout"] <= 128 and wf.is_contiguous():
             # the 1 x 1 x 1 convolution IS a row-linear layer over the voxels: semabs_linear_rows streams it at HBM speed (the gather kernel: 1.28 ms at 8 x 128^3)
             _lib.call("semabs_linear_rows", _lib.ptr(x), m["cin"], _lib.ptr(wf), m["cin"], 1, _lib.ptr(self.p[self.prefix + "final_conv.bias"]), _lib.ptr(y),
-                      B * D0 * D1 * D2, m["cin"], m["cout"], 0, 0.0, None, None, st)
+                      B * D0 * D1 * D2, m["cin"], m["cout"], 0, 0.0, None, None, None, None, st)
         else:
             _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(y), None, None,
                       _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1 | m["fwd"][2], st)
@@ -375,7 +375,10 @@ class UNetTrainer:
 
     def _block_bwd(self, recs, dOut, in_scale=None):
         r1, r2, r3 = recs
-        dS = self._ew(dOut, r3.y, 0, want_max=True, in_scale=in_scale)         # through the final ReLU of relu(conv3 + out1)
+        if getattr(dOut, "_semabs_relu_masked", False) and in_scale is None:
+            dS = dOut                                        # (the pooling backward already went through this block's final ReLU and recorded max |dS|)
+        else:
+            dS = self._ew(dOut, r3.y, 0, want_max=True, in_scale=in_scale)     # through the final ReLU of relu(conv3 + out1)
         dz2 = self._conv_bwd(r3, dS, relu_in=True)          # d out2, already through conv2's ReLU (r3.x = out2)
         dz1 = self._conv_bwd(r2, dz2, add1=dS, relu_in=True)   # d out1 = via conv2 + the residual branch, through conv1's ReLU
         return self._conv_bwd(r1, dz1)
@@ -426,7 +429,15 @@ class UNetTrainer:
                 sc, sh, s2 = self._scale(g, B, cout)
                 wf = self.p[self.prefix + "final_conv.weight"].detach()
                 if self.rows_linear and cout % 4 == 0 and cin <= 128 and wf.is_contiguous():      # dx = (s g) W: the transposed row-linear layer (see forward)
-                    _lib.call("semabs_linear_rows", _lib.ptr(g), cout, _lib.ptr(wf), 1, cin, None, _lib.ptr(dx), R, cout, cin, 0, 0.0, _lib.ptr(s2), None, st)
+                    # ... scaled back on the way out, through the mask of the ReLU that produced x (the last decoder block's final ReLU), max |dx| recorded:
+                    # that block's own mask pass over the 8 x 128^3 x 16 tensor (read, read, write: 0.58 ms) is not run
+                    bits = self.arena.zeros((1,), torch.int32)
+                    _lib.call("semabs_linear_rows", _lib.ptr(g), cout, _lib.ptr(wf), 1, cin, None, _lib.ptr(dx), R, cout, cin, 0, 0.0, _lib.ptr(s2), s2[1:].data_ptr(),
+                              _lib.ptr(x), _lib.ptr(bits), st)
+                    dx._semabs_absmax = bits
+                    dx._semabs_relu_masked = True
+                    g, g_scale = dx, None
+                    continue
                 else:
                     _lib.call("semabs_conv3d", _lib.ptr(g), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dx), _lib.ptr(sc), _lib.ptr(sh), None, None,
                               B, D0, D1, D2, cout, cin, 1, 0, 1 | m["bwd"][2], st)
@@ -449,7 +460,12 @@ class UNetTrainer:
                 B, D0, D1, D2, Cc = x.shape
                 dx = torch.empty_like(x)
                 # route the gradient to the arg-max AND add the skip's gradient, in one pass
-                _lib.call("semabs_maxpool3d_bwd_add", _lib.ptr(x), _lib.ptr(g), _lib.ptr(d_skip.pop(level)), _lib.ptr(dx), None, B, D0, D1, D2, Cc, st)
+                # ... AND apply the mask of the ReLU that produced x (= the output of the residual block whose backward comes next), with max |dx| for its
+                # dynamic gradient scale: the block's own mask pass (read dx, read x, write) is not run
+                bits = self.arena.zeros((1,), torch.int32)
+                _lib.call("semabs_maxpool3d_bwd_add", _lib.ptr(x), _lib.ptr(g), _lib.ptr(d_skip.pop(level)), _lib.ptr(dx), _lib.ptr(bits), 1, B, D0, D1, D2, Cc, st)
+                dx._semabs_absmax = bits
+                dx._semabs_relu_masked = True
                 g = dx
         assert not d_skip
         if g_scale is not None:                              # (a network whose first tape entry is not a block)
@@ -554,7 +570,7 @@ class VOOLTrainer:
             # (round 5) the matrix-core row kernel: the fp32 FMA kernel below took 0.73 ms per layer at 640 k - 1.6 M rows
             s2 = self.unet._scale(x, 1, Ci)[2] if grad_in else None
             _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), Ci, 1, _lib.ptr(b), _lib.ptr(y), R, Ci, Co, int(act), SLOPE,
-                      _lib.ptr(s2), None if s2 is None else s2[1:].data_ptr(), _lib.stream())
+                      _lib.ptr(s2), None if s2 is None else s2[1:].data_ptr(), None, None, _lib.stream())
             return y
         _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
         return y
@@ -573,7 +589,7 @@ class VOOLTrainer:
             s2 = self.unet._scale(x, 1, Ci)[2] if grad_in else None
             wd = w.detach()
             _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(wd), 1 if transposed else wd.shape[1], wd.shape[1] if transposed else 1,
-                      _lib.ptr(b), _lib.ptr(y), R, Ci, Co, 1 if act else 0, SLOPE, _lib.ptr(s2), None, _lib.stream())
+                      _lib.ptr(b), _lib.ptr(y), R, Ci, Co, 1 if act else 0, SLOPE, _lib.ptr(s2), None, None, None, _lib.stream())
             return (y, s2[1:]) if grad_in else y
         hi, lo, pk = self.unet.layouts.get(f"lin:{wkey}:{int(transposed)}", w, (lambda t: _flat_packed(_pad32(t.t().contiguous()))) if transposed else
                                            (lambda t: _flat_packed(_pad32(t.contiguous()))))

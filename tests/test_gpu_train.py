@@ -141,19 +141,27 @@ def test_linear_rows_vs_fp64(R, Ci, Co, act, transposed, scaled):
     s = torch.tensor([2.0 ** 20 if scaled else 1.0, 2.0 ** -20 if scaled else 1.0], device="cuda")
     y = torch.full((R + 16, Co), 7.0, device="cuda")
     _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
-              _lib.ptr(y), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, _lib.stream())
+              _lib.ptr(y), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, None, None, _lib.stream())
     ref = x.double() @ (w.double() if transposed else w.double().T)
     ref = ref * float(s[0]) + (0 if scaled else b.double())
     if scaled:                                               # ... and scaled back in the epilogue: the unscaled product of 1e-7-sized values
         y2 = torch.empty(R, Co, device="cuda")
         _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, None, _lib.ptr(y2), R, Ci, Co, 0, 0.01,
-                  _lib.ptr(s), s[1:].data_ptr(), _lib.stream())
+                  _lib.ptr(s), s[1:].data_ptr(), None, None, _lib.stream())
         assert float((y2.double() - ref / float(s[0])).abs().max()) < 2e-6 * float(ref.abs().max()) / float(s[0])
     if act:
         ref = torch.where(ref > 0, ref, 0.01 * ref)
     err = float((y[:R].double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-6, err
     assert bool((y[R:] == 7.0).all())
+    # the same through a ReLU mask (Y = 0 where mask <= 0) with max |Y| recorded
+    mask = torch.randn(R, Co, device="cuda", generator=g)
+    bits = torch.zeros(1, dtype=torch.int32, device="cuda")
+    y3 = torch.empty(R, Co, device="cuda")
+    _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
+              _lib.ptr(y3), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), _lib.ptr(bits), _lib.stream())
+    assert bool((y3 == torch.where(mask > 0, y[:R], torch.zeros_like(y3))).all())
+    assert float(bits.view(torch.float32)) == float(y3.abs().max())
 
 
 @pytest.mark.parametrize("P,M", [(3, 1001), (1, 16), (4, 40000)])
