@@ -366,8 +366,8 @@ int semabs_linear_f32(const float* X, const float* W, const float* bias, float* 
 /* The same layer on the matrix cores with fp32-like accuracy (operands split into fp16 hi + lo, three products): Y = act((s X) W^T + b), W addressed as
  * W[n * w_sn + k * w_sk] (plain: Ci, 1; transposed: 1, Co), in_scale = optional device scalar s (the power-of-two scale of a gradient input; the output
  * stays scaled unless out_scale - a device scalar the accumulator is multiplied by, e.g. 1 / s - is given).  Ci % 4 == 0, Co <= 128, act 0 none / 1 LeakyReLU(slope).                                  net.py:358-367, 215-256 (and their backward)
- * relu_mask (optional, like Y): Y = 0 where relu_mask <= 0 (Y is a gradient in front of the ReLU that produced relu_mask); absmax_bits (optional, uint32 [1],
- * zeroed by the caller): bit pattern of max |Y|. */
+ * relu_mask (optional, like Y): Y = 0 where relu_mask <= 0 (Y is a gradient in front of the ReLU that produced relu_mask), or with act = 2 Y *= slope
+ * there (LeakyReLU; no activation is applied to Y itself); absmax_bits (optional, uint32 [1], zeroed by the caller): bit pattern of max |Y|. */
 int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
                        int act, float slope, const float* in_scale, const float* out_scale, const float* relu_mask, unsigned int* absmax_bits, void* stream);
 

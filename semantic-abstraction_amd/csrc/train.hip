@@ -935,7 +935,8 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
                     float o = acc[j][i] * so + bv[j];
                     if (act == 1) o = o > 0.f ? o : slope * o;
                     if (r < R) {
-                        if (relu_mask && !(relu_mask[r * Co + j * 16 + vl] > 0.f)) o = 0.f;     // Y is a gradient in front of the ReLU that produced relu_mask
+                        // Y is a gradient in front of the ReLU (act 0) / LeakyReLU (act 2: factor `slope`) that produced relu_mask
+                        if (relu_mask && !(relu_mask[r * Co + j * 16 + vl] > 0.f)) o = act == 2 ? o * slope : 0.f;
                         Y[r * Co + j * 16 + vl] = o;
                         amax = fmaxf(amax, fabsf(o));
                     }
@@ -950,7 +951,7 @@ extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long
                                   void* stream) {
     if (R == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && W && Y && R > 0 && Ci > 0 && Co > 0, "semabs_linear_rows: bad args");
-    SEMABS_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0 && Ci <= 512 && Co <= 128 && (act == 0 || act == 1), "semabs_linear_rows: Ci % 4 == 0, Ci <= 512, Co <= 128, act 0 / 1");
+    SEMABS_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0 && Ci <= 512 && Co <= 128 && (act == 0 || act == 1 || (act == 2 && relu_mask)), "semabs_linear_rows: Ci % 4 == 0, Ci <= 512, Co <= 128, act 0 / 1 (2 with relu_mask)");
     const int Kp = (Ci + 31) / 32 * 32, Co16 = (Co + 15) / 16 * 16;
     const size_t lds = (size_t)Co16 * (Kp + 8) * 2 * 2;
     SEMABS_REQUIRE(lds <= 160 * 1024, "semabs_linear_rows: the weight matrix does not fit LDS");

@@ -575,13 +575,27 @@ class VOOLTrainer:
         _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
         return y
 
-    def _linear_mfma(self, x, wkey, b, act, grad_in=False, transposed=False):
+    def _linear_mfma(self, x, wkey, b, act, grad_in=False, transposed=False, mask=None):
         """The 128 -> 128 MLP layers as 1x1x1 convolutions on the split-fp16 MFMA kernel (fp32-like accuracy); wkey names the weight parameter,
         transposed = multiply by its transpose (the data gradient).  grad_in: x is a gradient (arbitrarily small): scaled by a power of two on
-        the way in and back on the way out."""
+        the way in and back on the way out.  mask (with grad_in): the layer input's pre-activation sign source h - the result is the UNSCALED gradient in
+        front of that LeakyReLU (y * (h > 0 ? 1 : SLOPE)) with its max |.| recorded, in the same pass where the row kernel runs."""
         R, Ci = x.shape
         w = self.params[wkey]
         Co = w.shape[1] if transposed else w.shape[0]
+        if mask is not None:
+            assert grad_in and b is None and not act
+            if self.rows_linear and Ci % 4 == 0 and Co <= 128:
+                y = torch.empty(R, Co, dtype=torch.float32, device=self.dev)
+                s2 = self.unet._scale(x, 1, Ci)[2]
+                bits = self.unet.arena.zeros((1,), torch.int32)
+                wd = w.detach()
+                _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(wd), 1 if transposed else wd.shape[1], wd.shape[1] if transposed else 1,
+                          None, _lib.ptr(y), R, Ci, Co, 2, SLOPE, _lib.ptr(s2), s2[1:].data_ptr(), _lib.ptr(mask), _lib.ptr(bits), _lib.stream())
+                y._semabs_absmax = bits
+                return y
+            y_, inv_ = self._linear_mfma(x, wkey, None, 0, grad_in=True, transposed=transposed)
+            return self.unet._ew(y_, mask, 1, want_max=True, in_scale=inv_)
         if self.rows_linear and Ci % 4 == 0 and Co <= 128:
             # (round 5) the matrix-core row kernel reads W (or its transpose, through strides) straight from the fp32 parameter and splits it while
             # staging: no per-step operand gather, and 0.05 - 0.1 ms per layer where the 1 x 1 x 1 "convolution" on the gather kernel took 0.7 - 0.9 ms
@@ -684,8 +698,7 @@ class VOOLTrainer:
             g["relation_embeddings." + n].add_(drel[d])
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
         u._colsum(dO, g[ss + "2.bias"])
-        y_, inv_ = self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True)
-        dh = u._ew(y_, h, 1, want_max=True, in_scale=inv_)
+        dh = self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True, mask=h)
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
         u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0, grad_in=True)               # [D*M, 36]
@@ -702,12 +715,10 @@ class VOOLTrainer:
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
-        y_, inv_ = self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True)
-        dh2 = u._ew(y_, h2, 1, want_max=True, in_scale=inv_)
+        dh2 = self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True, mask=h2)
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
         u._colsum(dh2, g[cn + "2.bias"])
-        y_, inv_ = self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True)
-        dh1 = u._ew(y_, h1, 1, want_max=True, in_scale=inv_)
+        dh1 = self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True, mask=h1)
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
         u._colsum(dh1, g[cn + "0.bias"])
 

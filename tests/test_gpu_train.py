@@ -162,6 +162,10 @@ def test_linear_rows_vs_fp64(R, Ci, Co, act, transposed, scaled):
               _lib.ptr(y3), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), _lib.ptr(bits), _lib.stream())
     assert bool((y3 == torch.where(mask > 0, y[:R], torch.zeros_like(y3))).all())
     assert float(bits.view(torch.float32)) == float(y3.abs().max())
+    if not act:                                              # act = 2: the LeakyReLU form of the mask (Y *= slope where mask <= 0)
+        _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
+                  _lib.ptr(y3), R, Ci, Co, 2, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), None, _lib.stream())
+        assert bool((y3 == torch.where(mask > 0, y[:R], y[:R] * 0.01)).all())
 
 
 @pytest.mark.parametrize("P,M", [(3, 1001), (1, 16), (4, 40000)])
