@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
         d[u] = ld_nt4(dXn + e); x[u] = ld_nt4(X + e);
         if (add1) a1[u] = ld_nt4(add1 + e);
         if (add2) a2[u] = ld_nt4(add2 + e);
-        if (mask_y) y[u] = ld_nt4(mask_y + e);
+        if (mask_y && mask_y != X) y[u] = ld_nt4(mask_y + e);           // (mask_y == X - the layer's input is the post-ReLU activation - is the usual case: no second load)
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
         if (add1) { o[0] += a1[u].x; o[1] += a1[u].y; o[2] += a1[u].z; o[3] += a1[u].w; }
         if (add2) { o[0] += a2[u].x; o[1] += a2[u].y; o[2] += a2[u].z; o[3] += a2[u].w; }
         if (mask_y) {                                      // X is the post-ReLU output of the previous layer only when the caller says so
-            o[0] = y[u].x > 0.f ? o[0] : 0.f; o[1] = y[u].y > 0.f ? o[1] : 0.f; o[2] = y[u].z > 0.f ? o[2] : 0.f; o[3] = y[u].w > 0.f ? o[3] : 0.f;
+            const float4 mk = mask_y == X ? x[u] : y[u];
+            o[0] = mk.x > 0.f ? o[0] : 0.f; o[1] = mk.y > 0.f ? o[1] : 0.f; o[2] = mk.z > 0.f ? o[2] : 0.f; o[3] = mk.w > 0.f ? o[3] : 0.f;
         }
         if (ok[u]) {
             *reinterpret_cast<float4*>(dX + (vbase + i) * 4) = make_float4(o[0], o[1], o[2], o[3]);

@@ -3,4 +3,4 @@ python -m pytest tests/test_gpu_train.py tests/test_gpu_autograd_boundary.py tes
 for i in 1 2; do
   echo "--- step"; python tools/train_bench.py --steps 6 --warmup 2 2>/dev/null | tail -1 | cut -c1-120
 done
-python tools/train_calls.py "semabs_ew" 8 2>/dev/null | head -8
+python tools/train_calls.py "semabs_gn_bwd_apply" 8 2>/dev/null | head -8
