@@ -495,6 +495,11 @@ struct ConvArgs {
     const f16* wp_hi; const f16* wp_lo;   // optional (k_conv_brick): fragment-packed copy of the weights, see SEMABS_CONV_PACKED
     int ncls; long cls_off[8];            // k_conv only: > 0 = ConvTranspose3d, all 8 output parity classes in ONE launch (blockIdx.z = class:
                                           // taps, weight block and output parity are derived from it in the kernel)
+    // k_conv16_lds<.., GNB> only (semabs_conv3d_gnbwd): the convolution is a DATA GRADIENT and its epilogue is the GroupNorm backward of the layer input
+    // `resid` = X: y = k0 acc - k1 - ((X - mean) rstd) k2 [masked by X > 0], coef = (k0, k1, k2) per (b, channel), mean / rstd per (b, group of gnb_G)
+    const float* gnb_coef = nullptr; const float* gnb_mean = nullptr; const float* gnb_rstd = nullptr; int gnb_G = 0, gnb_relu = 0;
+    unsigned int* gnb_bits = nullptr;     // optional: receives the bit pattern of max |y|
+    const float* gnb_add = nullptr;       // optional: a tensor like y added before the mask (the residual branch's gradient)
 };
 
 template <bool F32>
@@ -742,7 +747,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #define C16_H1 (C16_T1 + 2)
 #define C16_H2 (C16_T2 + 2)
 
-template <bool F32, int C16_T0>      // brick depth 8 (fp16: 2 x 57.6 KB LDS) or 4 (exact: 2 x 69 KB): one 8-wave workgroup per CU, two halo buffers
+// max |x| over the wave -> one atomicMax on the bit pattern (non-negative floats order like unsigned integers)
+__device__ __forceinline__ void conv_absmax_commit(unsigned int* bits, float m) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(bits, __float_as_uint(m));
+}
+// GNB (round 5, exact mode only): the launch is the DATA GRADIENT of a GroupNorm -> Conv3d layer and its epilogue applies the GroupNorm backward to the
+// accumulators (see ConvArgs::gnb_*): the layer input's rows come through the residual registers, the per-(volume, channel) coefficients through a small LDS
+// table - the separate apply pass (read dXn, read X, write dX: 0.55 ms per layer at 8 x 128^3 x 16) and the dXn tensor itself are gone.
+template <bool F32, int C16_T0, bool GNB = false>      // brick depth 8 (fp16: 2 x 57.6 KB LDS) or 4 (exact: 2 x 69 KB): one 8-wave workgroup per CU, two halo buffers
 __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2;
     // One plane = the 16-byte half-voxels (channels 0-7 or 8-15) of the whole halo.  Its size is rounded up to a multiple of 256 B: a
@@ -765,6 +779,17 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     // CONSUME brick i on the matrix pipe; one barrier per brick.  VALU and MFMA now overlap on every SIMD by construction.
     const bool producer = wid >= 4;
     const int ptid = tid - 256;                                     // producer thread index (valid when producer)
+    float* const s_gnb = reinterpret_cast<float*>(smem + (size_t)BUF_EL * 2 * 2);     // GNB: [B][3 = (A, Bx, C)][16 channels] behind the two halo buffers
+    if (GNB) {
+        // y = k0 acc - k1 - (x - mean) rstd k2 = A acc + Bx x + C
+        for (int e = tid; e < a.B * 16; e += 512) {
+            const int b = e >> 4, c = e & 15, g = c / (16 / a.gnb_G);
+            const float mu = a.gnb_mean[b * a.gnb_G + g], rs = a.gnb_rstd[b * a.gnb_G + g];
+            const float* k = a.gnb_coef + (long)e * 3;
+            s_gnb[b * 48 + c] = k[0]; s_gnb[b * 48 + 16 + c] = -rs * k[2]; s_gnb[b * 48 + 32 + c] = mu * rs * k[2] - k[1];
+        }
+    }
+    float amax = 0.f;
 
     auto produce = [&](int brick, int buf) {
         const int b = brick / per_vol; int t = brick - b * per_vol;
@@ -967,11 +992,34 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
 #endif
             // acc[mi][r] = out[voxel x0 + vl of row mi][cout = 4 * kg + r]
             float ps[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x4 cA, cB, cC;
+            // the optional added tensor's rows are requested two rows ahead of their use, behind the last MFMA (all eight at once, like the residual rows, do not
+            // fit: the kernel is at 253 of 256 registers)
+            f32x4 ad[MR];
+            if (GNB && a.gnb_add) {
+                ad[0] = *reinterpret_cast<const f32x4*>(a.gnb_add + vol_off + ooff[0]);
+                ad[1] = *reinterpret_cast<const f32x4*>(a.gnb_add + vol_off + ooff[1]);
+            }
+            if (GNB) {
+                cA = *reinterpret_cast<const f32x4*>(s_gnb + b * 48 + 4 * kg); cB = *reinterpret_cast<const f32x4*>(s_gnb + b * 48 + 16 + 4 * kg);
+                cC = *reinterpret_cast<const f32x4*>(s_gnb + b * 48 + 32 + 4 * kg);
+            }
 #pragma unroll
             for (int mi = 0; mi < MR; ++mi) {
                 float o[4];
+                if (GNB) {
+                    if (a.gnb_add && mi + 2 < MR) { ad[mi + 2] = *reinterpret_cast<const f32x4*>(a.gnb_add + vol_off + ooff[mi + 2]); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = acc[mi][e] * cA[e] + (res[mi][e] * cB[e] + cC[e]);
+                        if (a.gnb_add) o[e] += ad[mi][e];
+                        if (a.gnb_relu) o[e] = res[mi][e] > 0.f ? o[e] : 0.f;
+                        amax = fmaxf(amax, fabsf(o[e]));
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[mi][e] + bias4[e] + res[mi][e], relu_floor);
+                }
                 if (!F32) {                                          // statistics of the values as stored
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (float)(f16)o[e];
@@ -1020,6 +1068,7 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
             lds_barrier();
         }
         if (a.stats) flush_stats();
+        if (GNB && a.gnb_bits) conv_absmax_commit(a.gnb_bits, amax);
     }
 }
 
@@ -1060,6 +1109,13 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2 * 2;   // two half-voxel planes (256-B padded), hi + lo, two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
         long nb = semabs_num_cus(); if (nb > total) nb = total;
+        if (a.gnb_coef) {
+            static SemabsLdsAttr attrg;
+            semabs_ensure_lds(&k_conv16_lds<true, T0, true>, (int)(lds + 32 * 192), attrg);
+            hipLaunchKernelGGL((k_conv16_lds<true, T0, true>), dim3((unsigned)nb), dim3(512), lds + (size_t)a.B * 192, s, a);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
         static SemabsLdsAttr attr;
         semabs_ensure_lds(&k_conv16_lds<true, T0>, (int)lds, attr);
         hipLaunchKernelGGL((k_conv16_lds<true, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
@@ -1623,6 +1679,40 @@ extern "C" int semabs_conv3d_stats(const void* x, const void* w_hi, const void* 
                                    int relu, int act_f32, double* out_sums, int out_groups, void* stream) {
     SEMABS_REQUIRE(out_sums, "semabs_conv3d_stats: out_sums is null");
     return conv3d_impl(x, w_hi, w_lo, y, gn_scale, gn_shift, bias, resid, B, D0, D1, D2, Cin, Cout, ksize, relu, act_f32, out_sums, out_groups, stream);
+}
+
+// Data gradient of a GroupNorm -> Conv3d 3x3x3 layer WITH the GroupNorm backward applied in the epilogue (round 5):
+//   dX = k0 conv(dZ, Wbwd) - k1 - ((X - mean) rstd) k2 [+ add1]  [0 where X <= 0 if relu_mask],   coef fp32 [B, Cin_of_the_layer, 3] = (k0, k1, k2) of semabs_gn_bwd_coef,
+// i.e. semabs_conv3d(dZ ..) followed by semabs_gn_bwd_apply(.., add1) without the intermediate tensor.  dZ fp32 [B, D0, D1, D2, 16] with its dynamic
+// scale as the input affine (in_scale / in_shift), X fp32 = the layer's GroupNorm input, mean / rstd fp32 [B, G].  Shapes: 16 -> 16 channels, D0 % 8 == 0,
+// D1 % 8 == 0, D2 % 16 == 0, B <= 32, fewer than 2^31 elements per volume (the level-0 kernel); ask semabs_conv3d_gnbwd_supported.
+static bool conv3d_gnbwd_ok(int B, int D0, int D1, int D2, int Cin, int Cout) {
+    return B > 0 && B <= 32 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31);
+}
+extern "C" int semabs_conv3d_gnbwd_supported(int B, int D0, int D1, int D2, int Cin, int Cout, int* ok) {
+    SEMABS_REQUIRE(ok, "semabs_conv3d_gnbwd_supported: null pointer");
+    *ok = conv3d_gnbwd_ok(B, D0, D1, D2, Cin, Cout) ? 1 : 0;
+    return SEMABS_OK;
+}
+extern "C" int semabs_conv3d_gnbwd(const void* dZ, const void* w_hi, const void* w_lo, void* dX, const float* in_scale, const float* in_shift, const void* X,
+                                   const float* mean, const float* rstd, const float* coef, int G, const float* add1, int relu_mask, unsigned int* absmax_bits,
+                                   int B, int D0, int D1, int D2, int Cin, int Cout, int act_flags, void* stream) {
+    if (B == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(dZ && w_hi && w_lo && dX && X && mean && rstd && coef, "semabs_conv3d_gnbwd: null pointer");
+    SEMABS_REQUIRE((act_flags & 1) && conv3d_gnbwd_ok(B, D0, D1, D2, Cin, Cout) && G > 0 && 16 % G == 0, "semabs_conv3d_gnbwd: exact mode, 16 -> 16 channels, see semabs_conv3d_gnbwd_supported");
+    SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gnbwd: in_scale and in_shift go together");
+    ConvArgs a;
+    a.x = dZ; a.y = dX; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
+    a.bias = nullptr; a.resid = X; a.B = B; a.I0 = D0; a.I1 = D1; a.I2 = D2; a.O0 = D0; a.O1 = D1; a.O2 = D2;
+    a.M0 = D0; a.M1 = D1; a.M2 = D2; a.os = 1; a.is = 1; a.op0 = a.op1 = a.op2 = 0; a.Cin = Cin; a.Cout = Cout; a.relu = 0;
+    a.ntaps = 27; a.Kp = ((27 * Cin + 31) / 32) * 32;
+    a.stats = nullptr; a.ablate = 0; a.trace = nullptr; a.wp_hi = nullptr; a.wp_lo = nullptr; a.ncls = 0; a.ksplit = 1;
+    int t = 0;
+    for (int kd = 0; kd < 3; ++kd)
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw, ++t) { a.td0[t] = kd - 1; a.td1[t] = kh - 1; a.td2[t] = kw - 1; }
+    a.gnb_coef = coef; a.gnb_mean = mean; a.gnb_rstd = rstd; a.gnb_G = G; a.gnb_relu = relu_mask; a.gnb_bits = absmax_bits; a.gnb_add = add1;
+    return conv16_lds_launch(a, 1, (hipStream_t)stream);
 }
 
 // General gather convolution (used for the data gradients of training): y[b, m, :] = sum_taps W_tap . x[b, m * in_stride + td_tap, :]

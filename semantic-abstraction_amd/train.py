@@ -124,6 +124,9 @@ class UNetTrainer:
         # GroupNorm-backward reductions (sum dXn, sum dXn xhat) from the weight-gradient pass instead of a pass over (dXn, x): semabs_wgrad_conv3_gn.
         self.wgrad_gn = os.environ.get("SEMABS_WGRAD_GN", "1") == "1"      # A/B: 0 = semabs_wgrad_conv3 + semabs_chan_reduce
         self._wg_gn_ok = {}
+        # ... and, the sums being known before the data gradient, the GroupNorm-backward apply as that convolution's epilogue: semabs_conv3d_gnbwd
+        self.fuse_gn_apply = os.environ.get("SEMABS_FUSE_GN_APPLY", "1") == "1"      # A/B: 0 = semabs_conv3d + semabs_gn_bwd_apply
+        self._gnbwd_ok = {}
         self.mfma_wgrad = True          # tests / tuning: False = the fp32 VALU reduction kernel for every conv weight gradient
         self.debug = None               # tests: list collecting (tape kind, incoming gradient) during backward
         self.arena = _ZeroArena(self.dev)
@@ -279,6 +282,16 @@ class UNetTrainer:
             r = self._wg_gn_ok[key] = bool(k.value)
         return r
 
+    def _conv3d_gnbwd_ok(self, B, D0, D1, D2, cin_conv, cout_conv) -> bool:
+        key = (B, D0, D1, D2, cin_conv, cout_conv)
+        r = self._gnbwd_ok.get(key)
+        if r is None:
+            import ctypes as C
+            k = C.c_int(0)
+            _lib.call("semabs_conv3d_gnbwd_supported", B, D0, D1, D2, cin_conv, cout_conv, C.byref(k))
+            r = self._gnbwd_ok[key] = bool(k.value)
+        return r
+
     def _wg_scratch(self):
         """(pointer, capacity in floats) of the buffer semabs_wgrad_mfma parks its row chunks' partial sums in (64 MB, allocated once)."""
         if self._wgs is None:
@@ -356,6 +369,19 @@ class UNetTrainer:
         else:
             _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
                       cout, cin, 27, TAPS_CONV3, 1, st)
+        if have_red and self.fuse_gn_apply and self._conv3d_gnbwd_ok(B, D0, D1, D2, cout, cin):
+            # the sums are known BEFORE the data gradient (they came out of the weight-gradient pass), so the GroupNorm backward can be the data-gradient
+            # convolution's epilogue: no dXn tensor, no apply pass (read dXn, read x, write dX)
+            coef = torch.empty(B, cin, 3, dtype=torch.float32, device=self.dev)
+            _lib.call("semabs_gn_bwd_coef", _lib.ptr(red), _lib.ptr(self.p[key + "groupnorm.weight"]), _lib.ptr(r.rstd), _lib.ptr(inv), _lib.ptr(coef),
+                      _lib.ptr(self.g[key + "groupnorm.weight"]), _lib.ptr(self.g[key + "groupnorm.bias"]), B, cin, G, nvox, st)
+            dX = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
+            bits = self.arena.zeros((1,), torch.int32)
+            _lib.call("semabs_conv3d_gnbwd", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dX), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r.x),
+                      _lib.ptr(r.mean), _lib.ptr(r.rstd), _lib.ptr(coef), G, _lib.ptr(add1), 1 if relu_in else 0, _lib.ptr(bits), B, D0, D1, D2, cout, cin,
+                      1 | m["bwd"][2], st)
+            dX._semabs_absmax = bits
+            return dX
         dXn = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)      # = s * (d loss / d GN output)
         _lib.call("semabs_conv3d", _lib.ptr(dZ), _lib.ptr(m["bwd"][0]), _lib.ptr(m["bwd"][1]), _lib.ptr(dXn), _lib.ptr(sc), _lib.ptr(sh), None, None,
                   B, D0, D1, D2, cout, cin, 3, 0, 1 | m["bwd"][2], st)
