@@ -334,9 +334,9 @@ int semabs_wgrad_conv3_gn(const float* dZ, const float* X, const float* mean, co
  *   dX = k0 * conv(dZ, Wbwd) - k1 - ((X - mean) * rstd) * k2 [+ add1]  [0 where X <= 0 if relu_mask],   coef fp32 [B, 16, 3] = (k0, k1, k2) of semabs_gn_bwd_coef
  * = semabs_conv3d(dZ, ..) + semabs_gn_bwd_apply(.., add1) without the intermediate tensor and its two passes (add1: optional, like dX).  w_hi / w_lo = the layer's data-gradient
  * weights (as for semabs_conv3d), in_scale / in_shift = dZ's dynamic scale as an input affine, X = the layer's GroupNorm input, mean / rstd fp32 [B, G];
- * act_flags as semabs_conv3d (exact mode required); absmax_bits (optional, zeroed): max |dX|.  16 -> 16 channels, D0 % 8 == 0, D1 % 8 == 0, D2 % 16 == 0,
- * B <= 32: ask semabs_conv3d_gnbwd_supported.  Replaces, for these layers, the data-gradient + GroupNorm halves of loss.backward() (unet3d.py:63-118). */
-int semabs_conv3d_gnbwd_supported(int B, int D0, int D1, int D2, int Cin, int Cout, int* ok);
+ * act_flags as semabs_conv3d (exact mode required); absmax_bits (optional, zeroed): max |dX|.  16 -> 16 channels with D0 % 8 == 0, D1 % 8 == 0, D2 % 16 == 0,
+ * B <= 32, or - without add1 - channel counts that are multiples of 32 with D0 % 4 == 0: ask semabs_conv3d_gnbwd_supported.  Replaces, for these layers, the data-gradient + GroupNorm halves of loss.backward() (unet3d.py:63-118). */
+int semabs_conv3d_gnbwd_supported(int B, int D0, int D1, int D2, int Cin, int Cout, int G, int have_add1, int* ok);
 int semabs_conv3d_gnbwd(const void* dZ, const void* w_hi, const void* w_lo, void* dX, const float* in_scale, const float* in_shift, const void* X,
                         const float* mean, const float* rstd, const float* coef, int G, const float* add1, int relu_mask, unsigned int* absmax_bits, int B,
                         int D0, int D1, int D2, int Cin, int Cout, int act_flags, void* stream);

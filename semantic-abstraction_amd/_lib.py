@@ -97,7 +97,7 @@ SIGNATURES = {
     "semabs_wgrad_mfma": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, C.c_char_p, I, P, L, P],
     "semabs_wgrad_conv3": [P, P, P, P, P, P, I, I, I, I, I, I, I, P, L, P],
     "semabs_wgrad_conv3_supported": [I, I, I, I, I, L, C.POINTER(I)],
-    "semabs_conv3d_gnbwd_supported": [I, I, I, I, I, I, C.POINTER(I)],
+    "semabs_conv3d_gnbwd_supported": [I, I, I, I, I, I, I, I, C.POINTER(I)],
     "semabs_conv3d_gnbwd": [P, P, P, P, P, P, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, P],
     "semabs_wgrad_conv3_gn_supported": [I, I, I, I, I, I, L, C.POINTER(I)],
     "semabs_wgrad_conv3_gn": [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, P, L, P],

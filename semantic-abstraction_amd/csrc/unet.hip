@@ -1144,7 +1144,8 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
 // TX = tile extent along the innermost axis: 16 (one fragment = 16 consecutive voxels of a row, a wave owns 4 rows) or 8 (volumes 8 wide, the
 // 8^3 level: one fragment = two y-rows x 8 voxels, a wave owns 2 fragments; round 2 - that level used to run on the gather kernel at 0.11 of
 // its bound).
-template <bool F32, int CW, int NB, bool ONE, bool PERSIST, int TX = 16>   // CW = channels staged at a time (16 or 32); ONE: Cin == CW (compile-time offsets)
+// GNB (round 5): the data-gradient launch whose epilogue is the GroupNorm backward of the layer input (ConvArgs::gnb_*, as in k_conv16_lds<.., GNB>).
+template <bool F32, int CW, int NB, bool ONE, bool PERSIST, int TX = 16, bool GNB = false>   // CW = channels staged at a time (16 or 32); ONE: Cin == CW (compile-time offsets)
 __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
     constexpr int T0 = 4, H0 = T0 + 2, HX = TX + 2, HALO = H0 * C16_H1 * HX, NTHR = 512;
     constexpr int R = TX / 4;                               // fragments (16 voxels each) per wave: the tile has 2 * TX of them
@@ -1418,6 +1419,22 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
         float st_s[NB], st_q[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { st_s[nb] = 0.f; st_q[nb] = 0.f; }
+        // GNB: (k0, k1, k2) of this lane's four channels per output block - 12 contiguous floats - and their group's mean / rstd, requested together
+        // with the rows of the layer input (q): one round trip
+        float gk[NB][12], gmu[NB], grs[NB];
+        float amax = 0.f;
+        if (GNB) {
+            const int cg = a.Cout / a.gnb_G;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = cout0 + nb * 16 + 4 * k2;
+                const float4* kp = reinterpret_cast<const float4*>(a.gnb_coef + ((long)b * a.Cout + co) * 3);
+                const float4 k0 = kp[0], k1 = kp[1], k2v = kp[2];
+                gk[nb][0] = k0.x; gk[nb][1] = k0.y; gk[nb][2] = k0.z; gk[nb][3] = k0.w; gk[nb][4] = k1.x; gk[nb][5] = k1.y; gk[nb][6] = k1.z; gk[nb][7] = k1.w;
+                gk[nb][8] = k2v.x; gk[nb][9] = k2v.y; gk[nb][10] = k2v.z; gk[nb][11] = k2v.w;
+                gmu[nb] = a.gnb_mean[b * a.gnb_G + co / cg]; grs[nb] = a.gnb_rstd[b * a.gnb_G + co / cg];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int f = wid * R + r;
@@ -1443,10 +1460,23 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
                 const long oi = obase[r] + nb * 16;
                 const float a0 = acc[r][nb][0], a1 = acc[r][nb][1], a2 = acc[r][nb][2], a3 = acc[r][nb][3];
                 float o[4];
-                o[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a0))) + q[r][nb][0];
-                o[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a1))) + q[r][nb][1];
-                o[2] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a2))) + q[r][nb][2];
-                o[3] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a3))) + q[r][nb][3];
+                o[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a0)));
+                o[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a1)));
+                o[2] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a2)));
+                o[3] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a3)));
+                if (GNB) {                                   // o = the data gradient dXn of channels co .. co + 3, q = the layer input x: dX = k0 dXn - k1 - (x - mean) rstd k2
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = q[r][nb][j];
+                        float t = gk[nb][3 * j] * o[j] - gk[nb][3 * j + 1] - ((xv - gmu[nb]) * grs[nb]) * gk[nb][3 * j + 2];
+                        if (a.gnb_relu) t = xv > 0.f ? t : 0.f;
+                        o[j] = t;
+                        amax = fmaxf(amax, fabsf(t));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += q[r][nb][j];
+                }
                 if (a.bias) { const float4 bv = *reinterpret_cast<const float4*>(a.bias + co); o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w; }
                 if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
                 if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + oi) = make_float4(o[0], o[1], o[2], o[3]);
@@ -1459,6 +1489,7 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
                 st_q[nb] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
             }
         }
+        if (GNB && a.gnb_bits) conv_absmax_commit(a.gnb_bits, amax);
         // Fused GroupNorm statistics of the output (8 groups; a lane's four channels always lie in one group): fp32 per lane over its
         // R fragments -> reduction over the 16 voxel lanes -> LDS float atomics per group of this NB x 16-channel slice -> one fp64
         // atomic per (group, moment) per workgroup.  Saves the statistics pass over y that the next layer's GroupNorm needs.
@@ -1492,14 +1523,14 @@ __global__ __launch_bounds__(512) void k_conv_brick(ConvArgs a, int total) {
     BRICK_STAMP(7);
 }
 
-template <bool F32, int CW, int NB, bool ONE, bool PERSIST, int TX = 16>
+template <bool F32, int CW, int NB, bool ONE, bool PERSIST, int TX = 16, bool GNB = false>
 static int conv_brick_launch_p(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)((6 * C16_H1 * (TX + 2) * 8 + 127) / 128 * 128) * (CW / 8) * 2 * (F32 ? 2 : 1);      // CW / 8 planes (256-B padded), hi (+ lo), fp16
     static int per_cu = 0;                                  // co-resident workgroups per CU (LDS and registers), queried once
     if (!per_cu) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE, PERSIST, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_brick<F32, CW, NB, ONE, PERSIST, TX, GNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_brick<F32, CW, NB, ONE, PERSIST, TX>, 512, lds) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_brick<F32, CW, NB, ONE, PERSIST, TX, GNB>, 512, lds) != hipSuccess || n < 1) n = 1;
         per_cu = n;
     }
     const long total = (long)(a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / TX) * a.B * (a.Cout / (NB * 16));
@@ -1510,7 +1541,7 @@ static int conv_brick_launch_p(const ConvArgs& a, hipStream_t s) {
 #ifdef SEMABS_TUNING
     at.trace = g_conv_trace;
 #endif
-    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE, PERSIST, TX>), dim3((unsigned)nwg), dim3(512), lds, s, at, (int)total);
+    hipLaunchKernelGGL((k_conv_brick<F32, CW, NB, ONE, PERSIST, TX, GNB>), dim3((unsigned)nwg), dim3(512), lds, s, at, (int)total);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -1522,6 +1553,10 @@ static int conv_brick_launch_t(const ConvArgs& a, hipStream_t s) {
     return conv_brick_launch_p<F32, CW, NB, ONE, false>(a, s);
 }
 static int conv_brick_launch(const ConvArgs& a, int f32, hipStream_t s) {
+    if (a.gnb_coef) {                                       // semabs_conv3d_gnbwd below full resolution: exact mode, Cin % 32 == 0, Cout % 32 == 0, two output blocks per wave
+        if (a.Cin == 32) return conv_brick_launch_p<true, 32, 2, true, false, 16, true>(a, s);
+        return conv_brick_launch_p<true, 32, 2, false, false, 16, true>(a, s);
+    }
     if (a.I2 % C16_T2 != 0) {                               // 8 wide (the 8^3 level; Cin >= 32 there): 4 x 8 x 8 tiles, two output blocks
         return f32 ? conv_brick_launch_p<true, 32, 2, false, false, 8>(a, s) : conv_brick_launch_p<false, 32, 2, false, false, 8>(a, s);
     }
@@ -1685,13 +1720,18 @@ extern "C" int semabs_conv3d_stats(const void* x, const void* w_hi, const void* 
 //   dX = k0 conv(dZ, Wbwd) - k1 - ((X - mean) rstd) k2 [+ add1]  [0 where X <= 0 if relu_mask],   coef fp32 [B, Cin_of_the_layer, 3] = (k0, k1, k2) of semabs_gn_bwd_coef,
 // i.e. semabs_conv3d(dZ ..) followed by semabs_gn_bwd_apply(.., add1) without the intermediate tensor.  dZ fp32 [B, D0, D1, D2, 16] with its dynamic
 // scale as the input affine (in_scale / in_shift), X fp32 = the layer's GroupNorm input, mean / rstd fp32 [B, G].  Shapes: 16 -> 16 channels, D0 % 8 == 0,
-// D1 % 8 == 0, D2 % 16 == 0, B <= 32, fewer than 2^31 elements per volume (the level-0 kernel); ask semabs_conv3d_gnbwd_supported.
-static bool conv3d_gnbwd_ok(int B, int D0, int D1, int D2, int Cin, int Cout) {
-    return B > 0 && B <= 32 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31);
+// D1 % 8 == 0, D2 % 16 == 0, B <= 32 (the level-0 kernel), or channel counts that are multiples of 32 with D0 % 4 == 0 and without add1 (the brick kernel);
+// ask semabs_conv3d_gnbwd_supported.
+// 1 = the level-0 kernel (16 -> 16), 2 = the brick kernel (Cin % 32 == 0, Cout % 32 == 0: a lane's four output channels lie in one GroupNorm group; no add1), 0 = neither
+static int conv3d_gnbwd_route(int B, int D0, int D1, int D2, int Cin, int Cout, int G, bool have_add) {
+    if (B <= 0 || G <= 0) return 0;
+    if (B <= 32 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31) && 16 % G == 0) return 1;
+    if (!have_add && Cin % 32 == 0 && Cout % 32 == 0 && Cout % G == 0 && (Cout / G) % 4 == 0 && D0 % 4 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0) return 2;
+    return 0;
 }
-extern "C" int semabs_conv3d_gnbwd_supported(int B, int D0, int D1, int D2, int Cin, int Cout, int* ok) {
+extern "C" int semabs_conv3d_gnbwd_supported(int B, int D0, int D1, int D2, int Cin, int Cout, int G, int have_add1, int* ok) {
     SEMABS_REQUIRE(ok, "semabs_conv3d_gnbwd_supported: null pointer");
-    *ok = conv3d_gnbwd_ok(B, D0, D1, D2, Cin, Cout) ? 1 : 0;
+    *ok = conv3d_gnbwd_route(B, D0, D1, D2, Cin, Cout, G, have_add1 != 0) ? 1 : 0;
     return SEMABS_OK;
 }
 extern "C" int semabs_conv3d_gnbwd(const void* dZ, const void* w_hi, const void* w_lo, void* dX, const float* in_scale, const float* in_shift, const void* X,
@@ -1699,7 +1739,8 @@ extern "C" int semabs_conv3d_gnbwd(const void* dZ, const void* w_hi, const void*
                                    int B, int D0, int D1, int D2, int Cin, int Cout, int act_flags, void* stream) {
     if (B == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dZ && w_hi && w_lo && dX && X && mean && rstd && coef, "semabs_conv3d_gnbwd: null pointer");
-    SEMABS_REQUIRE((act_flags & 1) && conv3d_gnbwd_ok(B, D0, D1, D2, Cin, Cout) && G > 0 && 16 % G == 0, "semabs_conv3d_gnbwd: exact mode, 16 -> 16 channels, see semabs_conv3d_gnbwd_supported");
+    const int route = conv3d_gnbwd_route(B, D0, D1, D2, Cin, Cout, G, add1 != nullptr);
+    SEMABS_REQUIRE((act_flags & 1) && route, "semabs_conv3d_gnbwd: exact mode and a supported shape (see semabs_conv3d_gnbwd_supported)");
     SEMABS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "semabs_conv3d_gnbwd: in_scale and in_shift go together");
     ConvArgs a;
     a.x = dZ; a.y = dX; a.w_hi = (const f16*)w_hi; a.w_lo = (const f16*)w_lo; a.gn_scale = in_scale; a.gn_shift = in_shift;
@@ -1712,7 +1753,8 @@ extern "C" int semabs_conv3d_gnbwd(const void* dZ, const void* w_hi, const void*
         for (int kh = 0; kh < 3; ++kh)
             for (int kw = 0; kw < 3; ++kw, ++t) { a.td0[t] = kd - 1; a.td1[t] = kh - 1; a.td2[t] = kw - 1; }
     a.gnb_coef = coef; a.gnb_mean = mean; a.gnb_rstd = rstd; a.gnb_G = G; a.gnb_relu = relu_mask; a.gnb_bits = absmax_bits; a.gnb_add = add1;
-    return conv16_lds_launch(a, 1, (hipStream_t)stream);
+    if (act_flags & SEMABS_CONV_PACKED) { a.wp_hi = a.w_hi + (long)Cout * a.Kp; a.wp_lo = a.w_lo + (long)Cout * a.Kp; }
+    return route == 1 ? conv16_lds_launch(a, 1, (hipStream_t)stream) : conv_brick_launch(a, 1, (hipStream_t)stream);
 }
 
 // General gather convolution (used for the data gradients of training): y[b, m, :] = sum_taps W_tap . x[b, m * in_stride + td_tap, :]

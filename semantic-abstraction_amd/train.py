@@ -282,13 +282,13 @@ class UNetTrainer:
             r = self._wg_gn_ok[key] = bool(k.value)
         return r
 
-    def _conv3d_gnbwd_ok(self, B, D0, D1, D2, cin_conv, cout_conv) -> bool:
-        key = (B, D0, D1, D2, cin_conv, cout_conv)
+    def _conv3d_gnbwd_ok(self, B, D0, D1, D2, cin_conv, cout_conv, G, have_add) -> bool:
+        key = (B, D0, D1, D2, cin_conv, cout_conv, G, have_add)
         r = self._gnbwd_ok.get(key)
         if r is None:
             import ctypes as C
             k = C.c_int(0)
-            _lib.call("semabs_conv3d_gnbwd_supported", B, D0, D1, D2, cin_conv, cout_conv, C.byref(k))
+            _lib.call("semabs_conv3d_gnbwd_supported", B, D0, D1, D2, cin_conv, cout_conv, G, 1 if have_add else 0, C.byref(k))
             r = self._gnbwd_ok[key] = bool(k.value)
         return r
 
@@ -369,7 +369,7 @@ class UNetTrainer:
         else:
             _lib.call("semabs_wgrad", _lib.ptr(dZ), _lib.ptr(r.x), _lib.ptr(r.scale), _lib.ptr(r.shift), _lib.ptr(dW), B, D0, D1, D2, D0, D1, D2, 1,
                       cout, cin, 27, TAPS_CONV3, 1, st)
-        if have_red and self.fuse_gn_apply and self._conv3d_gnbwd_ok(B, D0, D1, D2, cout, cin):
+        if have_red and self.fuse_gn_apply and self._conv3d_gnbwd_ok(B, D0, D1, D2, cout, cin, G, add1 is not None):
             # the sums are known BEFORE the data gradient (they came out of the weight-gradient pass), so the GroupNorm backward can be the data-gradient
             # convolution's epilogue: no dXn tensor, no apply pass (read dXn, read x, write dX)
             coef = torch.empty(B, cin, 3, dtype=torch.float32, device=self.dev)

@@ -78,6 +78,35 @@ def test_gn_conv_layer_backward_strict(gscale, wgrad_gn):
         assert _rel(grads[key + "groupnorm.bias"].cpu().numpy(), be.grad.numpy()) < 1e-5, name
 
 
+@pytest.mark.parametrize("relu_in,with_add", [(False, False), (True, False), (True, True)])
+def test_conv3d_gnbwd_equals_conv_then_apply(relu_in, with_add):
+    """semabs_conv3d_gnbwd (the GroupNorm-backward apply as the epilogue of the level-0 data-gradient convolution) against the two-kernel path it replaces
+    (semabs_conv3d + semabs_gn_bwd_apply), through UNetTrainer._conv_bwd with the fusion on and off: data gradient, recorded max |dX| and every parameter
+    gradient - with the ReLU mask of the layer input and with the residual branch's gradient added."""
+    sd, params, grads, u, pre = _unet_setup(3, 5)
+    rng = np.random.default_rng(7)
+    name, cin, cout, s = "encoders.0.basic_module.conv2.", 16, 16, 16
+    x = np.maximum(rng.standard_normal((2, cin, s, s, s)).astype(np.float32) + 0.2, 0.0)          # a post-ReLU activation (zeros included)
+    dz = (rng.standard_normal((2, cout, s, s, s)) * 1e-4).astype(np.float32)
+    add = (rng.standard_normal((2, cin, s, s, s)) * 1e-4).astype(np.float32)
+    outs = []
+    for fuse in (True, False):
+        u.fuse_gn_apply = fuse
+        for k in grads:
+            grads[k].zero_()
+        r, _ = u._conv_fwd(_cl(x), name, False)
+        dx = u._conv_bwd(r, _cl(dz), add1=_cl(add) if with_add else None, relu_in=relu_in)
+        torch.cuda.synchronize()
+        outs.append((dx.cpu().numpy(), float(dx._semabs_absmax.view(torch.float32)), {k: v.cpu().numpy().copy() for k, v in grads.items() if name in k}))
+    (a, am, ga), (b, bm, gb) = outs
+    assert _rel(a, b) < 1e-5
+    assert am == float(np.abs(a).max()) and bm == float(np.abs(b).max())
+    if relu_in:
+        assert bool((a[np.transpose(x, (0, 2, 3, 4, 1)) <= 0] == 0).all())
+    for k in ga:
+        assert _rel(ga[k], gb[k]) < 1e-6, k
+
+
 @pytest.mark.parametrize("B,D,Ca,Cx,G,gscale", [(2, (8, 12, 32), 16, 16, 8, 1.0), (3, (4, 4, 16), 32, 16, 8, 1.0), (8, (16, 16, 16), 32, 32, 8, 1e-7),
                                                 (1, (8, 8, 16), 16, 32, 4, 1.0), (4, (16, 8, 32), 64, 64, 8, 1.0)])
 def test_wgrad_conv3_gn_vs_fp64(B, D, Ca, Cx, G, gscale):
