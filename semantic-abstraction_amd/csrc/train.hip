@@ -889,9 +889,15 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
     const float sx = in_scale ? in_scale[0] : 1.f, so = out_scale ? out_scale[0] : 1.f;
     const int vl = lane & 15, kg = lane >> 4;
     const int nt = Co16 / 16;
-    float bv[NT];
+    // (the weights are the A operand, the rows the B operand: a lane's four results are four CONSECUTIVE output channels of one row - 16-byte stores and mask
+    //  loads; with the operands the other way round a lane held one channel of four rows: 32 scalar stores and 32 scalar mask loads per tile for 128 outputs,
+    //  and the masked 128 x 128 data gradient ran at 0.6 ms for 1 GB)
+    float bv[NT][4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = (bias && j < nt && j * 16 + vl < Co) ? bias[j * 16 + vl] : 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[j][i] = (bias && j < nt && j * 16 + 4 * kg + i < Co) ? bias[j * 16 + 4 * kg + i] : 0.f;
+    const bool vec4 = Co % 4 == 0;
     const long ntiles = (R + 15) / 16;
     float amax = 0.f;
     for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
@@ -920,29 +926,85 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
                 if (j < nt) {
                     const f16x8 wh = *reinterpret_cast<const f16x8*>(s_hi + (j * 16 + vl) * KS + k0);
                     const f16x8 wl = *reinterpret_cast<const f16x8*>(s_lo + (j * 16 + vl) * KS + k0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[j], 0, 0, 0);
                 }
             }
         }
-        // acc[j][i] = Y[t * 16 + 4 * kg + i][j * 16 + vl]
+        // acc[j][i] = Y[t * 16 + vl][j * 16 + 4 * kg + i]
+        const long r = t * 16 + vl;
+        if (r < R) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (j < nt && j * 16 + vl < Co) {
+            for (int j = 0; j < NT; ++j) {
+                const int c0 = j * 16 + 4 * kg;
+                if (j < nt && c0 < Co) {
+                    float o[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (relu_mask) {
+                        if (vec4) { const float4 m4 = *reinterpret_cast<const float4*>(relu_mask + r * Co + c0); mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w; }
+                        else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long r = t * 16 + 4 * kg + i;
-                    float o = acc[j][i] * so + bv[j];
-                    if (act == 1) o = o > 0.f ? o : slope * o;
-                    if (r < R) {
+                            for (int i = 0; i < 4; ++i) if (c0 + i < Co) mk[i] = relu_mask[r * Co + c0 + i];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o[i] = acc[j][i] * so + bv[j][i];
+                        if (act == 1) o[i] = o[i] > 0.f ? o[i] : slope * o[i];
                         // Y is a gradient in front of the ReLU (act 0) / LeakyReLU (act 2: factor `slope`) that produced relu_mask
-                        if (relu_mask && !(relu_mask[r * Co + j * 16 + vl] > 0.f)) o = act == 2 ? o * slope : 0.f;
-                        Y[r * Co + j * 16 + vl] = o;
-                        amax = fmaxf(amax, fabsf(o));
+                        if (relu_mask && !(mk[i] > 0.f)) o[i] = act == 2 ? o[i] * slope : 0.f;
+                    }
+                    if (vec4) {
+                        *reinterpret_cast<float4*>(Y + r * Co + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (c0 + i < Co) { Y[r * Co + c0 + i] = o[i]; amax = fmaxf(amax, fabsf(o[i])); }
                     }
                 }
             }
+        }
+    }
+    if (bits) absmax_commit(bits, amax);
+}
+// The 16 -> 16 case (the UNet's final 1 x 1 x 1 convolution and its data gradient over 16.7 M voxels) on the FP32 matrix instruction: Y^T = W X^T with
+// v_mfma_f32_16x16x4_f32, four of them per 16-row tile.  A lane's operands are ONE float4 of W (loaded once) and ONE float4 of its row (k = 4 kg + s for MFMA s),
+// its result four consecutive output channels of one row: 16-byte loads and stores, a wave reads and writes 1 KB contiguous per tile, no operand split, no
+// LDS - the products are exact fp32.  (k_linear_rows<2> on these shapes: 0.66 / 0.52 ms for 2.1 GB; this kernel runs at the memory rate.)
+__global__ __launch_bounds__(256) void k_rows16_f32(const float* __restrict__ X, const float* __restrict__ W, long w_sn, long w_sk, const float* __restrict__ bias,
+                                                    float* __restrict__ Y, long R, int act, float slope, const float* __restrict__ in_scale,
+                                                    const float* __restrict__ out_scale, const float* __restrict__ relu_mask, unsigned int* __restrict__ bits) {
+    const int lane = threadIdx.x & 63, vl = lane & 15, kg = lane >> 4;
+    float wv[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) wv[s4] = W[vl * w_sn + (4 * kg + s4) * w_sk];        // A[m = vl][k = 4 kg + s]
+    const float sc = (in_scale ? in_scale[0] : 1.f) * (out_scale ? out_scale[0] : 1.f);     // (powers of two: exact)
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * kg);
+    const long ntiles = (R + 15) / 16, stride = (long)gridDim.x * 4;
+    float amax = 0.f;
+    for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += stride) {
+        const long row = t * 16 + vl;
+        const bool ok = row < R;
+        const float4 xv = ld_nt4(X + (ok ? row : R - 1) * 16 + 4 * kg);                    // B[k = 4 kg + s][n = row vl]
+        float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (relu_mask && ok) mk = ld_nt4(relu_mask + row * 16 + 4 * kg);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], xv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], xv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], xv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], xv.w, acc, 0, 0, 0);
+        // acc[i] = Y[row vl][cout = 4 kg + i]
+        float o[4] = {acc[0] * sc + bv.x, acc[1] * sc + bv.y, acc[2] * sc + bv.z, acc[3] * sc + bv.w};
+        const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (act == 1) o[i] = o[i] > 0.f ? o[i] : slope * o[i];
+            if (relu_mask && !(mv[i] > 0.f)) o[i] = act == 2 ? o[i] * slope : 0.f;
+        }
+        if (ok) {
+            *reinterpret_cast<float4*>(Y + row * 16 + 4 * kg) = make_float4(o[0], o[1], o[2], o[3]);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
         }
     }
     if (bits) absmax_commit(bits, amax);
@@ -953,11 +1015,20 @@ extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long
     if (R == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && W && Y && R > 0 && Ci > 0 && Co > 0, "semabs_linear_rows: bad args");
     SEMABS_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0 && Ci <= 512 && Co <= 128 && (act == 0 || act == 1 || (act == 2 && relu_mask)), "semabs_linear_rows: Ci % 4 == 0, Ci <= 512, Co <= 128, act 0 / 1 (2 with relu_mask)");
+    if (Ci == 16 && Co == 16 && ldx == 16 && R >= (1L << 16)) {
+        long nb16 = ((R + 15) / 16 + 3) / 4; if (nb16 > 4096) nb16 = 4096;
+        hipLaunchKernelGGL(k_rows16_f32, dim3((unsigned)nb16), dim3(256), 0, (hipStream_t)stream, X, W, w_sn, w_sk, bias, Y, R, act, slope, in_scale, out_scale,
+                           relu_mask, absmax_bits);
+        SEMABS_CHECK_LAUNCH();
+        return SEMABS_OK;
+    }
     const int Kp = (Ci + 31) / 32 * 32, Co16 = (Co + 15) / 16 * 16;
     const size_t lds = (size_t)Co16 * (Kp + 8) * 2 * 2;
     SEMABS_REQUIRE(lds <= 160 * 1024, "semabs_linear_rows: the weight matrix does not fit LDS");
     const long ntiles = (R + 15) / 16;
-    long nb = (ntiles + 3) / 4; const long cap = 2048; if (nb > cap) nb = cap;
+    // every block stages the whole weight matrix (through strides when it is the transpose: 4-byte reads 4 Co bytes apart): with the large matrices, whose LDS
+    // footprint allows two blocks per CU anyway, one wave of blocks - 2 per CU - instead of 2 048 (the 128 x 128 transposed layer: 640 -> us below)
+    long nb = (ntiles + 3) / 4; const long cap = lds > 48 * 1024 ? 512 : 2048; if (nb > cap) nb = cap;
     hipStream_t s = (hipStream_t)stream;
 #define LR_LAUNCH(NT)                                                                                                           \
     {                                                                                                                           \

@@ -156,11 +156,12 @@ def test_wgrad_conv3_gn_vs_fp64(B, D, Ca, Cx, G, gscale):
 
 @pytest.mark.parametrize("R,Ci,Co,act,transposed,scaled", [(100003, 4, 128, 1, False, False), (100003, 128, 128, 1, False, False), (50001, 128, 16, 0, False, False),
                                                             (70000, 36, 32, 1, False, False), (70000, 32, 64, 0, False, False), (70000, 64, 32, 0, True, True),
-                                                            (50001, 16, 128, 0, True, True), (33, 128, 128, 0, True, True), (70000, 32, 36, 0, False, False)])
+                                                            (50001, 16, 128, 0, True, True), (33, 128, 128, 0, True, True), (70000, 32, 36, 0, False, False),
+                                                            (70003, 16, 16, 0, False, False), (65541, 16, 16, 1, False, False), (100001, 16, 16, 0, True, True)])
 def test_linear_rows_vs_fp64(R, Ci, Co, act, transposed, scaled):
     """semabs_linear_rows (the MLP layers of the training step on the matrix cores, fp16 hi / lo split operands) against an fp64 product: fp32-like
     accuracy for every layer shape of the point and sampler MLPs, plain and transposed weights, ragged row counts, gradient-sized inputs through
-    the power-of-two input scale, rows past R untouched."""
+    the power-of-two input scale, rows past R untouched.  The 16 -> 16 cases with at least 2^16 rows run on k_rows16_f32 (fp32 MFMA)."""
     from semabs_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(R + Ci + Co)
     mag = 1e-7 if scaled else 1.0
