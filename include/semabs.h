@@ -378,9 +378,12 @@ int semabs_linear_f32(const float* X, const float* W, const float* bias, float* 
  * W[n * w_sn + k * w_sk] (plain: Ci, 1; transposed: 1, Co), in_scale = optional device scalar s (the power-of-two scale of a gradient input; the output
  * stays scaled unless out_scale - a device scalar the accumulator is multiplied by, e.g. 1 / s - is given).  Ci % 4 == 0, Co <= 128, act 0 none / 1 LeakyReLU(slope).                                  net.py:358-367, 215-256 (and their backward)
  * relu_mask (optional, like Y): Y = 0 where relu_mask <= 0 (Y is a gradient in front of the ReLU that produced relu_mask), or with act = 2 Y *= slope
- * there (LeakyReLU; no activation is applied to Y itself); absmax_bits (optional, uint32 [1], zeroed by the caller): bit pattern of max |Y|. */
+ * there (LeakyReLU; no activation is applied to Y itself); absmax_bits (optional, uint32 [1], zeroed by the caller): bit pattern of max |Y|;
+ * colsum (optional, fp32 [Co]): += the column sums of Y (the bias gradient of the layer whose output gradient Y is); x_colsum (optional, fp32 [16], only with
+ * Ci = Co = ldx = 16 and at least 2^16 rows): += the column sums of X (unscaled). */
 int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
-                       int act, float slope, const float* in_scale, const float* out_scale, const float* relu_mask, unsigned int* absmax_bits, void* stream);
+                       int act, float slope, const float* in_scale, const float* out_scale, const float* relu_mask, unsigned int* absmax_bits, float* colsum,
+                       float* x_colsum, void* stream);
 
 /* scatter-mean backward: dpf[b, p] = dvol[b, flat[p]] / count[flat[p]]; count int32 [nvox] zero-filled by the caller   net.py:185-201 */
 int semabs_scatter_mean_bwd(const long long* flat, int* count, const float* dvol, float* dpf, int P, long N, int C, long nvox, void* stream);
@@ -393,10 +396,10 @@ int semabs_vool_sample(const float* vol_t, const float* vol_r, const float* quer
 int semabs_vool_sample_bwd(const float* df, const float* query, const float* off3, const float* sc3, const int* shape3, int P, long M,
                            int* head, int* next, float* dvol_t, float* dvol_r, unsigned int* absmax_bits, void* stream);
 
-/* logits = cos(o, rel) / T; loss += sum w BCEwithlogits(logit, label) / n_total; dO and drel (accumulated) = d loss / d o, d rel
- *                                                                                                        net.py:566-579, train_vool.py:171-178 */
+/* logits = cos(o, rel) / T; loss += sum w BCEwithlogits(logit, label) / n_total; dO and drel (accumulated) = d loss / d o, d rel; dbias (optional,
+ * fp32 [P, 64], accumulated) = the column sums of dO per description                                     net.py:566-579, train_vool.py:171-178 */
 int semabs_cos_bce(const float* o, const float* rel, const float* label, const float* weight, int P, long M, float temperature, long n_total,
-                   float* logits, float* dO, float* drel, double* loss, void* stream);
+                   float* logits, float* dO, float* drel, double* loss, float* dbias, void* stream);
 
 /* per-step weight layouts: hi / lo[i] = fp16 hi / lo split of src[idx[i]] (idx < 0: zero) - one launch per matrix instead of torch permute / flip /
  * cat / cast chains; the index map of a layout (tap-major, flipped + transposed, parity classes, fragment-packed copy) depends on shapes only */

@@ -111,11 +111,11 @@ SIGNATURES = {
     "semabs_maxpool3d_bwd": [P, P, P, I, I, I, I, I, P],
     "semabs_maxpool3d_bwd_add": [P, P, P, P, P, I, I, I, I, I, I, P],
     "semabs_linear_f32": [P, P, P, P, L, I, I, I, F, P],
-    "semabs_linear_rows": [P, L, P, L, L, P, P, L, I, I, I, F, P, P, P, P, P],
+    "semabs_linear_rows": [P, L, P, L, L, P, P, L, I, I, I, F, P, P, P, P, P, P, P],
     "semabs_scatter_mean_bwd": [P, P, P, P, I, L, I, L, P],
     "semabs_vool_sample": [P, P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P],
     "semabs_vool_sample_bwd": [P, P, C.POINTER(F), C.POINTER(F), C.POINTER(I), I, L, P, P, P, P, P, P],
-    "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P],
+    "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P, P],
     "semabs_cos_head": [P, P, P, I, L, F, P, P, P, P],
     "semabs_gather_split16": [P, P, L, P, P, P],
     "semabs_clip_grad_norm": [P, I, P, I, F, F, P, P],

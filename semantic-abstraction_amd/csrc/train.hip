@@ -868,11 +868,18 @@ extern "C" int semabs_linear_f32(const float* X, const float* W, const float* bi
 // against the Co16 / 16 column tiles.  s (optional, a device scalar) is the dynamic power-of-two scale of a gradient input - REQUIRED for one: values of
 // 1e-7 are fp16 subnormals before the split; the accumulator is multiplied by out_scale (optional device scalar, e.g. 1 / s) in front of the bias.
 // =================================================================================================
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));     // quad_perm [1, 0, 3, 2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));     // quad_perm [2, 3, 0, 1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));    // row_mirror
+    return v;
+}
 template <int NT>                                            // column tiles of 16 kept in registers per pass (Co16 / 16 <= NT)
 __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X, long ldx, const float* __restrict__ W, long w_sn, long w_sk,
                                                      const float* __restrict__ bias, float* __restrict__ Y, long R, int Ci, int Co, int act, float slope,
                                                      const float* __restrict__ in_scale, const float* __restrict__ out_scale,
-                                                     const float* __restrict__ relu_mask, unsigned int* __restrict__ bits) {
+                                                     const float* __restrict__ relu_mask, unsigned int* __restrict__ bits, float* __restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Kp = (Ci + 31) / 32 * 32, KS = Kp + 8;         // padded K and LDS row stride (fp16 elements)
     const int Co16 = (Co + 15) / 16 * 16;
@@ -898,6 +905,11 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
 #pragma unroll
         for (int i = 0; i < 4; ++i) bv[j][i] = (bias && j < nt && j * 16 + 4 * kg + i < Co) ? bias[j * 16 + 4 * kg + i] : 0.f;
     const bool vec4 = Co % 4 == 0;
+    float cs[NT][4];                                         // colsum: this lane's share of the column sums of Y (the bias gradient when Y is a layer's dOut)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[j][i] = 0.f;
     const long ntiles = (R + 15) / 16;
     float amax = 0.f;
     for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
@@ -954,6 +966,10 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
                         // Y is a gradient in front of the ReLU (act 0) / LeakyReLU (act 2: factor `slope`) that produced relu_mask
                         if (relu_mask && !(mk[i] > 0.f)) o[i] = act == 2 ? o[i] * slope : 0.f;
                     }
+                    if (colsum) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cs[j][i] += (c0 + i < Co) ? o[i] : 0.f;
+                    }
                     if (vec4) {
                         *reinterpret_cast<float4*>(Y + r * Co + c0) = make_float4(o[0], o[1], o[2], o[3]);
                         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
@@ -966,6 +982,24 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
         }
     }
     if (bits) absmax_commit(bits, amax);
+    if (colsum) {                                            // rows of a wave by DPP, waves of the block through LDS (the weight planes are dead), one atomic per column and block
+        __syncthreads();
+        float* s_cs = reinterpret_cast<float*>(smem);
+        for (int c = tid; c < Co16; c += 256) s_cs[c] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j < nt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = row16_sum(cs[j][i]);
+                    if (vl == 0) atomicAdd(&s_cs[j * 16 + 4 * kg + i], v);
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < Co; c += 256) atomicAdd(&colsum[c], s_cs[c]);
+    }
 }
 // The 16 -> 16 case (the UNet's final 1 x 1 x 1 convolution and its data gradient over 16.7 M voxels) on the FP32 matrix instruction: Y^T = W X^T with
 // v_mfma_f32_16x16x4_f32, four of them per 16-row tile.  A lane's operands are ONE float4 of W (loaded once) and ONE float4 of its row (k = 4 kg + s for MFMA s),
@@ -973,8 +1007,10 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ X
 // LDS - the products are exact fp32.  (k_linear_rows<2> on these shapes: 0.66 / 0.52 ms for 2.1 GB; this kernel runs at the memory rate.)
 __global__ __launch_bounds__(256) void k_rows16_f32(const float* __restrict__ X, const float* __restrict__ W, long w_sn, long w_sk, const float* __restrict__ bias,
                                                     float* __restrict__ Y, long R, int act, float slope, const float* __restrict__ in_scale,
-                                                    const float* __restrict__ out_scale, const float* __restrict__ relu_mask, unsigned int* __restrict__ bits) {
+                                                    const float* __restrict__ out_scale, const float* __restrict__ relu_mask, unsigned int* __restrict__ bits,
+                                                    float* __restrict__ colsum, float* __restrict__ x_colsum) {
     const int lane = threadIdx.x & 63, vl = lane & 15, kg = lane >> 4;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cx[4] = {0.f, 0.f, 0.f, 0.f};
     float wv[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) wv[s4] = W[vl * w_sn + (4 * kg + s4) * w_sk];        // A[m = vl][k = 4 kg + s]
@@ -1005,23 +1041,38 @@ __global__ __launch_bounds__(256) void k_rows16_f32(const float* __restrict__ X,
         if (ok) {
             *reinterpret_cast<float4*>(Y + row * 16 + 4 * kg) = make_float4(o[0], o[1], o[2], o[3]);
             amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+            cs[0] += o[0]; cs[1] += o[1]; cs[2] += o[2]; cs[3] += o[3];
+            cx[0] += xv.x; cx[1] += xv.y; cx[2] += xv.z; cx[3] += xv.w;
         }
     }
     if (bits) absmax_commit(bits, amax);
+    if (colsum || x_colsum) {
+        __shared__ float s_cs[32];
+        if (threadIdx.x < 32) s_cs[threadIdx.x] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = row16_sum(cs[i]), u = row16_sum(cx[i]);
+            if (vl == 0) { atomicAdd(&s_cs[4 * kg + i], v); atomicAdd(&s_cs[16 + 4 * kg + i], u); }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) { if (colsum) atomicAdd(&colsum[threadIdx.x], s_cs[threadIdx.x]); if (x_colsum) atomicAdd(&x_colsum[threadIdx.x], s_cs[16 + threadIdx.x]); }
+    }
 }
 extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long w_sn, long w_sk, const float* bias, float* Y, long R, int Ci, int Co,
                                   int act, float slope, const float* in_scale, const float* out_scale, const float* relu_mask, unsigned int* absmax_bits,
-                                  void* stream) {
+                                  float* colsum, float* x_colsum, void* stream) {
     if (R == 0) return SEMABS_OK;
     SEMABS_REQUIRE(X && W && Y && R > 0 && Ci > 0 && Co > 0, "semabs_linear_rows: bad args");
     SEMABS_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0 && Ci <= 512 && Co <= 128 && (act == 0 || act == 1 || (act == 2 && relu_mask)), "semabs_linear_rows: Ci % 4 == 0, Ci <= 512, Co <= 128, act 0 / 1 (2 with relu_mask)");
     if (Ci == 16 && Co == 16 && ldx == 16 && R >= (1L << 16)) {
         long nb16 = ((R + 15) / 16 + 3) / 4; if (nb16 > 4096) nb16 = 4096;
         hipLaunchKernelGGL(k_rows16_f32, dim3((unsigned)nb16), dim3(256), 0, (hipStream_t)stream, X, W, w_sn, w_sk, bias, Y, R, act, slope, in_scale, out_scale,
-                           relu_mask, absmax_bits);
+                           relu_mask, absmax_bits, colsum, x_colsum);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
     }
+    SEMABS_REQUIRE(!x_colsum, "semabs_linear_rows: x_colsum only with the 16 -> 16 kernel (Ci = Co = ldx = 16, at least 2^16 rows)");
     const int Kp = (Ci + 31) / 32 * 32, Co16 = (Co + 15) / 16 * 16;
     const size_t lds = (size_t)Co16 * (Kp + 8) * 2 * 2;
     SEMABS_REQUIRE(lds <= 160 * 1024, "semabs_linear_rows: the weight matrix does not fit LDS");
@@ -1034,7 +1085,7 @@ extern "C" int semabs_linear_rows(const float* X, long ldx, const float* W, long
     {                                                                                                                           \
         static SemabsLdsAttr attr;                                                                                              \
         semabs_ensure_lds(&k_linear_rows<NT>, 160 * 1024, attr);                                                                \
-        hipLaunchKernelGGL(k_linear_rows<NT>, dim3((unsigned)nb), dim3(256), lds, s, X, ldx, W, w_sn, w_sk, bias, Y, R, Ci, Co, act, slope, in_scale, out_scale, relu_mask, absmax_bits); \
+        hipLaunchKernelGGL(k_linear_rows<NT>, dim3((unsigned)nb), dim3(256), lds, s, X, ldx, W, w_sn, w_sk, bias, Y, R, Ci, Co, act, slope, in_scale, out_scale, relu_mask, absmax_bits, colsum); \
     }
     if (Co16 <= 32) LR_LAUNCH(2) else if (Co16 <= 64) LR_LAUNCH(4) else LR_LAUNCH(8)
 #undef LR_LAUNCH
@@ -1210,17 +1261,14 @@ extern "C" int semabs_vool_sample_bwd(const float* df, const float* query, const
 // formed here; head mode: dz = dz_in (null = logits only).  16 lanes per point (E = 64 = one float4 per lane), four points per wave, row reductions by DPP:
 // ~25 instructions per point (one wave per point with two 64-lane reductions and the transcendentals in every lane: ~120, 760 us for 1.6 M points - VALU-bound
 // at 0.6 GB of traffic).  Writes logits, dO [R, 64]; accumulates drel [P, 64] and the loss.
-__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes of a DPP row, in every lane
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));     // quad_perm [1, 0, 3, 2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));     // quad_perm [2, 3, 0, 1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));    // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));    // row_mirror
-    return v;
-}
 __global__ __launch_bounds__(256) void k_cos_rows(const float* __restrict__ o, const float* __restrict__ rel, const float* __restrict__ label,
                                                   const float* __restrict__ weight, const float* __restrict__ dz_in, int P, long M, float inv_temp, float inv_n,
-                                                  float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel, double* __restrict__ loss) {
+                                                  float* __restrict__ logits, float* __restrict__ dO, float* __restrict__ drel, double* __restrict__ loss,
+                                                  float* __restrict__ dbias) {
     __shared__ float s_drel[64];
+    __shared__ float s_db[64];
+    if (threadIdx.x < 64) s_db[threadIdx.x] = 0.f;
+    float acc_db[4] = {0.f, 0.f, 0.f, 0.f};                 // column sums of dO (the bias gradient of the layer that produced o), per description
     __shared__ float s_loss;
     if (threadIdx.x < 64) s_drel[threadIdx.x] = 0.f;
     if (threadIdx.x == 0) s_loss = 0.f;
@@ -1252,27 +1300,29 @@ __global__ __launch_bounds__(256) void k_cos_rows(const float* __restrict__ o, c
             if (q == 0) acc_loss += l * wgt * inv_n;
         } else dz = dz_in[pt];
         const float dc = dz * inv_temp, ino = dc / no, dcr = dc * inr;
-        *reinterpret_cast<float4*>(dO + pt * 64 + q * 4) = make_float4((rh[0] - oh[0] * cs) * ino, (rh[1] - oh[1] * cs) * ino, (rh[2] - oh[2] * cs) * ino, (rh[3] - oh[3] * cs) * ino);
+        const float dv[4] = {(rh[0] - oh[0] * cs) * ino, (rh[1] - oh[1] * cs) * ino, (rh[2] - oh[2] * cs) * ino, (rh[3] - oh[3] * cs) * ino};
+        *reinterpret_cast<float4*>(dO + pt * 64 + q * 4) = make_float4(dv[0], dv[1], dv[2], dv[3]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc_drel[j] += (oh[j] - rh[j] * cs) * dcr;
+        for (int j = 0; j < 4; ++j) { acc_drel[j] += (oh[j] - rh[j] * cs) * dcr; acc_db[j] += dv[j]; }
     }
     if (!grad) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(&s_drel[q * 4 + j], acc_drel[j]);
+    for (int j = 0; j < 4; ++j) { atomicAdd(&s_drel[q * 4 + j], acc_drel[j]); if (dbias) atomicAdd(&s_db[q * 4 + j], acc_db[j]); }
     if (label && q == 0) atomicAdd(&s_loss, acc_loss);
     __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(&drel[d * 64 + threadIdx.x], s_drel[threadIdx.x]);
+    if (threadIdx.x < 64) { atomicAdd(&drel[d * 64 + threadIdx.x], s_drel[threadIdx.x]); if (dbias) atomicAdd(&dbias[d * 64 + threadIdx.x], s_db[threadIdx.x]); }
     if (label && threadIdx.x == 0) atomicAdd(loss, (double)s_loss);
 }
 // o fp32 [P*M, 64]; rel fp32 [P, 64]; label / weight fp32 [P*M] (weight optional); outputs: logits [P*M] (optional), dO [P*M, 64],
-// drel fp32 [P, 64] and loss fp64 [1] ACCUMULATED (zero them first).  n_total = element count of the mean reduction.
+// drel fp32 [P, 64] and loss fp64 [1] ACCUMULATED (zero them first).  n_total = element count of the mean reduction.  dbias (optional) fp32 [P, 64], accumulated:
+// the column sums of dO per description (summed over P they are the bias gradient of the layer that produced o).
 extern "C" int semabs_cos_bce(const float* o, const float* rel, const float* label, const float* weight, int P, long M, float temperature,
-                              long n_total, float* logits, float* dO, float* drel, double* loss, void* stream) {
+                              long n_total, float* logits, float* dO, float* drel, double* loss, float* dbias, void* stream) {
     if (P == 0 || M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(o && rel && label && dO && drel && loss && temperature > 0.f && n_total > 0, "semabs_cos_bce: bad args");
     int bx = semabs_cdiv(M, 16 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(k_cos_rows, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, label, weight, (const float*)nullptr, P, M, 1.0f / temperature,
-                       1.0f / (float)n_total, logits, dO, drel, loss);
+                       1.0f / (float)n_total, logits, dO, drel, loss, dbias);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -1286,7 +1336,7 @@ extern "C" int semabs_cos_head(const float* o, const float* rel, const float* dl
     SEMABS_REQUIRE(o && rel && temperature > 0.f && (dlogits ? (dO && drel) : (logits != nullptr)), "semabs_cos_head: bad args");
     int bx = semabs_cdiv(M, 16 * 8); if (bx < 1) bx = 1; if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(k_cos_rows, dim3(bx, P), dim3(256), 0, (hipStream_t)stream, o, rel, (const float*)nullptr, (const float*)nullptr, dlogits, P, M,
-                       1.0f / temperature, 0.f, logits, dO, drel, (double*)nullptr);
+                       1.0f / temperature, 0.f, logits, dO, drel, (double*)nullptr, (float*)nullptr);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

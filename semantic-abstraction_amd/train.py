@@ -248,7 +248,7 @@ class UNetTrainer:
         if self.rows_linear and m["cin"] % 4 == 0 and m["cout"] <= 128 and wf.is_contiguous():
             # the 1 x 1 x 1 convolution IS a row-linear layer over the voxels: semabs_linear_rows streams it at HBM speed (the gather kernel: 1.28 ms at 8 x 128^3)
             _lib.call("semabs_linear_rows", _lib.ptr(x), m["cin"], _lib.ptr(wf), m["cin"], 1, _lib.ptr(self.p[self.prefix + "final_conv.bias"]), _lib.ptr(y),
-                      B * D0 * D1 * D2, m["cin"], m["cout"], 0, 0.0, None, None, None, None, st)
+                      B * D0 * D1 * D2, m["cin"], m["cout"], 0, 0.0, None, None, None, None, None, None, st)
         else:
             _lib.call("semabs_conv3d", _lib.ptr(x), _lib.ptr(m["fwd"][0]), _lib.ptr(m["fwd"][1]), _lib.ptr(y), None, None,
                       _lib.ptr(self.p[self.prefix + "final_conv.bias"]), None, B, D0, D1, D2, m["cin"], m["cout"], 1, 0, 1 | m["fwd"][2], st)
@@ -450,16 +450,18 @@ class UNetTrainer:
                 R = B * D0 * D1 * D2
                 _lib.call("semabs_wgrad", _lib.ptr(g), _lib.ptr(x), None, None, _lib.ptr(self.g[self.prefix + "final_conv.weight"]), 1, 1, 1, R, 1, 1, R, 1,
                           cout, cin, 1, TAPS_ONE, 1, st)
-                self._colsum(g.view(R, cout), self.g[self.prefix + "final_conv.bias"])
                 dx = torch.empty(B, D0, D1, D2, cin, dtype=torch.float32, device=self.dev)
                 sc, sh, s2 = self._scale(g, B, cout)
                 wf = self.p[self.prefix + "final_conv.weight"].detach()
+                fast16 = self.rows_linear and cin == 16 and cout == 16 and R >= (1 << 16) and wf.is_contiguous()       # k_rows16_f32: also sums g's columns (the bias gradient)
+                if not fast16:
+                    self._colsum(g.view(R, cout), self.g[self.prefix + "final_conv.bias"])
                 if self.rows_linear and cout % 4 == 0 and cin <= 128 and wf.is_contiguous():      # dx = (s g) W: the transposed row-linear layer (see forward)
                     # ... scaled back on the way out, through the mask of the ReLU that produced x (the last decoder block's final ReLU), max |dx| recorded:
                     # that block's own mask pass over the 8 x 128^3 x 16 tensor (read, read, write: 0.58 ms) is not run
                     bits = self.arena.zeros((1,), torch.int32)
                     _lib.call("semabs_linear_rows", _lib.ptr(g), cout, _lib.ptr(wf), 1, cin, None, _lib.ptr(dx), R, cout, cin, 0, 0.0, _lib.ptr(s2), s2[1:].data_ptr(),
-                              _lib.ptr(x), _lib.ptr(bits), st)
+                              _lib.ptr(x), _lib.ptr(bits), None, _lib.ptr(self.g[self.prefix + "final_conv.bias"]) if fast16 else None, st)
                     dx._semabs_absmax = bits
                     dx._semabs_relu_masked = True
                     g, g_scale = dx, None
@@ -596,16 +598,17 @@ class VOOLTrainer:
             # (round 5) the matrix-core row kernel: the fp32 FMA kernel below took 0.73 ms per layer at 640 k - 1.6 M rows
             s2 = self.unet._scale(x, 1, Ci)[2] if grad_in else None
             _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), Ci, 1, _lib.ptr(b), _lib.ptr(y), R, Ci, Co, int(act), SLOPE,
-                      _lib.ptr(s2), None if s2 is None else s2[1:].data_ptr(), None, None, _lib.stream())
+                      _lib.ptr(s2), None if s2 is None else s2[1:].data_ptr(), None, None, None, None, _lib.stream())
             return y
         _lib.call("semabs_linear_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), R, Ci, Co, act, SLOPE, _lib.stream())
         return y
 
-    def _linear_mfma(self, x, wkey, b, act, grad_in=False, transposed=False, mask=None):
+    def _linear_mfma(self, x, wkey, b, act, grad_in=False, transposed=False, mask=None, colsum=None):
         """The 128 -> 128 MLP layers as 1x1x1 convolutions on the split-fp16 MFMA kernel (fp32-like accuracy); wkey names the weight parameter,
         transposed = multiply by its transpose (the data gradient).  grad_in: x is a gradient (arbitrarily small): scaled by a power of two on
         the way in and back on the way out.  mask (with grad_in): the layer input's pre-activation sign source h - the result is the UNSCALED gradient in
-        front of that LeakyReLU (y * (h > 0 ? 1 : SLOPE)) with its max |.| recorded, in the same pass where the row kernel runs."""
+        front of that LeakyReLU (y * (h > 0 ? 1 : SLOPE)) with its max |.| recorded - and its column sums added to `colsum` (the bias gradient of the layer
+        that produced h) - in the same pass where the row kernel runs."""
         R, Ci = x.shape
         w = self.params[wkey]
         Co = w.shape[1] if transposed else w.shape[0]
@@ -617,11 +620,14 @@ class VOOLTrainer:
                 bits = self.unet.arena.zeros((1,), torch.int32)
                 wd = w.detach()
                 _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(wd), 1 if transposed else wd.shape[1], wd.shape[1] if transposed else 1,
-                          None, _lib.ptr(y), R, Ci, Co, 2, SLOPE, _lib.ptr(s2), s2[1:].data_ptr(), _lib.ptr(mask), _lib.ptr(bits), _lib.stream())
+                          None, _lib.ptr(y), R, Ci, Co, 2, SLOPE, _lib.ptr(s2), s2[1:].data_ptr(), _lib.ptr(mask), _lib.ptr(bits), _lib.ptr(colsum), None, _lib.stream())
                 y._semabs_absmax = bits
                 return y
             y_, inv_ = self._linear_mfma(x, wkey, None, 0, grad_in=True, transposed=transposed)
-            return self.unet._ew(y_, mask, 1, want_max=True, in_scale=inv_)
+            y = self.unet._ew(y_, mask, 1, want_max=True, in_scale=inv_)
+            if colsum is not None:
+                self.unet._colsum(y, colsum)
+            return y
         if self.rows_linear and Ci % 4 == 0 and Co <= 128:
             # (round 5) the matrix-core row kernel reads W (or its transpose, through strides) straight from the fp32 parameter and splits it while
             # staging: no per-step operand gather, and 0.05 - 0.1 ms per layer where the 1 x 1 x 1 "convolution" on the gather kernel took 0.7 - 0.9 ms
@@ -629,7 +635,7 @@ class VOOLTrainer:
             s2 = self.unet._scale(x, 1, Ci)[2] if grad_in else None
             wd = w.detach()
             _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(wd), 1 if transposed else wd.shape[1], wd.shape[1] if transposed else 1,
-                      _lib.ptr(b), _lib.ptr(y), R, Ci, Co, 1 if act else 0, SLOPE, _lib.ptr(s2), None, None, None, _lib.stream())
+                      _lib.ptr(b), _lib.ptr(y), R, Ci, Co, 1 if act else 0, SLOPE, _lib.ptr(s2), None, None, None, None, None, _lib.stream())
             return (y, s2[1:]) if grad_in else y
         hi, lo, pk = self.unet.layouts.get(f"lin:{wkey}:{int(transposed)}", w, (lambda t: _flat_packed(_pad32(t.t().contiguous()))) if transposed else
                                            (lambda t: _flat_packed(_pad32(t.contiguous()))))
@@ -723,10 +729,13 @@ class VOOLTrainer:
         for d, n in enumerate(c["rel_names"]):
             g["relation_embeddings." + n].add_(drel[d])
         self._wgrad_linear(dO, h, g[ss + "2.weight"])
-        u._colsum(dO, g[ss + "2.bias"])
-        dh = self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True, mask=h)
+        dob = getattr(dO, "_semabs_colsum", None)
+        if dob is not None:
+            g[ss + "2.bias"].add_(dob.sum(0))                # (came out of the loss kernel that wrote dO)
+        else:
+            u._colsum(dO, g[ss + "2.bias"])
+        dh = self._linear_mfma(dO, ss + "2.weight", None, 0, grad_in=True, transposed=True, mask=h, colsum=g[ss + "0.bias"])
         self._wgrad_linear(dh, f, g[ss + "0.weight"], cols=35)
-        u._colsum(dh, g[ss + "0.bias"])
         df = self._linear(dh, w1p.t().contiguous(), None, 0, grad_in=True)               # [D*M, 36]
         dvol = torch.empty(P, S0, S1, S2, self.C, dtype=torch.float32, device=dev)
         cell_head = torch.empty(D * nvox, dtype=torch.int32, device=dev)
@@ -741,12 +750,10 @@ class VOOLTrainer:
         _lib.call("semabs_scatter_mean_bwd", _lib.ptr(flat), _lib.ptr(count), _lib.ptr(dscat), _lib.ptr(dpf), P, N, self.C, nvox, st)
         self._wgrad_linear(dpf, h2, g[cn + "4.weight"])
         u._colsum(dpf, g[cn + "4.bias"])
-        dh2 = self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True, mask=h2)
+        dh2 = self._linear_mfma(dpf, cn + "4.weight", None, 0, grad_in=True, transposed=True, mask=h2, colsum=g[cn + "2.bias"])
         self._wgrad_linear(dh2, h1, g[cn + "2.weight"])
-        u._colsum(dh2, g[cn + "2.bias"])
-        dh1 = self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True, mask=h1)
+        dh1 = self._linear_mfma(dh2, cn + "2.weight", None, 0, grad_in=True, transposed=True, mask=h1, colsum=g[cn + "0.bias"])
         self._wgrad_linear(dh1, x4, g[cn + "0.weight"])
-        u._colsum(dh1, g[cn + "0.bias"])
 
     def _scene(self, xyz, sal_t, sal_r, query, label, weight, rel_names, n_total, loss_acc, logits_out, last=False):
         """Fused form (VOOLTrainer.step): the BCE-with-logits loss and its gradient come out of the pointer-head kernel.
@@ -756,8 +763,10 @@ class VOOLTrainer:
             c["on_done"] = lambda name: self.buckets.ready(self.bucket_of[name]) if name in self.bucket_of else None
         dO = torch.empty_like(c["o"])
         drel = torch.zeros(c["D"], self.E, dtype=torch.float32, device=self.dev)
+        dob = self.unet.arena.zeros((c["D"], self.E), torch.float32)           # column sums of dO per description: the sampler MLP's last bias gradient
         _lib.call("semabs_cos_bce", _lib.ptr(c["o"]), _lib.ptr(c["rel"]), _lib.ptr(label), _lib.ptr(weight), c["D"], c["M"], self.temperature, n_total,
-                  _lib.ptr(logits_out), _lib.ptr(dO), _lib.ptr(drel), _lib.ptr(loss_acc), _lib.stream())
+                  _lib.ptr(logits_out), _lib.ptr(dO), _lib.ptr(drel), _lib.ptr(loss_acc), _lib.ptr(dob), _lib.stream())
+        dO._semabs_colsum = dob
         self._scene_bwd(c, dO, drel)
 
     # ---- autograd boundary (SemAbsVOOL.forward under grad mode) ---------------------------------------------------------------------

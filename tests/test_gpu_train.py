@@ -171,13 +171,13 @@ def test_linear_rows_vs_fp64(R, Ci, Co, act, transposed, scaled):
     s = torch.tensor([2.0 ** 20 if scaled else 1.0, 2.0 ** -20 if scaled else 1.0], device="cuda")
     y = torch.full((R + 16, Co), 7.0, device="cuda")
     _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
-              _lib.ptr(y), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, None, None, _lib.stream())
+              _lib.ptr(y), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, None, None, None, None, _lib.stream())
     ref = x.double() @ (w.double() if transposed else w.double().T)
     ref = ref * float(s[0]) + (0 if scaled else b.double())
     if scaled:                                               # ... and scaled back in the epilogue: the unscaled product of 1e-7-sized values
         y2 = torch.empty(R, Co, device="cuda")
         _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, None, _lib.ptr(y2), R, Ci, Co, 0, 0.01,
-                  _lib.ptr(s), s[1:].data_ptr(), None, None, _lib.stream())
+                  _lib.ptr(s), s[1:].data_ptr(), None, None, None, None, _lib.stream())
         assert float((y2.double() - ref / float(s[0])).abs().max()) < 2e-6 * float(ref.abs().max()) / float(s[0])
     if act:
         ref = torch.where(ref > 0, ref, 0.01 * ref)
@@ -189,12 +189,22 @@ def test_linear_rows_vs_fp64(R, Ci, Co, act, transposed, scaled):
     bits = torch.zeros(1, dtype=torch.int32, device="cuda")
     y3 = torch.empty(R, Co, device="cuda")
     _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
-              _lib.ptr(y3), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), _lib.ptr(bits), _lib.stream())
+              _lib.ptr(y3), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), _lib.ptr(bits), None, None, _lib.stream())
     assert bool((y3 == torch.where(mask > 0, y[:R], torch.zeros_like(y3))).all())
     assert float(bits.view(torch.float32)) == float(y3.abs().max())
+    cs = torch.full((Co,), 0.25, device="cuda")              # column sums of Y (accumulated): the bias gradient when Y is a layer's output gradient
+    _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
+              _lib.ptr(y3), R, Ci, Co, act, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), None, _lib.ptr(cs), None, _lib.stream())
+    ref_cs = y3.double().sum(0)
+    assert float(((cs.double() - 0.25) - ref_cs).abs().max()) <= 2e-5 * float(y3.double().abs().sum(0).max()) + 1e-6
+    if Ci == 16 and Co == 16 and R >= 65536:                # the 16 -> 16 kernel also sums the columns of its INPUT (the final convolution's bias gradient)
+        xs = torch.full((16,), 0.0, device="cuda")
+        _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, None, _lib.ptr(y3), R, Ci, Co, 0, 0.01,
+                  _lib.ptr(s) if scaled else None, None, None, None, None, _lib.ptr(xs), _lib.stream())
+        assert float((xs.double() - x.double().sum(0)).abs().max()) <= 2e-5 * float(x.double().abs().sum(0).max())
     if not act:                                              # act = 2: the LeakyReLU form of the mask (Y *= slope where mask <= 0)
         _lib.call("semabs_linear_rows", _lib.ptr(x), Ci, _lib.ptr(w), 1 if transposed else Ci, Co if transposed else 1, _lib.ptr(b) if not scaled else None,
-                  _lib.ptr(y3), R, Ci, Co, 2, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), None, _lib.stream())
+                  _lib.ptr(y3), R, Ci, Co, 2, 0.01, _lib.ptr(s) if scaled else None, None, _lib.ptr(mask), None, None, None, _lib.stream())
         assert bool((y3 == torch.where(mask > 0, y[:R], y[:R] * 0.01)).all())
 
 
@@ -215,8 +225,10 @@ def test_cos_bce_and_cos_head_vs_torch_fp64(P, M):
     dev = [t.cuda().contiguous() for t in (o, rel, label, weight)]
     logits = torch.empty(P * M, device="cuda"); dO = torch.empty(P * M, 64, device="cuda")
     drel = torch.zeros(P, 64, device="cuda"); lossd = torch.zeros(1, dtype=torch.float64, device="cuda")
+    dob = torch.zeros(P, 64, device="cuda")
     _lib.call("semabs_cos_bce", _lib.ptr(dev[0]), _lib.ptr(dev[1]), _lib.ptr(dev[2]), _lib.ptr(dev[3]), P, M, 0.07, P * M, _lib.ptr(logits), _lib.ptr(dO),
-              _lib.ptr(drel), _lib.ptr(lossd), _lib.stream())
+              _lib.ptr(drel), _lib.ptr(lossd), _lib.ptr(dob), _lib.stream())
+    assert _rel(dob.cpu().numpy(), od.grad.reshape(P, M, 64).sum(1).numpy()) < 1e-5
     assert _rel(logits.cpu().numpy(), z.detach().numpy()) < 2e-6
     assert abs(float(lossd) - float(loss)) < 1e-6 * float(loss)
     assert _rel(dO.cpu().numpy(), od.grad.numpy()) < 1e-5
