@@ -1,3 +1,4 @@
+# (round 5, historical) same-box A/B of the two-workgroup k_wgrad3_tr experiment against lib/libsemabs_hip_prev.so (profiles/r05_negative_results.md)
 mkdir -p gpurun_out/r5h
 python -m pytest tests/test_gpu_train.py -q -x -k "strict or wgrad or golden_64" > gpurun_out/r5h/train_tests.txt 2>&1; tail -3 gpurun_out/r5h/train_tests.txt
 for i in 1 2; do
