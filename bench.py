@@ -913,6 +913,14 @@ def main():
                          "mfma_probe": MFMA_PROBE and dict(MFMA_PROBE, frac_of_random_operand_skeleton=ach / MFMA_PROBE["skeleton_random_operands_tflops"])},
         }
         out["roofline"].update(smi.summary())
+        # context beside `frac` (which stays against the 2.4 GHz dense peak): the same achieved rate against the peak at the shader clock the part actually held
+        # during the timed region - at its power cap the part clocks down under matrix load, so this is the fraction of the matrix pipe's cycles that did work
+        sclk = out["roofline"].get("sclk_mhz_under_load")
+        if sclk:
+            out["roofline"]["peak_at_measured_sclk"] = PEAK_F16_TFLOPS * float(sclk) / 2400.0
+            out["roofline"]["frac_at_measured_sclk"] = ach / (PEAK_F16_TFLOPS * float(sclk) / 2400.0)
+            out["roofline"]["frac_at_measured_sclk_note"] = ("achieved / (peak x sclk_mhz_under_load / 2400): the scene-wide median clock; the GEMM phases alone hold a LOWER "
+                                                             "clock than the median (profiles/r04_mfma_probes.txt), so this is a lower bound of the matrix pipe's busy fraction")
         out["timed_region"] = ("per scene, everything from the uint8 frame + fp32 depth resident in HBM to the label volume: " +
                                ("the text tower on the 16 labels' token ids (the reference encodes the label set on every get_clip_saliency call), " if text_enc is not None else "") +
                                "colour jitter, tiling, ViT + rollout, aggregation, unprojection + compaction + sub-sample, point MLP, scatter, UNet, decoder, TSDF, "
