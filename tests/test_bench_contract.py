@@ -55,6 +55,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert rf["smi_samples"] > 0 and (rf["sclk_mhz_under_load"] or rf["power_w"])
         assert rf["sclk_mhz_under_load"] is None or 100 < rf["sclk_mhz_under_load"] < 3000
         assert rf["power_w"] is None or 50 < rf["power_w"] < 2000
+        if rf["sclk_mhz_under_load"]:                       # the clock-adjusted context figure: same rate, peak scaled to the sampled clock; `frac` itself stays against 2.4 GHz
+            assert abs(rf["frac_at_measured_sclk"] * rf["peak_at_measured_sclk"] - rf["achieved"]) < 1e-6 * rf["achieved"]
+            assert abs(rf["peak_at_measured_sclk"] - rf["peak"] * rf["sclk_mhz_under_load"] / 2400.0) < 1e-6 * rf["peak"]
+            assert abs(rf["frac"] * rf["peak"] - rf["achieved"]) < 1e-6 * rf["achieved"]
 
 
 @pytest.mark.gpu
