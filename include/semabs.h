@@ -147,18 +147,22 @@ int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const float* bias,
  * (sum, sum of squares) [M, N / 256, 2]; epi 0 / 1 with (ln_rowac, ln_colsum): C = rstd_row * (A W^T) - mean_row * rstd_row * colsum[n] + bias[n]
  * (A = such an xg, K % 128 == 0; colsum[n] = sum_k gamma_k W[n, k]; bias must already contain sum_k beta_k W[n, k]).  reverse: tile order (zigzag).
  * epi 0 with lo_out (precision = "parity"): additionally lo_out[m, n] = fp16(v - fp16(v)) for n < lo_cols (lo_cols % 256 == 0, row pitch ld_lo): the low
- * halves of q | k, consumed by semabs_attention_split.  semabs_ln_rowstats: partials -> (rstd, -mean * rstd) [M, 2]. */
+ * halves of q | k, consumed by semabs_attention_split.  semabs_ln_rowstats: partials -> (rstd, -mean * rstd) [M, 2].
+ * ln_center (producer, optional, [M]): a per-row centre c - the mean the previous LayerNorm of the row saw - subtracted before the fp16 copy and the
+ * partial sums: xg = fp16((x_new - c) * gamma), partials of x_new - c.  semabs_ln_rowstats(center_in, center_out) then yields (rstd, -mean(x - c) * rstd),
+ * which makes the consumer's formula exact again, and center_out = c + mean(x - c), the next producer's centre (center_out may alias center_in). */
 int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
-                       void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum,
+                       void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_center, const float* ln_rowac, const float* ln_colsum,
                        void* lo_out, int lo_cols, long ld_lo, int reverse,
                        void* start_event, void* stop_event, void* stream);
-int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, void* stream);
+int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, const float* center_in, float* center_out, void* stream);
 
 /* ============================ transformer pieces (csrc/vit.hip) ========================================= */
 
-/* LayerNorm (fp32 statistics)                                        model_explainability.py:188-194 */
+/* LayerNorm (fp32 statistics)                                        model_explainability.py:188-194
+ * mean_out (optional, [M]): the row means, the first centre of a folded-LayerNorm chain (semabs_gemm_f16_ln). */
 int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D, float eps,
-                     int out_f32, long ld_in, void* stream);
+                     int out_f32, long ld_in, float* mean_out, void* stream);
 /* Residual add fused into the LayerNorm pass: x fp32 [M, D] += delta fp16 [M, D] (in place), out fp16 [M, D] = LayerNorm(x); out NULL = the
  * addition only.  ResidualAttentionBlock.forward's `x = x + ...; ln_2(x)` (model_explainability.py:232-255) with the read-modify-write of
  * the residual stream taken out of the GEMM epilogue. */
@@ -177,19 +181,22 @@ int semabs_attention(const void* qkv, void* out, void* row_stats, int n_seq, int
  * scores = q_hi k_hi + q_hi k_lo + q_lo k_hi in fp32                                                      CLIP/clip/auxiliary.py:307-337 */
 int semabs_attention_split(const void* qkv, const void* qk_lo, void* out, void* row_stats, int n_seq, int T, int H, int head_dim, int ld, int ld_lo,
                            int causal, void* stream);
-int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, void* stream);
+/* "split" fp16 outputs (semabs_attention_cls / _quickgelu / _logit_grad / _ln_bwd / _gelu_bwd: `split` != 0; semabs_layernorm: out_f32 bit 3): a row
+ * of W values is stored as [hi | lo] with a pitch of 2 W - hi = fp16(v), lo = fp16(v - hi) - and consumed by a GEMM with K = 2 W against the weight
+ * matrix repeated twice along K: the operand enters to ~2^-22.  The last block and the VJP chain behind it run this way (clip/vit.py). */
+int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, int split, void* stream);
 int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
 /* x[arange(B), tokens.argmax(-1)] of the text tower (the EOT rows)        CLIP/clip/model_explainability.py:480
  * tokens int64 [B, T] (device), x fp32 [B * T, D] -> dst fp32 [B, D]. */
 int semabs_eot_rows_gather(const long long* tokens, const float* x, float* dst, int B, int T, int D, void* stream);
-int semabs_quickgelu(const float* fc, void* act, long n, void* stream);                 /* model_explainability.py:197-199 */
+int semabs_quickgelu(const float* fc, void* act, long n, int split_w, void* stream);    /* model_explainability.py:197-199; split_w > 0: rows of split_w values, split output */
 /* gd = d quickgelu(x) / dx on fp32 pre-activations (fp32, n % 4 == 0): the derivative table of semabs_gemm_f16 epi 5 */
 int semabs_quickgelu_grad(const float* fc, float* gd, long n, void* stream);
 /* logits = 100 f/|f| . w_l and d logit / d f, rows normalised to max-abs 1            clip_gradcam.py:62-67 */
-int semabs_logit_grad(const float* feat, const float* w_text, int n, int L, int E, float* logits, void* dfeat, float* scale, void* stream);
+int semabs_logit_grad(const float* feat, const float* w_text, int n, int L, int E, float* logits, void* dfeat, float* scale, int split, void* stream);
 int semabs_ln_bwd(const float* x, const float* gamma, const float* gy, const float* resid, float* out32, void* out16,
-                  long M, int D, int n_x, long ld_x, float eps, void* stream);
-int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, void* stream);
+                  long M, int D, int n_x, long ld_x, float eps, int split, void* stream);
+int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, int split, void* stream);
 /* closed form of ClipGradcam.interpret for the only contributing block             clip_gradcam.py:70-132 */
 int semabs_rollout(const float* probs, const void* v /* fp16 [n, T, D] */, const float* u, const float* scale, float* rel, int n, int T, int H,
                    int L, int positive_only, long n_total, long tile0, void* stream);

@@ -53,22 +53,22 @@ SIGNATURES = {
     # gemm.hip
     "semabs_gemm_f16": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), P],
     "semabs_gemm_f16_ex": [P, P, P, P, P, L, I, I, L, I, L, I, C.POINTER(I), I, P, P, P],
-    "semabs_gemm_f16_ln": [P, P, P, P, L, I, I, L, I, L, I, P, P, P, P, P, P, I, L, I, P, P, P],
-    "semabs_ln_rowstats": [P, L, I, I, F, P, P],
+    "semabs_gemm_f16_ln": [P, P, P, P, L, I, I, L, I, L, I, P, P, P, P, P, P, P, I, L, I, P, P, P],
+    "semabs_ln_rowstats": [P, L, I, I, F, P, P, P, P],
     # vit.hip
-    "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P],
+    "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P, P],
     "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],
     "semabs_embed_finish": [P, P, P, I, I, I, P],
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
     "semabs_attention_split": [P, P, P, P, I, I, I, I, I, I, I, P],
-    "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, P],
+    "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, I, P],
     "semabs_rows_gather": [P, P, L, I, L, L, P],
     "semabs_eot_rows_gather": [P, P, P, I, I, I, P],
-    "semabs_quickgelu": [P, P, L, P],
+    "semabs_quickgelu": [P, P, L, I, P],
     "semabs_quickgelu_grad": [P, P, L, P],
-    "semabs_logit_grad": [P, P, I, I, I, P, P, P, P],
-    "semabs_ln_bwd": [P, P, P, P, P, P, L, I, I, L, F, P],
-    "semabs_gelu_bwd": [P, P, P, L, I, I, P],
+    "semabs_logit_grad": [P, P, I, I, I, P, P, P, I, P],
+    "semabs_ln_bwd": [P, P, P, P, P, P, L, I, I, L, F, I, P],
+    "semabs_gelu_bwd": [P, P, P, L, I, I, I, P],
     "semabs_rollout": [P, P, P, P, P, I, I, I, I, I, L, L, P],
     "semabs_gather_text": [P, P, P, P, I, I, I, P],
     # vitl.hip (multi-layer rollout: attention backward)

@@ -99,7 +99,7 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, k
 _gemm = gemm
 
 
-def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, part=None, rowac=None, colsum=None, reverse=0, lo=None, lo_cols=0):
+def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, part=None, rowac=None, colsum=None, reverse=0, lo=None, lo_cols=0, center=None):
     """A GEMM with the LayerNorm that precedes (consumer: rowac, colsum) or follows (producer: xg, gamma, part) it folded in - see
     `semabs_gemm_f16_ln` (csrc/gemm.hip, LNP / LNC).  Timed by GEMM_TIMER like every other GEMM launch; the producer's algorithmic bytes include
     the fp16 copy it writes."""
@@ -112,18 +112,20 @@ def gemm_ln(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, xg=None, gamma=None, par
             t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else 8) + (M * N * 2 if xg is not None else 0)
                               + (M * lo_cols * 2 if lo is not None else 0), (int(N), int(K), int(epi))))
     _lib.call("semabs_gemm_f16_ln", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), int(M), int(N), int(K), int(lda), int(ldb), int(ldc), int(epi),
-              _lib.ptr(xg), _lib.ptr(gamma), _lib.ptr(part), _lib.ptr(rowac), _lib.ptr(colsum), _lib.ptr(lo), int(lo_cols), int(lo.shape[1]) if lo is not None else 0,
+              _lib.ptr(xg), _lib.ptr(gamma), _lib.ptr(part), _lib.ptr(center), _lib.ptr(rowac), _lib.ptr(colsum), _lib.ptr(lo), int(lo_cols), int(lo.shape[1]) if lo is not None else 0,
               int(reverse), e0, e1, _lib.stream())
 
 
-def ln_rowstats(part, M, ntile, D, rowac, eps=1e-5):
-    _lib.call("semabs_ln_rowstats", _lib.ptr(part), int(M), int(ntile), int(D), float(eps), _lib.ptr(rowac), _lib.stream())
+def ln_rowstats(part, M, ntile, D, rowac, eps=1e-5, center=None, center_out=None):
+    """center: the per-row centres the producer subtracted (None = 0); center_out (may be `center`): the rows' true means = the next producer's centres."""
+    _lib.call("semabs_ln_rowstats", _lib.ptr(part), int(M), int(ntile), int(D), float(eps), _lib.ptr(rowac), _lib.ptr(center), _lib.ptr(center_out), _lib.stream())
 
 
-def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5, order=0):
-    """order: 0 = rows in dispatch order, 1 / 2 = XCD-contiguous runs of rows walked forwards / backwards (the zigzag schedule of the trunk)."""
+def layernorm(x, gamma, beta, out, M, D, out_f32=False, ld_in=None, eps=1e-5, order=0, mean_out=None):
+    """order: 0 = rows in dispatch order, 1 / 2 = XCD-contiguous runs of rows walked forwards / backwards (the zigzag schedule of the trunk).
+    mean_out fp32 [M] (optional): the row means."""
     _lib.call("semabs_layernorm", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out), int(M), int(D), float(eps),
-              int(out_f32) | (int(order) << 1), int(ld_in if ld_in is not None else D), _lib.stream())
+              int(out_f32) | (int(order) << 1), int(ld_in if ld_in is not None else D), _lib.ptr(mean_out), _lib.stream())
 
 
 def add_layernorm(x, delta, gamma, beta, out, M, D, eps=1e-5):
@@ -171,6 +173,11 @@ class _BlockWeights:
             self.w_o_t = h(sd[pre + "attn.out_proj.weight"].float().t())
             self.w_fc_t = h(sd[pre + "mlp.c_fc.weight"].float().t())
             self.w_pr_t = h(sd[pre + "mlp.c_proj.weight"].float().t())
+        if last:         # [W | W] along K: B operands of the GEMMs whose A operand is a split [hi | lo] row (vit.hip store_split4)
+            two = lambda t: torch.cat([t, t], dim=1).contiguous()
+            self.w_q2, self.w_k2 = two(self.w_in[:D]), two(self.w_in[D:2 * D])
+            self.w_o2, self.w_fc2, self.w_pr2 = two(self.w_o), two(self.w_fc), two(self.w_pr)
+            self.w_o_t2, self.w_fc_t2, self.w_pr_t2 = two(self.w_o_t), two(self.w_fc_t), two(self.w_pr_t)
         if bwd:          # d(ln_1 out) = dqkv . W_in (q rows carry the folded 1 / sqrt(dh), like the forward)
             self.w_in_t = h(w_in.t())
 
@@ -219,8 +226,16 @@ class VisionRollout:
         self.ln_post = (f(sd["visual.ln_post.weight"]), f(sd["visual.ln_post.bias"]))
         self.proj = h(sd["visual.proj"])                                    # [D, E] = B operand of dy = dfeat . proj^T
         self.proj_t = h(sd["visual.proj"].float().t())                      # [E, D] = B operand of feat = y . proj
+        self.proj2 = torch.cat([self.proj, self.proj], dim=1).contiguous()          # [W | W] along K for split A operands (head_split)
+        self.proj_t2 = torch.cat([self.proj_t, self.proj_t], dim=1).contiguous()
         self.blocks = [_BlockWeights(sd, f"visual.transformer.resblocks.{i}.", self.D, heads, dev, last=(i == self.layers - 1))
                        for i in range(self.layers)]
+        # Split operands in the last block and the VJP chain (round 6, default on; SEMABS_HEAD_SPLIT=0: A/B): every fp16 GEMM A operand behind the trunk -
+        # the last LayerNorm output feeding K and the CLS query, the CLS row's attention output / LayerNorm / QuickGELU outputs, the logit gradient and the
+        # LayerNorm / QuickGELU VJP outputs - is carried as an [hi | lo] pair (K doubled against [W | W]): n or L n rows except the K projection, ~1 % of the
+        # flops.  With the peaked softmax of a trained checkpoint (CLS scores up to ~60) the fp16 rounding of that LayerNorm output alone moved the kept
+        # softmax row by 2e-3 and the per-tile relevance by 3 - 5e-3 of its maximum (tests/test_gpu_trained_stats.py; budget: test_vit_precision_budget.py).
+        self.head_split = os.environ.get("SEMABS_HEAD_SPLIT", "1") == "1"
         self.chunk = int(chunk_tiles)
         self.max_labels = int(max_labels)
         self._wss = {}
@@ -233,10 +248,15 @@ class VisionRollout:
         # LayerNorm passes of a scene disappear (each a 1.48 GB fp32 read + 0.74 GB fp16 write at the benchmark batch); the residual GEMMs write the
         # fp16 (x * gamma) copy from their epilogue instead.  SEMABS_LN_FOLD=0 runs the LayerNorm kernels (A/B).
         self.ln_fold = os.environ.get("SEMABS_LN_FOLD", "1") == "1"
+        # Row centring of the fold (round 6): the fp16 copy is fp16((x - c) * gamma) with c = the row's mean at its previous LayerNorm.  Released
+        # checkpoints carry a per-token DC offset of several sigma of the bulk; un-centred, the copy rounds relative to |mean| instead of |x - mean|
+        # (tests/test_gpu_trained_stats.py, test_gpu_gemm.py::test_gemm_layernorm_fold_with_row_dc_offset_and_massive_channels).  SEMABS_LN_CENTER=0: A/B.
+        self.ln_center = os.environ.get("SEMABS_LN_CENTER", "1") == "1"
         # precision = "parity" (opt-in; ClipWrapper(..., precision="parity") or SEMABS_QK_SPLIT=1): the QKV GEMM also stores the LOW fp16 halves of q and k
         # and the attention kernel forms the scores from hi + lo pairs (three MFMA products in fp32) - the fp16 rounding of q and k is the largest
         # single term of the maps' deviation from the fp32 reference.  + 1.48 GB written and read per block, one attention workgroup per CU.
         self.qk_split = os.environ.get("SEMABS_QK_SPLIT", "0") == "1"
+        self._warned_qk = False
         self.slot = 0          # active workspace (one per HIP stream when tile chunks are pipelined on two streams)
 
     # ---- workspace ---------------------------------------------------------------------------------
@@ -256,11 +276,12 @@ class VisionRollout:
             R = Lm * n
             self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), delta=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
-                ln_part=e32(n * T, max(1, D // 256), 2), ln_rowac=e32(n * T, 2), qk_lo=e16(n * T, 2 * D) if self.qk_split else None,
-                k32=e32(n * T, D), v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, D), x1c=e32(n, D),
-                h2c=e16(n, D), fc=e32(n, 4 * D), actc=e16(n, 4 * D), x2c=e32(n, D), yc=e16(n, D), feat=e32(n, E),
-                logits=e32(n, Lm), dfeat=e16(R, E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, D),
-                dact=e32(R, 4 * D), dfc=e16(R, 4 * D), dh2=e32(R, D), g1h=e16(R, D), u=e32(R, D),
+                ln_part=e32(n * T, max(1, D // 256), 2), ln_rowac=e32(n * T, 2), ln_center=e32(n * T), qk_lo=e16(n * T, 2 * D) if self.qk_split else None,
+                k32=e32(n * T, D), v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, 2 * D), x1c=e32(n, D),
+                h2c=e16(n, 2 * D), fc=e32(n, 4 * D), actc=e16(n, 8 * D), x2c=e32(n, D), yc=e16(n, 2 * D), feat=e32(n, E),
+                logits=e32(n, Lm), dfeat=e16(R, 2 * E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, 2 * D),
+                dact=e32(R, 4 * D), dfc=e16(R, 8 * D), dh2=e32(R, D), g1h=e16(R, 2 * D), u=e32(R, D),
+                h_last=e16(n * T, 2 * D) if self.head_split else None,      # the last block's LayerNorm-1 output as [hi | lo] rows (the trunk's `h` is [n T, D])
             )
         return self._wss[self.slot]
 
@@ -293,12 +314,15 @@ class VisionRollout:
             if self.ln_fold and M >= 2048 and D % 256 == 0 and D % 128 == 0:
                 # h doubles as xg = fp16(x * gamma_next): written by the residual GEMMs' epilogues, read as the next GEMM's A operand
                 part, rowac, nt = ws["ln_part"], ws["ln_rowac"], D // 256
+                # row centres (LN_CENTER): block 0's ln_1 pass leaves the row means; every producer subtracts the mean its row had at the previous LayerNorm
+                # before the fp16 copy, ln_rowstats turns the centred partials into the consumer's pair and the row's new mean
+                cen = ws["ln_center"] if self.ln_center else None
                 trunk_blocks = self.blocks[:-1]
                 d = (lambda: step()) if zz else (lambda: 0)
                 qk_lo = ws["qk_lo"] if (self.qk_split and (2 * D) % 256 == 0) else None
                 for bi, b in enumerate(trunk_blocks):
                     if bi == 0:                              # ln_1 of the first block follows ln_pre, not a GEMM
-                        layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=(1 + d()) if zz else 0)
+                        layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=(1 + d()) if zz else 0, mean_out=cen)
                         if qk_lo is None:
                             gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, kernel=2 | (d() << 8))
                         else:
@@ -310,15 +334,22 @@ class VisionRollout:
                     else:
                         _lib.call("semabs_attention_split", _lib.ptr(qkv), _lib.ptr(qk_lo), _lib.ptr(att), None, n, T, H, 64, 3 * D, 2 * D,
                                   ((1 + d()) << 3) if zz else 0, _lib.stream())
-                    gemm_ln(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32, xg=h, gamma=b.ln2_w, part=part, reverse=d())
-                    ln_rowstats(part, M, nt, D, rowac)
+                    gemm_ln(att, b.w_o, x, b.b_o, M, D, D, D, D, D, EPI_RESID_F32, xg=h, gamma=b.ln2_w, part=part, reverse=d(), center=cen)
+                    ln_rowstats(part, M, nt, D, rowac, center=cen, center_out=cen)
                     gemm_ln(h, b.w_fc, hid, b.b_fc_f, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16, rowac=rowac, colsum=b.cs_fc, reverse=d())
                     if bi + 1 < len(trunk_blocks):
-                        gemm_ln(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32, xg=h, gamma=trunk_blocks[bi + 1].ln1_w, part=part, reverse=d())
-                        ln_rowstats(part, M, nt, D, rowac)
+                        gemm_ln(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32, xg=h, gamma=trunk_blocks[bi + 1].ln1_w, part=part, reverse=d(), center=cen)
+                        ln_rowstats(part, M, nt, D, rowac, center=cen, center_out=cen)
                     else:                                    # the last block's ln_1 feeds K | V | the CLS query: stays a LayerNorm pass (head)
                         gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32, kernel=2 | (d() << 8))
                 return
+            if self.qk_split and not self._warned_qk:
+                # precision = "parity" needs the persistent QKV kernel (M >= 2048 token rows, D % 256 == 0, LayerNorm fold on); say so instead of silently
+                # returning default-precision maps
+                import warnings
+                warnings.warn(f'precision="parity" (fp16 hi + lo q | k) is not available for this batch ({M} token rows < 2048 or SEMABS_LN_FOLD=0): '
+                              "running the default precision", RuntimeWarning, stacklevel=2)
+                self._warned_qk = True
             for b in self.blocks[:-1]:
                 if not zz:
                     layernorm(x, b.ln1_w, b.ln1_b, h, M, D)
@@ -357,31 +388,35 @@ class VisionRollout:
             add_layernorm(x, delta, None, None, None, M, D)            # the last block's MLP delta
 
     def head(self, n: int):
-        """last block for the CLS token + ln_post + proj -> ws['feat'] [n, E]; keeps probs / v16 / x1c / fc / x2c."""
+        """last block for the CLS token + ln_post + proj -> ws['feat'] [n, E]; keeps probs / v16 / x1c / fc / x2c.
+        head_split: every fp16 A operand is an [hi | lo] row pair of pitch 2 K, multiplied against [W | W] (K doubled)."""
         ws = self._workspace()
         T, D, H, E = self.T, self.D, self.H, self.E
         b = self.blocks[-1]
-        x, h = ws["x"], ws["h"]
+        x = ws["x"]
         st = _lib.stream()
-        layernorm(x, b.ln1_w, b.ln1_b, h, n * T, D)
+        sp = 1 if self.head_split else 0
+        k2 = 2 if sp else 1                                   # K multiplier of the split operands
+        h = ws["h_last"] if sp else ws["h"]
+        layernorm(x, b.ln1_w, b.ln1_b, h, n * T, D, out_f32=8 if sp else 0)
         # K and V for every token.  K in fp32: it feeds the kept softmax row directly.  V in fp16 like every other block's: it only enters
         # through averages (the CLS output, itself stored in fp16, and the rollout's 64-long V . u dots), where its rounding is ~6e-5
         # relative - and it is read five times (CLS attention + four label groups of the rollout), so its width is bandwidth
-        gemm(h, b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, D, D, D, D, EPI_F32)
-        gemm(h, b.w_in[2 * D:], ws["v16"], b.b_in[2 * D:], n * T, D, D, D, D, D, EPI_F16)
-        # Q for the CLS rows only (row stride T * D)
-        gemm(h, b.w_in[:D], ws["q32"], b.b_in[:D], n, D, D, T * D, D, D, EPI_F32)
+        gemm(h, b.w_k2 if sp else b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, k2 * D, k2 * D, k2 * D, D, EPI_F32)
+        gemm(h, b.w_in[2 * D:], ws["v16"], b.b_in[2 * D:], n * T, D, D, k2 * D, D, D, EPI_F16)          # the hi halves only (row pitch k2 D)
+        # Q for the CLS rows only (row stride T * k2 D)
+        gemm(h, b.w_q2 if sp else b.w_in[:D], ws["q32"], b.b_in[:D], n, D, k2 * D, T * k2 * D, k2 * D, D, EPI_F32)
         _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["k32"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
-                  n, T, H, 64, st)
+                  n, T, H, 64, sp, st)
         _lib.call("semabs_rows_gather", _lib.ptr(x), _lib.ptr(ws["x1c"]), n, D, T * D, 0, st)
-        gemm(ws["o_cls"], b.w_o, ws["x1c"], b.b_o, n, D, D, D, D, D, EPI_RESID_F32)
-        layernorm(ws["x1c"], b.ln2_w, b.ln2_b, ws["h2c"], n, D)
-        gemm(ws["h2c"], b.w_fc, ws["fc"], b.b_fc, n, 4 * D, D, D, D, 4 * D, EPI_F32)
-        _lib.call("semabs_quickgelu", _lib.ptr(ws["fc"]), _lib.ptr(ws["actc"]), n * 4 * D, st)
+        gemm(ws["o_cls"], b.w_o2 if sp else b.w_o, ws["x1c"], b.b_o, n, D, k2 * D, k2 * D, k2 * D, D, EPI_RESID_F32)
+        layernorm(ws["x1c"], b.ln2_w, b.ln2_b, ws["h2c"], n, D, out_f32=8 if sp else 0)
+        gemm(ws["h2c"], b.w_fc2 if sp else b.w_fc, ws["fc"], b.b_fc, n, 4 * D, k2 * D, k2 * D, k2 * D, 4 * D, EPI_F32)
+        _lib.call("semabs_quickgelu", _lib.ptr(ws["fc"]), _lib.ptr(ws["actc"]), n * 4 * D, 4 * D if sp else 0, st)
         _lib.call("semabs_rows_gather", _lib.ptr(ws["x1c"]), _lib.ptr(ws["x2c"]), n, D, D, 0, st)
-        gemm(ws["actc"], b.w_pr, ws["x2c"], b.b_pr, n, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
-        layernorm(ws["x2c"], *self.ln_post, ws["yc"], n, D)
-        gemm(ws["yc"], self.proj_t, ws["feat"], None, n, E, D, D, D, E, EPI_F32)
+        gemm(ws["actc"], b.w_pr2 if sp else b.w_pr, ws["x2c"], b.b_pr, n, D, k2 * 4 * D, k2 * 4 * D, k2 * 4 * D, D, EPI_RESID_F32)
+        layernorm(ws["x2c"], *self.ln_post, ws["yc"], n, D, out_f32=8 if sp else 0)
+        gemm(ws["yc"], self.proj_t2 if sp else self.proj_t, ws["feat"], None, n, E, k2 * D, k2 * D, k2 * D, E, EPI_F32)
 
     def rollout(self, n: int, w_text: torch.Tensor, positive_attn_only: bool, rel_out: torch.Tensor, tile0: int):
         """w_text fp32 [L, E] on the GPU; writes rel_out[:, tile0:tile0+n] (rel_out fp32 [L, N_total, g, g])."""
@@ -392,17 +427,19 @@ class VisionRollout:
         R = L * n
         b = self.blocks[-1]
         st = _lib.stream()
+        sp = 1 if self.head_split else 0
+        k2 = 2 if sp else 1
         _lib.call("semabs_logit_grad", _lib.ptr(ws["feat"]), _lib.ptr(w_text), n, L, E, _lib.ptr(ws["logits"]),
-                  _lib.ptr(ws["dfeat"]), _lib.ptr(ws["scale"]), st)
-        gemm(ws["dfeat"], self.proj, ws["dy"], None, R, D, E, E, E, D, EPI_F32)
+                  _lib.ptr(ws["dfeat"]), _lib.ptr(ws["scale"]), sp, st)
+        gemm(ws["dfeat"], self.proj2 if sp else self.proj, ws["dy"], None, R, D, k2 * E, k2 * E, k2 * E, D, EPI_F32)
         _lib.call("semabs_ln_bwd", _lib.ptr(ws["x2c"]), _lib.ptr(self.ln_post[0]), _lib.ptr(ws["dy"]), None,
-                  _lib.ptr(ws["dx2"]), _lib.ptr(ws["dx2h"]), R, D, n, D, 1e-5, st)
-        gemm(ws["dx2h"], b.w_pr_t, ws["dact"], None, R, 4 * D, D, D, D, 4 * D, EPI_F32)
-        _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(ws["fc"]), _lib.ptr(ws["dfc"]), R, 4 * D, n, st)
-        gemm(ws["dfc"], b.w_fc_t, ws["dh2"], None, R, D, 4 * D, 4 * D, 4 * D, D, EPI_F32)
+                  _lib.ptr(ws["dx2"]), _lib.ptr(ws["dx2h"]), R, D, n, D, 1e-5, sp, st)
+        gemm(ws["dx2h"], b.w_pr_t2 if sp else b.w_pr_t, ws["dact"], None, R, 4 * D, k2 * D, k2 * D, k2 * D, 4 * D, EPI_F32)
+        _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(ws["fc"]), _lib.ptr(ws["dfc"]), R, 4 * D, n, sp, st)
+        gemm(ws["dfc"], b.w_fc_t2 if sp else b.w_fc_t, ws["dh2"], None, R, D, k2 * 4 * D, k2 * 4 * D, k2 * 4 * D, D, EPI_F32)
         _lib.call("semabs_ln_bwd", _lib.ptr(ws["x1c"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh2"]), _lib.ptr(ws["dx2"]),
-                  None, _lib.ptr(ws["g1h"]), R, D, n, D, 1e-5, st)
-        gemm(ws["g1h"], b.w_o_t, ws["u"], None, R, D, D, D, D, D, EPI_F32)
+                  None, _lib.ptr(ws["g1h"]), R, D, n, D, 1e-5, sp, st)
+        gemm(ws["g1h"], b.w_o_t2 if sp else b.w_o_t, ws["u"], None, R, D, k2 * D, k2 * D, k2 * D, D, EPI_F32)
         _lib.call("semabs_rollout", _lib.ptr(ws["probs"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["u"]), _lib.ptr(ws["scale"]),
                   _lib.ptr(rel_out), n, T, H, L, int(positive_attn_only), int(rel_out.shape[1]), int(tile0), st)
 
@@ -541,7 +578,7 @@ class VisionRolloutDeep:
                 gemm(h, b.w_fc, hid, b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_GELU_F16)
             else:                                                            # keep the pre-activation: the QuickGELU VJP needs it
                 gemm(h, b.w_fc, sv["fc"], b.b_fc, M, 4 * D, D, D, D, 4 * D, EPI_F32)
-                _lib.call("semabs_quickgelu", _lib.ptr(sv["fc"]), _lib.ptr(hid), M * 4 * D, st)
+                _lib.call("semabs_quickgelu", _lib.ptr(sv["fc"]), _lib.ptr(hid), M * 4 * D, 0, st)
             gemm(hid, b.w_pr, x, b.b_pr, M, D, 4 * D, 4 * D, 4 * D, D, EPI_RESID_F32)
 
     def head(self, n: int):
@@ -561,10 +598,10 @@ class VisionRolloutDeep:
         M = R * T
         st = _lib.stream()
         _lib.call("semabs_logit_grad", _lib.ptr(ws["feat"]), _lib.ptr(w_text), n, L, E, _lib.ptr(ws["logits"]), _lib.ptr(ws["dfeat"]),
-                  _lib.ptr(ws["scale"]), st)
+                  _lib.ptr(ws["scale"]), 0, st)
         gemm(ws["dfeat"], self.proj, ws["dy"], None, R, D, E, E, E, D, EPI_F32)
         _lib.call("semabs_ln_bwd", _lib.ptr(ws["xcls"]), _lib.ptr(self.ln_post[0]), _lib.ptr(ws["dy"]), None, _lib.ptr(ws["dxc"]), None,
-                  R, D, n, D, 1e-5, st)
+                  R, D, n, D, 1e-5, 0, st)
         g32, g16, gscale, rvec, cacc = ws["g32"], ws["g16"], ws["gscale"], ws["rvec"], ws["cacc"]
         g32[:M].zero_()
         g32[:M].view(R, T, D)[:, 0, :] = ws["dxc"][:R]                       # only the class token of the last block reaches the feature
@@ -582,10 +619,10 @@ class VisionRolloutDeep:
                 gemm(g16, b.w_pr_t, ws["dfc"], None, M, 4 * D, D, D, D, 4 * D, EPI_GELUBWD, addend=ws["dact"], rowmap=(NT, 1, 0))
             else:
                 gemm(g16, b.w_pr_t, ws["dact"], None, M, 4 * D, D, D, D, 4 * D, EPI_F32)
-                _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(sv["fc"]), _lib.ptr(ws["dfc"]), M, 4 * D, NT, st)
+                _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(sv["fc"]), _lib.ptr(ws["dfc"]), M, 4 * D, NT, 0, st)
             gemm(ws["dfc"], b.w_fc_t, ws["dh"], None, M, D, 4 * D, 4 * D, 4 * D, D, EPI_F32)
             _lib.call("semabs_ln_bwd", _lib.ptr(sv["x_mid"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh"]), _lib.ptr(g32), _lib.ptr(ws["gmid32"]),
-                      _lib.ptr(ws["gmid16"]), M, D, NT, D, 1e-5, st)
+                      _lib.ptr(ws["gmid16"]), M, D, NT, D, 1e-5, 0, st)
             # attention sub-layer: dO = g_mid W_o, then (dQ | dK | dV) and this block's rollout update
             gemm(ws["gmid16"], b.w_o_t, ws["dO"], None, M, D, D, D, D, D, EPI_F16)
             last = i == self.first_roll
@@ -596,7 +633,7 @@ class VisionRolloutDeep:
             if not last:
                 gemm(ws["dqkv"], b.w_in_t, ws["dh"], None, M, D, 3 * D, 3 * D, 3 * D, D, EPI_F32)
                 _lib.call("semabs_ln_bwd", _lib.ptr(sv["x_in"]), _lib.ptr(b.ln1_w), _lib.ptr(ws["dh"]), _lib.ptr(ws["gmid32"]), _lib.ptr(g32),
-                          _lib.ptr(g16), M, D, NT, D, 1e-5, st)
+                          _lib.ptr(g16), M, D, NT, D, 1e-5, 0, st)
                 _lib.call("semabs_seq_rescale", _lib.ptr(g32), _lib.ptr(g16), _lib.ptr(gscale), R, T * D, st)
         rel_out[:L, tile0:tile0 + n] = rvec[:R].view(L, n, T)[:, :, 1:].reshape(L, n, self.g, self.g)
 

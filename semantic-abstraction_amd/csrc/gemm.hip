@@ -33,7 +33,8 @@ struct GemmArgs {
     int sc_w;                   // column panels per super-column of the raster (see tile_of in k_gemm8); 0 = all of them
     int reverse;                // k_gemm8: every XCD walks its run of tiles backwards (zigzag with the producer of A, semabs_common.h)
     // LayerNorm folded into the GEMMs on either side of it (semabs_gemm_f16_ln; k_gemm8's LNP / k_gemm8p's LNC template parameters):
-    f16* ln_xg; const float* ln_gamma; float* ln_part;      // producer (fp32 residual epilogue): fp16 (x_new * gamma) [M, N], gamma [N], row partials [M, N / 256, 2]
+    f16* ln_xg; const float* ln_gamma; float* ln_part;      // producer (fp32 residual epilogue): fp16 ((x_new - centre) * gamma) [M, N], gamma [N], row partials [M, N / 256, 2]
+    const float* ln_center;                                 // producer: per-row centre [M] subtracted before the fp16 copy and the partial sums (NULL = 0)
     const float* ln_rowac; const float* ln_colsum;          // consumer (fp16 outputs): per row (rstd, -mean * rstd) [M, 2], per column sum_k gamma_k W[n, k] [N]
     f16* lo_out; int lo_cols; long ld_lo;                   // k_gemm8p<.., QKLO>: the LOW fp16 half of the first lo_cols output columns, lo_out[m, n] = fp16(v - fp16(v))
 #ifdef SEMABS_TUNING
@@ -679,6 +680,17 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                     }
                     gvoff = (unsigned)(crow + (odd ? RPI : 0)) * ldgb + (unsigned)((cchunk & ~1) * 8);
                 }
+                // the rows' centres (round 6): the mean the previous LayerNorm of each row saw, subtracted before the fp16 rounding and the partial sums - an
+                // un-centred copy of a row with |mean| >> spread (trained checkpoints: a per-token DC offset of several sigma) spends its 11 bits on the offset
+                [[maybe_unused]] float cen[2][NIT];
+                if constexpr (LNP) {
+                    const __amdgpu_buffer_rsrc_t rCen = gemm_rsrc(g.ln_center ? g.ln_center + mw : nullptr, (g.ln_center && rows > 0) ? rows * 4 : 0);
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+                            cen[ha][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rCen, (unsigned)(ha * 128 + it * RPI + crow) * 4u, 0, 0));
+                }
                 auto dpp = [](float x, auto ctrl) {            // x of the lane selected by the DPP control word (all rows / banks, no bound control)
                     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
                 };
@@ -701,8 +713,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                         if constexpr (LNP) {
                             const int hb = pass >> 1;
                             typedef f16 f16x2v __attribute__((ext_vector_type(2)));
-                            const f16x2v h01 = f16x2v{(f16)(nw[0] * gam[hb][0]), (f16)(nw[1] * gam[hb][1])};
-                            const f16x2v h23 = f16x2v{(f16)(nw[2] * gam[hb][2]), (f16)(nw[3] * gam[hb][3])};
+                            const float cr = cen[pass & 1][it];
+                            const f32x4 y = f32x4{nw[0] - cr, nw[1] - cr, nw[2] - cr, nw[3] - cr};
+                            const f16x2v h01 = f16x2v{(f16)(y[0] * gam[hb][0]), (f16)(y[1] * gam[hb][1])};
+                            const f16x2v h23 = f16x2v{(f16)(y[2] * gam[hb][2]), (f16)(y[3] * gam[hb][3])};
                             const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
                             if ((it & 1) == 0) { keep0 = u01; keep1 = u23; }
                             else {
@@ -716,8 +730,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                                 asm volatile("s_nop 7" ::: "memory");
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-                            float s1 = (nw[0] + nw[1]) + (nw[2] + nw[3]);
-                            float s2 = (nw[0] * nw[0] + nw[1] * nw[1]) + (nw[2] * nw[2] + nw[3] * nw[3]);
+                            float s1 = (y[0] + y[1]) + (y[2] + y[3]);
+                            float s2 = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
                             s1 += dpp(s1, XOR1{}); s2 += dpp(s2, XOR1{});
                             s1 += dpp(s1, XOR2{}); s2 += dpp(s2, XOR2{});
                             s1 += dpp(s1, HMIR{}); s2 += dpp(s2, HMIR{});
@@ -725,6 +739,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmArgs g) {
                                 const int row = (pass & 1) * 128 + wr * 64 + it * RPI + crow;
                                 *reinterpret_cast<float2*>(sred + ((row * 4 + wc) * 2 + hb) * 2) = make_float2(s1, s2);
                             }
+                            // nw is the data of the 16-byte store above: keep its registers LIVE (not re-used) down to here.  With the centring the compiler formed
+                            // y in place (v_sub nw, nw, c right behind the store) and the store-data hazard described at store_pad put y[1] into x for the last four
+                            // lanes of every 16 (found with tools/gemm_probe.py-style row-index centres, round 6)
+                            asm volatile("" :: "v"(nw[0]), "v"(nw[1]), "v"(nw[2]), "v"(nw[3]));
                         }
                     }
                     store_pad();
@@ -1791,7 +1809,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
         g.g_in = rowmap3[0]; g.g_out = rowmap3[1]; g.g_off = rowmap3[2];
     }
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = (kernel >> 8) & 1;
-    g.ln_xg = nullptr; g.ln_gamma = nullptr; g.ln_part = nullptr; g.ln_rowac = nullptr; g.ln_colsum = nullptr;
+    g.ln_xg = nullptr; g.ln_gamma = nullptr; g.ln_part = nullptr; g.ln_rowac = nullptr; g.ln_colsum = nullptr; g.ln_center = nullptr;
     g.lo_out = nullptr; g.lo_cols = 0; g.ld_lo = 0;
     const int ring = (kernel >> 9) & 1;                     // bit 9: the K = 32 ring schedule of the phased kernel (A/B)
     const int v2 = ((kernel >> 11) & 1) == 0;               // the deep schedule of the phased kernel is the default since round 4; bit 11 selects the round-3 PF schedule (A/B), bit 10 is accepted and ignored
@@ -1822,7 +1840,7 @@ extern "C" int semabs_gemm_f16_ex(const void* A, const void* B, void* C, const f
 //   pitch ld_lo elements) - the low halves of q | k for precision = "parity" (semabs_attention_split).
 // reverse: walk the tiles backwards per XCD (the zigzag schedule of the trunk, like kernel | 256 of semabs_gemm_f16_ex).
 extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const float* bias, long M, int N, int K, long lda, int ldb, long ldc, int epi,
-                                  void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_rowac, const float* ln_colsum,
+                                  void* ln_xg, const float* ln_gamma, float* ln_part, const float* ln_center, const float* ln_rowac, const float* ln_colsum,
                                   void* lo_out, int lo_cols, long ld_lo, int reverse,
                                   void* start_event, void* stop_event, void* stream) {
     SEMABS_REQUIRE(A && B && C, "semabs_gemm_f16_ln: null operand");
@@ -1843,6 +1861,7 @@ extern "C" int semabs_gemm_f16_ln(const void* A, const void* B, void* C, const f
     g.g_in = 1; g.g_out = 1; g.g_off = 0;
     g.n_tiles_n = 0; g.n_blocks = 0; g.sc_w = 0; g.reverse = reverse ? 1 : 0;
     g.ln_xg = (f16*)ln_xg; g.ln_gamma = ln_gamma; g.ln_part = ln_part; g.ln_rowac = ln_rowac; g.ln_colsum = ln_colsum;
+    g.ln_center = producer ? ln_center : nullptr;
     g.lo_out = (f16*)lo_out; g.lo_cols = lo_out ? lo_cols : 0; g.ld_lo = ld_lo;
     GemmOpts o{2, (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, 1, 0};
     hipStream_t s = (hipStream_t)stream;

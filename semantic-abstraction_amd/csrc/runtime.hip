@@ -11,7 +11,7 @@ void semabs_set_error(const char* msg) {
 
 extern "C" const char* semabs_last_error(void) { return g_err; }
 
-extern "C" int semabs_abi_version(void) { return 7; }   // bumped whenever an exported signature changes or disappears (round 3: + semabs_cos_head, semabs_compact_subsample; 4: semabs_wgrad_conv3 takes a scratch buffer, + semabs_wgrad_mfma, semabs_quickgelu_grad, GEMM epilogue 5; 5: + semabs_unflip_average; 6 (round 5): + semabs_color_jitter_op, hue factor range checked; 7: + semabs_wgrad_conv3_gn, semabs_vool_sample_bwd takes absmax_bits)
+extern "C" int semabs_abi_version(void) { return 8; }   // bumped whenever an exported signature changes or disappears (round 3: + semabs_cos_head, semabs_compact_subsample; 4: semabs_wgrad_conv3 takes a scratch buffer, + semabs_wgrad_mfma, semabs_quickgelu_grad, GEMM epilogue 5; 5: + semabs_unflip_average; 6 (round 5): + semabs_color_jitter_op, hue factor range checked; 7: + semabs_wgrad_conv3_gn, semabs_vool_sample_bwd takes absmax_bits; 8 (round 6): row centres in semabs_gemm_f16_ln / semabs_ln_rowstats / semabs_layernorm)
 
 // Returns 0 and fills name/cu_count for the current device; the library only carries gfx950 code objects.
 extern "C" int semabs_device_info(char* name, int name_len, int* cu_count, long long* hbm_bytes) {

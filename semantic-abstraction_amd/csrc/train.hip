@@ -1973,10 +1973,11 @@ __global__ __launch_bounds__(256) void k_dz_boundary_sums(const float* __restric
 #pragma unroll
     for (int k = 0; k < 3; ++k) { n[k] = sel[k] ? 1 : D[k]; lo[k] = sel[k] == 2 ? D[k] - 1 : 0; }
     const long nv = (long)n[0] * n[1] * n[2];
-    const int cq = Ca / 4, tq = threadIdx.x % cq;            // Ca / 4 divides 256 for Ca = 16 .. 128
-    const int vpb = 256 / cq;
+    const int cq = Ca / 4, tq = threadIdx.x % cq;
+    const int vpb = 256 / cq;                               // voxel slots per pass; Ca / 4 need not divide 256 (Ca = 48, 80, 96, 112: the routes admit any Ca % 16 == 0)
+    const bool live = (int)threadIdx.x / cq < vpb;          // ... then the surplus threads would form slot `vpb` = the next pass's slot 0 and count its voxels twice
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long v = (long)blockIdx.z * vpb + threadIdx.x / cq; v < nv; v += (long)gridDim.z * vpb) {
+    for (long v = (long)blockIdx.z * vpb + threadIdx.x / cq; live && v < nv; v += (long)gridDim.z * vpb) {
         const int x = lo[2] + (int)(v % n[2]), y = lo[1] + (int)((v / n[2]) % n[1]), z = lo[0] + (int)(v / n[2] / n[1]);
         const float4 t = *reinterpret_cast<const float4*>(dZ + ((((long)b * D0 + z) * D1 + y) * D2 + x) * Ca + tq * 4);
         acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;

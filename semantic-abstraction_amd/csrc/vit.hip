@@ -11,12 +11,23 @@
 //   zeroshot_classifier normalise + mean   CLIP/clip/clip_gradcam.py:24-27
 #include "semabs_common.h"
 
+// "Split" fp16 outputs (round 6): a row of W values is stored as [hi | lo] with a pitch of 2 W fp16 - hi = fp16(v), lo = fp16(v - hi) - so that the
+// GEMM that consumes it (K = 2 W against the weight matrix repeated twice along K) sees the value to ~2^-22 instead of 2^-11.  Used for the operands of
+// the LAST block and of the VJP chain behind it (n or L n rows - a percent of the trunk's flops): with trained-checkpoint statistics (peaked softmax:
+// CLS scores up to ~60) the fp16 rounding of the last LayerNorm output alone moves the kept softmax row by 2e-3 (tests/test_gpu_trained_stats.py).
+__device__ __forceinline__ void store_split4(f16* row, int W, int c0, float a, float b, float c, float d) {
+    f16x4 h; h[0] = (f16)a; h[1] = (f16)b; h[2] = (f16)c; h[3] = (f16)d;
+    f16x4 l; l[0] = (f16)(a - (float)h[0]); l[1] = (f16)(b - (float)h[1]); l[2] = (f16)(c - (float)h[2]); l[3] = (f16)(d - (float)h[3]);
+    *reinterpret_cast<f16x4*>(row + c0) = h;
+    *reinterpret_cast<f16x4*>(row + W + c0) = l;
+}
+
 // =================================================================================================
 // LayerNorm: one wave per row, row held in registers (D <= 1024, D % 256 == 0), two-pass mean / variance.
 // =================================================================================================
-template <int VPL, bool OUT_F32>   // VPL = float4 vectors per lane (D = 256 * VPL)
+template <int VPL, int OUT_MODE>   // VPL = float4 vectors per lane (D = 256 * VPL); OUT_MODE 0 = fp16, 1 = fp32, 2 = fp16 [hi | lo] (pitch 2 D)
 __global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, void* __restrict__ out, long M, float eps, int order) {
+                            const float* __restrict__ beta, void* __restrict__ out, long M, float eps, int order, float* __restrict__ mean_out) {
     const int lane = threadIdx.x & 63;
     // order: 0 = rows in dispatch order; 1 / 2 = XCD-contiguous runs walked forwards / backwards (zigzag with the neighbouring GEMMs)
     const long blk = order ? semabs_xcd_item((int)blockIdx.x, (int)gridDim.x, order == 2) : (long)blockIdx.x;
@@ -33,6 +44,7 @@ __global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / D;
+    if (mean_out && lane == 0) mean_out[row] = mean;       // the row centre the LayerNorm-fold producer behind this pass starts from (gemm.hip LNP)
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -48,8 +60,10 @@ __global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float
         float4 o;
         o.x = (v[i].x - mean) * rstd * gm.x + bt.x; o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
         o.z = (v[i].z - mean) * rstd * gm.z + bt.z; o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-        if (OUT_F32) {
+        if (OUT_MODE == 1) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * D + c0) = o;
+        } else if (OUT_MODE == 2) {
+            store_split4(reinterpret_cast<f16*>(out) + row * 2 * D, D, c0, o.x, o.y, o.z, o.w);
         } else {
             f16x4 h; h[0] = (f16)o.x; h[1] = (f16)o.y; h[2] = (f16)o.z; h[3] = (f16)o.w;
             *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(out) + row * D + c0) = h;
@@ -118,9 +132,10 @@ extern "C" int semabs_add_layernorm(float* x, const void* delta, const float* ga
     return SEMABS_OK;
 }
 
-// x fp32 rows (stride ld_in elements) -> out [M, D] dense, fp16 (out_f32 = 0) or fp32 (1; may alias x when ld_in == D)
+// x fp32 rows (stride ld_in elements) -> out [M, D] dense, fp16 (out_f32 = 0) or fp32 (1; may alias x when ld_in == D); mean_out (optional) [M] = the row means
+// out_f32 bit 3 (value 8): fp16 [hi | lo] rows of pitch 2 D (see store_split4)
 extern "C" int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D,
-                                float eps, int out_f32, long ld_in, void* stream) {
+                                float eps, int out_f32, long ld_in, float* mean_out, void* stream) {
     if (M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(x && gamma && beta && out && M > 0, "semabs_layernorm: bad args");
     SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024 && ld_in % 4 == 0, "semabs_layernorm: D must be 256..1024 step 256");
@@ -129,8 +144,9 @@ extern "C" int semabs_layernorm(const float* x, const float* gamma, const float*
     const int order = (out_f32 >> 1) & 3;                   // bits 1-2 of out_f32: 0 dispatch order, 1 / 2 XCD-contiguous runs forwards / backwards
 #define LN_CASE(V)                                                                                              \
     case V:                                                                                                     \
-        if (out_f32 & 1) hipLaunchKernelGGL((k_layernorm<V, true>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order); \
-        else hipLaunchKernelGGL((k_layernorm<V, false>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order);        \
+        if (out_f32 & 1) hipLaunchKernelGGL((k_layernorm<V, 1>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order, mean_out); \
+        else if (out_f32 & 8) hipLaunchKernelGGL((k_layernorm<V, 2>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order, mean_out); \
+        else hipLaunchKernelGGL((k_layernorm<V, 0>), grid, block, 0, s, x, ld_in, gamma, beta, out, M, eps, order, mean_out);        \
         break;
     switch (D / 256) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) }
 #undef LN_CASE
@@ -142,8 +158,12 @@ extern "C" int semabs_layernorm(const float* x, const float* gamma, const float*
 // LayerNorm folded into the GEMMs (gemm.hip, LNP / LNC): the producer GEMM leaves per-row partial sums (sum x, sum x^2) per 256-column tile;
 // this turns them into the two per-row numbers the consumer GEMM's epilogue applies: (rstd, -mean * rstd).   model_explainability.py:188-194
 // The tiles' fp32 sums are combined in fp64 (the variance is a difference of two large numbers when |mean| >> sigma).
+// Centred form (round 6): the producer subtracted a per-row centre c (the row mean the PREVIOUS LayerNorm of this row saw) before forming xg and the
+// partials, so the sums are those of y = x - c: rstd is unchanged, the consumer's second coefficient becomes -mean(y) * rstd (the part of the mean the
+// fp16 copy still carries), and center_out = c + mean(y) = the row's true mean, the centre of the next producer on this row.
 // =================================================================================================
-__global__ void k_ln_rowstats(const float* __restrict__ part, long M, int ntile, int D, float eps, float* __restrict__ rowac) {
+__global__ void k_ln_rowstats(const float* __restrict__ part, long M, int ntile, int D, float eps, float* __restrict__ rowac,
+                              const float* __restrict__ center_in, float* __restrict__ center_out) {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= M) return;
     double s1 = 0.0, s2 = 0.0;
@@ -154,11 +174,12 @@ __global__ void k_ln_rowstats(const float* __restrict__ part, long M, int ntile,
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     rowac[r * 2] = rstd;
     rowac[r * 2 + 1] = (float)(-mean) * rstd;
+    if (center_out) center_out[r] = (float)((center_in ? (double)center_in[r] : 0.0) + mean);
 }
-extern "C" int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, void* stream) {
+extern "C" int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, float* rowac, const float* center_in, float* center_out, void* stream) {
     if (M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(part && rowac && ntile > 0 && D > 0, "semabs_ln_rowstats: bad args");
-    hipLaunchKernelGGL(k_ln_rowstats, dim3(semabs_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, part, M, ntile, D, eps, rowac);
+    hipLaunchKernelGGL(k_ln_rowstats, dim3(semabs_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, part, M, ntile, D, eps, rowac, center_in, center_out);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -662,7 +683,7 @@ static int attention_impl(const void* qkv, void* out, void* row_stats, int n_seq
 //   o fp16 [n, D] (input of out_proj)
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__ q, const float* __restrict__ kmat, const f16* __restrict__ vmat,
-                                                       float* __restrict__ probs, f16* __restrict__ o, int n, int T, int H) {
+                                                       float* __restrict__ probs, f16* __restrict__ o, int n, int T, int H, int split) {
     __shared__ float sp[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long wh = (long)blockIdx.x * 4 + w;
@@ -708,16 +729,22 @@ __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__
     const f16* vb = vmat + (long)i * T * D + h * 64 + lane;       // lane = d
     float acc = 0.f;
     for (int j = 0; j < T; ++j) acc += sp[w][j] * (float)vb[(long)j * D];
-    o[(long)i * D + h * 64 + lane] = (f16)acc;
+    if (split) {                                                 // [hi | lo] rows of pitch 2 D (store_split4's layout)
+        const f16 hi = (f16)acc;
+        o[(long)i * 2 * D + h * 64 + lane] = hi;
+        o[(long)i * 2 * D + D + h * 64 + lane] = (f16)(acc - (float)hi);
+    } else {
+        o[(long)i * D + h * 64 + lane] = (f16)acc;
+    }
 }
 
 extern "C" int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H,
-                                    int head_dim, void* stream) {
+                                    int head_dim, int split, void* stream) {
     if (n == 0) return SEMABS_OK;
     SEMABS_REQUIRE(q && k && v && probs && o && n > 0, "semabs_attention_cls: bad args");
     SEMABS_REQUIRE(head_dim == 64 && T <= 256 && T > 0, "semabs_attention_cls: head_dim 64, T <= 256");
     hipLaunchKernelGGL(k_attention_cls, dim3(semabs_cdiv((long)n * H, 4)), dim3(256), 0, (hipStream_t)stream, q, k, (const f16*)v, probs,
-                       (f16*)o, n, T, H);
+                       (f16*)o, n, T, H, split);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -763,16 +790,25 @@ extern "C" int semabs_eot_rows_gather(const long long* tokens, const float* x, f
 }
 
 // quick-GELU forward on fp32 pre-activations -> fp16 (CLS-row MLP of the last block keeps fc for the VJP)
-__global__ void k_quickgelu(const float* __restrict__ fc, f16* __restrict__ act, long n) {
+// split_w > 0: rows of split_w values stored as [hi | lo] with pitch 2 split_w (store_split4's layout)
+__global__ void k_quickgelu(const float* __restrict__ fc, f16* __restrict__ act, long n, int split_w) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float v = fc[i];
-    act[i] = (f16)(v / (1.f + __expf(-1.702f * v)));
+    const float a = v / (1.f + __expf(-1.702f * v));
+    if (split_w > 0) {
+        const long r = i / split_w; const int c = (int)(i - r * split_w);
+        const f16 hi = (f16)a;
+        act[r * 2 * split_w + c] = hi;
+        act[r * 2 * split_w + split_w + c] = (f16)(a - (float)hi);
+    } else {
+        act[i] = (f16)a;
+    }
 }
-extern "C" int semabs_quickgelu(const float* fc, void* act, long n, void* stream) {
+extern "C" int semabs_quickgelu(const float* fc, void* act, long n, int split_w, void* stream) {
     if (n == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(fc && act && n > 0, "semabs_quickgelu: bad args");
-    hipLaunchKernelGGL(k_quickgelu, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, fc, (f16*)act, n);
+    SEMABS_REQUIRE(fc && act && n > 0 && split_w >= 0 && (split_w == 0 || n % split_w == 0), "semabs_quickgelu: bad args");
+    hipLaunchKernelGGL(k_quickgelu, dim3(semabs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, fc, (f16*)act, n, split_w);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -807,7 +843,7 @@ extern "C" int semabs_quickgelu_grad(const float* fc, float* gd, long n, void* s
 template <int PER>   // E = 64 * PER
 __global__ __launch_bounds__(256) void k_logit_grad(const float* __restrict__ feat, const float* __restrict__ wt, int n, int L,
                                                     float* __restrict__ logits, f16* __restrict__ dfeat,
-                                                    float* __restrict__ scale) {
+                                                    float* __restrict__ scale, int split) {
     constexpr int E = 64 * PER;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -832,18 +868,27 @@ __global__ __launch_bounds__(256) void k_logit_grad(const float* __restrict__ fe
         mx = wave_max(mx);
         const float sc = mx > 0.f ? mx : 1.f;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) dfeat[((long)l * n + i) * E + k * 64 + lane] = (f16)(g[k] / sc);
+        for (int k = 0; k < PER; ++k) {
+            const float gv = g[k] / sc;
+            const f16 hi = (f16)gv;
+            if (split) {                                         // [hi | lo] rows of pitch 2 E
+                dfeat[((long)l * n + i) * 2 * E + k * 64 + lane] = hi;
+                dfeat[((long)l * n + i) * 2 * E + E + k * 64 + lane] = (f16)(gv - (float)hi);
+            } else {
+                dfeat[((long)l * n + i) * E + k * 64 + lane] = hi;
+            }
+        }
         if (lane == 0) scale[(long)l * n + i] = sc;
     }
 }
 extern "C" int semabs_logit_grad(const float* feat, const float* w_text, int n, int L, int E, float* logits, void* dfeat,
-                                 float* scale, void* stream) {
+                                 float* scale, int split, void* stream) {
     if (n == 0 || L == 0) return SEMABS_OK;
     SEMABS_REQUIRE(feat && w_text && dfeat && scale, "semabs_logit_grad: bad args");
     SEMABS_REQUIRE(E == 512 || E == 768, "semabs_logit_grad: embed dim must be 512 or 768");
     dim3 grid(semabs_cdiv(n, 4)), block(256);
-    if (E == 512) hipLaunchKernelGGL(k_logit_grad<8>, grid, block, 0, (hipStream_t)stream, feat, w_text, n, L, logits, (f16*)dfeat, scale);
-    else hipLaunchKernelGGL(k_logit_grad<12>, grid, block, 0, (hipStream_t)stream, feat, w_text, n, L, logits, (f16*)dfeat, scale);
+    if (E == 512) hipLaunchKernelGGL(k_logit_grad<8>, grid, block, 0, (hipStream_t)stream, feat, w_text, n, L, logits, (f16*)dfeat, scale, split);
+    else hipLaunchKernelGGL(k_logit_grad<12>, grid, block, 0, (hipStream_t)stream, feat, w_text, n, L, logits, (f16*)dfeat, scale, split);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -853,7 +898,7 @@ extern "C" int semabs_logit_grad(const float* feat, const float* w_text, int n, 
 template <int VPL>
 __global__ void k_ln_bwd(const float* __restrict__ x, long ld_x, const float* __restrict__ gamma, const float* __restrict__ gy,
                          const float* __restrict__ resid, float* __restrict__ out32, f16* __restrict__ out16, long M, int n_x,
-                         float eps) {
+                         float eps, int split) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -898,23 +943,27 @@ __global__ void k_ln_bwd(const float* __restrict__ x, long ld_x, const float* __
         }
         if (out32) *reinterpret_cast<float4*>(out32 + row * D + c0) = o;
         if (out16) {
-            f16x4 h; h[0] = (f16)o.x; h[1] = (f16)o.y; h[2] = (f16)o.z; h[3] = (f16)o.w;
-            *reinterpret_cast<f16x4*>(out16 + row * D + c0) = h;
+            if (split) {
+                store_split4(out16 + row * 2 * D, D, c0, o.x, o.y, o.z, o.w);
+            } else {
+                f16x4 h; h[0] = (f16)o.x; h[1] = (f16)o.y; h[2] = (f16)o.z; h[3] = (f16)o.w;
+                *reinterpret_cast<f16x4*>(out16 + row * D + c0) = h;
+            }
         }
     }
 }
 extern "C" int semabs_ln_bwd(const float* x, const float* gamma, const float* gy, const float* resid, float* out32,
-                             void* out16, long M, int D, int n_x, long ld_x, float eps, void* stream) {
+                             void* out16, long M, int D, int n_x, long ld_x, float eps, int split, void* stream) {
     if (M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(x && gamma && gy && (out32 || out16) && M > 0 && n_x > 0, "semabs_ln_bwd: bad args");
     SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024, "semabs_ln_bwd: D must be 256..1024 step 256");
     dim3 grid(semabs_cdiv(M, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     switch (D / 256) {
-        case 1: hipLaunchKernelGGL(k_ln_bwd<1>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
-        case 2: hipLaunchKernelGGL(k_ln_bwd<2>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
-        case 3: hipLaunchKernelGGL(k_ln_bwd<3>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
-        case 4: hipLaunchKernelGGL(k_ln_bwd<4>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps); break;
+        case 1: hipLaunchKernelGGL(k_ln_bwd<1>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps, split); break;
+        case 2: hipLaunchKernelGGL(k_ln_bwd<2>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps, split); break;
+        case 3: hipLaunchKernelGGL(k_ln_bwd<3>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps, split); break;
+        case 4: hipLaunchKernelGGL(k_ln_bwd<4>, grid, block, 0, s, x, ld_x, gamma, gy, resid, out32, (f16*)out16, M, n_x, eps, split); break;
     }
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
@@ -923,11 +972,11 @@ extern "C" int semabs_ln_bwd(const float* x, const float* gamma, const float* gy
 // quick-GELU VJP: dfc[m, :] = dact[m, :] * (s (1 + 1.702 fc (1 - s))),  s = sigmoid(1.702 fc[m % n_x, :])   -> fp16
 // One workgroup per row m: the pre-activation row m % n_x is a scalar decision, 4 float4 per operand in flight per thread (one float4 per
 // thread with two 64-bit divisions per element ran at 3.7 TB/s: 1.79 ms per ViT-L block at 16 labels x 63 tiles).
-__global__ __launch_bounds__(256) void k_gelu_bwd(const float* __restrict__ dact, const float* __restrict__ fc, f16* __restrict__ dfc, long M, int W, int n_x) {
+__global__ __launch_bounds__(256) void k_gelu_bwd(const float* __restrict__ dact, const float* __restrict__ fc, f16* __restrict__ dfc, long M, int W, int n_x, int split) {
     const long m = blockIdx.x;
     const float* a_row = dact + m * W;
     const float* f_row = fc + (m % n_x) * W;
-    f16* o_row = dfc + m * W;
+    f16* o_row = dfc + m * W * (split ? 2 : 1);
     auto d = [](float x) { float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); };
     for (int c0 = threadIdx.x * 4; c0 < W; c0 += 4096) {
         float4 a[4], f[4];
@@ -942,17 +991,22 @@ __global__ __launch_bounds__(256) void k_gelu_bwd(const float* __restrict__ dact
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * 1024;
             if (c < W) {
-                f16x4 h;
-                h[0] = (f16)(a[u].x * d(f[u].x)); h[1] = (f16)(a[u].y * d(f[u].y)); h[2] = (f16)(a[u].z * d(f[u].z)); h[3] = (f16)(a[u].w * d(f[u].w));
-                *reinterpret_cast<f16x4*>(o_row + c) = h;
+                const float r0 = a[u].x * d(f[u].x), r1 = a[u].y * d(f[u].y), r2 = a[u].z * d(f[u].z), r3 = a[u].w * d(f[u].w);
+                if (split) {
+                    store_split4(o_row, W, c, r0, r1, r2, r3);
+                } else {
+                    f16x4 h;
+                    h[0] = (f16)r0; h[1] = (f16)r1; h[2] = (f16)r2; h[3] = (f16)r3;
+                    *reinterpret_cast<f16x4*>(o_row + c) = h;
+                }
             }
         }
     }
 }
-extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, void* stream) {
+extern "C" int semabs_gelu_bwd(const float* dact, const float* fc, void* dfc, long M, int W, int n_x, int split, void* stream) {
     if (M == 0) return SEMABS_OK;
     SEMABS_REQUIRE(dact && fc && dfc && M > 0 && M < (1L << 31) && W % 4 == 0 && n_x > 0, "semabs_gelu_bwd: bad args");
-    hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, dact, fc, (f16*)dfc, M, W, n_x);
+    hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, dact, fc, (f16*)dfc, M, W, n_x, split);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

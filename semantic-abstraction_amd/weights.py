@@ -55,13 +55,71 @@ def _block(rng, prefix, width, sd, attn_std, proj_std, fc_std, sharpen, half=Tru
     sd[prefix + "ln_2.bias"] = 0.05 * n(width)
 
 
+def _trained_tower(sd: dict, prefix: str, ln_in: str, width: int, layers: int, rng, qk_gain, half=True) -> list:
+    """In-place edit of one transformer tower towards the activation statistics of a TRAINED CLIP checkpoint (none can be fetched here).
+    What released ViT-B/32, B/16 checkpoints show in their residual stream and random-init weights do not:
+
+    * massive-activation channels: three fixed channels carry |x| 50 - 150 x the median of the others from the first blocks on - here through the gains
+      and offsets of the tower's input LayerNorm (`ln_in`, vision tower only) and the c_proj rows / biases of blocks 1 - 3; the later LayerNorm gains on those
+      channels are small (0.05 - 0.5), as in trained models, so that they dominate the row variance without drowning the projections;
+    * a per-row DC offset: every token's channels share an offset of several sigma of the bulk, different per token (a rank-one `1 v^T` component in
+      the out_proj / c_proj weights of blocks 0 - 4 plus a constant in their biases) - |mean| >> spread of the bulk is what an un-centred fp16
+      copy of the row loses bits to;
+    * peaked attention: q / k rows scaled per block (`qk_gain[i]`) so the scaled scores have sigma 2 - 4 in the trunk and 6 - 10 in the last block.
+    Returns the massive channel indices."""
+    r = _f16 if half else (lambda a: a.astype(np.float32))
+    t = lambda k: sd[prefix + k]
+    massive = sorted(int(c) for c in rng.choice(width, size=3, replace=False))
+    signs = np.array([1.0, -1.0, 1.0], np.float32)
+    if ln_in is not None:
+        sd[ln_in + ".weight"][massive] = np.array([10.0, 16.0, 7.0], np.float32)
+        sd[ln_in + ".bias"][massive] = signs * np.array([35.0, 50.0, 24.0], np.float32)
+    ones = np.ones(width, np.float32)
+    for i in range(layers):
+        pre = f"transformer.resblocks.{i}."
+        if 1 <= i <= 3:
+            w = t(pre + "mlp.c_proj.weight")
+            w[massive] *= 24.0
+            sd[prefix + pre + "mlp.c_proj.weight"] = r(w)
+            b = t(pre + "mlp.c_proj.bias")
+            b[massive] += signs * np.float32(6.0 * i)
+            sd[prefix + pre + "mlp.c_proj.bias"] = r(b)
+        if i <= 4:
+            for name, amp, const in (("attn.out_proj", 1.2, 0.5), ("mlp.c_proj", 0.5, 0.4)):
+                w = t(pre + name + ".weight")
+                v = rng.standard_normal(w.shape[1], dtype=np.float32) * np.float32(amp / np.sqrt(w.shape[1])) * (w.std() * np.sqrt(w.shape[1]))
+                sd[prefix + pre + name + ".weight"] = r(w + ones[:, None] * v[None, :])
+                sd[prefix + pre + name + ".bias"] = r(t(pre + name + ".bias") + np.float32(const))
+        for ln in ("ln_1", "ln_2"):
+            g = t(pre + ln + ".weight")
+            g *= np.exp(0.35 * rng.standard_normal(width, dtype=np.float32))            # log-normal spread of the gains (trained: 0.3 - 3)
+            g[massive] = rng.uniform(0.05, 0.5, size=3).astype(np.float32)
+            t(pre + ln + ".bias")[:] += 0.3 * rng.standard_normal(width, dtype=np.float32)
+        w = t(pre + "attn.in_proj_weight")
+        w[: 2 * width] *= np.float32(qk_gain[i])
+        sd[prefix + pre + "attn.in_proj_weight"] = r(w)
+        b = t(pre + "attn.in_proj_bias")
+        b[: 2 * width] *= np.float32(qk_gain[i])
+        sd[prefix + pre + "attn.in_proj_bias"] = r(b)
+    return massive
+
+
+# q / k gains of stats="trained" per block, calibrated (tools/clip_stats.py) so that the scaled scores q.k / sqrt(dh) of the synthetic tiles have a standard
+# deviation of 2 - 4 in the trunk and 6 - 10 in block 11, the regime of the released checkpoints (near one-hot rows in the last blocks)
+TRAINED_QK_GAIN = {"visual": [3.0] * 11 + [4.7], "text": [2.0] * 12}
+
+
 def make_clip_state_dict(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 2.0,
-                         text_tower: bool = True) -> dict:
+                         text_tower: bool = True, stats: str = "init") -> dict:
     """State dict with the OpenAI CLIP key names for a ViT-B model, values from `seed`.
 
     Standard deviations follow `CLIP.initialize_parameters` (`model_explainability.py:418-452`);
     biases / LayerNorm affine parameters are made non-trivial on purpose so parity tests exercise them.
+    stats = "init": the benign statistics of a fresh initialisation (every golden before g29).  stats = "trained": the same draw edited towards the
+    residual-stream statistics of a trained checkpoint (`_trained_tower`: massive-activation channels, per-row DC offsets, peaked softmax, class
+    embedding norm >> patch norm) - the numbers the fp16 operand paths are hardest on (goldens g29).
     """
+    assert stats in ("init", "trained")
     a = CLIP_ARCHS[arch]
     rng = np.random.default_rng(seed)
     n = lambda *s: rng.standard_normal(s, dtype=np.float32)
@@ -91,6 +149,12 @@ def make_clip_state_dict(arch: str = "ViT-B/32", seed: int = 0, sharpen: float =
         sd["ln_final.bias"] = 0.05 * n(TW)
         sd["text_projection"] = _f16(n(TW, a["embed"]) * TW ** -0.5)
         sd["logit_scale"] = np.float32(np.log(1 / 0.07)) * np.ones((), dtype=np.float32)
+    if stats == "trained":
+        trng = np.random.default_rng(seed + 104729)              # its own stream: the "init" draw above is unchanged
+        sd["visual.class_embedding"] = sd["visual.class_embedding"] * np.float32(12.0)
+        _trained_tower(sd, "visual.", "visual.ln_pre", W, a["layers"], trng, TRAINED_QK_GAIN["visual"])
+        if text_tower:
+            _trained_tower(sd, "", None, a["twidth"], a["tlayers"], trng, TRAINED_QK_GAIN["text"])
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 
 

@@ -1281,3 +1281,69 @@ def g28_color_jitter():
 
 if __name__ == "__main__" and "g28" in sys.argv[1:]:
     g28_color_jitter()
+
+
+# ---- appended (round 6): the relevancy path on weights with TRAINED-checkpoint statistics ------------------------------------
+def g29_trained_stats(which=("b32", "b16", "e2e", "head")):
+    """`make_clip_state_dict(stats="trained")` (massive-activation channels, per-row DC offsets of ~4 sigma, peaked softmax; tools/clip_stats.py prints the
+    statistics) loaded into the UNMODIFIED reference, text tower included:
+      g29_vit_{b32,b16}: the g3g4 per-tile form - `ClipGradcam.forward` + `interpret` (autograd) on 3 tiles x 4 labels, positive_attn_only True / False,
+                         zero-shot weights from the reference's own tokenizer + text tower, token ids stored (the GPU box has no BPE table);
+      g29_e2e:           `get_clip_saliency`, "ours" with augmentations = 0, 4 labels: ViT-B/32 at 120 x 120 (positive_attn_only True and False), ViT-B/16 at 240 x 240;
+      g29_headline_aug0: the BASELINE shape (480 x 480, ViT-B/16, 16 labels, "ours", augmentations = 0), stored like g16."""
+    labels = ["chair", "table", "lamp", "sofa"]
+    for arch, tag in (("ViT-B/32", "b32"), ("ViT-B/16", "b16")):
+        if tag not in which:
+            continue
+        rc = refimport.load_reference_clip(arch, seed=0, stats="trained")
+        import CLIP.clip.clip_explainability as rexp
+        gc = rc.ClipWrapper.clip_gradcam
+        gc.templates = [DEFAULT_PROMPT]
+        gc.set_classes(labels)
+        w_text = torch.cat([gc.class_to_language_feature[c] for c in labels], dim=1)
+        tiles = _tiles_from_seed(rc, 3, seed=7)
+        out = {"w_text": w_text.numpy(), "tokens": rexp.tokenize([DEFAULT_PROMPT.format(c) for c in labels]).numpy(), "labels": np.asarray(labels),
+               "tiles_sum": np.float64(tiles.double().sum().item())}
+        with torch.no_grad():
+            out["feat"] = gc.model.encode_image(tiles).numpy()
+        for pos in (True, False):
+            gc.positive_attn_only = pos
+            out[f"rel_pos{int(pos)}"] = gc(x=tiles, o=labels).detach().numpy()
+        blk = list(gc.model.visual.transformer.resblocks.children())[-1]
+        T = blk.attn_probs.shape[-1]
+        out["probs_cls"] = blk.attn_probs.detach().view(3, 12, T, T)[:, :, 0, :].numpy()
+        feats = gc.model.encode_image(tiles)
+        feats = feats / feats.norm(dim=-1, keepdim=True)
+        out["logits"] = (100.0 * feats @ w_text).detach().numpy()
+        save(f"g29_vit_{tag}", **out)
+    if "e2e" in which:
+        out = {}
+        for arch, name, H, pos in (("ViT-B/32", "b32_ours120", 120, True), ("ViT-B/32", "b32_ours120_signed", 120, False), ("ViT-B/16", "b16_ours240", 240, True)):
+            rc = refimport.load_reference_clip(arch, seed=0, stats="trained")
+            cfg = dict(rc.saliency_configs["ours"](H), augmentations=0, positive_attn_only=pos)
+            img = synth_rgb(H, H, seed=42)
+            t = time.time()
+            maps, feats = rc.ClipWrapper.get_clip_saliency(img=img, text_labels=labels, prompts=[DEFAULT_PROMPT], **cfg)
+            print(f"    g29 e2e {name}: {time.time() - t:.1f}s  max|map| {maps.abs().max():.4g}", flush=True)
+            out[f"{name}_maps"] = maps.numpy()
+            out[f"{name}_text"] = feats.numpy()
+        save("g29_e2e", **out)
+    if "head" in which:
+        from semabs_amd.weights import DEFAULT_LABELS
+        rc = refimport.load_reference_clip("ViT-B/16", seed=0, stats="trained")
+        lab16 = list(DEFAULT_LABELS[:16])
+        img = synth_rgb(480, 480, seed=0)
+        cfg = dict(rc.saliency_configs["ours"](480), augmentations=0)
+        t = time.time()
+        maps, feats = rc.ClipWrapper.get_clip_saliency(img=img, text_labels=lab16, prompts=[DEFAULT_PROMPT], **cfg)
+        dt = time.time() - t
+        m = maps.numpy()
+        print(f"    g29 headline aug0 (trained statistics): {dt:.1f}s  max|map| {np.abs(m).max():.5g}", flush=True)
+        rows = np.asarray([0, 61, 122, 183, 244, 305, 366, 479])
+        save("g29_headline_aug0", sub=m[:, ::4, ::4].copy(), rows_idx=rows, rows=m[:, rows, :].copy(), absmax=np.abs(m).reshape(16, -1).max(1),
+             sums=m.astype(np.float64).reshape(16, -1).sum(1), sha=np.stack([digest(m[l]) for l in range(16)]), text=feats.numpy(),
+             labels=np.asarray(lab16), seconds=np.float64(dt), cores=np.int64(os.cpu_count()))
+
+
+if __name__ == "__main__" and any(a.startswith("g29") for a in sys.argv[1:]):
+    g29_trained_stats(tuple(a.split(":")[1] for a in sys.argv[1:] if a.startswith("g29:")) or ("b32", "b16", "e2e", "head"))

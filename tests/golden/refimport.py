@@ -166,16 +166,16 @@ def install_stubs():
 _CKPT = {}
 
 
-def checkpoint_path(arch: str, seed: int, sharpen: float = 2.0) -> str:
+def checkpoint_path(arch: str, seed: int, sharpen: float = 2.0, stats: str = "init") -> str:
     """Save our seeded state dict once to a temp .pt the reference `load()` can read."""
     import semabs_amd  # noqa: F401
     from semabs_amd.weights import make_clip_state_dict
 
-    key = (arch, seed, sharpen)
+    key = (arch, seed, sharpen, stats)
     if key not in _CKPT:
-        sd = make_clip_state_dict(arch, seed, sharpen)
+        sd = make_clip_state_dict(arch, seed, sharpen, stats=stats)
         # the reference derives the architecture from these (model_explainability.py:530-594)
-        path = os.path.join(tempfile.gettempdir(), f"semabs_clip_{arch.replace('/', '-')}_{seed}_{sharpen}.pt")
+        path = os.path.join(tempfile.gettempdir(), f"semabs_clip_{arch.replace('/', '-')}_{seed}_{sharpen}_{stats}.pt")
         torch.save(sd, path)
         _CKPT[key] = path
     return _CKPT[key]
@@ -202,7 +202,7 @@ class TileList:
         return len(self.items)
 
 
-def load_reference_clip(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 2.0):
+def load_reference_clip(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 2.0, stats: str = "init"):
     """Return the reference `CLIP.clip` package with ClipWrapper initialised on our seeded weights."""
     install_stubs()
     if REF not in sys.path:
@@ -211,7 +211,7 @@ def load_reference_clip(arch: str = "ViT-B/32", seed: int = 0, sharpen: float = 
     import CLIP.clip.clip as rclip
     import CLIP.clip.clip_explainability as rexp
 
-    path = checkpoint_path(arch, seed, sharpen)
+    path = checkpoint_path(arch, seed, sharpen, stats)
     rclip._download = lambda url, root=None: path
     rexp._download = lambda url, root=None: path
     W = rc.ClipWrapper

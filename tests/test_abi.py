@@ -36,7 +36,7 @@ def test_library_exports_header_symbols():
 def test_ctypes_table_matches_header():
     from semabs_amd import _lib
     assert sorted(set(_lib.SIGNATURES) | {"semabs_last_error"}) == _header_symbols()
-    assert _lib.lib().semabs_abi_version() == 7
+    assert _lib.lib().semabs_abi_version() == 8
 
 
 def test_product_fails_loudly_without_gpu():

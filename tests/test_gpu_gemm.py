@@ -137,7 +137,7 @@ def test_gemm_quickgelu_vjp_epilogue():
         d32 = torch.empty(M, N, device="cuda")
         gemm(A, B, d32, bias, M, N, K, K, K, N, EPI_F32, kernel=2)
         two = torch.empty(M, N, dtype=torch.float16, device="cuda")
-        _lib.call("semabs_gelu_bwd", _lib.ptr(d32), _lib.ptr(pre), _lib.ptr(two), M, N, n_x, _lib.stream())
+        _lib.call("semabs_gelu_bwd", _lib.ptr(d32), _lib.ptr(pre), _lib.ptr(two), M, N, n_x, 0, _lib.stream())
         assert float((out.float() - two.float()).abs().max()) <= 2e-3 * float(ref5.abs().max())      # two fp16 roundings of nearly equal fp32 values
     with pytest.raises(RuntimeError):                                            # small M: the ring kernel has no such epilogue
         gemm(A[:300], B, out[:300], bias, 300, N, K, K, K, N, 5, addend=table, rowmap=(n_x, 1, 0))
@@ -265,6 +265,67 @@ def test_gemm_layernorm_consumer_epilogue_equals_layernorm_then_gemm(M, N, epi):
         assert bool((out[M:] == 7.0).all())
         outs.append(out)
     assert torch.equal(outs[0], outs[1])                                            # the tile order does not enter the result
+
+
+@pytest.mark.parametrize("dc", [4.0, 20.0])
+@pytest.mark.parametrize("N,epi", [(2304, EPI_F16), (3072, EPI_GELU_F16)])
+def test_gemm_layernorm_fold_with_row_dc_offset_and_massive_channels(N, epi, dc):
+    """The whole fold (producer epilogue -> semabs_ln_rowstats -> consumer) on rows the released checkpoints produce and random-init weights do not:
+    every row shifted by its own DC offset of ~dc sigma of the bulk (|mean| >> spread) and three channels at 80 x the spread.  An un-centred
+    fp16(x * gamma) copy spends its 11 bits on the offset; the producer therefore centres each row on the previous LayerNorm's mean of that row
+    (`ln_center`), which this test provides with the error a real chain has (the mean before the residual update).  Bar: as accurate as the
+    LayerNorm kernel followed by the plain GEMM (which centres exactly before rounding)."""
+    from semabs_amd.clip.vit import gemm, gemm_ln, layernorm, ln_rowstats
+    M, K = 4099, 768
+    D = K
+    g = torch.Generator(device="cuda").manual_seed(N + int(dc))
+    x_prev = torch.randn(M, D, device="cuda", generator=g)
+    x_prev += dc * (1.0 + 0.5 * torch.randn(M, 1, device="cuda", generator=g))              # per-row offset
+    x_prev[:, [5, 300, 701]] += torch.tensor([80.0, -60.0, 70.0], device="cuda")
+    gamma = (1.0 + 0.2 * torch.randn(D, device="cuda", generator=g)) * torch.exp(0.35 * torch.randn(D, device="cuda", generator=g))
+    gamma[[5, 300, 701]] = torch.tensor([0.1, 0.3, 0.05], device="cuda")
+    beta = 0.3 * torch.randn(D, device="cuda", generator=g)
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
+    b = torch.randn(N, device="cuda", generator=g)
+    # the residual update the producer GEMM applies: x = x_prev + A Wp^T + bp (a delta of the size one sub-layer adds, incl. its own DC component)
+    Kp = 768
+    A = (torch.randn(M, Kp, device="cuda", generator=g) * 0.5).half()
+    Wp = (torch.randn(D, Kp, device="cuda", generator=g) * 0.03).half()
+    bp = 0.3 + 0.1 * torch.randn(D, device="cuda", generator=g)
+    colsum = (W.double() @ gamma.double()).float()
+    bias_f = (b.double() + W.double() @ beta.double()).float()
+    errs = {}
+    for centred in (False, True):
+        x = x_prev.clone()
+        xg = torch.empty(M, D, dtype=torch.float16, device="cuda")
+        part = torch.empty(M, D // 256, 2, dtype=torch.float32, device="cuda")
+        center = x_prev.mean(-1).contiguous() if centred else None                            # what the previous LayerNorm knew about the row
+        gemm_ln(A, Wp, x, bp, M, D, Kp, Kp, Kp, D, EPI_RESID_F32, xg=xg, gamma=gamma, part=part, center=center)
+        rowac = torch.empty(M, 2, dtype=torch.float32, device="cuda")
+        center2 = torch.empty(M, dtype=torch.float32, device="cuda")
+        ln_rowstats(part, M, D // 256, D, rowac, center=center, center_out=center2)
+        mean = x.double().mean(-1)
+        assert float((center2.double() - mean).abs().max()) <= 2e-6 * float(mean.abs().max())
+        rstd = (x.double().var(-1, unbiased=False) + 1e-5).rsqrt()
+        assert float((rowac[:, 0].double() - rstd).abs().max()) <= 2e-5 * float(rstd.max())
+        if centred:
+            assert torch.equal(xg, ((x - center[:, None]) * gamma).half())
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-5) @ W.double().T + b.double()
+        if epi == EPI_GELU_F16:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        scale = float(ref.abs().max())
+        out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        gemm_ln(xg, W, out, bias_f, M, N, K, K, K, N, epi, rowac=rowac, colsum=colsum)
+        errs[centred] = float((out.double() - ref).abs().max())
+    h = torch.empty(M, D, dtype=torch.float16, device="cuda")
+    layernorm(x, gamma, beta, h, M, D)
+    out_u = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    gemm(h, W, out_u, b, M, N, K, K, K, N, epi, kernel=2)
+    err_u = float((out_u.double() - ref).abs().max())
+    print(f"LayerNorm fold, rows with a {dc:.0f}-sigma DC offset + 3 massive channels, {M}x{N} epi {epi}: centred fold {errs[True] / scale:.3e}, un-centred fold "
+          f"{errs[False] / scale:.3e}, LayerNorm-then-GEMM kernels {err_u / scale:.3e} of max|ref| {scale:.2f}")
+    assert errs[True] <= 1.5 * err_u + 3e-4 * scale
+    assert errs[True] < errs[False]
 
 
 def test_trunk_with_and_without_layernorm_fold():

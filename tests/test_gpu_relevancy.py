@@ -248,9 +248,10 @@ def _tiles(n, seed):
 def test_vit_gradcam(golden, arch, tag):
     """HIP ViT + analytic rollout vs the reference's autograd result (golden) and vs the oracle.
     Tolerance: RELATIVE L-infinity (max|ours - ref| / max|ref|) <= conftest.tol(measured) = 1.3 x the value measured on MI355X for THAT case (fp16 GEMM
-    operands over 12 blocks vs the fp32 CPU reference): B/32 1.65e-3 / 1.68e-3, B/16 7.5e-4 / 1.83e-3 for positive_attn_only True / False."""
+    operands over the 11 trunk blocks vs the fp32 CPU reference; round 6: the last block and the VJP chain run on [hi | lo] operand pairs): B/32 9.9e-4 /
+    1.01e-3, B/16 7.55e-4 / 1.08e-3 for positive_attn_only True / False (round 5: 1.65e-3 / 1.68e-3, 7.5e-4 / 1.83e-3)."""
     from conftest import tol
-    measured = {("b32", True): 1.65e-3, ("b32", False): 1.68e-3, ("b16", True): 7.5e-4, ("b16", False): 1.83e-3}
+    measured = {("b32", True): 9.90e-4, ("b32", False): 1.01e-3, ("b16", True): 7.55e-4, ("b16", False): 1.08e-3}
     CW, sd = _init_clip(arch)
     g = golden(f"g3g4_vit_{tag}")
     tiles = _tiles(3, 7)
@@ -272,7 +273,9 @@ def test_vit_gradcam(golden, arch, tag):
                                      torch.from_numpy(g["w_text"]), True)
     e_f = np.abs(rel_f.cpu().numpy() - ref_f.numpy()).max() / ref_f.abs().max().item()
     print(f"{arch} flipped tiles vs the oracle: {e_f:.2e} relative")
-    assert e_f <= tol({"b32": 4.84e-4, "b16": 6.98e-4}[tag])  # measured, against the ORACLE's fp32 run of the flipped tiles
+    # measured, against the ORACLE's fp32 run of the flipped tiles.  (B/16 was 6.98e-4 in round 5 WITH the last block's and the VJP chain's fp16 roundings: on
+    # these three tiles they happened to cancel part of the trunk's error - the CPU model reproduces it: trunk roundings alone 1.24e-3, all roundings 4.3e-4.)
+    assert e_f <= tol({"b32": 4.85e-4, "b16": 1.13e-3}[tag])
 
 
 def test_text_tower(golden):
@@ -433,6 +436,6 @@ def test_imagenet_prompt_ensemble_vs_reference(golden):
     print(f"prompt ensemble (2 labels x 80 templates): text feature rel L-inf {e_t:.2e}, map L-inf {err:.3e} / max|ref| {np.abs(g['maps']).max():.3e}")
     from conftest import tol
     assert e_t <= tol(5.05e-4)                                          # measured 5.05e-4
-    assert err <= tol(2.289e-5)                                         # measured 2.289e-5 absolute = 1.2e-3 of max|ref|
+    assert err <= tol(3.052e-5)                                         # measured 3.052e-5 absolute = 1.6e-3 of max|ref| - ONE tile: an L-infinity over 196 cells (round 5: 2.289e-5)
     # the mean over templates is NOT re-normalised (clip_gradcam.py:23-26): the ensemble weight is shorter than a unit vector
     assert float(np.linalg.norm(feats.numpy(), axis=1).max()) < 0.999

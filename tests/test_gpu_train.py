@@ -108,7 +108,8 @@ def test_conv3d_gnbwd_equals_conv_then_apply(relu_in, with_add):
 
 
 @pytest.mark.parametrize("B,D,Ca,Cx,G,gscale", [(2, (8, 12, 32), 16, 16, 8, 1.0), (3, (4, 4, 16), 32, 16, 8, 1.0), (8, (16, 16, 16), 32, 32, 8, 1e-7),
-                                                (1, (8, 8, 16), 16, 32, 4, 1.0), (4, (16, 8, 32), 64, 64, 8, 1.0)])
+                                                (1, (8, 8, 16), 16, 32, 4, 1.0), (4, (16, 8, 32), 64, 64, 8, 1.0),
+                                                (2, (8, 8, 16), 48, 16, 8, 1.0), (1, (8, 12, 16), 96, 32, 8, 1.0)])     # Ca / 4 does not divide 256 (boundary sums counted twice)
 def test_wgrad_conv3_gn_vs_fp64(B, D, Ca, Cx, G, gscale):
     """semabs_wgrad_conv3_gn: the weight gradient and the GroupNorm-backward sums (sum dXn, sum dXn xhat) of a GroupNorm -> Conv3d layer from ONE pass over
     (dZ, x), against torch fp64 autograd / fp64 sums over the materialised dXn - non-cubic volumes (every face of the restricted sums differs), batch sizes

@@ -89,6 +89,30 @@ def test_vit_gradcam(golden, arch, tag):
     assert g["grad_l1_noncls_absmax"] == 0.0      # only the CLS query row carries gradient
 
 
+@pytest.mark.parametrize("arch,tag", [("ViT-B/32", "b32"), ("ViT-B/16", "b16")])
+def test_vit_gradcam_trained_statistics(golden, arch, tag):
+    """g29: the same closed form against the reference's AUTOGRAD result on weights with trained-checkpoint statistics (massive-activation channels,
+    per-row DC offsets, peaked softmax - `make_clip_state_dict(stats="trained")`), zero-shot weights from the reference's tokenizer + text tower."""
+    g = golden(f"g29_vit_{tag}")
+    sd = make_clip_state_dict(arch, 0, stats="trained")
+    tiles = _tiles(3, 7)
+    assert abs(tiles.double().sum().item() - g["tiles_sum"]) < 1e-6
+    with torch.no_grad():
+        w_text = orl.zeroshot_weights(sd, torch.from_numpy(g["tokens"]), 4, 1)
+        np.testing.assert_allclose(w_text.numpy(), g["w_text"], rtol=2e-4, atol=2e-6)
+        w_text = torch.from_numpy(g["w_text"])
+        feat, last = orl.vit_forward(sd, tiles)
+        np.testing.assert_allclose(feat.numpy(), g["feat"], rtol=2e-4, atol=1e-4)
+        np.testing.assert_allclose(last["probs"][:, :, 0, :].numpy(), g["probs_cls"], rtol=2e-4, atol=1e-7)
+        assert float(last["probs"][:, :, 0, :].max(-1).values.mean()) > 0.3          # the CLS rows ARE peaked (random-init weights: ~0.05)
+        for pos in (True, False):
+            rel, logits = orl.gradcam_tiles(sd, tiles, w_text, pos)
+            ref = g[f"rel_pos{int(pos)}"]
+            scale = np.abs(ref).max()
+            assert np.abs(rel.numpy() - ref).max() <= 5e-5 * scale + 1e-9, (np.abs(rel.numpy() - ref).max(), scale)
+        np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-4)
+
+
 def test_text_weights(golden):
     g = golden("g7_text")
     sd = make_clip_state_dict("ViT-B/32", 0)
