@@ -727,6 +727,8 @@ def main():
                     "all-reduce of the gradients, /root/reference/utils.py:255-258) - samples/s over all ranks, all-reduce bytes and time in the JSON")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for --gpus > 1: nccl = RCCL over xGMI, one rank per GPU.  gloo: the "
                     "ranks may share one device (contract tests on a 1-GPU box; device collectives are staged through the host)")
+    ap.add_argument("--cu-split", default="0", help="throughput mode: N[:layout] = run scene i's voxel stage on a stream masked to N CUs concurrently with scene "
+                    "i + 1's relevancy stage on the remaining CUs (semabs_amd.scene.CuPartition; layout balanced | low).  0 (default) = one stream, stages in sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (reference goldens, outside the timed region)")
     ap.add_argument("--no-stages", action="store_true", help="skip the stage / kernel-class leg (configs 2, 3, 5 and the per-class table, outside the timed region)")
@@ -799,10 +801,35 @@ def main():
         w = text_enc.zeroshot_weights(text_tokens, N_LABELS, 1) if text_enc is not None else w_text
         return pipe.run_sharded(scenes[i], w, seed=i) if latency else pipe.run(scenes[i], w, seed=i)
 
+    part = None
+    if args.cu_split != "0" and not latency:
+        from semabs_amd.scene import CuPartition
+        ncu, _, lay = args.cu_split.partition(":")
+        part = CuPartition(int(ncu), lay or "balanced")
+
     def run_range(lo, hi):
         res = None
+        if part is None:
+            for i in range(lo, hi):
+                res = step(i)
+            return res
+        # CU-partitioned pipeline: relevancy(i) is queued on the large partition, then voxels(i - 1) on the small one - they run concurrently
+        prev = None
+        cur = torch.cuda.current_stream()
+        for s_ in part.streams:
+            s_.wait_stream(cur)
         for i in range(lo, hi):
-            res = step(i)
+            with torch.cuda.stream(part.vit):
+                w = text_enc.zeroshot_weights(text_tokens, N_LABELS, 1) if text_enc is not None else w_text
+                st = pipe.run_relevancy(scenes[i], w, seed=i)
+            if prev is not None:
+                with torch.cuda.stream(part.voxel):
+                    res = pipe.run_voxels(prev)
+            prev = st
+        with torch.cuda.stream(part.voxel):
+            res = pipe.run_voxels(prev)
+        for s_ in part.streams:
+            cur.wait_stream(s_)
         return res
 
     run_range(0, args.warmup)
@@ -892,7 +919,8 @@ def main():
             "config": {"workload": f"end-to-end relevancy->fusion->OVSSC per scene: {IMG}x{IMG} RGB-D, {N_LABELS} labels, {args.arch}, "
                                    f"'ours' saliency config (2448 tile forwards), {VOXEL}^3 voxels, 80000 input points; scene-sharded",
                        "arch": args.arch, "unet_precision": args.precision, "tile_chunk_streams": args.streams, "scenes_per_gpu": args.steps, "parallelism": (f"tile-shard + label-shard x{world} (one scene per step)" if latency else f"scene-shard x{world}"),
-                       "mode": args.mode, "backend": args.backend if world > 1 else None},
+                       "mode": args.mode, "backend": args.backend if world > 1 else None,
+                       "cu_split": None if part is None else {"voxel_cus": part.cus[0], "vit_cus": part.cus[1], "layout": part.layout}},
             "relevancy_tflops_algorithmic": 2448 * FLOPS_PER_TILE[args.arch] * total_scenes / dt / 1e12,
             "roofline": {"kernel": "fp16 GEMM: k_gemm8 (large shapes) + k_gemm_f16 (small), all epilogues", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

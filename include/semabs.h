@@ -27,6 +27,12 @@ extern "C" {
 
 const char* semabs_last_error(void);
 int semabs_abi_version(void);
+/* CU-masked streams (round 6; no reference counterpart - the reference runs one CUDA stream per process, utils.py:131-138): a stream whose kernels are
+ * confined to the CUs of `mask` (bit i = CU i in the runtime's enumeration, n_words x 32 bits).  The library's persistent kernels size their grids to the CUs
+ * of the stream they are launched on (semabs_stream_cu_count), so two streams with complementary masks share the chip without over-subscribing it. */
+int semabs_stream_create_cumask(const unsigned int* mask, int n_words, void** stream);
+int semabs_stream_destroy(void* stream);
+int semabs_stream_cu_count(void* stream, int* cus);
 
 /* Host-side buffer utilities (no reference counterpart: what torch.zeros / torch.full / Tensor.repeat / masked_fill_ did on the hot path; the
  * product issues no ATen kernel inside a scene).  semabs_fill_u32: nbytes (a multiple of 4) of a 32-bit pattern.  semabs_replicate: dst = reps

@@ -28,6 +28,9 @@ D = C.c_double
 # name -> argtypes (all return int).  Kept in the order of include/semabs.h.
 SIGNATURES = {
     "semabs_abi_version": [],
+    "semabs_stream_create_cumask": [P, I, P],
+    "semabs_stream_destroy": [P],
+    "semabs_stream_cu_count": [P, P],
     "semabs_fill_u32": [P, C.c_longlong, C.c_uint, P],
     "semabs_replicate": [P, P, C.c_longlong, I, P],
     "semabs_poison_empty": [P, P, C.c_longlong, P, C.c_longlong, P],

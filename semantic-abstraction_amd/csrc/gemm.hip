@@ -1642,12 +1642,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(GemmArgs g) {
 // (super-columns that keep a W slice resident re-read A once per slice instead: QKV 1.61 - 1.68 at -3 .. -5 % TFLOP/s, not taken).
 static inline int gemm8_group_m(int n_tiles_n) { return n_tiles_n <= 3 ? 2 : (n_tiles_n <= 9 ? 4 : 8); }
 
-// multiprocessor count of the current device, queried once (not per launch)
-static int gemm_num_cus() {
-    static int n = 0;
-    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
-    return n;
-}
+// CUs the launch stream can occupy (the device's multiprocessor count, or the popcount of the stream's CU mask): semabs_stream_cus, cached per stream
 
 template <int EPI>
 static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
@@ -1671,7 +1666,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
     if (g_persist) {
         static SemabsLdsAttr attr_p;
         semabs_ensure_lds(&k_gemm8<EPI, true, true>, LDS, attr_p);
-        const int ncu = gemm_num_cus();
+        const int ncu = semabs_stream_cus(s);
         gemm_dispatch(k_gemm8<EPI, true, true>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDS, s, g, o);
         SEMABS_CHECK_LAUNCH();
         return SEMABS_OK;
@@ -1709,7 +1704,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
         if (g.ln_rowac || g.lo_out) {                        // LayerNorm consumer and / or low halves (persistent workgroups): + 2 x 1 KB colsum rows + 2 x 2 KB row pairs
             if ((g.K / 64) % 2 != 0) { semabs_set_error("semabs_gemm_f16_ln: the persistent kernel needs an even number of 64-wide K tiles"); return SEMABS_EINVAL; }
             constexpr int LDSC = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024 + 2 * 1024 + 2 * 2048;
-            const int ncu = gemm_num_cus();
+            const int ncu = semabs_stream_cus(s);
             const dim3 grid(g.n_blocks < ncu ? g.n_blocks : ncu);
             if constexpr (EPI == EPI_BIAS_F16) {
                 if (g.lo_out && g.ln_rowac) {
@@ -1749,7 +1744,7 @@ static int launch_gemm8(GemmArgs g, hipStream_t s, const GemmOpts& o) {
             constexpr int LDSP = 2 * 4 * 16384 + 8 * 2048 + 2 * 1024;
             static SemabsLdsAttr attr_p4;
             semabs_ensure_lds(&k_gemm8p<EPI>, LDSP, attr_p4);
-            const int ncu = gemm_num_cus();
+            const int ncu = semabs_stream_cus(s);
             gemm_dispatch(k_gemm8p<EPI>, dim3(g.n_blocks < ncu ? g.n_blocks : ncu), dim3(512), LDSP, s, g, o);
             SEMABS_CHECK_LAUNCH();
             return SEMABS_OK;

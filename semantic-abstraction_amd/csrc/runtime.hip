@@ -25,6 +25,61 @@ extern "C" int semabs_device_info(char* name, int name_len, int* cu_count, long 
     return SEMABS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// CU-masked streams (round 6): a stream created with a CU mask confines its kernels to those CUs; the persistent kernels ask how many that is.
+// ------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <unordered_map>
+static int device_cus() {
+    static int n = 0;
+    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
+static std::mutex g_cu_mu;
+static std::unordered_map<hipStream_t, int> g_cu_cache;     // a stream's mask is fixed at creation; semabs_stream_destroy / _create_cumask drop a handle's entry
+int semabs_stream_cus(hipStream_t s) {
+    const int all = device_cus();
+    if (!s) return all;
+    {
+        std::lock_guard<std::mutex> lk(g_cu_mu);
+        auto it = g_cu_cache.find(s);
+        if (it != g_cu_cache.end()) return it->second;
+    }
+    uint32_t mask[16] = {0};
+    int n = all;
+    if (hipExtStreamGetCUMask(s, 16, mask) == hipSuccess) {
+        int c = 0;
+        for (int i = 0; i < 16; ++i) c += __builtin_popcount(mask[i]);
+        if (c > 0 && c < all) n = c;
+    } else {
+        (void)hipGetLastError();
+    }
+    std::lock_guard<std::mutex> lk(g_cu_mu);
+    g_cu_cache[s] = n;
+    return n;
+}
+// A stream whose kernels run on the CUs of `mask` only (n_words x 32 bits, bit i = CU i in the runtime's enumeration).  The caller owns it (semabs_stream_destroy).
+extern "C" int semabs_stream_create_cumask(const unsigned int* mask, int n_words, void** stream) {
+    SEMABS_REQUIRE(mask && n_words > 0 && n_words <= 16 && stream, "semabs_stream_create_cumask: bad args");
+    hipStream_t s;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask) != hipSuccess) { (void)hipGetLastError(); semabs_set_error("hipExtStreamCreateWithCUMask failed"); return SEMABS_EHIP; }
+    { std::lock_guard<std::mutex> lk(g_cu_mu); g_cu_cache.erase(s); }
+    *stream = (void*)s;
+    return SEMABS_OK;
+}
+extern "C" int semabs_stream_destroy(void* stream) {
+    if (stream) {
+        { std::lock_guard<std::mutex> lk(g_cu_mu); g_cu_cache.erase((hipStream_t)stream); }
+        (void)hipStreamDestroy((hipStream_t)stream);
+    }
+    return SEMABS_OK;
+}
+extern "C" int semabs_stream_cu_count(void* stream, int* cus) {
+    SEMABS_REQUIRE(cus, "semabs_stream_cu_count: null pointer");
+    *cus = semabs_stream_cus((hipStream_t)stream);
+    return SEMABS_OK;
+}
+
 // HIP event helpers for the per-launch GEMM timing of bench.py (events with timing enabled; passed to semabs_gemm_f16_ex)
 extern "C" int semabs_event_create(void** ev) {
     SEMABS_REQUIRE(ev, "semabs_event_create: null pointer");

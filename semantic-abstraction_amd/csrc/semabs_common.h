@@ -73,6 +73,10 @@ __device__ __forceinline__ int semabs_xcd_item(int vb, int nb, bool reverse) {
     return lo + (reverse ? cnt - 1 - k : k);
 }
 
+// CUs a launch on stream `s` can occupy: the popcount of the stream's CU mask (hipExtStreamCreateWithCUMask; the whole device for ordinary streams), cached per
+// stream handle (runtime.hip).  Persistent kernels size their grids with it, so that two streams with complementary masks each fill exactly their share.
+int semabs_stream_cus(hipStream_t s);
+
 // Fill nbytes (a multiple of 4, pointer 4-byte aligned) with a 32-bit pattern.  A kernel launch, not hipMemsetAsync: on this runtime a memset
 // queued between kernels costs ~1.5 ms of stream time (measured on the 4-byte fill of semabs_grad_scale: 78.8 -> 77.1 ms per training step).
 static __global__ __launch_bounds__(256) void semabs_k_fill32(unsigned int* __restrict__ p, long n, unsigned int v) {

@@ -43,7 +43,6 @@ __device__ __forceinline__ int xcd_persistent_tile(int vb, int G, int it, int to
     return o < cnt ? lo + (int)o : -1;
 }
 
-static int semabs_num_cus();
 
 // =================================================================================================
 // Point MLP: (xyz | feat) 4 -> H -> H -> C, LeakyReLU(0.01); fp32 FMAs, weights in LDS, one thread per (label, point)
@@ -242,7 +241,7 @@ extern "C" int semabs_point_mlp(const float* xyz, const float* feat, const float
     static SemabsLdsAttr attr2;
     semabs_ensure_lds(&k_point_mlp_mfma, (int)lds2, attr2);
     const long groups = ((long)P * N + 63) / 64;
-    long grid2 = (groups + 7) / 8; if (grid2 > semabs_num_cus()) grid2 = semabs_num_cus();
+    long grid2 = (groups + 7) / 8; if (grid2 > semabs_stream_cus((hipStream_t)stream)) grid2 = semabs_stream_cus((hipStream_t)stream);
     hipLaunchKernelGGL(k_point_mlp_mfma, dim3((unsigned)grid2), dim3(512), lds2, (hipStream_t)stream, xyz, feat, w1, b1, w2, b2, w3, b3, out, P, N);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
@@ -1094,11 +1093,6 @@ extern "C" int semabs_conv_tune(int key, long long value) {
 }
 #endif
 
-static int semabs_num_cus() {
-    static int n = 0;
-    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
-    return n;
-}
 static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
     ConvArgs a = a_in;
 #ifdef SEMABS_TUNING
@@ -1108,7 +1102,7 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
         constexpr int T0 = 4;
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2 * 2;   // two half-voxel planes (256-B padded), hi + lo, two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
-        long nb = semabs_num_cus(); if (nb > total) nb = total;
+        long nb = semabs_stream_cus(s); if (nb > total) nb = total;
         if (a.gnb_coef) {
             static SemabsLdsAttr attrg;
             semabs_ensure_lds(&k_conv16_lds<true, T0, true>, (int)(lds + 32 * 192), attrg);
@@ -1123,7 +1117,7 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
         constexpr int T0 = 8;
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2;       // two half-voxel planes (256-B padded), two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
-        long nb = semabs_num_cus(); if (nb > total) nb = total;
+        long nb = semabs_stream_cus(s); if (nb > total) nb = total;
         static SemabsLdsAttr attr;
         semabs_ensure_lds(&k_conv16_lds<false, T0>, (int)lds, attr);
         hipLaunchKernelGGL((k_conv16_lds<false, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
@@ -1536,7 +1530,7 @@ static int conv_brick_launch_p(const ConvArgs& a, hipStream_t s) {
     const long total = (long)(a.I0 / 4) * (a.I1 / C16_T1) * (a.I2 / TX) * a.B * (a.Cout / (NB * 16));
     SEMABS_REQUIRE(total < (1L << 30), "conv brick: too many tiles");
     long nwg = total;
-    if (PERSIST) { nwg = (long)semabs_num_cus() * per_cu; if (nwg > total) nwg = total; }   // as many workgroups as fit the chip at once
+    if (PERSIST) { nwg = (long)semabs_stream_cus(s) * per_cu; if (nwg > total) nwg = total; }   // as many workgroups as fit the chip at once
     ConvArgs at = a;
 #ifdef SEMABS_TUNING
     at.trace = g_conv_trace;

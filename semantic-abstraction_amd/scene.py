@@ -224,6 +224,60 @@ class ScenePipeline:
         return frustum_mask_device(self._grid_points64, H, W, scene["cam_pose"], scene["cam_intr"], prm=scene.get("_fr_prm"))
 
 
+def cu_mask_words(n_cus: int, select, total: int = 256):
+    """32-bit mask words with bit i set for the first n_cus CU indices i (in increasing order) for which select(i) holds."""
+    words = [0] * ((total + 31) // 32)
+    left = n_cus
+    for i in range(total):
+        if left and select(i):
+            words[i // 32] |= 1 << (i % 32)
+            left -= 1
+    return words
+
+
+class CuPartition:
+    """Two HIP streams with complementary CU masks (round 6): `voxel` confined to `voxel_cus` CUs, `vit` to the rest.  In throughput mode
+    scene i's voxel stage (UNet / decoder / TSDF: HBM-bound, ~1.1 kW) runs on the small partition WHILE scene i + 1's relevancy stage (persistent GEMMs at the
+    socket's power cap) runs on the large one - the library's persistent kernels size their grids to their stream's CUs (semabs_stream_cu_count).  Results are
+    bit-identical to the sequential schedule (tests/test_gpu_scene.py).
+    layout: "balanced" = the same number of CUs of every XCD (CU indices i with i % 32 < voxel_cus / 8: evenly spread whether the runtime enumerates CUs
+    XCD-major or round-robin over the XCDs), "low" = CU indices 0 .. voxel_cus - 1."""
+
+    def __init__(self, voxel_cus: int = 64, layout: str = "balanced"):
+        import ctypes as C
+        n = C.c_int(0)
+        _lib.call("semabs_stream_cu_count", None, C.byref(n))
+        total = int(n.value)
+        assert 0 < voxel_cus < total and voxel_cus % 8 == 0 and layout in ("balanced", "low")
+        per = voxel_cus // 8
+        sel = (lambda i: i % (total // 8) < per) if layout == "balanced" else (lambda i: i < voxel_cus)
+        vox = cu_mask_words(voxel_cus, sel, total)
+        vit = [(~w) & 0xFFFFFFFF for w in vox]
+        if total % 32:
+            vit[-1] &= (1 << (total % 32)) - 1
+        self.total, self.voxel_cus, self.layout = total, voxel_cus, layout
+        self._handles = []
+        self.streams = []
+        for words in (vox, vit):
+            arr = (C.c_uint * len(words))(*words)
+            h = C.c_void_p()
+            _lib.call("semabs_stream_create_cumask", arr, len(words), C.byref(h))
+            self._handles.append(h)
+            self.streams.append(torch.cuda.ExternalStream(h.value))
+        self.voxel, self.vit = self.streams
+        got = []
+        for h in self._handles:
+            _lib.call("semabs_stream_cu_count", h, C.byref(n))
+            got.append(int(n.value))
+        self.cus = tuple(got)                                 # what the runtime reports for the two streams
+
+    def close(self):
+        torch.cuda.synchronize()
+        for h in self._handles:
+            _lib.call("semabs_stream_destroy", h)
+        self._handles = []
+
+
 def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 2448,
                   max_labels: int = 16, voxel: int = 128, text_tower: bool = True, **pipe_kwargs) -> ScenePipeline:
     """Seeded random-init weights of the released architectures (no checkpoints / network here)."""

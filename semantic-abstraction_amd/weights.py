@@ -202,8 +202,12 @@ def make_unet_state_dict(seed: int, in_channels: int, out_channels: int, f_maps:
 def make_semabs3d_state_dict(seed: int = 0, unet_num_channels: int = 16, unet_f_maps: int = 16,
                              unet_num_groups: int = 8, unet_num_levels: int = 6,
                              pts_feat_extractor_hidden_dim: int = 128, pts_feature_dim: int = 1,
-                             output_dim: int = 1, decoder_concat_xyz_pts: bool = True) -> dict:
-    """fp32 state dict for `SemAbs3D` (`net.py:319-381`) with torch-default-like init scales."""
+                             output_dim: int = 1, decoder_concat_xyz_pts: bool = True, stats: str = "init") -> dict:
+    """fp32 state dict for `SemAbs3D` (`net.py:319-381`) with torch-default-like init scales.
+    stats = "trained" (golden g30): GroupNorm affine parameters with the spread of a trained checkpoint - gains log-normal around 1 (0.2 - 4, two channels per
+    layer near zero, one at 6 x), offsets of +-0.5 - and convolution kernels with a few dominant output channels (x 4), so that the hi / lo operand split and the
+    folded GroupNorm tables see uneven channel magnitudes; drawn from a separate stream, the "init" draw is unchanged."""
+    assert stats in ("init", "trained")
     rng = np.random.default_rng(seed)
     n = lambda *s: rng.standard_normal(s, dtype=np.float32)
     u = lambda fan_in, *s: ((rng.random(s, dtype=np.float32) * 2 - 1) / np.sqrt(fan_in)).astype(np.float32)
@@ -225,6 +229,18 @@ def make_semabs3d_state_dict(seed: int = 0, unet_num_channels: int = 16, unet_f_
         else:
             sd[k + "weight"] = u(cin, cout, cin, 1, 1, 1)
             sd[k + "bias"] = u(cin, cout)
+    if stats == "trained":
+        trng = np.random.default_rng(seed + 15485863)
+        for pre, kind, cin, cout in unet_layer_plan(unet_num_channels, unet_num_channels, unet_f_maps, unet_num_levels):
+            k = "vol_feature_extractor." + pre
+            if kind in ("gcr", "gc"):
+                g = np.exp(0.6 * trng.standard_normal(cin)).astype(np.float32)
+                g[trng.choice(cin, 2, replace=False)] = np.float32(0.02)
+                g[trng.choice(cin, 1)] = np.float32(6.0)
+                sd[k + "groupnorm.weight"] = g
+                sd[k + "groupnorm.bias"] = (0.5 * trng.standard_normal(cin)).astype(np.float32)
+                w = sd[k + "conv.weight"]
+                w[trng.choice(cout, max(1, cout // 16), replace=False)] *= np.float32(4.0)
     hid = unet_num_channels
     din = hid + 3 * int(decoder_concat_xyz_pts)
     sd["visual_sampler.mlp.0.weight"] = u(din, hid, din)

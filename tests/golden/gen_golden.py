@@ -306,14 +306,15 @@ def _semabs_inputs(S, N, M, P, seed):
     return xyz, feat, q
 
 
-def g9_semabs3d():
+def g9_semabs3d(stats="init", name="g9_semabs3d"):
+    """stats = "trained" -> g30_semabs3d_trained: the same forward on weights with trained-like GroupNorm gains / offsets and dominant channels."""
     net, unet3d = refimport.load_reference_net()
     S, N, M, P = 32, 3000, 2048, 2
     m = net.SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16,
                      unet_num_groups=8, unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True,
                      pts_feat_extractor_hidden_dim=128, reduce_method="max", output_dim=1, device="cpu",
                      decoder_concat_xyz_pts=True, batch_size=1)
-    sd = make_semabs3d_state_dict(seed=3)
+    sd = make_semabs3d_state_dict(seed=3, stats=stats)
     missing = m.load_state_dict(sd, strict=True)
     m.eval()
     assert m.vg.reduce_method == "mean"
@@ -339,7 +340,7 @@ def g9_semabs3d():
             res[f"tap_{k}_sum"] = np.float64(v.double().sum().item())
             res[f"tap_{k}_abs"] = np.float64(v.double().abs().sum().item())
             res[f"tap_{k}_sub"] = v.numpy()[:, ::max(1, v.shape[1] // 8), ::2, ::2, ::2].copy()
-    save("g9_semabs3d", **res)
+    save(name, **res)
 
 
 def g10_unet128():
@@ -1347,3 +1348,7 @@ def g29_trained_stats(which=("b32", "b16", "e2e", "head")):
 
 if __name__ == "__main__" and any(a.startswith("g29") for a in sys.argv[1:]):
     g29_trained_stats(tuple(a.split(":")[1] for a in sys.argv[1:] if a.startswith("g29:")) or ("b32", "b16", "e2e", "head"))
+
+
+if __name__ == "__main__" and "g30" in sys.argv[1:]:
+    g9_semabs3d(stats="trained", name="g30_semabs3d_trained")

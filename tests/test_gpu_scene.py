@@ -64,3 +64,38 @@ def test_scene_with_no_point_in_bounds_is_loud():
     # ... and a valid scene through the same pipeline afterwards is untouched
     ok = pipe.run(pipe.upload(synth_scene(H, H, seed=8)), (w / w.norm(dim=1, keepdim=True)).cuda(), seed=1)
     assert not bool(torch.isnan(ok.logits).any()) and ok.n_in_bounds > 0
+
+
+def test_cu_partitioned_pipeline_is_bit_identical():
+    """semabs_amd.scene.CuPartition: scene i's voxel stage on a stream masked to 64 CUs concurrently with scene i + 1's relevancy stage on the other 192 (the
+    schedule of `bench.py --cu-split`, a measured negative result - profiles/r06_cu_split_ab.txt) gives the SAME bits as the sequential schedule; the streams
+    report their CU counts, which is what the persistent kernels size their grids with."""
+    from semabs_amd.scene import CuPartition, build_default
+    S, H, L, npts = 32, 96, 3, 4000
+    pipe = build_default("ViT-B/32", precision="exact", chunk_tiles=64, max_labels=4, voxel=S, text_tower=False, num_input_pts=npts, config="ours")
+    w = torch.randn(L, 512, generator=torch.Generator().manual_seed(0))
+    w = (w / w.norm(dim=1, keepdim=True)).cuda()
+    scenes = [pipe.upload(synth_scene(H, H, seed=20 + i)) for i in range(3)]
+    seq = [pipe.run(s, w, seed=i) for i, s in enumerate(scenes)]
+    torch.cuda.synchronize()
+    part = CuPartition(64, "balanced")
+    assert part.cus == (64, part.total - 64)
+    cur = torch.cuda.current_stream()
+    for s_ in part.streams:
+        s_.wait_stream(cur)
+    out, prev = [], None
+    for i, s in enumerate(scenes):
+        with torch.cuda.stream(part.vit):
+            st = pipe.run_relevancy(s, w, seed=i)
+        if prev is not None:
+            with torch.cuda.stream(part.voxel):
+                out.append(pipe.run_voxels(prev))
+        prev = st
+    with torch.cuda.stream(part.voxel):
+        out.append(pipe.run_voxels(prev))
+    for s_ in part.streams:
+        cur.wait_stream(s_)
+    torch.cuda.synchronize()
+    for a, b in zip(seq, out):
+        assert torch.equal(a.relevancies, b.relevancies) and torch.equal(a.logits, b.logits) and torch.equal(a.labels, b.labels) and torch.equal(a.tsdf, b.tsdf)
+    part.close()

@@ -187,21 +187,23 @@ def semabs_inputs(S, N, M, P, seed):
     return xyz, feat, q
 
 
-def _model(S, precision):
+def _model(S, precision, stats="init"):
     from semabs_amd.net import SemAbs3D
     m = SemAbs3D(voxel_shape=(S, S, S), scene_bounds=SCENE_BOUNDS, unet_num_channels=16, unet_f_maps=16, unet_num_groups=8,
                  unet_num_levels=6, network_inputs=["saliency"], use_pts_feat_extractor=True, pts_feat_extractor_hidden_dim=128,
                  reduce_method="max", output_dim=1, device="cuda", decoder_concat_xyz_pts=True, batch_size=1, precision=precision)
-    m.load_state_dict(make_semabs3d_state_dict(seed=3))
+    m.load_state_dict(make_semabs3d_state_dict(seed=3, stats=stats))
     return m
 
 
+@pytest.mark.parametrize("stats", ["init", "trained"])
 @pytest.mark.parametrize("precision,tol_feat,tol_out", [("exact", 2e-4, 2e-4), ("fp16", 2e-2, 1e-2)])
-def test_semabs3d_forward_vs_golden(golden, precision, tol_feat, tol_out, bar):
-    """SemAbs3D.forward at 32^3 (point MLP -> scatter-mean -> 6-level UNet -> decoder) vs the reference's outputs."""
-    g = golden("g9_semabs3d")
+def test_semabs3d_forward_vs_golden(golden, precision, tol_feat, tol_out, bar, stats):
+    """SemAbs3D.forward at 32^3 (point MLP -> scatter-mean -> 6-level UNet -> decoder) vs the reference's outputs.  stats = "trained" (golden g30): GroupNorm
+    gains spread over 0.02 - 6, offsets of +-0.5, dominant convolution channels (weights.make_semabs3d_state_dict) - the same relative bars."""
+    g = golden("g9_semabs3d" if stats == "init" else "g30_semabs3d_trained")
     S, N, M, P, seed, wseed = (int(v) for v in g["meta"])
-    m = _model(S, precision)
+    m = _model(S, precision, stats)
     xyz, feat, q = semabs_inputs(S, N, M, P, seed)
     taps = {}
     f = m.feature_volume(torch.from_numpy(xyz[0]).cuda(), torch.from_numpy(feat[0, :, :, 0]).cuda(), taps=taps)

@@ -205,10 +205,11 @@ def semabs_inputs(S, N, M, P, seed):
     return xyz, feat, q
 
 
-def test_semabs3d(golden):
-    g = golden("g9_semabs3d")
+@pytest.mark.parametrize("stats,name", [("init", "g9_semabs3d"), ("trained", "g30_semabs3d_trained")])
+def test_semabs3d(golden, stats, name):
+    g = golden(name)
     S, N, M, P, seed, wseed = g["meta"]
-    sd = make_semabs3d_state_dict(seed=int(wseed))
+    sd = make_semabs3d_state_dict(seed=int(wseed), stats=stats)
     xyz, feat, q = semabs_inputs(S, N, M, P, int(seed))
     taps = {}
     with torch.no_grad():

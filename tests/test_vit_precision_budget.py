@@ -13,6 +13,12 @@ So the deviation is the 11 trunk blocks' fp16 operands - 97 % of the flops.  Run
 +2 ms per scene for the last block's K | V GEMMs over all tokens) would take the total from ~2.2e-3 to ~2.05e-3 in quadrature: not worth it, not done.
 A headline bar of 5e-4 relative is not reachable with fp16 MFMA operands in the trunk; the reference's own GPU path (fp16 weights AND activations
 AND accumulation in places, `convert_weights`) is no closer to its CPU path than this one.
+
+Round 6: that verdict held for random-init weights only.  On weights with TRAINED-checkpoint statistics (`make_clip_state_dict(stats="trained")`: peaked
+softmax, massive channels, row DC offsets) the last block and the VJP chain carry MORE than the trunk - ViT-B/16, the three golden tiles: trunk 1.0e-3, last
+block 3.2e-3, VJP chain 1.5e-3, everything 6.7e-3 (measured on the GPU: 3.1 - 5.0e-3) - because the kept softmax row of block 11 turns a score error d s into
+p (1 - p) d s and the CLS scores reach ~60.  They now run on [hi | lo] operand pairs (clip/vit.py head_split, `H16X2` below; V stays fp16):
+`test_split_head_leaves_the_trunk_error` asserts that what is left is the trunk's share.
 """
 import math
 
@@ -25,6 +31,7 @@ from oracle import relevancy as orl
 from semabs_amd.weights import make_clip_state_dict
 
 H16 = lambda t: t.half().float()
+H16X2 = lambda t: t.half().float() + (t - t.half().float()).half().float()       # an [hi | lo] operand pair (vit.hip store_split4)
 ID = lambda t: t
 
 
@@ -64,16 +71,21 @@ def _block(sd, pre, x, heads, r, want=None, last=False):
     return x2
 
 
-def relevance(sd, tiles, w_text, trunk=(), last=False, vjp=False, heads=12, layers=12, trunk_round=None):
+SPLIT_LAST = {"ln1": H16X2, "v": H16, "o": H16X2, "ln2": H16X2, "act": H16X2}     # round 6: the last block's operands as the HIP path carries them
+
+
+def relevance(sd, tiles, w_text, trunk=(), last=False, vjp=False, heads=12, layers=12, trunk_round=None, clamp=True):
     """Closed-form rollout (oracle.relevancy.gradcam_tiles) with the chosen rounding groups on.  trunk_round: what the trunk blocks in `trunk` round
-    (default everything to fp16; a dict {operand class: function} rounds one class)."""
+    (default everything to fp16; a dict {operand class: function} rounds one class).  last / vjp: False, True (= fp16, the round-5 path) or "split"
+    (= [hi | lo] pairs, the round-6 path)."""
     x = orl.vit_embed(sd, tiles)
     keep = {}
     for i in range(layers):
         is_last = i == layers - 1
-        r = H16 if (is_last and last) else ((trunk_round if trunk_round is not None else H16) if (not is_last and i in trunk) else ID)
+        r = (SPLIT_LAST if last == "split" else H16) if (is_last and last) else ((trunk_round if trunk_round is not None else H16) if (not is_last and i in trunk) else ID)
         x = _block(sd, f"visual.transformer.resblocks.{i}.", x, heads, r, want=keep if is_last else None, last=is_last)
-    rl, rv = (H16 if last else ID), (H16 if vjp else ID)
+    rl = H16X2 if last == "split" else (H16 if last else ID)
+    rv = H16X2 if vjp == "split" else (H16 if vjp else ID)
     pre = f"visual.transformer.resblocks.{layers - 1}."
     x2c = x[:, 0, :]
     y = rl(orl._ln(x2c, sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]))
@@ -95,8 +107,35 @@ def relevance(sd, tiles, w_text, trunk=(), last=False, vjp=False, heads=12, laye
     L, n, D = u.shape
     u = u.view(L, n, heads, D // heads)
     cam = torch.einsum("nhjd,lnhd->lnhj", keep["v"], u) * keep["probs"][:, :, 0, :][None]
-    cam = cam.clamp(min=0).mean(dim=2)
+    cam = (cam.clamp(min=0) if clamp else cam).mean(dim=2)
     return cam[:, :, 1:]
+
+
+def test_split_head_leaves_the_trunk_error():
+    """Trained-checkpoint statistics, ViT-B/32, the golden tiles and the reference's zero-shot weights (g29): with fp16 operands behind the trunk (round 5) the
+    last block + VJP chain exceed the trunk's share; as [hi | lo] pairs (round 6) they fall well under it (2.5 - 5.0e-4 against 8e-4: V stays fp16) and the total is the trunk's."""
+    from oracle import preprocess as op
+    from semabs_amd.synth import synth_rgb
+    sd = make_clip_state_dict("ViT-B/32", 0, text_tower=False, stats="trained")
+    sizes = [120, 80, 60, 30, 97]
+    tiles = torch.from_numpy(np.stack([op.preprocess_tile(synth_rgb(sizes[i % 5], sizes[i % 5], seed=7 + i)) for i in range(3)]))
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g29_vit_b32.npz"))
+    w_text = torch.from_numpy(g["w_text"])
+    allb = tuple(range(11))
+    with torch.no_grad():
+        for clamp in (True, False):
+            ref = relevance(sd, tiles, w_text, clamp=clamp)
+            top = float(ref.abs().max())
+            err = lambda **kw: float((relevance(sd, tiles, w_text, clamp=clamp, **kw) - ref).abs().max()) / top
+            e_trunk = err(trunk=allb)
+            e_tail16, e_tail_split = err(last=True, vjp=True), err(last="split", vjp="split")
+            e_all16, e_all_split = err(trunk=allb, last=True, vjp=True), err(trunk=allb, last="split", vjp="split")
+            print(f"trained statistics, positive_attn_only={clamp}: trunk {e_trunk:.2e} | last block + VJP chain fp16 {e_tail16:.2e} -> [hi | lo] {e_tail_split:.2e} | "
+                  f"everything {e_all16:.2e} -> {e_all_split:.2e}")
+            assert e_tail16 > e_trunk                        # what round 5 left on the table for these statistics
+            assert e_tail_split < 0.65 * e_trunk and e_tail_split < 0.45 * e_tail16     # what remains of the tail is V (fp16 product of the hi half, fp16 storage)
+            assert e_all_split < 1.5 * e_trunk
 
 
 def test_where_the_fp16_error_comes_from():
