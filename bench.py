@@ -378,18 +378,6 @@ HBM_COPY_TBS = 6.3                                                # what a float
 EPI_NAMES = {0: "bias -> fp16", 1: "bias + QuickGELU -> fp16", 2: "bias + fp32 residual read-modify-write", 3: "bias -> fp32", 4: "row-remapped fp32", 5: "row-table multiply -> fp16"}
 
 
-def _load_probe():
-    """Imported context (NOT measured in this run, and labelled so): the round's matrix-pipe probes, profiles/r04_mfma_probes.json."""
-    pth = os.path.join(ROOT, "profiles", "r04_mfma_probes.json")
-    try:
-        d = json.load(open(pth))
-        d["source"] = "profiles/r04_mfma_probes.json (tools/mfma_skeleton.cpp + tools/gemm_probe.py abltrace, round 4; imported, not measured in this run)"
-        return d
-    except Exception:
-        return None
-
-
-MFMA_PROBE = _load_probe()
 
 
 def gemm_shape_name(N, K, epi, M=None):
@@ -544,7 +532,7 @@ def stage_report(pipe, scenes, w_text, arch, precision):
     if trunk:
         fl = sum(v.get("algorithmic_tflop") or 0.0 for v in trunk); gb = sum(v.get("algorithmic_gb") or 0.0 for v in trunk); ms = sum(v["ms_per_scene"] for v in trunk)
         counted = None
-        for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json"):
+        for name in ("r06_gemm_pmc.json", "r05_gemm_pmc.json"):
             pth = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pth):
                 try:
@@ -692,10 +680,14 @@ def train_workload(args, rank, world, dist):
                        "backend": args.backend if world > 1 else None},
             "collectives": {"allreduce_bytes_per_rank_per_step": int(tr.flat_grad.numel() * 4), "allreduce_ms_alone": ar_ms, "parameters_identical_across_ranks": same,
                             "overlapped_with_backward": bool(tr.overlap_allreduce), "buckets_bytes": [int((b - a) * 4) for a, b in tr.buckets.ranges],
+                            "exposed_ms_per_step": None if per_rank is None else max(
+                                (r["collectives"].get("all_reduce_wait", {}).get("device_ms", 0.0) + r["collectives"].get("all_reduce", {}).get("device_ms", 0.0)) / args.steps for r in per_rank),
+                            "exposed_ms_note": "device time the COMPUTE stream spent waiting for the gradient all-reduce (HIP events around the waits of BucketedAllReduce.finish / "
+                                               "around the single blocking all-reduce), per step, maximum over the ranks: the communication the backward pass did not hide",
                             "per_rank": per_rank,
-                            "per_rank_note": "payload bytes and HOST-side milliseconds of every collective each rank issued inside the timed region, by kind: "
+                            "per_rank_note": "payload bytes, HOST-side and DEVICE-side milliseconds of every collective each rank issued inside the timed region, by kind: "
                                              "all_reduce_bucket = the asynchronous bucket launches (host time = launch cost), all_reduce_wait = making the compute "
-                                             "stream wait for them (host time; the device-side exposed time is ms_per_step minus the single-rank step)"},
+                                             "stream wait for them (device_ms = exposed communication)"},
             "loss": float(out["loss"])}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -901,7 +893,7 @@ def main():
         # HBM bytes per GEMM launch: PMC counters cannot be read from inside the process that is being timed (rocprofv3 owns them and
         # serialises the kernels), so this figure is IMPORTED from the committed counter run of this same command and labelled as such
         traffic, traffic_src = None, None
-        for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
+        for name in ("r06_gemm_pmc.json", "r05_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
@@ -937,8 +929,7 @@ def main():
                                        for k, v in sorted(gs["shapes"].items(), key=lambda kv: -kv[1][1]) if v[1] > 0},
                          "frac_of_per_launch_roofs": (sum(gemm_roof_ms(v[2] / v[0], v[3] / v[0])[0] * v[0] for v in gs["shapes"].values() if v[0]) / gs["total_ms"]) if gs["total_ms"] > 0 else None,
                          "gemm_share_of_step": gs["total_ms"] * 1e-3 * gs["seen"] / max(1, gs["launches"]) / dt if world == 1 else None,
-                         # context, not the judged fraction: what back-to-back MFMAs reach on this part (imported probe results, profiles/r03_mfma_probes.txt)
-                         "mfma_probe": MFMA_PROBE and dict(MFMA_PROBE, frac_of_random_operand_skeleton=ach / MFMA_PROBE["skeleton_random_operands_tflops"])},
+                         },
         }
         out["roofline"].update(smi.summary())
         # context beside `frac` (which stays against the 2.4 GHz dense peak): the same achieved rate against the peak at the shader clock the part actually held
@@ -958,6 +949,9 @@ def main():
                                "host->HBM upload of the frame (5 MB, 0.08 ms over PCIe Gen5)")
         out["text_tower_in_timed_region"] = text_enc is not None
         if wire is not None:
+            wire["exposed_ms_per_step"] = max(sum(v.get("device_ms", 0.0) for v in r["collectives"].values()) / args.steps for r in per_rank)
+            wire["exposed_ms_note"] = ("device time the compute stream spent inside the (blocking) all-gathers of the timed region, per step, maximum over the ranks - HIP events "
+                                       "around each call (semabs_amd.dist); scene-shard mode has ONE gather of the final label volumes in the whole run")
             out["collectives"] = wire
         if world == 1 and not args.no_parity:
             out["parity"] = parity_report(pipe, args.arch, args.precision)

@@ -40,6 +40,8 @@ int semabs_stream_cu_count(void* stream, int* cus);
  * reference, visualize.py:193) -> logits = NaN, labels = -1; nothing otherwise. */
 int semabs_fill_u32(void* p, long long nbytes, unsigned int value, void* stream);
 int semabs_replicate(const void* src, void* dst, long long nbytes, int reps, void* stream);
+/* rows x width_bytes from a pitched source to a pitched destination (all multiples of 4 bytes): pack / unpack of the tile-sharded all-gather (dist.py) */
+int semabs_copy2d(const void* src, long long src_pitch_bytes, void* dst, long long dst_pitch_bytes, long long width_bytes, long long rows, void* stream);
 int semabs_poison_empty(const long long* n_in, float* logits, long long n_logits, int* labels, long long n_labels, void* stream);
 int semabs_device_info(char* name /*host*/, int name_len, int* cu_count /*host*/, long long* hbm_bytes /*host*/);
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "semabs_stream_cu_count": [P, P],
     "semabs_fill_u32": [P, C.c_longlong, C.c_uint, P],
     "semabs_replicate": [P, P, C.c_longlong, I, P],
+    "semabs_copy2d": [P, C.c_longlong, P, C.c_longlong, C.c_longlong, C.c_longlong, P],
     "semabs_poison_empty": [P, P, C.c_longlong, P, C.c_longlong, P],
     "semabs_device_info": [C.c_char_p, I, C.POINTER(I), C.POINTER(C.c_longlong)],
     # geometry.hip

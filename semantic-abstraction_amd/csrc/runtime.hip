@@ -143,6 +143,27 @@ extern "C" int semabs_replicate(const void* src, void* dst, long long nbytes, in
     return SEMABS_OK;
 }
 
+// rows x width 32-bit words from a pitched source to a pitched destination (pitches in words): the pack / unpack of the tile-sharded relevancy all-gather
+// (dist.allgather_tile_relevance) without torch.cat / slice-assign kernels.
+static __global__ __launch_bounds__(256) void k_copy2d(const unsigned int* __restrict__ src, long src_pitch, unsigned int* __restrict__ dst, long dst_pitch, long width, long rows) {
+    const long n = width * rows;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / width, c = i - r * width;
+        dst[r * dst_pitch + c] = src[r * src_pitch + c];
+    }
+}
+extern "C" int semabs_copy2d(const void* src, long long src_pitch_bytes, void* dst, long long dst_pitch_bytes, long long width_bytes, long long rows, void* stream) {
+    if (width_bytes == 0 || rows == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(src && dst && width_bytes > 0 && rows > 0 && (width_bytes | src_pitch_bytes | dst_pitch_bytes) % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0 &&
+                   src_pitch_bytes >= width_bytes && dst_pitch_bytes >= width_bytes, "semabs_copy2d: 4-byte aligned pointers / pitches / width, pitches >= width");
+    const long n = (long)(width_bytes / 4 * rows);
+    long nb = (n + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const unsigned int*)src, (long)(src_pitch_bytes / 4), (unsigned int*)dst,
+                       (long)(dst_pitch_bytes / 4), (long)(width_bytes / 4), (long)rows);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // A scene whose depth image has no point inside scene_bounds is an error in the reference (np.random.choice on an empty population, visualize.py:193).
 // The device path learns the count without a host synchronisation: when *n_in == 0 the logits become NaN and the labels -1 (one load and an early
 // exit otherwise), so the result cannot be mistaken for a valid one; SceneResult.n_in_bounds raises on first read.

@@ -18,24 +18,61 @@ import torch
 import torch.distributed as dist
 
 
-# Per-process collective accounting: payload bytes this rank contributed and host-side wall time of every collective issued through
-# this module, by kind - bench.py prints it per rank in every N > 1 line, so the first real multi-GPU run explains itself.
+# Per-process collective accounting: payload bytes this rank contributed, host-side wall time AND device-side time of every
+# collective issued through this module, by kind - bench.py prints it per rank in every N > 1 line, so the first real multi-GPU run explains itself.
+# device_ms: HIP events on the COMPUTE stream around the call.  For a blocking collective (the all-gathers) that is the time the compute stream spent in it
+# (issue -> data complete), i.e. exposed communication; for the asynchronous gradient buckets the pair around `finish()`'s waits ("all_reduce_wait") is the
+# part of the all-reduce the backward pass did NOT hide - `exposed_ms` in bench.py's line - while the buckets' own entries show issue cost only.
 STATS: dict = {}
+_EVENTS: list = []          # (kind, start event, stop event) not yet resolved (elapsed_time needs the events to have completed)
+_EVENT_POOL: list = []
 
 
 def _account(kind: str, nbytes: int, seconds: float, calls: int = 1) -> None:
-    d = STATS.setdefault(kind, {"calls": 0, "bytes": 0, "host_ms": 0.0})
+    d = STATS.setdefault(kind, {"calls": 0, "bytes": 0, "host_ms": 0.0, "device_ms": 0.0})
     d["calls"] += calls
     d["bytes"] += int(nbytes)
     d["host_ms"] += seconds * 1e3
 
 
+class _DeviceTimed:
+    """with _DeviceTimed(kind, on_cuda): ... - a pair of timing events on the current stream around the body; resolved lazily by stats_snapshot()."""
+
+    def __init__(self, kind: str, on: bool):
+        self.kind, self.on = kind, bool(on) and torch.cuda.is_available()
+
+    def __enter__(self):
+        if self.on:
+            self.a = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+            self.b = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            _EVENTS.append((self.kind, self.a, self.b))
+        return False
+
+
+def _resolve_events() -> None:
+    if not _EVENTS:
+        return
+    torch.cuda.synchronize()
+    for kind, a, b in _EVENTS:
+        STATS.setdefault(kind, {"calls": 0, "bytes": 0, "host_ms": 0.0, "device_ms": 0.0})["device_ms"] += a.elapsed_time(b)
+        _EVENT_POOL.extend((a, b))
+    _EVENTS.clear()
+
+
 def reset_stats() -> None:
+    _resolve_events()
     STATS.clear()
 
 
 def stats_snapshot() -> dict:
-    return {k: dict(v, host_ms=round(v["host_ms"], 3)) for k, v in STATS.items()}
+    _resolve_events()
+    return {k: dict(v, host_ms=round(v["host_ms"], 3), device_ms=round(v["device_ms"], 3)) for k, v in STATS.items()}
 
 
 def rank_world() -> Tuple[int, int]:
@@ -63,16 +100,44 @@ def _all_gather_list(local: torch.Tensor) -> List[torch.Tensor]:
     import time
     world = dist.get_world_size()
     t0 = time.perf_counter()
-    if local.is_cuda and dist.get_backend() == "gloo":
-        host = local.detach().cpu().contiguous()
-        out = [torch.empty_like(host) for _ in range(world)]
-        dist.all_gather(out, host)
-        res = [o.to(local.device) for o in out]
-    else:
-        res = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(res, local.contiguous())
+    with _DeviceTimed("all_gather", local.is_cuda):
+        if local.is_cuda and dist.get_backend() == "gloo":
+            host = local.detach().cpu().contiguous()
+            out = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(out, host)
+            res = [o.to(local.device) for o in out]
+        else:
+            res = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(res, local.contiguous())
     _account("all_gather", local.numel() * local.element_size(), time.perf_counter() - t0)
     return res
+
+
+def _all_gather_into(recv: torch.Tensor, send: torch.Tensor) -> None:
+    """recv [world, *send.shape] <- every rank's `send`, in place (pre-allocated arenas: no allocation, no list of tensors).  RCCL: all_gather_into_tensor on the
+    device buffers; gloo (CPU / single-GPU tests) has no such collective for device memory: staged through the host."""
+    import time
+    t0 = time.perf_counter()
+    with _DeviceTimed("all_gather", send.is_cuda):
+        if send.is_cuda and dist.get_backend() == "gloo":
+            host = send.detach().cpu()
+            out = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+            dist.all_gather(out, host)
+            recv.copy_(torch.stack(out))
+        else:
+            dist.all_gather_into_tensor(recv, send)
+    _account("all_gather", send.numel() * send.element_size(), time.perf_counter() - t0)
+
+
+_ARENAS: dict = {}
+
+
+def _arena(key, shape, dtype, device, zero=False) -> torch.Tensor:
+    """A buffer that lives as long as the process, keyed by use and shape (the latency path re-uses the same shapes every scene)."""
+    k = (key, tuple(shape), dtype, str(device))
+    if k not in _ARENAS:
+        _ARENAS[k] = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
+    return _ARENAS[k]
 
 
 def allgather_tile_relevance(rel_local: List[torch.Tensor], n_tiles: int) -> List[torch.Tensor]:
@@ -89,11 +154,36 @@ def allgather_tile_relevance(rel_local: List[torch.Tensor], n_tiles: int) -> Lis
     pad = max(hi - lo for lo, hi in ranges)
     lo, hi = ranges[rank]
     assert all(int(r.shape[1]) == hi - lo for r in rel_local), "rel_local must hold exactly this rank's tile slice"
-    send = torch.zeros(passes, L, pad, g, g, dtype=rel_local[0].dtype, device=rel_local[0].device)
+    # No ATen kernel on this path (round 6): send / receive arenas allocated once per shape, pack and unpack as pitched copies of the library
+    # (semabs_copy2d: L rows per pass), one all_gather_into_tensor.  The returned tensors are views of an arena: valid until the next call with the same shapes
+    # (the caller aggregates them right away on the same stream).  Host tensors (the CPU tests) take the slice / cat form of the same layout.
+    t = rel_local[0]
+    gg = g * g
+    if not t.is_cuda:
+        send = torch.zeros(passes, L, pad, g, g, dtype=t.dtype)
+        for p in range(passes):
+            send[p, :, : hi - lo] = rel_local[p]
+        parts = _all_gather_list(send)
+        return [torch.cat([parts[r][p, :, : ranges[r][1] - ranges[r][0]] for r in range(world)], dim=1).contiguous() for p in range(passes)]
+    from . import _lib
+    assert t.dtype == torch.float32
+    send = _arena("tile_send", (passes, L, pad * gg), t.dtype, t.device, zero=True)
+    recv = _arena("tile_recv", (world, passes, L, pad * gg), t.dtype, t.device)
+    out = _arena("tile_out", (passes, L, n_tiles * gg), t.dtype, t.device)
+    st = _lib.stream()
     for p in range(passes):
-        send[p, :, : hi - lo] = rel_local[p]
-    parts = _all_gather_list(send)
-    return [torch.cat([parts[r][p, :, : ranges[r][1] - ranges[r][0]] for r in range(world)], dim=1).contiguous() for p in range(passes)]
+        src = rel_local[p]
+        assert src.is_contiguous()
+        _lib.call("semabs_copy2d", _lib.ptr(src), (hi - lo) * gg * 4, _lib.ptr(send[p]), pad * gg * 4, (hi - lo) * gg * 4, L, st)
+    _all_gather_into(recv, send)
+    for r in range(world):
+        rlo, rhi = ranges[r]
+        if rhi == rlo:
+            continue
+        for p in range(passes):
+            dst = out[p].view(-1)[rlo * gg:]
+            _lib.call("semabs_copy2d", _lib.ptr(recv[r, p]), pad * gg * 4, _lib.ptr(dst), n_tiles * gg * 4, (rhi - rlo) * gg * 4, L, st)
+    return [out[p].view(L, n_tiles, g, g) for p in range(passes)]
 
 
 def gather_results(local: torch.Tensor) -> torch.Tensor:
@@ -113,7 +203,8 @@ def allreduce_flat_gradients(flat: torch.Tensor, n_flags: int = 0) -> Tuple[floa
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world > 1:
         t0 = time.perf_counter()
-        _allreduce_sum(flat)
+        with _DeviceTimed("all_reduce", flat.is_cuda):
+            _allreduce_sum(flat)
         _account("all_reduce", flat.numel() * flat.element_size(), time.perf_counter() - t0)
     flags = None
     if n_flags:
@@ -157,6 +248,10 @@ class BucketedAllReduce:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def begin_step(self) -> None:
+        # Collectives of a previous forward_backward that never reached finish() (a loss-only call, an exception in between) are still running on the process
+        # group's stream: the new step's writes to the flat buffer must not race with them, and the ranks' collective sequences must stay aligned
+        for w in self.works:
+            w.wait()
         self.started = [False] * len(self.ranges)
         self.works = []
 
@@ -180,8 +275,9 @@ class BucketedAllReduce:
         for i in range(len(self.ranges)):
             self.ready(i)
         t0 = time.perf_counter()
-        for w in self.works:
-            w.wait()                                         # (RCCL: the compute stream waits for the collective's stream; the host does not block)
+        with _DeviceTimed("all_reduce_wait", self.flat.is_cuda):                 # device_ms of this entry = the all-reduce time the backward pass did not hide
+            for w in self.works:
+                w.wait()                                     # (RCCL: the compute stream waits for the collective's stream; the host does not block)
         self.works = []
         _account("all_reduce_wait", 0, time.perf_counter() - t0)
         return 1.0 / dist.get_world_size()

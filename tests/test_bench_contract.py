@@ -45,8 +45,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for name, row in rf.get("per_shape", {}).items():
         assert row["frac_of_roof"] <= 1.0, (name, row)
     # imported counter / probe figures must come from THIS round's profiles and say that they are imported
-    assert "profiles/r05_" in (rf.get("traffic_source") or "profiles/r05_"), rf.get("traffic_source")
-    assert rf["mfma_probe"] is None or "imported" in rf["mfma_probe"]["source"]
+    src = rf.get("traffic_source")
+    assert src is None or (("profiles/r06_" in src or "profiles/r05_" in src) and "imported" in src), src
+    assert "mfma_probe" not in rf                              # round-4 probe figures are no longer carried forward
     assert d.get("text_tower_in_timed_region") is True
     # clock and power under load, sampled in THIS run: the keys are always there; on a box with any SMI source they carry numbers
     for k in ("sclk_mhz_under_load", "power_w", "power_cap_w", "smi_source", "smi_samples"):
