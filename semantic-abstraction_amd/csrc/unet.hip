@@ -1085,10 +1085,12 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
 static int g_conv16_ablate = 0;      // tuning build only (libsemabs_hip_tune.so)
 static long long* g_conv_trace = nullptr;
 static int g_brick_persist = 0;      // k_conv_brick: persistent-workgroup variant (measured slower, kept in the tuning build for A/B)
+static int g_convt_no_line = 0;      // k_convT_brick: 1 = the per-class half-line stores of round 5 (A/B of the LINE variant)
 extern "C" int semabs_conv_tune(int key, long long value) {
     if (key == 0) g_conv16_ablate = (int)value & 7;
     else if (key == 1) g_conv_trace = reinterpret_cast<long long*>(value);
     else if (key == 2) g_brick_persist = (int)value;
+    else if (key == 3) g_convt_no_line = (int)value;
     return SEMABS_OK;
 }
 #endif
@@ -1788,7 +1790,11 @@ struct ConvTArgs {
     double* stats;              // optional: fp64 [B, 8, 2] GroupNorm statistics (8 groups) of the output (after bias and skip), accumulated
     long packed_off;            // > 0: element offset of the fragment-packed copies of the class matrices (SEMABS_CONV_PACKED), same class offsets
 };
-template <bool F32, int P0>                              // P0 = output parity along axis 0: two launches of four classes each (acc registers)
+// LINE (round 6; fp32, Cout == 16: the 128^3 level, 3/4 of the kernel's bytes): the outputs of input voxel x for the classes p2 = 0 / 1 are the adjacent 64-byte
+// records of output voxels 2 x, 2 x + 1 = ONE 128-byte line per lane quad, but a store instruction of one class touched only its half of 16 different lines (and the
+// skip loads likewise).  Neighbouring lanes (x, x + 1) swap one class (DPP) so that each instruction covers WHOLE lines: the even-x lines in the first, the odd-x
+// lines in the second.  Same values, same arithmetic, same addresses in total: bit-identical output.
+template <bool F32, int P0, bool LINE = false>           // P0 = output parity along axis 0: two launches of four classes each (acc registers)
 __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
     constexpr int T0 = 4, T1 = 8, T2 = 16, H0 = T0 + 1, H1 = T1 + 1, H2 = T2 + 1, HALO = H0 * H1 * H2, NTHR = 512, CW = 32, CPV = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1900,45 +1906,92 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
         if (tid < 16) s_stat[tid] = 0.f;
         __syncthreads();
     }
+    if constexpr (LINE) {
+        static_assert(!LINE || F32, "the full-line store variant is for fp32 activations with 16 output channels");
+        const bool odd = (vl & 1) != 0;
+        auto xchg = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };   // lane ^ 1
+        // slot [r][p1][i]: i = 0 -> the line of the even x of this lane pair, i = 1 -> the odd x's line; this lane's 16 bytes sit at (odd ? 64 : 0) + 16 kg of it
+        float sk[4][2][2][4];
+        long oidx[4][2][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wid * 4 + r;
+            const int z = z0 + (row >> 3), y = y0 + (row & 7);
+#pragma unroll
+            for (int p1 = 0; p1 < 2; ++p1)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int x = x0 + ((vl & ~1) | i);
+                    const long ovox = (((long)b * 2 * a.D0 + 2 * z + P0) * O1 + 2 * y + p1) * O2 + 2 * x + (odd ? 1 : 0);
+                    oidx[r][p1][i] = ovox * 16 + 4 * kg;
+                    if (a.skip) {
+                        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.skip) + oidx[r][p1][i]));
+                        sk[r][p1][i][0] = q[0]; sk[r][p1][i][1] = q[1]; sk[r][p1][i][2] = q[2]; sk[r][p1][i][3] = q[3];
+                    } else {
+                        sk[r][p1][i][0] = sk[r][p1][i][1] = sk[r][p1][i][2] = sk[r][p1][i][3] = 0.f;
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int p1 = 0; p1 < 2; ++p1) {
+                float o0[4], o1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float va = acc[r][2 * p1][e], vb = acc[r][2 * p1 + 1][e];          // this lane's class p2 = 0 / p2 = 1 values
+                    const float got = xchg(odd ? va : vb);                                  // even lanes receive the odd neighbour's p2 = 0, odd lanes the even neighbour's p2 = 1
+                    o0[e] = ((odd ? got : va) + bb[e]) + sk[r][p1][0][e];                    // goes to the even x's line
+                    o1[e] = ((odd ? vb : got) + bb[e]) + sk[r][p1][1][e];                    // goes to the odd x's line
+                }
+                __builtin_nontemporal_store(f32x4{o0[0], o0[1], o0[2], o0[3]}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + oidx[r][p1][0]));
+                __builtin_nontemporal_store(f32x4{o1[0], o1[1], o1[2], o1[3]}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + oidx[r][p1][1]));
+                st_s[0] += (o0[0] + o0[1]) + (o1[0] + o1[1]); st_q[0] += (o0[0] * o0[0] + o0[1] * o0[1]) + (o1[0] * o1[0] + o1[1] * o1[1]);
+                st_s[1] += (o0[2] + o0[3]) + (o1[2] + o1[3]); st_q[1] += (o0[2] * o0[2] + o0[3] * o0[3]) + (o1[2] * o1[2] + o1[3] * o1[3]);
+            }
+    } else {
     // The skip rows of ALL 16 (row, class) outputs are requested before the first store: `skip` and `y` may alias as far as the compiler
-    // knows, so load - add - store per output was 16 dependent round trips.
-    float sk[4][4][4];
+        // knows, so load - add - store per output was 16 dependent round trips.
+        float sk[4][4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = wid * 4 + r;
-        const int z = z0 + (row >> 3), y = y0 + (row & 7), x = x0 + vl;
+        for (int r = 0; r < 4; ++r) {
+            const int row = wid * 4 + r;
+            const int z = z0 + (row >> 3), y = y0 + (row & 7), x = x0 + vl;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
-            const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
-            const long oidx = ovox * a.Cout + cout0 + 4 * kg;
-            if (a.skip) {
-                if (F32) { const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.skip) + oidx)); sk[r][c4][0] = q[0]; sk[r][c4][1] = q[1]; sk[r][c4][2] = q[2]; sk[r][c4][3] = q[3]; }
-                else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); sk[r][c4][0] = (float)q[0]; sk[r][c4][1] = (float)q[1]; sk[r][c4][2] = (float)q[2]; sk[r][c4][3] = (float)q[3]; }
-            } else {
-                sk[r][c4][0] = sk[r][c4][1] = sk[r][c4][2] = sk[r][c4][3] = 0.f;
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
+                const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
+                const long oidx = ovox * a.Cout + cout0 + 4 * kg;
+                if (a.skip) {
+                    if (F32) { const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.skip) + oidx)); sk[r][c4][0] = q[0]; sk[r][c4][1] = q[1]; sk[r][c4][2] = q[2]; sk[r][c4][3] = q[3]; }
+                    else { const f16x4 q = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(a.skip) + oidx); sk[r][c4][0] = (float)q[0]; sk[r][c4][1] = (float)q[1]; sk[r][c4][2] = (float)q[2]; sk[r][c4][3] = (float)q[3]; }
+                } else {
+                    sk[r][c4][0] = sk[r][c4][1] = sk[r][c4][2] = sk[r][c4][3] = 0.f;
+                }
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = wid * 4 + r;
-        const int z = z0 + (row >> 3), y = y0 + (row & 7), x = x0 + vl;
+        for (int r = 0; r < 4; ++r) {
+            const int row = wid * 4 + r;
+            const int z = z0 + (row >> 3), y = y0 + (row & 7), x = x0 + vl;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
-            const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
-            const long oidx = ovox * a.Cout + cout0 + 4 * kg;
-            float o[4] = {acc[r][c4][0] + bv.x + sk[r][c4][0], acc[r][c4][1] + bv.y + sk[r][c4][1], acc[r][c4][2] + bv.z + sk[r][c4][2], acc[r][c4][3] + bv.w + sk[r][c4][3]};
-            if (F32) __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + oidx));
-            else {
-                f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int p0 = P0, p1 = (c4 >> 1) & 1, p2 = c4 & 1;
+                const long ovox = (((long)b * 2 * a.D0 + 2 * z + p0) * O1 + 2 * y + p1) * O2 + 2 * x + p2;
+                const long oidx = ovox * a.Cout + cout0 + 4 * kg;
+                float o[4] = {acc[r][c4][0] + bv.x + sk[r][c4][0], acc[r][c4][1] + bv.y + sk[r][c4][1], acc[r][c4][2] + bv.z + sk[r][c4][2], acc[r][c4][3] + bv.w + sk[r][c4][3]};
+                if (F32) __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + oidx));
+                else {
+                    f16x4 h; h[0] = (f16)o[0]; h[1] = (f16)o[1]; h[2] = (f16)o[2]; h[3] = (f16)o[3]; *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(a.y) + oidx) = h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (float)h[e];                  // statistics of the values as stored
+                    for (int e = 0; e < 4; ++e) o[e] = (float)h[e];                  // statistics of the values as stored
+                }
+                st_s[0] += o[0] + o[1]; st_q[0] += o[0] * o[0] + o[1] * o[1];
+                st_s[1] += o[2] + o[3]; st_q[1] += o[2] * o[2] + o[3] * o[3];
             }
-            st_s[0] += o[0] + o[1]; st_q[0] += o[0] * o[0] + o[1] * o[1];
-            st_s[1] += o[2] + o[3]; st_q[1] += o[2] * o[2] + o[3] * o[3];
         }
     }
     if (a.stats) {
@@ -1958,6 +2011,11 @@ __global__ __launch_bounds__(512) void k_convT_brick(ConvTArgs a) {
         if (tid < ngl * 2) atomicAdd(a.stats + ((long)b * 8 + cout0 / cg + (tid >> 1)) * 2 + (tid & 1), (double)s_stat[tid]);
     }
 }
+#ifdef SEMABS_TUNING
+#define CONVT_NO_LINE (g_convt_no_line != 0)                 // tuning build: semabs_conv_tune(3, 1)
+#else
+#define CONVT_NO_LINE (false)
+#endif
 template <bool F32>
 static int convT_brick_launch(const ConvTArgs& a, hipStream_t s) {
     const size_t lds = (size_t)5 * 9 * 17 * 32 * 2 * (F32 ? 2 : 1);
@@ -1965,6 +2023,17 @@ static int convT_brick_launch(const ConvTArgs& a, hipStream_t s) {
     semabs_ensure_lds(&k_convT_brick<F32, 0>, (int)lds, attr0);
     semabs_ensure_lds(&k_convT_brick<F32, 1>, (int)lds, attr1);
     dim3 grid((a.D0 / 4) * (a.D1 / 8) * (a.D2 / 16), a.B, a.Cout / 16);
+    if constexpr (F32) {
+        if (a.Cout == 16 && !CONVT_NO_LINE) {                // whole-line stores / skip loads (see the kernel's LINE comment)
+            static SemabsLdsAttr attr0l, attr1l;
+            semabs_ensure_lds(&k_convT_brick<true, 0, true>, (int)lds, attr0l);
+            semabs_ensure_lds(&k_convT_brick<true, 1, true>, (int)lds, attr1l);
+            hipLaunchKernelGGL((k_convT_brick<true, 0, true>), grid, dim3(512), lds, s, a);
+            hipLaunchKernelGGL((k_convT_brick<true, 1, true>), grid, dim3(512), lds, s, a);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
+    }
     hipLaunchKernelGGL((k_convT_brick<F32, 0>), grid, dim3(512), lds, s, a);
     hipLaunchKernelGGL((k_convT_brick<F32, 1>), grid, dim3(512), lds, s, a);
     SEMABS_CHECK_LAUNCH();

@@ -7,6 +7,10 @@ import torch
 import semabs_amd  # noqa
 from semabs_amd.unet3d import ResidualUNet3D
 from semabs_amd.weights import make_semabs3d_state_dict
+if os.environ.get("SEMABS_TUNE_LIB") == "1" and os.environ.get("UNET_TUNE"):      # A/B switches of the tuning build: UNET_TUNE="key:value,..." -> semabs_conv_tune
+    from semabs_amd import _lib
+    for kv in os.environ["UNET_TUNE"].split(","):
+        _lib.call("semabs_conv_tune", int(kv.split(":")[0]), int(kv.split(":")[1]))
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 S = 128
