@@ -419,6 +419,9 @@ int semabs_cos_bce(const float* o, const float* rel, const float* label, const f
 /* per-step weight layouts: hi / lo[i] = fp16 hi / lo split of src[idx[i]] (idx < 0: zero) - one launch per matrix instead of torch permute / flip /
  * cat / cast chains; the index map of a layout (tap-major, flipped + transposed, parity classes, fragment-packed copy) depends on shapes only */
 int semabs_gather_split16(const float* src, const int* idx, long n, void* hi, void* lo, void* stream);
+/* ... and all layouts of a step in ONE launch: jobs = device array of njobs x {src, idx, hi, lo, n, first block} (six 64-bit words each; first block =
+ * running sum of ceil(n / 1024)), total_blocks = the sum */
+int semabs_gather_split16_batched(const void* jobs, int njobs, long total_blocks, void* stream);
 
 /* the pointer head with the loss left to the caller (autograd boundary of SemAbsVOOL: `loss.backward()` of utils.py:404-417):
  * dlogits == NULL: logits = cos(o, rel) / T only; dlogits = d loss / d logits [P*M]: dO, drel (accumulated) = d loss / d o, d rel   net.py:566-579 */

@@ -122,6 +122,7 @@ SIGNATURES = {
     "semabs_cos_bce": [P, P, P, P, I, L, F, L, P, P, P, P, P, P],
     "semabs_cos_head": [P, P, P, I, L, F, P, P, P, P],
     "semabs_gather_split16": [P, P, L, P, P, P],
+    "semabs_gather_split16_batched": [P, I, L, P],
     "semabs_clip_grad_norm": [P, I, P, I, F, F, P, P],
     # relio.hip
     "semabs_relevancy_pack": [P, P, I, I, I, I, I, P],
