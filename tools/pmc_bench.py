@@ -33,7 +33,7 @@ for k, c in vals.items():
     write = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])) * 1024
     res[k] = dict(dispatches=n, fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write)
 g = res.get("k_gemm", {})
-json.dump(dict(round=5, scenes_in_run=scenes, trunk_counted_gb_per_scene=trunk / scenes / 1e9,
+json.dump(dict(round=6, commit=os.environ.get("SEMABS_COMMIT", "unknown"), scenes_in_run=scenes, trunk_counted_gb_per_scene=trunk / scenes / 1e9,
                kernel="k_gemm8 / k_gemm_f16 (all GEMM launches)", method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-stages`; "
                "KB units; FETCH_SIZE doubled (gfx950 counts 128-B requests of wide reads at 64 B)", **g,
                per_kernel={k: v for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:14]}),

@@ -6,6 +6,8 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 rows = []
 for k, v in d.items():
+    if not isinstance(v, dict):
+        continue
     g = lambda c: v.get(c, {}).get("mean_per_dispatch", 0.0)
     n = v.get("GRBM_GUI_ACTIVE", {}).get("dispatches", 0)
     cyc = g("GRBM_GUI_ACTIVE") / 8

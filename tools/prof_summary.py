@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 *_kernel_stats.csv: python tools/prof_summary.py <csv> [scenes] [top]"""
 import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = list(csv.DictReader(l for l in open(sys.argv[1]) if not l.startswith("#")))
 scenes = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
