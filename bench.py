@@ -380,10 +380,15 @@ EPI_NAMES = {0: "bias -> fp16", 1: "bias + QuickGELU -> fp16", 2: "bias + fp32 r
 
 
 
+# GEMMs of the last block and the VJP chain whose A operand is an [hi | lo] pair (K = 2 x the layer's width; clip/vit.py head_split): algorithmic flops = half the issued ones
+SPLIT_GEMMS = {(768, 1536, 3): "last-block K / CLS q / W_o^T g1", (768, 1536, 2): "CLS out-proj", (3072, 1536, 3): "CLS c_fc / W_pr^T dx2", (768, 6144, 3): "W_fc^T dfc",
+               (768, 6144, 2): "CLS c_proj", (512, 1536, 3): "CLS feature projection", (768, 1024, 3): "proj^T dfeat"}
+
+
 def gemm_shape_name(N, K, epi, M=None):
     """The GEMM shapes of the ViT-B trunk by role (width D = 768; reference: CLIP/clip/auxiliary.py:129,340, model_explainability.py:210-217)."""
     role = {(2304, 768, 0): "QKV", (768, 768, 2): "out-proj", (3072, 768, 1): "c_fc", (768, 3072, 2): "c_proj", (1536, 768, 3): "K|V (last block)",
-            (768, 768, 4): "patch embedding"}.get((int(N), int(K), int(epi)))
+            (768, 768, 4): "patch embedding", **{k: v + ", [hi | lo] A operand" for k, v in SPLIT_GEMMS.items()}}.get((int(N), int(K), int(epi)))
     small = M is not None and M < 2048
     return f"{role or ('small' if small else 'other')} N={int(N)} K={int(K)} ({EPI_NAMES.get(int(epi), epi)})"
 
@@ -402,7 +407,8 @@ def _classify(name, a):
                 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1) else 8) + (M * N * 2 if a[11] else 0))
     if name.startswith("semabs_gemm_f16"):
         M, N, K, epi = a[5], a[6], a[7], a[11]
-        return "fp16 GEMM: " + gemm_shape_name(N, K, epi, M), 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4))
+        return ("fp16 GEMM: " + gemm_shape_name(N, K, epi, M), (1.0 if (int(N), int(K), int(epi)) in SPLIT_GEMMS else 2.0) * M * N * K,
+                M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4)))
     if name == "semabs_attention":
         n, T, H = a[3], a[4], a[5]
         return "attention (k_attention)", 4.0 * n * H * T * T * 64, n * T * H * 64 * 2 * 4

@@ -82,15 +82,16 @@ DELTA_RESIDUAL = os.environ.get("SEMABS_DELTA_RESIDUAL", "0") == "1"
 FUSE_GELU_BWD = os.environ.get("SEMABS_FUSE_GELU_BWD", "1") == "1"      # A/B: 0 = fp32 GEMM output + k_gelu_bwd
 
 
-def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, kernel=0):
-    """kernel: 0 = the library's heuristic, 1 = ring kernel, 2 = phased 256 x 256 kernel (per call; tests pin a path with it)."""
+def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, epi, addend=None, rowmap=None, kernel=0, split=False):
+    """kernel: 0 = the library's heuristic, 1 = ring kernel, 2 = phased 256 x 256 kernel (per call; tests pin a path with it).
+    split: A is an [hi | lo] operand pair (K = 2 x the layer's width): the timer books the ALGORITHMIC flops (half of the issued ones)."""
     t = GEMM_TIMER
     e0 = e1 = None
     if t is not None:
         t.seen += 1
         if t.every == 1 or ((t.seen * 2654435761) >> 7) % t.every == 0:     # hashed: no phase lock with the launch pattern
             e0, e1 = t._pair()
-            t.records.append((e0, e1, 2.0 * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4)), (int(N), int(K), int(epi))))   # A + W + C (fp32 residual: read + write)
+            t.records.append((e0, e1, (1.0 if split else 2.0) * M * N * K, M * K * 2 + N * K * 2 + M * N * (2 if epi in (0, 1, 5) else (8 if epi == 2 else 4)), (int(N), int(K), int(epi))))   # A + W + C (fp32 residual: read + write)
     _lib.call("semabs_gemm_f16_ex", _lib.ptr(A), _lib.ptr(B), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(addend), int(M), int(N),
               int(K), int(lda), int(ldb), int(ldc), int(epi), _lib.iarr(rowmap) if rowmap is not None else None, int(kernel), e0, e1,
               _lib.stream())
@@ -402,21 +403,21 @@ class VisionRollout:
         # K and V for every token.  K in fp32: it feeds the kept softmax row directly.  V in fp16 like every other block's: it only enters
         # through averages (the CLS output, itself stored in fp16, and the rollout's 64-long V . u dots), where its rounding is ~6e-5
         # relative - and it is read five times (CLS attention + four label groups of the rollout), so its width is bandwidth
-        gemm(h, b.w_k2 if sp else b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, k2 * D, k2 * D, k2 * D, D, EPI_F32)
+        gemm(h, b.w_k2 if sp else b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, k2 * D, k2 * D, k2 * D, D, EPI_F32, split=bool(sp))
         gemm(h, b.w_in[2 * D:], ws["v16"], b.b_in[2 * D:], n * T, D, D, k2 * D, D, D, EPI_F16)          # the hi halves only (row pitch k2 D)
         # Q for the CLS rows only (row stride T * k2 D)
-        gemm(h, b.w_q2 if sp else b.w_in[:D], ws["q32"], b.b_in[:D], n, D, k2 * D, T * k2 * D, k2 * D, D, EPI_F32)
+        gemm(h, b.w_q2 if sp else b.w_in[:D], ws["q32"], b.b_in[:D], n, D, k2 * D, T * k2 * D, k2 * D, D, EPI_F32, split=bool(sp))
         _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["k32"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
                   n, T, H, 64, sp, st)
         _lib.call("semabs_rows_gather", _lib.ptr(x), _lib.ptr(ws["x1c"]), n, D, T * D, 0, st)
-        gemm(ws["o_cls"], b.w_o2 if sp else b.w_o, ws["x1c"], b.b_o, n, D, k2 * D, k2 * D, k2 * D, D, EPI_RESID_F32)
+        gemm(ws["o_cls"], b.w_o2 if sp else b.w_o, ws["x1c"], b.b_o, n, D, k2 * D, k2 * D, k2 * D, D, EPI_RESID_F32, split=bool(sp))
         layernorm(ws["x1c"], b.ln2_w, b.ln2_b, ws["h2c"], n, D, out_f32=8 if sp else 0)
-        gemm(ws["h2c"], b.w_fc2 if sp else b.w_fc, ws["fc"], b.b_fc, n, 4 * D, k2 * D, k2 * D, k2 * D, 4 * D, EPI_F32)
+        gemm(ws["h2c"], b.w_fc2 if sp else b.w_fc, ws["fc"], b.b_fc, n, 4 * D, k2 * D, k2 * D, k2 * D, 4 * D, EPI_F32, split=bool(sp))
         _lib.call("semabs_quickgelu", _lib.ptr(ws["fc"]), _lib.ptr(ws["actc"]), n * 4 * D, 4 * D if sp else 0, st)
         _lib.call("semabs_rows_gather", _lib.ptr(ws["x1c"]), _lib.ptr(ws["x2c"]), n, D, D, 0, st)
-        gemm(ws["actc"], b.w_pr2 if sp else b.w_pr, ws["x2c"], b.b_pr, n, D, k2 * 4 * D, k2 * 4 * D, k2 * 4 * D, D, EPI_RESID_F32)
+        gemm(ws["actc"], b.w_pr2 if sp else b.w_pr, ws["x2c"], b.b_pr, n, D, k2 * 4 * D, k2 * 4 * D, k2 * 4 * D, D, EPI_RESID_F32, split=bool(sp))
         layernorm(ws["x2c"], *self.ln_post, ws["yc"], n, D, out_f32=8 if sp else 0)
-        gemm(ws["yc"], self.proj_t2 if sp else self.proj_t, ws["feat"], None, n, E, k2 * D, k2 * D, k2 * D, E, EPI_F32)
+        gemm(ws["yc"], self.proj_t2 if sp else self.proj_t, ws["feat"], None, n, E, k2 * D, k2 * D, k2 * D, E, EPI_F32, split=bool(sp))
 
     def rollout(self, n: int, w_text: torch.Tensor, positive_attn_only: bool, rel_out: torch.Tensor, tile0: int):
         """w_text fp32 [L, E] on the GPU; writes rel_out[:, tile0:tile0+n] (rel_out fp32 [L, N_total, g, g])."""
@@ -431,15 +432,15 @@ class VisionRollout:
         k2 = 2 if sp else 1
         _lib.call("semabs_logit_grad", _lib.ptr(ws["feat"]), _lib.ptr(w_text), n, L, E, _lib.ptr(ws["logits"]),
                   _lib.ptr(ws["dfeat"]), _lib.ptr(ws["scale"]), sp, st)
-        gemm(ws["dfeat"], self.proj2 if sp else self.proj, ws["dy"], None, R, D, k2 * E, k2 * E, k2 * E, D, EPI_F32)
+        gemm(ws["dfeat"], self.proj2 if sp else self.proj, ws["dy"], None, R, D, k2 * E, k2 * E, k2 * E, D, EPI_F32, split=bool(sp))
         _lib.call("semabs_ln_bwd", _lib.ptr(ws["x2c"]), _lib.ptr(self.ln_post[0]), _lib.ptr(ws["dy"]), None,
                   _lib.ptr(ws["dx2"]), _lib.ptr(ws["dx2h"]), R, D, n, D, 1e-5, sp, st)
-        gemm(ws["dx2h"], b.w_pr_t2 if sp else b.w_pr_t, ws["dact"], None, R, 4 * D, k2 * D, k2 * D, k2 * D, 4 * D, EPI_F32)
+        gemm(ws["dx2h"], b.w_pr_t2 if sp else b.w_pr_t, ws["dact"], None, R, 4 * D, k2 * D, k2 * D, k2 * D, 4 * D, EPI_F32, split=bool(sp))
         _lib.call("semabs_gelu_bwd", _lib.ptr(ws["dact"]), _lib.ptr(ws["fc"]), _lib.ptr(ws["dfc"]), R, 4 * D, n, sp, st)
-        gemm(ws["dfc"], b.w_fc_t2 if sp else b.w_fc_t, ws["dh2"], None, R, D, k2 * 4 * D, k2 * 4 * D, k2 * 4 * D, D, EPI_F32)
+        gemm(ws["dfc"], b.w_fc_t2 if sp else b.w_fc_t, ws["dh2"], None, R, D, k2 * 4 * D, k2 * 4 * D, k2 * 4 * D, D, EPI_F32, split=bool(sp))
         _lib.call("semabs_ln_bwd", _lib.ptr(ws["x1c"]), _lib.ptr(b.ln2_w), _lib.ptr(ws["dh2"]), _lib.ptr(ws["dx2"]),
                   None, _lib.ptr(ws["g1h"]), R, D, n, D, 1e-5, sp, st)
-        gemm(ws["g1h"], b.w_o_t2 if sp else b.w_o_t, ws["u"], None, R, D, k2 * D, k2 * D, k2 * D, D, EPI_F32)
+        gemm(ws["g1h"], b.w_o_t2 if sp else b.w_o_t, ws["u"], None, R, D, k2 * D, k2 * D, k2 * D, D, EPI_F32, split=bool(sp))
         _lib.call("semabs_rollout", _lib.ptr(ws["probs"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["u"]), _lib.ptr(ws["scale"]),
                   _lib.ptr(rel_out), n, T, H, L, int(positive_attn_only), int(rel_out.shape[1]), int(tile0), st)
 
