@@ -193,6 +193,10 @@ int semabs_attention_split(const void* qkv, const void* qk_lo, void* out, void* 
  * of W values is stored as [hi | lo] with a pitch of 2 W - hi = fp16(v), lo = fp16(v - hi) - and consumed by a GEMM with K = 2 W against the weight
  * matrix repeated twice along K: the operand enters to ~2^-22.  The last block and the VJP chain behind it run this way (clip/vit.py). */
 int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H, int head_dim, int split, void* stream);
+/* The kept softmax row of the last block without the K projection: s[h, j] = (W_k,h^T q_h) . x_j + q_h . b_k,h for the CLS query only (the one row
+ * clip_gradcam.py:124-131 reads; auxiliary.py:307-337).  q fp32 [n, D] (scaled, bias included), wk fp16 [D, D] = in_proj_weight[D:2D], bk fp32 [D], x = the block's
+ * LayerNorm-1 rows, fp16 of pitch ldx ([hi | lo] when split) -> probs fp32 [n, H, T]; then semabs_attention_cls(q = k = NULL) forms o = P . V from them. */
+int semabs_cls_scores(const float* q, const void* wk, const float* bk, const void* x, long ldx, int split, float* probs, int n, int T, int D, void* stream);
 int semabs_rows_gather(const float* src, float* dst, long rows, int cols, long src_stride, long offset, void* stream);
 /* x[arange(B), tokens.argmax(-1)] of the text tower (the EOT rows)        CLIP/clip/model_explainability.py:480
  * tokens int64 [B, T] (device), x fp32 [B * T, D] -> dst fp32 [B, D]. */

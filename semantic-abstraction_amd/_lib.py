@@ -66,6 +66,7 @@ SIGNATURES = {
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],
     "semabs_attention_split": [P, P, P, P, I, I, I, I, I, I, I, P],
     "semabs_attention_cls": [P, P, P, P, P, I, I, I, I, I, P],
+    "semabs_cls_scores": [P, P, P, P, L, I, P, I, I, I, P],
     "semabs_rows_gather": [P, P, L, I, L, L, P],
     "semabs_eot_rows_gather": [P, P, P, I, I, I, P],
     "semabs_quickgelu": [P, P, L, I, P],

@@ -237,6 +237,7 @@ class VisionRollout:
         # flops.  With the peaked softmax of a trained checkpoint (CLS scores up to ~60) the fp16 rounding of that LayerNorm output alone moved the kept
         # softmax row by 2e-3 and the per-tile relevance by 3 - 5e-3 of its maximum (tests/test_gpu_trained_stats.py; budget: test_vit_precision_budget.py).
         self.head_split = os.environ.get("SEMABS_HEAD_SPLIT", "1") == "1"
+        self.cls_scores = os.environ.get("SEMABS_CLS_SCORES", "1") == "1"      # A/B: 0 = K projection for all tokens + semabs_attention_cls
         self.chunk = int(chunk_tiles)
         self.max_labels = int(max_labels)
         self._wss = {}
@@ -278,7 +279,7 @@ class VisionRollout:
             self._wss[self.slot] = dict(
                 x=e32(n * T, D), h=e16(n * T, D), delta=e16(n * T, D), qkv=e16(n * T, 3 * D), att=e16(n * T, D), hid=e16(n * T, 4 * D),
                 ln_part=e32(n * T, max(1, D // 256), 2), ln_rowac=e32(n * T, 2), ln_center=e32(n * T), qk_lo=e16(n * T, 2 * D) if self.qk_split else None,
-                k32=e32(n * T, D), v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, 2 * D), x1c=e32(n, D),
+                k32=e32(n * T, D) if not (self.cls_scores and D == 768 and T <= 224) else None, v16=e16(n * T, D), q32=e32(n, D), probs=e32(n, self.H, T), o_cls=e16(n, 2 * D), x1c=e32(n, D),
                 h2c=e16(n, 2 * D), fc=e32(n, 4 * D), actc=e16(n, 8 * D), x2c=e32(n, D), yc=e16(n, 2 * D), feat=e32(n, E),
                 logits=e32(n, Lm), dfeat=e16(R, 2 * E), scale=e32(R), dy=e32(R, D), dx2=e32(R, D), dx2h=e16(R, 2 * D),
                 dact=e32(R, 4 * D), dfc=e16(R, 8 * D), dh2=e32(R, D), g1h=e16(R, 2 * D), u=e32(R, D),
@@ -403,12 +404,19 @@ class VisionRollout:
         # K and V for every token.  K in fp32: it feeds the kept softmax row directly.  V in fp16 like every other block's: it only enters
         # through averages (the CLS output, itself stored in fp16, and the rollout's 64-long V . u dots), where its rounding is ~6e-5
         # relative - and it is read five times (CLS attention + four label groups of the rollout), so its width is bandwidth
-        gemm(h, b.w_k2 if sp else b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, k2 * D, k2 * D, k2 * D, D, EPI_F32, split=bool(sp))
         gemm(h, b.w_in[2 * D:], ws["v16"], b.b_in[2 * D:], n * T, D, D, k2 * D, D, D, EPI_F16)          # the hi halves only (row pitch k2 D)
         # Q for the CLS rows only (row stride T * k2 D)
         gemm(h, b.w_q2 if sp else b.w_in[:D], ws["q32"], b.b_in[:D], n, D, k2 * D, T * k2 * D, k2 * D, D, EPI_F32, split=bool(sp))
-        _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["k32"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
-                  n, T, H, 64, sp, st)
+        if self.cls_scores and D == 768 and T <= 224:
+            # the kept softmax row without the K projection (round 6): s[h, j] = (W_k,h^T q_h) . x_j + q_h . b_k,h - only the CLS query's scores exist in this
+            # block, so the [M, D] x [D, D] GEMM with fp32 output (1.1 ms per scene with split rows; 1.48 GB written and read back) is 12 x D values per tile instead
+            _lib.call("semabs_cls_scores", _lib.ptr(ws["q32"]), _lib.ptr(b.w_in[D:2 * D]), _lib.ptr(b.b_in[D:2 * D]), _lib.ptr(h), k2 * D, sp, _lib.ptr(ws["probs"]),
+                      n, T, D, st)
+            _lib.call("semabs_attention_cls", None, None, _lib.ptr(ws["v16"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]), n, T, H, 64, sp, st)
+        else:
+            gemm(h, b.w_k2 if sp else b.w_in[D:2 * D], ws["k32"], b.b_in[D:2 * D], n * T, D, k2 * D, k2 * D, k2 * D, D, EPI_F32, split=bool(sp))
+            _lib.call("semabs_attention_cls", _lib.ptr(ws["q32"]), _lib.ptr(ws["k32"]), _lib.ptr(ws["v16"]), _lib.ptr(ws["probs"]), _lib.ptr(ws["o_cls"]),
+                      n, T, H, 64, sp, st)
         _lib.call("semabs_rows_gather", _lib.ptr(x), _lib.ptr(ws["x1c"]), n, D, T * D, 0, st)
         gemm(ws["o_cls"], b.w_o2 if sp else b.w_o, ws["x1c"], b.b_o, n, D, k2 * D, k2 * D, k2 * D, D, EPI_RESID_F32, split=bool(sp))
         layernorm(ws["x1c"], b.ln2_w, b.ln2_b, ws["h2c"], n, D, out_f32=8 if sp else 0)

@@ -692,6 +692,23 @@ __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__
     const int i = (int)(wh / H), h = (int)(wh % H);
     const float* qr = q + (long)i * D + h * 64;
     const float* kb = kmat + (long)i * T * D + h * 64;
+    if (!kmat) {                                              // the softmax rows are given (semabs_cls_scores): P . V only
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int j = t * 64 + lane; sp[w][j] = j < T ? probs[wh * T + j] : 0.f; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const f16* vb0 = vmat + (long)i * T * D + h * 64 + lane;
+        float a0 = 0.f;
+        for (int j = 0; j < T; ++j) a0 += sp[w][j] * (float)vb0[(long)j * D];
+        if (split) {
+            const f16 hi = (f16)a0;
+            o[(long)i * 2 * D + h * 64 + lane] = hi;
+            o[(long)i * 2 * D + D + h * 64 + lane] = (f16)(a0 - (float)hi);
+        } else {
+            o[(long)i * D + h * 64 + lane] = (f16)a0;
+        }
+        return;
+    }
     float sc[4];
     float mx = -INFINITY;
 #pragma unroll
@@ -741,10 +758,124 @@ __global__ __launch_bounds__(256) void k_attention_cls(const float* __restrict__
 extern "C" int semabs_attention_cls(const float* q, const float* k, const void* v, float* probs, void* o, int n, int T, int H,
                                     int head_dim, int split, void* stream) {
     if (n == 0) return SEMABS_OK;
-    SEMABS_REQUIRE(q && k && v && probs && o && n > 0, "semabs_attention_cls: bad args");
+    SEMABS_REQUIRE((q || !k) && v && probs && o && n > 0, "semabs_attention_cls: bad args (k = NULL: probs are an input, semabs_cls_scores)");
     SEMABS_REQUIRE(head_dim == 64 && T <= 256 && T > 0, "semabs_attention_cls: head_dim 64, T <= 256");
     hipLaunchKernelGGL(k_attention_cls, dim3(semabs_cdiv((long)n * H, 4)), dim3(256), 0, (hipStream_t)stream, q, k, (const f16*)v, probs,
                        (f16*)o, n, T, H, split);
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
+// =================================================================================================
+// Last block, CLS query: the kept softmax row WITHOUT the K projection (round 6).  Only the CLS query's scores are ever needed, and
+//   s[h, j] = q_h . (W_k,h x_j + b_k,h) = (W_k,h^T q_h) . x_j + q_h . b_k,h,
+// so instead of K = X W_k^T for every token (an [M, D] x [D, D] GEMM with fp32 output: 1.1 ms per scene and 1.48 GB written and read back) a workgroup per tile
+// forms R[h, :] = W_k,h^T q_h (12 x D values, fp32 FMAs over the fp16-exact weights), splits it into fp16 hi / lo planes in LDS - the A operand, rows = heads
+// padded to 16 - and multiplies it with the tile's LayerNorm-1 rows x_j ([hi | lo] rows of pitch 2 D, or plain fp16 rows) on v_mfma_f32_16x16x32_f16: three
+// products, so both factors enter to ~2^-22.  Softmax per head in fp32 -> probs [n, H, T], the input of semabs_attention_cls(k = NULL).
+//   q fp32 [n, D] (scaled CLS query incl. bias), wk fp16 [D, D] ([out, in] rows of in_proj_weight[D:2D]), bk fp32 [D], x fp16 rows of pitch ldx.
+// CLIP/clip/auxiliary.py:307-337 for the one query row that clip_gradcam.py:124-131 reads.
+// =================================================================================================
+template <int D>
+__global__ __launch_bounds__(384) void k_cls_scores(const float* __restrict__ q, const f16* __restrict__ wk, const float* __restrict__ bk, const f16* __restrict__ x,
+                                                    long ldx, int split, float* __restrict__ probs, int T) {
+    constexpr int H = D / 64, PITCH = D + 8, CG = D / 8;    // CG threads cover one weight row with 16-byte loads
+    static_assert(H <= 16 && CG * 4 == 384, "built for D = 768 (12 heads, 96 column groups x 4 head slots)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* r_hi = reinterpret_cast<f16*>(smem);               // [16][PITCH]
+    f16* r_lo = r_hi + 16 * PITCH;
+    float* s_q = reinterpret_cast<float*>(r_lo + 16 * PITCH);   // [D]
+    float* s_sb = s_q + D;                                  // [16]: q_h . b_k,h
+    float* s_s = s_sb + 16;                                 // [16][224] scores
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long tile = blockIdx.x;
+    for (int c = tid; c < D; c += 384) s_q[c] = q[tile * D + c];
+    for (int c = tid; c < 4 * PITCH; c += 384) { r_hi[12 * PITCH + c] = (f16)0.f; r_lo[12 * PITCH + c] = (f16)0.f; }     // rows 12 .. 15 of the A operand
+    __syncthreads();
+    if (tid < H) {
+        float a = 0.f;
+        for (int d = 0; d < 64; ++d) a += s_q[tid * 64 + d] * bk[tid * 64 + d];
+        s_sb[tid] = a;
+    }
+    // R: thread (cg, hs) owns 8 columns of heads hs, hs + 4, hs + 8; a weight row is read by 96 consecutive threads (1 536 contiguous bytes)
+    const int cg = tid % CG, hs = tid / CG;
+#pragma unroll 1
+    for (int hh = 0; hh < H / 4; ++hh) {
+        const int h = hh * 4 + hs;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f16* wrow = wk + (long)(h * 64) * D + cg * 8;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) {
+            const f16x8 w = *reinterpret_cast<const f16x8*>(wrow + (long)d * D);
+            const float qv = s_q[h * 64 + d];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += qv * (float)w[e];
+        }
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { vh[e] = (f16)acc[e]; vl[e] = (f16)(acc[e] - (float)vh[e]); }
+        *reinterpret_cast<f16x8*>(r_hi + h * PITCH + cg * 8) = vh;
+        *reinterpret_cast<f16x8*>(r_lo + h * PITCH + cg * 8) = vl;
+    }
+    __syncthreads();
+    // scores: a wave takes every sixth block of 16 tokens; lane = (token of the block, 8-wide k chunk)
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int nblk = (T + 15) / 16;
+    for (int tb = wid; tb < nblk; tb += 6) {
+        int j = tb * 16 + l15;
+        if (j >= T) j = T - 1;                              // clamped rows are computed and dropped
+        const f16* xr = x + (tile * T + j) * ldx + kg * 8;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 6
+        for (int ks = 0; ks < D / 32; ++ks) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(xr + ks * 32);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(r_hi + l15 * PITCH + ks * 32 + kg * 8);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(r_lo + l15 * PITCH + ks * 32 + kg * 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+            if (split) {
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(xr + D + ks * 32);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+            }
+        }
+        // acc[r] = s[head 4 kg + r][token tb * 16 + l15]
+        if (tb * 16 + l15 < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_s[(kg * 4 + r) * 224 + tb * 16 + l15] = acc[r];
+        }
+    }
+    __syncthreads();
+    for (int h = wid; h < H; h += 6) {
+        float v[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = t * 64 + lane;
+            v[t] = j < T ? s_s[h * 224 + j] + s_sb[h] : -INFINITY;
+            mx = fmaxf(mx, v[t]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[t] = (t * 64 + lane < T) ? __expf(v[t] - mx) : 0.f; sum += v[t]; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = t * 64 + lane;
+            if (j < T) probs[(tile * H + h) * T + j] = v[t] * inv;
+        }
+    }
+}
+extern "C" int semabs_cls_scores(const float* q, const void* wk, const float* bk, const void* x, long ldx, int split, float* probs, int n, int T, int D, void* stream) {
+    if (n == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(q && wk && bk && x && probs && n > 0, "semabs_cls_scores: bad args");
+    SEMABS_REQUIRE(D == 768 && T > 0 && T <= 224 && ldx >= (split ? 2 : 1) * (long)D && ldx % 8 == 0, "semabs_cls_scores: D = 768, T <= 224, 16-byte aligned rows of pitch >= D (2 D when split)");
+    constexpr int PITCH = 768 + 8;
+    const size_t lds = (size_t)2 * 16 * PITCH * 2 + (768 + 16 + 16 * 224) * 4;
+    static SemabsLdsAttr attr;
+    semabs_ensure_lds(&k_cls_scores<768>, (int)lds, attr);
+    hipLaunchKernelGGL(k_cls_scores<768>, dim3((unsigned)n), dim3(384), lds, (hipStream_t)stream, q, (const f16*)wk, bk, (const f16*)x, ldx, split, probs, T);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }

@@ -89,7 +89,20 @@ class ScenePipeline:
         d["_fr_prm"] = frustum_params(scene["cam_pose"], scene["cam_intr"])
         if self.with_tsdf:
             d["_tsdf_prm"] = self._tsdf_volume_spec()[2](scene["cam_pose"])
+        d["_cam_key"] = self._cam_key(scene)                  # the cached blocks belong to THIS camera (checked on every use: _fresh_camera)
         return d
+
+    @staticmethod
+    def _cam_key(scene: dict) -> bytes:
+        return np.asarray(scene["cam_pose"], np.float64).tobytes() + np.asarray(scene["cam_intr"], np.float64).tobytes()
+
+    def _fresh_camera(self, scene: dict) -> dict:
+        """An uploaded dict whose cam_pose / cam_intr were changed afterwards (a frame stream re-using one dict) must not run with the stale device argument
+        blocks of `upload`: they are dropped, the kernels then build them from the current camera (one small host -> device copy each)."""
+        if "_cam_key" in scene and scene["_cam_key"] != self._cam_key(scene):
+            for k in ("_pc_prm", "_fr_prm", "_tsdf_prm", "_cam_key"):
+                scene.pop(k, None)
+        return scene
 
     def _tsdf_volume_spec(self):
         """(bounds [3, 2], voxel size, cam_pose -> device argument block) of the scene's TSDF volume (visualize.py:217-227)."""
@@ -119,6 +132,7 @@ class ScenePipeline:
         given, geometry runs on `geo_stream` (its host sync then waits for nothing else) and the ViT on `vit_stream`; the returned state
         carries the events `run_voxels` waits for - this is what lets a caller overlap scene i's voxel stage with scene i + 1's ViT."""
         dev, net = self.dev, self.net
+        scene = self._fresh_camera(scene)
         H, W = scene["depth"].shape
         cfg = saliency_configs[self.config](H)
         cur = torch.cuda.current_stream()

@@ -49,7 +49,10 @@ for announce in ((), (0, 2), (0, 1, 2, 3)):
         buf2 = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")      # compute queued behind the announcement
     assert br.finish() == 1.0 / world
     torch.cuda.synchronize()
-    assert torch.equal(buf, want), announce
+    if world <= 2:                                          # two addends: the order cannot matter - bit-identical to the single call (ADVICE r5)
+        assert torch.equal(buf, want), announce
+    else:                                                   # more ranks: RCCL may pick another reduction order per message size
+        assert float((buf - want).abs().max()) <= 1e-5 * float(want.abs().max()), announce
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL_OK", rank, world, flush=True)

@@ -439,3 +439,38 @@ def test_imagenet_prompt_ensemble_vs_reference(golden):
     assert err <= tol(3.052e-5)                                         # measured 3.052e-5 absolute = 1.6e-3 of max|ref| - ONE tile: an L-infinity over 196 cells (round 5: 2.289e-5)
     # the mean over templates is NOT re-normalised (clip_gradcam.py:23-26): the ensemble weight is shorter than a unit vector
     assert float(np.linalg.norm(feats.numpy(), axis=1).max()) < 0.999
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("T", [50, 197])
+def test_cls_scores_kernel_vs_fp64(T, split):
+    """semabs_cls_scores: the CLS query's softmax row of the last block from (W_k^T q) . x instead of q . (W_k x): against the fp64 softmax of the direct form on the
+    same operands (q fp32, W_k fp16-exact, x as fp16 rows or [hi | lo] pairs), peaked scores (sigma ~8), and semabs_attention_cls(k = NULL) against P . V."""
+    from semabs_amd import _lib
+    n, D, H = 7, 768, 12
+    g = torch.Generator(device="cuda").manual_seed(T + split)
+    x32 = torch.randn(n * T, D, device="cuda", generator=g) * 1.5 + 0.3
+    wk = (torch.randn(D, D, device="cuda", generator=g) * 0.05).half()
+    bk = torch.randn(D, device="cuda", generator=g) * 0.2
+    q = torch.randn(n, D, device="cuda", generator=g) * 0.9
+    hi = x32.half()
+    if split:
+        x = torch.cat([hi, (x32 - hi.float()).half()], dim=1).contiguous()
+        xd = hi.double() + x[:, D:].double()
+    else:
+        x = hi.contiguous()
+        xd = hi.double()
+    probs = torch.full((n + 1, H, T), 7.0, dtype=torch.float32, device="cuda")
+    _lib.call("semabs_cls_scores", _lib.ptr(q), _lib.ptr(wk), _lib.ptr(bk), _lib.ptr(x), x.shape[1], split, _lib.ptr(probs), n, T, D, _lib.stream())
+    k = (xd @ wk.double().T + bk.double()).view(n, T, H, 64)
+    s = torch.einsum("nhd,nthd->nht", q.double().view(n, H, 64), k)
+    ref = torch.softmax(s, dim=-1)
+    err = float((probs[:n].double() - ref).abs().max())
+    print(f"semabs_cls_scores T={T} split={split}: probs L-inf {err:.2e} (score sigma {float(s.std(-1).mean()):.1f}, max prob {float(ref.max()):.3f})")
+    assert err < 2e-5 and bool((probs[n] == 7.0).all())
+    v = (torch.randn(n * T, D, device="cuda", generator=g)).half()
+    o = torch.full((n + 1, 2 * D if split else D), 7.0, dtype=torch.float16, device="cuda")
+    _lib.call("semabs_attention_cls", None, None, _lib.ptr(v), _lib.ptr(probs), _lib.ptr(o), n, T, H, 64, split, _lib.stream())
+    want = torch.einsum("nht,nthd->nhd", probs[:n].double(), v.double().view(n, T, H, 64)).reshape(n, D)
+    got = o[:n, :D].double() + (o[:n, D:].double() if split else 0.0)
+    assert float((got - want).abs().max()) < (2e-6 if split else 2e-3) * float(want.abs().max()) and bool((o[n] == 7.0).all())
