@@ -286,10 +286,10 @@ class CuPartition:
         self.cus = tuple(got)                                 # what the runtime reports for the two streams
 
     def close(self):
+        """Drain the two streams.  They are NOT destroyed: torch's caching allocator keeps per-stream block pools keyed by the stream handle and touches it again
+        when those blocks are re-used (destroying the handles under it segfaulted in the GPU suite); two idle streams per partition live until process exit.
+        (`semabs_stream_destroy` exists for callers that own their allocations.)"""
         torch.cuda.synchronize()
-        for h in self._handles:
-            _lib.call("semabs_stream_destroy", h)
-        self._handles = []
 
 
 def build_default(arch: str = "ViT-B/16", precision: str = "exact", clip_seed: int = 0, net_seed: int = 3, chunk_tiles: int = 2448,
