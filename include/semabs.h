@@ -171,6 +171,10 @@ int semabs_ln_rowstats(const float* part, long M, int ntile, int D, float eps, f
  * mean_out (optional, [M]): the row means, the first centre of a folded-LayerNorm chain (semabs_gemm_f16_ln). */
 int semabs_layernorm(const float* x, const float* gamma, const float* beta, void* out, long M, int D, float eps,
                      int out_f32, long ld_in, float* mean_out, void* stream);
+/* Two LayerNorms in one pass: out1 fp32 = LN(x; g1, b1) (may alias x), out2 fp16 = LN(out1; g2, b2); bit-identical to two semabs_layernorm calls.  ln_pre
+ * followed by block 0's ln_1 (model_explainability.py:345, 232-255).  order as in semabs_layernorm (0 / 1 / 2); mean_out (optional): row means of out1. */
+int semabs_layernorm2(const float* x, const float* g1, const float* b1, float* out1, const float* g2, const float* b2, void* out2, long M, int D, float eps,
+                      int order, float* mean_out, void* stream);
 /* Residual add fused into the LayerNorm pass: x fp32 [M, D] += delta fp16 [M, D] (in place), out fp16 [M, D] = LayerNorm(x); out NULL = the
  * addition only.  ResidualAttentionBlock.forward's `x = x + ...; ln_2(x)` (model_explainability.py:232-255) with the read-modify-write of
  * the residual stream taken out of the GEMM epilogue. */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "semabs_ln_rowstats": [P, L, I, I, F, P, P, P, P],
     # vit.hip
     "semabs_layernorm": [P, P, P, P, L, I, F, I, L, P, P],
+    "semabs_layernorm2": [P, P, P, P, P, P, P, L, I, F, I, P, P],
     "semabs_add_layernorm": [P, P, P, P, P, L, I, F, P],
     "semabs_embed_finish": [P, P, P, I, I, I, P],
     "semabs_attention": [P, P, P, I, I, I, I, I, I, P],

@@ -324,7 +324,11 @@ class ClipWrapper:
                 m = sum(cnt for _, _, cnt in segs)
                 v0 = i * eng.chunk                              # first (pass, tile) forward of the chunk = row v0 * G of the patch matrix
                 patches = patches_all[v0 * G:(v0 + m) * G]
-                eng.embed(patches, m); eng.trunk(m); eng.head(m)
+                if isinstance(eng, VisionRollout):              # ln_pre + block 0's ln_1 as one pass when the batch takes the folded launch sequence
+                    eng.embed(patches, m, defer_ln_pre=os.environ.get("SEMABS_LN2", "1") == "1")
+                else:
+                    eng.embed(patches, m)
+                eng.trunk(m); eng.head(m)
                 col0 = i * eng.chunk                            # the chunk's tiles are consecutive columns of rel_all
                 for li, wl in enumerate(w_chunks):
                     l0 = li * eng.max_labels

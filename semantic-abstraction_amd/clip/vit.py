@@ -288,8 +288,9 @@ class VisionRollout:
         return self._wss[self.slot]
 
     # ---- forward ---------------------------------------------------------------------------------
-    def embed(self, patches: torch.Tensor, n: int):
-        """patches fp16 [n * g*g, 3 p p] -> ws['x'] = ln_pre(cat(cls, conv) + pos)  [n * T, D] fp32."""
+    def embed(self, patches: torch.Tensor, n: int, defer_ln_pre: bool = False):
+        """patches fp16 [n * g*g, 3 p p] -> ws['x'] = ln_pre(cat(cls, conv) + pos)  [n * T, D] fp32.
+        defer_ln_pre: leave x un-normalised; trunk() then runs ln_pre and block 0's ln_1 as ONE pass (semabs_layernorm2: bit-identical, one read of x less)."""
         assert n <= self.chunk
         self._reserve(n)
         ws = self._workspace()
@@ -298,7 +299,14 @@ class VisionRollout:
         gemm(patches, self.w_patch, x, None, n * G, D, 3 * self.p * self.p, 3 * self.p * self.p, 3 * self.p * self.p, D,
              EPI_ROWMAP, addend=self.pos, rowmap=(G, T, 1))
         _lib.call("semabs_embed_finish", _lib.ptr(x), _lib.ptr(self.cls), _lib.ptr(self.pos), n, T, D, _lib.stream())
-        layernorm(x, *self.ln_pre, x, n * T, D, out_f32=True)
+        self._ln_pre_pending = bool(defer_ln_pre) and self._fold_taken(n)
+        if not self._ln_pre_pending:
+            layernorm(x, *self.ln_pre, x, n * T, D, out_f32=True)
+
+    def _fold_taken(self, n: int) -> bool:
+        """trunk(n) will take the LayerNorm-fold launch sequence (the one the benchmark batch runs)."""
+        M, D = n * self.T, self.D
+        return (not self.delta_residual) and self.ln_fold and M >= 2048 and D % 256 == 0
 
     def trunk(self, n: int):
         """blocks 0 .. layers-2 on ws['x'] in place."""
@@ -324,7 +332,12 @@ class VisionRollout:
                 qk_lo = ws["qk_lo"] if (self.qk_split and (2 * D) % 256 == 0) else None
                 for bi, b in enumerate(trunk_blocks):
                     if bi == 0:                              # ln_1 of the first block follows ln_pre, not a GEMM
-                        layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=(1 + d()) if zz else 0, mean_out=cen)
+                        if getattr(self, "_ln_pre_pending", False):
+                            self._ln_pre_pending = False     # ln_pre (in place, fp32) and ln_1 (fp16) in one pass over the rows
+                            _lib.call("semabs_layernorm2", _lib.ptr(x), _lib.ptr(self.ln_pre[0]), _lib.ptr(self.ln_pre[1]), _lib.ptr(x), _lib.ptr(b.ln1_w),
+                                      _lib.ptr(b.ln1_b), _lib.ptr(h), M, D, 1e-5, (1 + d()) if zz else 0, _lib.ptr(cen), _lib.stream())
+                        else:
+                            layernorm(x, b.ln1_w, b.ln1_b, h, M, D, order=(1 + d()) if zz else 0, mean_out=cen)
                         if qk_lo is None:
                             gemm(h, b.w_in, qkv, b.b_in, M, 3 * D, D, D, D, 3 * D, EPI_F16, kernel=2 | (d() << 8))
                         else:
@@ -455,7 +468,7 @@ class VisionRollout:
     def gradcam_patches(self, patches: torch.Tensor, n: int, w_text: torch.Tensor, positive_attn_only: bool,
                         rel_out: torch.Tensor, tile0: int):
         assert n <= self.chunk
-        self.embed(patches, n)
+        self.embed(patches, n, defer_ln_pre=os.environ.get("SEMABS_LN2", "1") == "1")
         self.trunk(n)
         self.head(n)
         self.rollout(n, w_text, positive_attn_only, rel_out, tile0)

@@ -71,6 +71,80 @@ __global__ void k_layernorm(const float* __restrict__ x, long ld_in, const float
     }
 }
 
+// Two LayerNorms in one pass (round 6): out1 = LN(x; g1, b1) in fp32 (may alias x) and out2 = fp16 LN(out1; g2, b2) - ln_pre followed by block 0's ln_1
+// (model_explainability.py:345, 232-255) - with the same per-lane partial sums and wave reductions as two k_layernorm launches: bit-identical to them, one
+// read of the 1.48 GB row set less.  mean_out (optional) = the row means of out1 (the first centre of the LayerNorm-fold chain).
+template <int VPL>
+__global__ void k_layernorm2(const float* __restrict__ x, const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ out1,
+                             const float* __restrict__ g2, const float* __restrict__ b2, f16* __restrict__ out2, long M, float eps, int order, float* __restrict__ mean_out) {
+    const int lane = threadIdx.x & 63;
+    const long blk = order ? semabs_xcd_item((int)blockIdx.x, (int)gridDim.x, order == 2) : (long)blockIdx.x;
+    const long row = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D = 256 * VPL;
+    const float* xr = x + row * D;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4));
+        v[i] = make_float4(t[0], t[1], t[2], t[3]);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    float rstd = rsqrtf(wave_sum(q) / D + eps);
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        const float4 gm = *reinterpret_cast<const float4*>(g1 + c0), bt = *reinterpret_cast<const float4*>(b1 + c0);
+        v[i].x = (v[i].x - mean) * rstd * gm.x + bt.x; v[i].y = (v[i].y - mean) * rstd * gm.y + bt.y;
+        v[i].z = (v[i].z - mean) * rstd * gm.z + bt.z; v[i].w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        *reinterpret_cast<float4*>(out1 + row * D + c0) = v[i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    mean = wave_sum(s) / D;
+    if (mean_out && lane == 0) mean_out[row] = mean;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (i * 64 + lane) * 4;
+        const float4 gm = *reinterpret_cast<const float4*>(g2 + c0), bt = *reinterpret_cast<const float4*>(b2 + c0);
+        f16x4 h;
+        h[0] = (f16)((v[i].x - mean) * rstd * gm.x + bt.x); h[1] = (f16)((v[i].y - mean) * rstd * gm.y + bt.y);
+        h[2] = (f16)((v[i].z - mean) * rstd * gm.z + bt.z); h[3] = (f16)((v[i].w - mean) * rstd * gm.w + bt.w);
+        *reinterpret_cast<f16x4*>(out2 + row * D + c0) = h;
+    }
+}
+extern "C" int semabs_layernorm2(const float* x, const float* g1, const float* b1, float* out1, const float* g2, const float* b2, void* out2, long M, int D, float eps,
+                                 int order, float* mean_out, void* stream) {
+    if (M == 0) return SEMABS_OK;
+    SEMABS_REQUIRE(x && g1 && b1 && out1 && g2 && b2 && out2 && M > 0, "semabs_layernorm2: bad args");
+    SEMABS_REQUIRE(D % 256 == 0 && D >= 256 && D <= 1024 && order >= 0 && order <= 2, "semabs_layernorm2: D must be 256..1024 step 256");
+    dim3 grid(semabs_cdiv(M, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(k_layernorm2<1>, grid, block, 0, s, x, g1, b1, out1, g2, b2, (f16*)out2, M, eps, order, mean_out); break;
+        case 2: hipLaunchKernelGGL(k_layernorm2<2>, grid, block, 0, s, x, g1, b1, out1, g2, b2, (f16*)out2, M, eps, order, mean_out); break;
+        case 3: hipLaunchKernelGGL(k_layernorm2<3>, grid, block, 0, s, x, g1, b1, out1, g2, b2, (f16*)out2, M, eps, order, mean_out); break;
+        case 4: hipLaunchKernelGGL(k_layernorm2<4>, grid, block, 0, s, x, g1, b1, out1, g2, b2, (f16*)out2, M, eps, order, mean_out); break;
+    }
+    SEMABS_CHECK_LAUNCH();
+    return SEMABS_OK;
+}
+
 // Residual add fused into the LayerNorm pass: x[row, :] += delta[row, :] (fp16 GEMM output), x written back, out = fp16 LayerNorm(x).
 // The fp32 read-modify-write of the residual stream leaves the GEMM epilogue (where it serialises with the MFMA work of the tile: the
 // out-proj GEMM spent 37 of its 80 us there) for this streaming kernel, which already reads the row.
