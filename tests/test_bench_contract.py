@@ -80,6 +80,9 @@ def test_bench_multi_rank_modes_over_gloo_on_one_gpu(extra, metric_part):
     # every N > 1 line says what each rank put on the wire and how long its host spent issuing it
     assert len(c["per_rank"]) == 2 and sorted(r["rank"] for r in c["per_rank"]) == [0, 1]
     assert all(sum(k["bytes"] for k in r["collectives"].values()) > 0 for r in c["per_rank"])
+    # ... and how long the COMPUTE stream spent in / waiting for communication (device-side events)
+    assert c["exposed_ms_per_step"] is not None and c["exposed_ms_per_step"] >= 0.0
+    assert all("device_ms" in k for r in c["per_rank"] for k in r["collectives"].values())
     if "--mode" in extra:
         assert d["scaling"] == "strong" and c["identical_across_ranks"] is True and len(c["maps_checksums_by_rank"]) == 2
         assert c["tile_relevance_allgather_bytes_per_rank_per_scene"] == 2 * 16 * 612 * 14 * 14 * 4          # 1224 tiles / 2 ranks, 16 labels, 14 x 14, two flip passes
