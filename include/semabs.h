@@ -249,6 +249,11 @@ int semabs_scatter_mean(const long long* flat, const float* feat, int* head, int
  * (unet3d.py:66-79): summed over the occupied voxels while they are written.  C must be 16. */
 int semabs_scatter_mean_stats(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
                               long nvox, int vol_f32, double* out_sums, void* stream);
+/* Sparse form (round 6): vol is NOT zero-filled; occ uint32 [ceil(nvox / 32)] (zero-filled by the caller) receives the occupancy bitmap shared by the P volumes
+ * (net.py:185-201 scatters the same points for every label); only occupied voxels are written.  Consumed by semabs_conv3d_sparse_stats, which treats every other
+ * voxel as zero without reading it (2.1 GB of fill and 2.1 GB of loads per 16 x 128^3 scene). */
+int semabs_scatter_mean_sparse(const long long* flat, const float* feat, int* head, int* next, void* vol, unsigned int* occ, int P, long N, int C, long nvox,
+                               int vol_f32, double* out_sums, void* stream);
 /* GroupNorm statistics / affine                                       unet3d.py:66-79 (nn.GroupNorm) */
 int semabs_gn_stats(const void* x, double* sums, int B, long nvox, int C, int G, int x_f32, void* stream);
 int semabs_gn_finalize(const double* sums, const float* gamma, const float* beta, float* scale, float* shift, int B, int C,
@@ -268,6 +273,10 @@ int semabs_conv3d(const void* x, const void* w_hi, const void* w_lo, void* y, co
 int semabs_conv3d_stats(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                         const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu,
                         int act_f32, double* out_sums, int out_groups, void* stream);
+/* semabs_conv3d_stats on a sparse input volume (see semabs_scatter_mean_sparse): 16 -> 16 channels, 3 x 3 x 3, D0 % 8 == D1 % 8 == D2 % 16 == 0 */
+int semabs_conv3d_sparse_stats(const void* x, const unsigned int* occ, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                               const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize, int relu, int act_f32,
+                               double* out_sums, int out_groups, void* stream);
 /* ConvTranspose3d k3 s2 p1 (output_size = skip size) + bias + sum joining          unet3d.py:428-440, 385-396 */
 int semabs_convtranspose3d(const void* x, const void* w_hi, const void* w_lo, const long* class_off /*host*/, void* y,
                            const float* bias, const void* skip, int B, int D0, int D1, int D2, int Cin, int Cout, int act_f32,

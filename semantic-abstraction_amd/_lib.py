@@ -87,10 +87,12 @@ SIGNATURES = {
     "semabs_point_mlp_fma": [P, P, P, P, P, P, P, P, P, I, L, I, I, P],
     "semabs_scatter_mean": [P, P, P, P, P, I, L, I, L, I, P],
     "semabs_scatter_mean_stats": [P, P, P, P, P, I, L, I, L, I, P, P],
+    "semabs_scatter_mean_sparse": [P, P, P, P, P, P, I, L, I, L, I, P, P],
     "semabs_gn_stats": [P, P, I, L, I, I, I, P],
     "semabs_gn_finalize": [P, P, P, P, P, I, I, I, L, F, P],
     "semabs_conv3d": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "semabs_conv3d_stats": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
+    "semabs_conv3d_sparse_stats": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
     "semabs_convtranspose3d": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P],
     "semabs_convtranspose3d_stats": [P, P, P, C.POINTER(C.c_long), P, P, P, I, I, I, I, I, I, I, P, I, P],
     "semabs_maxpool3d": [P, P, I, I, I, I, I, I, P],

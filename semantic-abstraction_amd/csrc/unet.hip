@@ -278,13 +278,15 @@ __global__ void k_scatter_link(const long long* __restrict__ flat, long N, int* 
 #define SCATTER_MAXLIST 32
 template <typename TOut>
 __global__ void k_scatter_mean(const long long* __restrict__ flat, const float* __restrict__ feat, const int* __restrict__ head,
-                               const int* __restrict__ next, TOut* __restrict__ vol, int P, long N, int C, long nvox, double* __restrict__ stats) {
+                               const int* __restrict__ next, TOut* __restrict__ vol, int P, long N, int C, long nvox, double* __restrict__ stats,
+                               unsigned int* __restrict__ occ) {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = t < (long)P * N;
     if (!in_range) t = (long)P * N - 1;
     const long p = t % N; const int b = (int)(t / N);
     const long v = flat[p];
     const bool worker = in_range && head[v] == (int)p;     // one worker per occupied voxel (and label)
+    if (occ && worker && b == 0) atomicOr(occ + (v >> 5), 1u << (v & 31));     // occupancy bitmap (zeroed by the caller): the volume's other voxels stay unwritten
     // `stats` (optional, C == 16): GroupNorm statistics (8 groups of 2 channels) of the volume being written - empty voxels add nothing, so
     // the sums over the workers' voxels are the sums over the dense volume.  A wave reduces its workers' sums and issues 16 fp64 atomics.
     float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -356,13 +358,13 @@ __global__ void k_scatter_mean(const long long* __restrict__ flat, const float* 
 // flat int64 [N]; feat fp32 [P, N, C]; vol [P, nvox, C] (fp16 or fp32), must be zero-filled by the caller;
 // head int32 [nvox] filled with -1 by the caller; next int32 [N] scratch.
 static int scatter_mean_impl(const long long* flat, const float* feat, int* head, int* next, void* vol, int P, long N, int C,
-                             long nvox, int vol_f32, double* stats, void* stream) {
+                             long nvox, int vol_f32, double* stats, void* stream, unsigned int* occ = nullptr) {
     if (P == 0 || N == 0) return SEMABS_OK;
     SEMABS_REQUIRE(flat && feat && head && next && vol && C > 0 && nvox > 0, "semabs_scatter_mean: bad args");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_scatter_link, dim3(semabs_cdiv(N, 256)), dim3(256), 0, s, flat, N, head, next);
-    if (vol_f32) hipLaunchKernelGGL(k_scatter_mean<float>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (float*)vol, P, N, C, nvox, stats);
-    else hipLaunchKernelGGL(k_scatter_mean<f16>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (f16*)vol, P, N, C, nvox, stats);
+    if (vol_f32) hipLaunchKernelGGL(k_scatter_mean<float>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (float*)vol, P, N, C, nvox, stats, occ);
+    else hipLaunchKernelGGL(k_scatter_mean<f16>, dim3(semabs_cdiv((long)P * N, 256)), dim3(256), 0, s, flat, feat, head, next, (f16*)vol, P, N, C, nvox, stats, occ);
     SEMABS_CHECK_LAUNCH();
     return SEMABS_OK;
 }
@@ -376,6 +378,13 @@ extern "C" int semabs_scatter_mean_stats(const long long* flat, const float* fea
                                          long nvox, int vol_f32, double* out_sums, void* stream) {
     SEMABS_REQUIRE(out_sums && C == 16, "semabs_scatter_mean_stats: needs out_sums and C == 16");
     return scatter_mean_impl(flat, feat, head, next, vol, P, N, C, nvox, vol_f32, out_sums, stream);
+}
+// ... and SPARSE: vol is NOT zero-filled by the caller; occ (uint32 [ceil(nvox / 32)], zero-filled by the caller) receives the occupancy bitmap, one for all P
+// volumes (they scatter the same points); only occupied voxels of vol are written.  The consumer is semabs_conv3d_sparse_stats.
+extern "C" int semabs_scatter_mean_sparse(const long long* flat, const float* feat, int* head, int* next, void* vol, unsigned int* occ, int P, long N, int C,
+                                          long nvox, int vol_f32, double* out_sums, void* stream) {
+    SEMABS_REQUIRE(out_sums && occ && C == 16, "semabs_scatter_mean_sparse: needs out_sums, occ and C == 16");
+    return scatter_mean_impl(flat, feat, head, next, vol, P, N, C, nvox, vol_f32, out_sums, stream, occ);
 }
 
 // =================================================================================================
@@ -498,6 +507,9 @@ struct ConvArgs {
     // `resid` = X: y = k0 acc - k1 - ((X - mean) rstd) k2 [masked by X > 0], coef = (k0, k1, k2) per (b, channel), mean / rstd per (b, group of gnb_G)
     const float* gnb_coef = nullptr; const float* gnb_mean = nullptr; const float* gnb_rstd = nullptr; int gnb_G = 0, gnb_relu = 0;
     unsigned int* gnb_bits = nullptr;     // optional: receives the bit pattern of max |y|
+    // k_conv16_lds only (semabs_conv3d_sparse_stats, round 6): occupancy bitmap of the INPUT (bit v & 31 of word v >> 5 for voxel v of a volume; shared by the
+    // B volumes: they are scatters of the same points).  Voxels whose bit is clear ARE zero and their memory is neither initialised nor read.
+    const unsigned int* occ = nullptr;
     const float* gnb_add = nullptr;       // optional: a tensor like y added before the mask (the residual branch's gradient)
 };
 
@@ -755,7 +767,8 @@ __device__ __forceinline__ void conv_absmax_commit(unsigned int* bits, float m) 
 // GNB (round 5, exact mode only): the launch is the DATA GRADIENT of a GroupNorm -> Conv3d layer and its epilogue applies the GroupNorm backward to the
 // accumulators (see ConvArgs::gnb_*): the layer input's rows come through the residual registers, the per-(volume, channel) coefficients through a small LDS
 // table - the separate apply pass (read dXn, read X, write dX: 0.55 ms per layer at 8 x 128^3 x 16) and the dXn tensor itself are gone.
-template <bool F32, int C16_T0, bool GNB = false>      // brick depth 8 (fp16: 2 x 57.6 KB LDS) or 4 (exact: 2 x 69 KB): one 8-wave workgroup per CU, two halo buffers
+// SPARSE (round 6): the input is described by an occupancy bitmap (ConvArgs::occ) - a compile-time variant, so that the other instantiations keep their registers.
+template <bool F32, int C16_T0, bool GNB = false, bool SPARSE = false>      // brick depth 8 (fp16: 2 x 57.6 KB LDS) or 4 (exact: 2 x 69 KB): one 8-wave workgroup per CU, two halo buffers
 __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
     constexpr int C16_H0 = C16_T0 + 2, C16_HALO = C16_H0 * C16_H1 * C16_H2;
     // One plane = the 16-byte half-voxels (channels 0-7 or 8-15) of the whole halo.  Its size is rounded up to a multiple of 256 B: a
@@ -823,6 +836,21 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
         const f16* xbh = reinterpret_cast<const f16*>(a.x) + (size_t)b * a.I0 * a.I1 * a.I2 * 16;
         float raw[NT][8];
         bool inb[NT];
+        // Sparse input (a.occ, the scattered point features: ~1 - 4 % of the voxels are occupied): the bitmap words of all tasks are requested first; a task whose
+        // voxel is empty then reads the volume's first line (one cache line for all of them) and is zeroed BEFORE the GroupNorm affine - the volume's empty
+        // voxels are never written by the scatter and never read here (2.1 GB of zero-fill and 2.1 GB of loads per scene).
+        [[maybe_unused]] unsigned oword[NT];
+        [[maybe_unused]] int vflat[NT];
+        if constexpr (SPARSE) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int v = min(vsub + k * 128, C16_HALO - 1);
+                const int hx = v % C16_H2, hy = (v / C16_H2) % C16_H1, hz = v / (C16_H2 * C16_H1);
+                const int cz = min(max(z0 + hz - 1, 0), a.I0 - 1), cy = min(max(y0 + hy - 1, 0), a.I1 - 1), cx = min(max(x0 + hx - 1, 0), a.I2 - 1);
+                vflat[k] = (cz * a.I1 + cy) * a.I2 + cx;
+                oword[k] = a.occ[vflat[k] >> 5];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int v = min(vsub + k * 128, C16_HALO - 1);
@@ -830,7 +858,12 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             inb[k] = gz >= 0 && gz < a.I0 && gy >= 0 && gy < a.I1 && gx >= 0 && gx < a.I2;
             const int cz = min(max(gz, 0), a.I0 - 1), cy = min(max(gy, 0), a.I1 - 1), cx = min(max(gx, 0), a.I2 - 1);
-            const unsigned eo = (unsigned)(((cz * a.I1 + cy) * a.I2 + cx) * 16 + hsel * 8);      // < 2^31 elements per volume (checked on the host)
+            unsigned eo = (unsigned)(((cz * a.I1 + cy) * a.I2 + cx) * 16 + hsel * 8);      // < 2^31 elements per volume (checked on the host)
+            if constexpr (SPARSE) {
+                const bool full = (oword[k] >> (vflat[k] & 31)) & 1u;
+                oword[k] = full ? 1u : 0u;
+                if (!full) eo = (unsigned)(hsel * 8);
+            }
             {
                 if (F32) {
                     const float4 q0 = *reinterpret_cast<const float4*>(xb + eo), q1 = *reinterpret_cast<const float4*>(xb + eo + 4);
@@ -848,7 +881,8 @@ __global__ __launch_bounds__(512) void k_conv16_lds(ConvArgs a) {
             f16x8 h, l;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float val = inb[k] ? raw[k][c] * gs[c] + gh[c] : 0.f;          // zero padding AFTER the normalisation
+                const float rv = (SPARSE && !oword[k]) ? 0.f : raw[k][c];            // an empty voxel of a sparse input is zero (its memory holds anything)
+                const float val = inb[k] ? rv * gs[c] + gh[c] : 0.f;                 // zero padding AFTER the normalisation
                 h[c] = (f16)val;
                 if (F32) l[c] = (f16)(val - (float)h[c]);
             }
@@ -1112,6 +1146,13 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
             SEMABS_CHECK_LAUNCH();
             return SEMABS_OK;
         }
+        if (a.occ) {
+            static SemabsLdsAttr attrs;
+            semabs_ensure_lds(&k_conv16_lds<true, T0, false, true>, (int)lds, attrs);
+            hipLaunchKernelGGL((k_conv16_lds<true, T0, false, true>), dim3((unsigned)nb), dim3(512), lds, s, a);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
         static SemabsLdsAttr attr;
         semabs_ensure_lds(&k_conv16_lds<true, T0>, (int)lds, attr);
         hipLaunchKernelGGL((k_conv16_lds<true, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
@@ -1120,6 +1161,13 @@ static int conv16_lds_launch(const ConvArgs& a_in, int f32, hipStream_t s) {
         const size_t lds = (size_t)(((T0 + 2) * C16_H1 * C16_H2 * 8 + 127) / 128 * 128) * 2 * 2 * 2;       // two half-voxel planes (256-B padded), two buffers; fp16
         const long total = (long)a.B * (a.I0 / T0) * (a.I1 / C16_T1) * (a.I2 / C16_T2);
         long nb = semabs_stream_cus(s); if (nb > total) nb = total;
+        if (a.occ) {
+            static SemabsLdsAttr attrs;
+            semabs_ensure_lds(&k_conv16_lds<false, T0, false, true>, (int)lds, attrs);
+            hipLaunchKernelGGL((k_conv16_lds<false, T0, false, true>), dim3((unsigned)nb), dim3(512), lds, s, a);
+            SEMABS_CHECK_LAUNCH();
+            return SEMABS_OK;
+        }
         static SemabsLdsAttr attr;
         semabs_ensure_lds(&k_conv16_lds<false, T0>, (int)lds, attr);
         hipLaunchKernelGGL((k_conv16_lds<false, T0>), dim3((unsigned)nb), dim3(512), lds, s, a);
@@ -1661,7 +1709,7 @@ static int conv_common_checks(const void* x, const void* w_hi, const void* w_lo,
 // statistics pass over y on the same stream.
 static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
                        const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
-                       int relu, int act_flags, double* out_sums, int out_groups, void* stream) {
+                       int relu, int act_flags, double* out_sums, int out_groups, void* stream, const unsigned int* occ = nullptr) {
     if (B == 0) return SEMABS_OK;
     const int act_f32 = act_flags & 1;
     const bool bricks = !(act_flags & SEMABS_CONV_GENERIC);
@@ -1689,7 +1737,11 @@ static int conv3d_impl(const void* x, const void* w_hi, const void* w_lo, void* 
     bool fused = false;
     if (bricks && ksize == 3 && Cin == 16 && Cout == 16 && D0 % 8 == 0 && D1 % C16_T1 == 0 && D2 % C16_T2 == 0 && (long)D0 * D1 * D2 * 16 < (1L << 31)) {
         if (out_sums && out_groups == 8) { a.stats = out_sums; fused = true; }
+        a.occ = occ;
         rc = conv16_lds_launch(a, act_f32, (hipStream_t)stream);
+    } else if (occ) {
+        semabs_set_error("semabs_conv3d_sparse_stats: the occupancy bitmap is read by the 16 -> 16 level-0 kernel only (D0 % 8, D1 % 8, D2 % 16 == 0)");
+        return SEMABS_EINVAL;
     } else if (bricks && ksize == 3 && (Cout % 32 == 0 || (Cout == 16 && Cin % 32 == 0 && D2 % C16_T2 == 0)) && (Cin == 16 || Cin % 32 == 0) && relu != 2 &&
                D0 % 4 == 0 && D1 % C16_T1 == 0 && (D2 % C16_T2 == 0 || (D2 % 8 == 0 && Cin % 32 == 0))) {
         if (out_sums && out_groups == 8 && Cout >= 32) { a.stats = out_sums; fused = true; }     // (a lane's four output channels lie in one of the 8 groups: Cout >= 32)
@@ -1710,6 +1762,16 @@ extern "C" int semabs_conv3d_stats(const void* x, const void* w_hi, const void* 
                                    int relu, int act_f32, double* out_sums, int out_groups, void* stream) {
     SEMABS_REQUIRE(out_sums, "semabs_conv3d_stats: out_sums is null");
     return conv3d_impl(x, w_hi, w_lo, y, gn_scale, gn_shift, bias, resid, B, D0, D1, D2, Cin, Cout, ksize, relu, act_f32, out_sums, out_groups, stream);
+}
+
+// semabs_conv3d_stats on a SPARSE input: occ = occupancy bitmap of x (semabs_scatter_mean_stats(.., occ)), bit v & 31 of word v >> 5 for voxel v, one bitmap for
+// all B volumes.  Empty voxels are zero by definition: x need not be initialised there and is not read.  16 -> 16 channels, 3 x 3 x 3, D0 % 8 == D1 % 8 == D2 % 16 == 0.
+extern "C" int semabs_conv3d_sparse_stats(const void* x, const unsigned int* occ, const void* w_hi, const void* w_lo, void* y, const float* gn_scale, const float* gn_shift,
+                                          const float* bias, const void* resid, int B, int D0, int D1, int D2, int Cin, int Cout, int ksize,
+                                          int relu, int act_f32, double* out_sums, int out_groups, void* stream) {
+    SEMABS_REQUIRE(out_sums && occ, "semabs_conv3d_sparse_stats: out_sums / occ is null");
+    SEMABS_REQUIRE(!(act_f32 & SEMABS_CONV_GENERIC), "semabs_conv3d_sparse_stats: the generic kernel reads the whole volume");
+    return conv3d_impl(x, w_hi, w_lo, y, gn_scale, gn_shift, bias, resid, B, D0, D1, D2, Cin, Cout, ksize, relu, act_f32, out_sums, out_groups, stream, occ);
 }
 
 // Data gradient of a GroupNorm -> Conv3d 3x3x3 layer WITH the GroupNorm backward applied in the epilogue (round 5):

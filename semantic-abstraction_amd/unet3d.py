@@ -193,9 +193,10 @@ class ResidualUNet3D(torch.nn.Module):
                   B, Cc, G, nvox, 1e-5, st)
         return scale, shift
 
-    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None, in_sums=None, out_groups=0, generic=False):
+    def _conv(self, x, conv: _Conv, relu, resid=None, gn=True, out_dtype=None, in_sums=None, out_groups=0, generic=False, occ=None):
         """out_groups > 0: also return the GroupNorm statistics of the output (fp64 [B, out_groups, 2]) for the next layer.
-        generic: run the generic gather kernel even where an LDS-brick kernel exists (bit 8 of the flag word; per-call cross-check for tests)."""
+        generic: run the generic gather kernel even where an LDS-brick kernel exists (bit 8 of the flag word; per-call cross-check for tests).
+        occ: x is SPARSE (semabs_scatter_mean_sparse): uint32 occupancy bitmap; voxels whose bit is clear are zero and are not read."""
         B, D0, D1, D2, _ = x.shape
         y = torch.empty(B, D0, D1, D2, conv.cout, dtype=self.act_dtype, device=self.dev)
         scale, shift = self._gn(x, conv, in_sums) if gn else (None, None)
@@ -203,15 +204,25 @@ class ResidualUNet3D(torch.nn.Module):
                 _lib.ptr(conv.bias), _lib.ptr(resid), B, D0, D1, D2, conv.cin, conv.cout, conv.k, int(relu), self.f32 | (256 if generic else 0) | conv.packed)
         if out_groups:
             sums = self._zero_sums(B, out_groups)
-            _lib.call("semabs_conv3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
+            if occ is not None:
+                _lib.call("semabs_conv3d_sparse_stats", args[0], _lib.ptr(occ), *args[1:], _lib.ptr(sums), out_groups, _lib.stream())
+            else:
+                _lib.call("semabs_conv3d_stats", *args, _lib.ptr(sums), out_groups, _lib.stream())
             return y, sums
+        assert occ is None
         _lib.call("semabs_conv3d", *args, _lib.stream())
         return y
 
-    def _block(self, x, convs, in_sums=None):
+    @staticmethod
+    def sparse_input_supported(shape, conv: "_Conv") -> bool:
+        """The first convolution can read a sparse (bitmap-described) input: the 16 -> 16 level-0 kernel's shapes."""
+        _, D0, D1, D2, Cc = shape
+        return conv.k == 3 and conv.cin == 16 and conv.cout == 16 and Cc == 16 and D0 % 8 == 0 and D1 % 8 == 0 and D2 % 16 == 0 and D0 * D1 * D2 * 16 < 2 ** 31
+
+    def _block(self, x, convs, in_sums=None, occ=None):
         # conv1 / conv2 hand the statistics of their outputs to the GroupNorm of conv2 / conv3 (fused into the epilogue where supported);
         # in_sums: the statistics of x when its producer already has them (the transposed convolution of a decoder level)
-        out1, s1 = self._conv(x, convs[0], relu=True, in_sums=in_sums, out_groups=convs[1].groups)
+        out1, s1 = self._conv(x, convs[0], relu=True, in_sums=in_sums, out_groups=convs[1].groups, occ=occ)
         out2, s2 = self._conv(out1, convs[1], relu=True, in_sums=s1, out_groups=convs[2].groups)
         return self._conv(out2, convs[2], relu=True, resid=out1, in_sums=s2)          # conv3 (no ReLU) + residual, then ReLU
 
@@ -237,9 +248,9 @@ class ResidualUNet3D(torch.nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_cl(self, x: torch.Tensor, taps: dict | None = None, skip_final: bool = False, in_sums=None) -> torch.Tensor:
+    def forward_cl(self, x: torch.Tensor, taps: dict | None = None, skip_final: bool = False, in_sums=None, occ=None) -> torch.Tensor:
         """x [B, D0, D1, D2, Cin] channels-last (act dtype, GPU) -> [B, D0, D1, D2, Cout]  (skip_final: the input of `final_conv`;
-        in_sums: GroupNorm statistics of x, fp64 [B, groups, 2], when its producer already has them)."""
+        in_sums: GroupNorm statistics of x, fp64 [B, groups, 2], when its producer already has them; occ: x is sparse - occupancy bitmap, see _conv)."""
         self._sync()
         assert x.dtype == self.act_dtype and x.is_contiguous()
         # statistics arena of this pass: (3 per residual block + 1 per transposed convolution) x [B, <= num_groups, 2] doubles, zeroed by one launch;
@@ -247,16 +258,16 @@ class ResidualUNet3D(torch.nn.Module):
         n_layers = 3 * (len(self.enc) + len(self.dec)) + len(self.dec) + 2
         self._sums_arena = [_lib.filled((n_layers * int(x.shape[0]) * max(1, self.num_groups) * 2,), torch.float64, 0, self.dev), 0]
         try:
-            return self._forward_cl(x, taps, skip_final, in_sums)
+            return self._forward_cl(x, taps, skip_final, in_sums, occ)
         finally:
             self._sums_arena = None
 
-    def _forward_cl(self, x, taps, skip_final, in_sums):
+    def _forward_cl(self, x, taps, skip_final, in_sums, occ=None):
         feats = []
         for i, convs in enumerate(self.enc):
             if i > 0:
                 x = self._pool(x)
-            x = self._block(x, convs, in_sums=in_sums if i == 0 else None)
+            x = self._block(x, convs, in_sums=in_sums if i == 0 else None, occ=occ if i == 0 else None)
             if taps is not None:
                 taps[f"enc{i}"] = x
             feats.insert(0, x)

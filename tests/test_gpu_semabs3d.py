@@ -421,3 +421,31 @@ def test_scatter_mean_statistics(vol_f32):
     vd = vols[1].double().reshape(P, nvox, 8, 2)
     want = torch.stack([vd.sum(dim=(1, 3)), (vd * vd).sum(dim=(1, 3))], dim=-1)
     np.testing.assert_allclose(sums.cpu().numpy(), want.cpu().numpy(), rtol=3e-6, atol=2e-6 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["exact", "fp16"])
+def test_sparse_scatter_equals_dense(precision):
+    """semabs_scatter_mean_sparse + semabs_conv3d_sparse_stats (the volume is neither zero-filled nor read where the occupancy bitmap is clear) against the dense
+    form on the same points: the UNet's first block and everything behind it see the same values.  The scattered volume of the dense run is poisoned with NaN
+    bit patterns in a second sparse run's allocation to show that empty voxels are never read."""
+    import semabs_amd.net as snet
+    S, N, P = 32, 3000, 3
+    m = _model(S, precision)
+    xyz, feat, _ = semabs_inputs(S, N, 64, P, 5)
+    x, f = torch.from_numpy(xyz[0]).cuda(), torch.from_numpy(feat[0, :, :, 0]).cuda()
+    old = snet.SPARSE_SCATTER
+    try:
+        snet.SPARSE_SCATTER = False
+        dense = m.feature_volume(x, f).clone()
+        snet.SPARSE_SCATTER = True
+        # poison what the caching allocator will hand to the sparse run's torch.empty volume
+        junk = torch.full((P, S, S, S, 16), float("nan"), dtype=m.vol_feature_extractor.act_dtype, device="cuda")
+        del junk
+        sparse = m.feature_volume(x, f).clone()
+    finally:
+        snet.SPARSE_SCATTER = old
+    assert bool(torch.isfinite(sparse).all())
+    d = float((sparse.float() - dense.float()).abs().max())
+    print(f"{precision}: sparse vs dense scatter, UNet feature L-inf {d:.3e} (max {float(dense.float().abs().max()):.3f})")
+    # the first GroupNorm's statistics are fp64 atomics in both forms: a few ulps of run-to-run spread, nothing more
+    assert d <= (2e-5 if precision == "exact" else 2e-2) * float(dense.float().abs().max())
